@@ -1,0 +1,55 @@
+"""pytest configuration: markers, import path, shared fixtures."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.fixture(scope="session")
+def g1():
+    return load_golden("g1_big5")
+
+
+@pytest.fixture(scope="session")
+def g2_small():
+    return load_golden("g2_planted_small")
+
+
+@pytest.fixture(scope="session")
+def g2_mid():
+    return load_golden("g2_planted_mid")
+
+
+@pytest.fixture(scope="session")
+def g3():
+    return load_golden("g3_c2_step")
+
+
+@pytest.fixture(scope="session")
+def g4():
+    return load_golden("g4_edges")
+
+
+@pytest.fixture(scope="session")
+def g5():
+    return load_golden("g5_outliers")
+
+
+@pytest.fixture(scope="session")
+def g6():
+    return load_golden("g6_adni_missing")

@@ -1,0 +1,222 @@
+"""Pin the CPU oracle (oracle/corex_oracle.py) to outputs of the reference itself.
+
+The fixtures were produced by tests/golden/make_golden.py, which imports /root/reference in the
+build container.  The oracle restates the same NumPy arithmetic in the same order, so on the same
+NumPy/BLAS build it is expected to match bit for bit; tolerances below leave room for a different
+BLAS on another host (summation order), nothing more.
+"""
+import numpy as np
+import pytest
+
+from oracle import corex_oracle as O
+
+DT = {"f32": np.float32, "f64": np.float64}
+# different-BLAS headroom; on the generating host every comparison below is exact
+RTOL = {"f32": 2e-4, "f64": 1e-9}
+
+
+def key_name(k):
+    return k.replace(" ", "_").replace("^", "p").replace("|", "g").replace(";", "s") \
+            .replace("(", "").replace(")", "").replace("-", "m")
+
+
+QUICK = ["uj", "rho", "ry", "Y_j^2", "invrho", "rhoinvrho", "Qij", "Si", "Qi-Si^2", "TC"]
+DETAIL = ["MI", "X_i Y_j", "X_i Z_j", "X_i^2 | Y", "I(Y_j ; X)", "I(X_i ; Y)", "TCs",
+          "TC_no_overlap", "TC_direct", "additivity"]
+
+
+def close(a, b, tag, scale=1.0):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    tol = RTOL[tag] * scale
+    assert a.shape == b.shape
+    assert np.allclose(a, b, rtol=tol, atol=tol * max(1.0, float(np.abs(b).max()) if b.size else 1.0)), \
+        float(np.abs(a - b).max())
+
+
+def thin_of(arr, g, name, nv):
+    """Compare helper for thinned fixtures: returns (ours thinned the same way, golden)."""
+    arr = np.asarray(arr)
+    if name in g.files:
+        return arr, g[name]
+    gold = g[name + "_thin"]
+    ax = list(arr.shape).index(nv)
+    step = int(round(arr.shape[ax] / gold.shape[ax]))
+    sl = [slice(None)] * arr.ndim
+    sl[ax] = slice(None, None, step)
+    return arr[tuple(sl)], gold
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_big5_end_to_end(g1, tag):
+    r = O.fit_ns(g1["x_raw"].astype(np.float64), 5, seed=0, dtype=DT[tag], keep_x=True)
+    assert len(r.history_tc) == len(g1[tag + "_history_tc"]) == {"f32": 263, "f64": 261}[tag]
+    close(r.history_tc, g1[tag + "_history_tc"], tag)
+    close(r.x_tilde, g1[tag + "_x_tilde"], tag)
+    close(r.w_init, g1[tag + "_w_init"], tag)
+    close(r.ws, g1[tag + "_ws"], tag, 50)
+    assert np.array_equal(r.clusters(), g1[tag + "_clusters"])
+    assert np.array_equal(r.clusters(), np.array([0, 2, 4, 1, 3])[np.arange(50) % 5])
+    close(r.get_covariance(), g1[tag + "_cov"], tag, 50)
+    close(r.transform(r.x_tilde), g1[tag + "_transform"], tag, 50)
+    for k in QUICK + DETAIL:
+        close(r.moments[k], g1[tag + "_mom_" + key_name(k)], tag, 50)
+    assert abs(float(r.moments["TC"]) - 8.2089) < 1e-3
+    assert r.n_trials + 10 == int(g1[tag + "_n_moment_calls"])     # 1 init + 7 stage starts + 2 final
+
+
+def test_moment_call_accounting(g1):
+    # reference issues: 1 (init, ref :122) + 7 (stage starts, :134) + 2 (final, :160/:163) + trials
+    # + 0 from _norm (it does its own GEMM).  n_moment_calls counts _calculate_moments_ns only.
+    for tag in ("f32", "f64"):
+        trials = int(g1[tag + "_trials_per_iter"].sum())
+        assert trials + 10 == int(g1[tag + "_n_moment_calls"])
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("it", [0, 1, 160, 230])
+def test_big5_step_level(g1, tag, it):
+    p = "%s_step%d_" % (tag, it)
+    x = g1[tag + "_x_tilde"]
+    w = g1[p + "w_in"]
+    eps = float(g1[p + "eps"])
+    mo = {k: g1[p + "in_" + key_name(k)] for k in QUICK}
+    # moments at w_in reproduce the captured ones
+    mine = O.moments_ns(x, w, eps, quick=True)
+    for k in QUICK:
+        close(mine[k], mo[k], tag, 10)
+    d = O.update_direction(x, w, mo, eps)
+    close(d["grad"], g1[p + "grad"], tag, 10)
+    close(d["sig_grad"], g1[p + "sig_grad"], tag, 10)
+    w2, m2, info = O.update_ns(x, w, mo, eps)
+    assert info["n_trials"] == int(g1[p + "n_trials"])
+    close(w2, g1[p + "w_out"], tag, 10)
+    close(m2["TC"], g1[p + "out_TC"], tag, 10)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("which", ["g2_small", "g2_mid"])
+def test_planted(request, tag, which):
+    g = request.getfixturevalue(which)
+    n, v, m = (int(t) for t in g["shape"])
+    if which == "g2_mid" and tag == "f32":
+        pytest.skip("covered by f64 at this size; keeps the CPU suite short")
+    x, grp = O.gen_planted(n, v, m)
+    assert np.array_equal(grp, g["grp"])
+    r = O.fit_ns(x, m, seed=0, dtype=DT[tag], keep_x=True)
+    assert len(r.history_tc) == len(g[tag + "_history_tc"])
+    close(r.history_tc, g[tag + "_history_tc"], tag, 10)
+    assert np.array_equal(r.clusters(), g[tag + "_clusters"])
+    # planted structure is recovered exactly (purity 1): same cluster <=> same group
+    cl = r.clusters()
+    assert all(len(set(cl[grp == k])) == 1 for k in range(m))
+    a, b = thin_of(r.ws, g, tag + "_ws", v)
+    close(a, b, tag, 100)
+    cov = r.get_covariance()
+    close(cov[:256, :256], g[tag + "_cov_block"], tag, 100)
+    close(cov[-4:], g[tag + "_cov_lastrows"], tag, 100)
+    close(np.linalg.norm(cov.astype(np.float64)), g[tag + "_cov_fro"], tag, 100)
+    assert r.n_trials == int(g[tag + "_trials_per_iter"].sum())
+    assert r.n_invalid == int(g[tag + "_n_invalid"])
+    for k in QUICK + DETAIL:
+        a, b = thin_of(r.moments[k], g, tag + "_mom_" + key_name(k), v)
+        close(a, b, tag, 100)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_c2_shaped_steps(g3, tag):
+    n, v, m = (int(t) for t in g3["shape"])
+    x = O.gen_iid(n, v, seed=1, dtype=np.float64)
+    seen = []
+
+    def hook(stage, it, w, mo, info):
+        seen.append((stage, it, float(mo["TC"]), info["n_trials"]))
+
+    r = O.fit_ns(x, m, seed=0, dtype=DT[tag], max_iter=2, on_iteration=hook)
+    close(r.history_tc, g3[tag + "_history_tc"], tag, 10)
+    assert [s[3] for s in seen] == list(g3[tag + "_trials_per_iter"])
+    # step 0: captured inputs -> direction
+    p = tag + "_step0_"
+    xt = O.preprocess(x.astype(DT[tag]))[0]
+    w = O.initial_weights(0, m, v, DT[tag])
+    w /= (10.0 * O.norm(xt, w, 0))[:, np.newaxis]
+    a, b = thin_of(w, g3, p + "w_in", v)
+    close(a, b, tag, 10)
+    eps = float(g3[p + "eps"])
+    mo = O.moments_ns(xt, w, eps, quick=True)
+    close(mo["uj"], g3[p + "in_uj"], tag, 10)
+    close(mo["TC"], g3[p + "in_TC"], tag, 10)
+    d = O.update_direction(xt, w, mo, eps)
+    a, b = thin_of(d["grad"], g3, p + "grad", v)
+    close(a, b, tag, 10)
+    close(np.linalg.norm(d["sig_grad"].astype(np.float64)), g3[p + "sig_grad_fro"], tag, 10)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_edges(g4, tag):
+    dt = DT[tag]
+    x, w = g4["x"].astype(dt), g4["w"]
+    assert bool(g4[tag + "_invalid_is_false"])
+    assert O.moments_ns(x, (w * 3.0).astype(dt), 0, quick=True) is False       # ref :250-251
+    with np.errstate(all="ignore"):
+        full = O.moments_ns(x, (w * 3.0).astype(dt), 0, quick=False)
+    close(full["uj"], g4[tag + "_invalid_uj"], tag)
+    assert full["uj"].max() >= 1
+    ws = (w * 0.02).astype(dt)
+    mo = O.moments_ns(x, ws, 0.36, quick=False)
+    for k in QUICK + DETAIL:
+        close(mo[k], g4[tag + "_eps036_" + key_name(k)], tag, 10)
+    close(O.sig(x, ws, 0.36), g4[tag + "_eps036_sig"], tag, 10)
+    close(O.norm(x, ws, 0.36), g4[tag + "_eps036_norm"], tag, 10)
+    # duplicated columns (near-singular covariance)
+    r = O.fit_ns(g4["dup_x"], 3, seed=0, dtype=dt, max_iter=300)
+    assert len(r.history_tc) == len(g4[tag + "_dup_history_tc"])
+    close(r.history_tc, g4[tag + "_dup_history_tc"], tag, 100)
+    close(r.ws, g4[tag + "_dup_ws"], tag, 1000)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_outliers(g5, tag):
+    n, v, m = (int(t) for t in g5["shape"])
+    x, grp = O.gen_planted(n, v, m, seed=3)
+    heavy = np.arange(v) % 20 == 0
+    x[:, heavy] = np.sign(x[:, heavy]) * np.abs(x[:, heavy]) ** 1.5
+    r = O.fit_ns(x, m, seed=0, dtype=DT[tag], gaussianize="outliers", keep_x=True)
+    close(r.x_tilde[::10, ::10], g5[tag + "_x_tilde_thin"], tag)
+    assert len(r.history_tc) == len(g5[tag + "_history_tc"])
+    close(r.history_tc, g5[tag + "_history_tc"], tag, 10)
+    assert np.array_equal(r.clusters(), g5[tag + "_clusters"])
+    close(r.get_covariance()[:128, :128], g5[tag + "_cov_block"], tag, 100)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_missing_values(g6, tag):
+    x = g6["x_raw"]
+    r = O.fit_ns(x, 6, seed=0, dtype=DT[tag], missing_values=-1e6, max_iter=60, keep_x=True)
+    xt, theta, n_obs = O.preprocess(np.asarray(x, DT[tag]), None, "standard", -1e6)
+    assert np.array_equal(n_obs, g6[tag + "_n_obs"])
+    close(theta[0], g6[tag + "_theta_mean"], tag)
+    close(theta[1], g6[tag + "_theta_std"], tag)
+    assert len(r.history_tc) == len(g6[tag + "_history_tc"])
+    close(r.history_tc, g6[tag + "_history_tc"], tag, 100)
+    assert np.array_equal(r.clusters(), g6[tag + "_clusters"])
+    close(r.get_covariance(), g6[tag + "_cov"], tag, 1000)
+
+
+def test_tail_squash_roundtrip():
+    z = np.linspace(-9, 9, 181)
+    s = O.squash_tails(z)
+    assert np.all(np.abs(s) < 5.0)
+    assert np.allclose(s[np.abs(z) <= 4], z[np.abs(z) <= 4])
+    assert np.allclose(O.unsquash_tails(s), z, atol=1e-6)
+
+
+def test_schedule_and_rescale():
+    assert np.allclose(O.anneal_schedule(True), [0.6, 0.36, 0.216, 0.1296, 0.07776, 0.046656, 0.0])
+    assert O.anneal_schedule(False) == [0.0] and O.anneal_schedule(True, warm_start=True) == [0.0]
+    w = np.ones((2, 3))
+    uj = np.array([1.5, 2.0])                     # u_j >= eps0^2 * |w_j|^2 always holds (ref :249)
+    out = O.rescale_for_stage(w, uj, 0.6, 0.36)
+    delta = (0.36 ** 2 - 0.6 ** 2) / (1 - 0.36 ** 2) * 3.0 / uj
+    a = np.sqrt((1 - 0.6 ** 2) / ((1 - 0.36 ** 2) * (1 + delta)))
+    assert np.allclose(out[:, 0], 0.001 * np.floor(1000 * a))
+    assert np.allclose(out * 1000, np.round(out * 1000))                       # 0.001*floor(1000 a)

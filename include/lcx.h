@@ -1,0 +1,199 @@
+/*
+ * lcx.h - C ABI of the MI355X-native Linear CorEx fit engine (liblcx_hip.so).
+ *
+ * This is the drop-in boundary for the reference's accelerator seam.  The reference
+ * (linearcorex/linearcorex.py) switches on `self.gpu` and calls the un-vendored `cudamat`
+ * package at six sites:
+ *     cm.cublas_init()                       linearcorex.py:85-86
+ *     cm.CUDAMatrix(x)   (upload X once)     linearcorex.py:427-428
+ *     cm.dot(x, u.T) / cm.dot(x.T, y)        linearcorex.py:199-208   (_sig)
+ *                                            linearcorex.py:217-224   (_norm)
+ *                                            linearcorex.py:240-257   (_calculate_moments_ns)
+ * i.e. its seam is "one SGEMM, then back to the host".  Here the seam moves up to whole
+ * dependency levels of the algorithm so that X, W and every moment stay resident in HBM and the
+ * host only reads a handful of scalars for control flow.  Each entry point below names the
+ * reference lines it replaces.
+ *
+ * Conventions
+ *   - every function returns an lcx_status (0 = OK); lcx_last_error() gives the message;
+ *   - plain pointers and sizes only; host buffers are borrowed for the duration of the call;
+ *   - device memory is owned by the handle, except the two exchange buffers which a multi-GPU
+ *     caller may bind to its own allocations (lcx_bind_exchange) so that it can all-reduce them
+ *     (RCCL through torch.distributed in linearcorex_amd/comm.py);
+ *   - one caller per handle at a time (the reference is single-threaded too);
+ *   - "which" selects a moment set: 0 = current solution (self.ws / self.moments),
+ *     1 = line-search trial (w_update / m_update, linearcorex.py:320-321).
+ *   - host matrices are C-order (row-major) in the reference's orientation: W and the "m by nv"
+ *     moments are (n_hidden, nv_local).
+ *
+ * Multi-GPU: n_variables is sharded; every handle owns nv_local columns.  The quantities that
+ * need a sum over all variables are written to the exchange buffers between the *_a/_b/_c
+ * halves of a level; with one GPU the halves are simply called back to back.
+ */
+#ifndef LCX_H
+#define LCX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lcx_ctx lcx_ctx;
+
+typedef enum {
+    LCX_OK = 0,
+    LCX_ERR_ARG = 1,        /* bad argument                                  */
+    LCX_ERR_HIP = 2,        /* a HIP runtime call failed (see lcx_last_error) */
+    LCX_ERR_NO_DEVICE = 3,  /* no usable gfx950 device                        */
+    LCX_ERR_STATE = 4       /* call sequence violated                         */
+} lcx_status;
+
+typedef enum { LCX_F32 = 0, LCX_F64 = 1 } lcx_dtype;
+
+/* scalar slots returned by lcx_read_state() */
+enum {
+    LCX_S_TC = 0,        /* m["TC"]                    linearcorex.py:272-274 */
+    LCX_S_MAX_UJ = 1,    /* max_j m["uj"]              linearcorex.py:250     */
+    LCX_S_INVALID = 2,   /* 1.0 if quick and max uj>=1 (the `False` sentinel, :251) */
+    LCX_S_TANGENT = 3,   /* update_tangent             linearcorex.py:305     */
+    LCX_S_SUM_LOG_RJ = 4,/* sum_j log(1-uj)                                   */
+    LCX_S_COUNT = 8
+};
+
+/* keys for lcx_get_moment(); shapes are the reference's (linearcorex.py:249-287) */
+typedef enum {
+    LCX_M_UJ = 0,          /* (m,)        */
+    LCX_M_RHO = 1,         /* (m, nv)     */
+    LCX_M_RY = 2,          /* (m, m)      */
+    LCX_M_INVRHO = 3,      /* (m, nv)     */
+    LCX_M_RHOINVRHO = 4,   /* (m, nv)     */
+    LCX_M_QIJ = 5,         /* (m, nv)     */
+    LCX_M_SI = 6,          /* (nv,)       */
+    LCX_M_QISI2 = 7,       /* (nv,)       */
+    LCX_M_MI = 8,          /* (m, nv)     */
+    LCX_M_XIZJ = 9,        /* (nv, m)     */
+    LCX_M_XI2_GIVEN_Y = 10,/* (nv,)       */
+    LCX_M_GRAD = 11,       /* (m, nv)  last gradient      (:296-300) */
+    LCX_M_UPDATE = 12,     /* (m, nv)  last update        (:303)     */
+    LCX_M_SIG_GRAD = 13,   /* (m, nv)  last _sig(grad)    (:301)     */
+    LCX_M_H = 14,          /* (m, m)   last H             (:294-295) */
+    LCX_M_Y = 15           /* (n_samples, m)  X.W^T of the set (:247); all-reduced if sharded */
+} lcx_moment_key;
+
+/* ---- library ------------------------------------------------------------------------------ */
+int         lcx_abi_version(void);
+const char* lcx_last_error(void);
+int         lcx_device_count(int* out_count);
+
+/* ---- handle -------------------------------------------------------------------------------- */
+/* Replaces cm.cublas_init() (:85-86).  Allocates all device state for an
+ * (n_samples x nv_local) shard with n_hidden factors on HIP device `device`. */
+int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
+               int dtype, int device);
+int lcx_destroy(lcx_ctx* h);
+/* stream all work is enqueued on (a hipStream_t); NULL = the handle's own stream. */
+int lcx_set_stream(lcx_ctx* h, void* hip_stream);
+int lcx_synchronize(lcx_ctx* h);
+
+/* Exchange buffers (device pointers).  ybuf: n_samples_padded*m_padded + m_padded*m_padded
+ * elements of the working dtype; sbuf: lcx_sbuf_count doubles.  lcx_exchange_layout reports
+ * element counts; lcx_bind_exchange(NULL, NULL) restores the handle's own buffers. */
+int lcx_exchange_layout(lcx_ctx* h, int64_t* ybuf_elems, int64_t* sbuf_elems,
+                        void** ybuf_dev, void** sbuf_dev);
+int lcx_bind_exchange(lcx_ctx* h, void* ybuf_dev, void* sbuf_dev);
+
+/* ---- data ---------------------------------------------------------------------------------- */
+/* Replaces cm.CUDAMatrix(x) (:427-428): upload the preprocessed shard, row-major, leading
+ * dimension ld (elements of the working dtype). */
+int lcx_upload_x(lcx_ctx* h, const void* x_host, int64_t ld);
+/* On-device synthetic shard for sizes that cannot be staged on the host (SURVEY.md 8d Gen-A/B):
+ * element (row, col_offset+col) of a counter-based N(0,1) generator keyed by seed; kind 0 = iid,
+ * kind 1 = planted groups (n_groups latent factors + unit noise).  Columns are standardised on
+ * device (mean 0, variance 1 over samples, as preprocess 'standard' does, :409-415). */
+int lcx_generate_x(lcx_ctx* h, uint64_t seed, int kind, int n_groups, int64_t col_offset);
+/* copy the resident shard back (tests) */
+int lcx_download_x(lcx_ctx* h, void* x_host, int64_t ld);
+
+/* self.ws (m x nv_local, row-major) */
+int lcx_set_ws(lcx_ctx* h, const void* w_host);
+int lcx_get_ws(lcx_ctx* h, int which, void* w_host);
+/* ws[order] (:162) */
+int lcx_permute_factors(lcx_ctx* h, const int32_t* order);
+
+/* ---- moments: _calculate_moments_ns (:236-275), split at the sums over all variables ------- */
+/* a: Y_partial = X_shard . W_shard^T (:247) and W_shard.W_shard^T  -> ybuf                      */
+int lcx_moments_a(lcx_ctx* h, int which);
+/* b: (ybuf now holds the global sums) uj (:248-249), early-exit flag (:250-251), X^T.Y (:259),
+ *    rho (:260), ry (:261,:263), invrho, rhoinvrho, Qij, Si, Qi-Si^2 (:264-269), and the two
+ *    per-shard log sums of TC (:272-273) -> sbuf[0..1]                                           */
+int lcx_moments_b(lcx_ctx* h, int which, double eps, int quick);
+/* c: (sbuf[0..1] global) TC (:272-274) -> state scalars                                         */
+int lcx_moments_c(lcx_ctx* h, int which);
+
+/* detail part (:277-287): per-shard sums -> sbuf[0 .. m+3):
+ *   [0..m) sum_i MI_ji, [m] sum_i max_j MI_ji, [m+1] sum_i I(X_i;Y), [m+2] sum_ij MI_ji          */
+int lcx_moments_detail(lcx_ctx* h, int which);
+
+/* ---- update: _update_ns (:290-305) ---------------------------------------------------------- */
+/* a: H partial (:294) -> sbuf[0 .. m_padded^2)                                                  */
+int lcx_update_a(lcx_ctx* h);
+/* b: grad (:296-300), Bj partial (:302), Y_g partial = X.grad^T (first half of _sig, :210)
+ *    -> ybuf (Bj in the tail)                                                                    */
+int lcx_update_b(lcx_ctx* h, double eps);
+/* c: X^T.Y_g, sig_grad (:211-212), update (:303), tangent partial (:305) -> sbuf[0]             */
+int lcx_update_c(lcx_ctx* h, double eps);
+/* d: tangent -> state scalars of set 0                                                           */
+int lcx_update_d(lcx_ctx* h);
+/* w_update = ws + eta*update (:320) into set 1                                                   */
+int lcx_make_trial(lcx_ctx* h, double eta);
+/* self.ws, self.moments = w_update, m_update (:139,:334): swap sets                              */
+int lcx_accept_trial(lcx_ctx* h);
+
+/* ---- stage change (:129-133) ---------------------------------------------------------------- */
+int lcx_rescale_ws(lcx_ctx* h, double eps_old, double eps_new);
+/* ws /= (10 * _norm(x, ws)) (:117); needs lcx_moments_a + exchange done for set 0 with eps=0    */
+int lcx_init_scale_ws(lcx_ctx* h);
+
+/* ---- readback -------------------------------------------------------------------------------- */
+/* synchronises the stream and copies the LCX_S_COUNT scalars of a set */
+int lcx_read_state(lcx_ctx* h, int which, double* out);
+/* host_out: the reference-shaped array, working dtype (see lcx_moment_key) */
+int lcx_get_moment(lcx_ctx* h, int which, int key, double eps, void* host_out);
+/* upload a moment of set `which` (only LCX_M_RHOINVRHO and LCX_M_SI: what get_covariance needs,
+ * :447) - used to restore a pickled model (vis_corex.py:549-551) without refitting */
+int lcx_set_moment(lcx_ctx* h, int which, int key, const void* host_in);
+/* synchronise and copy the first `count` doubles of the scalar exchange buffer */
+int lcx_read_sbuf(lcx_ctx* h, int64_t count, double* out);
+
+/* ---- outputs ---------------------------------------------------------------------------------- */
+/* get_covariance (:443-451), rows [row0, row0+nrows) of the nv_local x nv_local matrix;
+ * std_host = theta[1] (nv_local, working dtype); out_host is nrows x nv_local row-major. */
+int lcx_covariance_rows(lcx_ctx* h, double eps, const void* std_host, int64_t row0, int64_t nrows,
+                        void* out_host);
+/* transform (:386-395): out (n_rows x m) = x (n_rows x nv_local, ld) . ws^T  (per-shard partial) */
+int lcx_project(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, void* out_host);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* HIP-event timing of the two X-streaming GEMM kernels on the handle's stream.
+ * kind 0 = X.B^T ("nt", :247/:210), kind 1 = X^T.Y ("tn", :259/:211). */
+int lcx_timing_enable(lcx_ctx* h, int enable);
+int lcx_timing_read(lcx_ctx* h, int kind, int64_t* launches, double* total_ms);
+int lcx_timing_reset(lcx_ctx* h);
+/* geometry actually used (for the roofline arithmetic): padded sizes and launch shapes */
+int lcx_geometry(lcx_ctx* h, int64_t* n_pad, int64_t* ldx, int* m_pad, int64_t* info8);
+
+/* ---- kernel unit tests (parity of the two GEMM kernels in isolation) -------------------------- */
+/* out (n_rows x m_pad) = A (n_rows x k, ld=lda) . B^T with B given as (k x m_pad) row-major     */
+int lcx_test_gemm_nt(int dtype, int device, const void* a_host, int64_t n_rows, int64_t k, int64_t lda,
+                     const void* b_host, int m_pad, void* out_host, int force_split, int force_kw);
+/* out (v x m_pad) = A^T . B, A (k x v, ld=lda), B (k x m_pad)                                    */
+int lcx_test_gemm_tn(int dtype, int device, const void* a_host, int64_t k, int64_t v, int64_t lda,
+                     const void* b_host, int m_pad, const void* rowscale_host, void* out_host,
+                     int force_split, int force_kw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCX_H */

@@ -1,0 +1,245 @@
+"""HipBackend: one n_variables shard of a fit, resident on one MI355X, driven through the C ABI.
+
+The method set below is the *backend interface* the host driver (`corex.Corex`) talks to; it
+mirrors the dependency levels of the reference's `_calculate_moments_ns` / `_update_ns`
+(linearcorex.py:236-334), cut where a sum over all variables is needed.  Tests exercise the
+multi-rank host logic with a NumPy test double of the same interface (tests/shard_double.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+# reference moment name -> (ABI key, per-variable?)   (linearcorex.py:249-287)
+MOMENT_KEYS = {
+    "uj": _abi.M_UJ, "rho": _abi.M_RHO, "ry": _abi.M_RY, "invrho": _abi.M_INVRHO,
+    "rhoinvrho": _abi.M_RHOINVRHO, "Qij": _abi.M_QIJ, "Si": _abi.M_SI, "Qi-Si^2": _abi.M_QISI2,
+    "MI": _abi.M_MI, "X_i Z_j": _abi.M_XIZJ, "X_i^2 | Y": _abi.M_XI2_GIVEN_Y,
+    "grad": _abi.M_GRAD, "update": _abi.M_UPDATE, "sig_grad": _abi.M_SIG_GRAD, "H": _abi.M_H,
+    "Y": _abi.M_Y,
+}
+
+
+class HipBackend:
+    def __init__(self, n_samples, nv_local, n_hidden, dtype=np.float32, device=0):
+        self.lib = _abi.load()
+        self.dtype = np.dtype(dtype)
+        self.n_samples, self.nv, self.m = int(n_samples), int(nv_local), int(n_hidden)
+        self.device = int(device)
+        h = C.c_void_p()
+        _abi.check(self.lib.lcx_create(C.byref(h), self.n_samples, self.nv, self.m,
+                                       _abi.dtype_code(self.dtype), self.device))
+        self.h = h
+        self._ex = None            # torch exchange tensors when sharded
+        self.generation = 0        # bumps whenever moment set 0 changes (guards lazy readback)
+
+    # ---- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lcx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _a(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        return arr, _abi.np_ptr(arr)
+
+    # ---- geometry / timing -------------------------------------------------------------------
+    def geometry(self):
+        n_pad, ldx, mp = C.c_int64(), C.c_int64(), C.c_int()
+        info = (C.c_int64 * 8)()
+        _abi.check(self.lib.lcx_geometry(self.h, C.byref(n_pad), C.byref(ldx), C.byref(mp), info))
+        names = ["nt_split", "nt_waves", "tn_split", "tn_waves", "gram_n_split", "gram_v_split",
+                 "pv_grid", "target_waves"]
+        g = dict(zip(names, [int(v) for v in info]))
+        g.update(n_pad=n_pad.value, ldx=ldx.value, m_pad=mp.value)
+        return g
+
+    def timing_enable(self, on=True):
+        _abi.check(self.lib.lcx_timing_enable(self.h, 1 if on else 0))
+
+    def timing_reset(self):
+        _abi.check(self.lib.lcx_timing_reset(self.h))
+
+    def timing_read(self):
+        out = {}
+        for kind, name in ((0, "gemm_nt"), (1, "gemm_tn")):
+            n, ms = C.c_int64(), C.c_double()
+            _abi.check(self.lib.lcx_timing_read(self.h, kind, C.byref(n), C.byref(ms)))
+            out[name] = (n.value, ms.value)
+        return out
+
+    def synchronize(self):
+        _abi.check(self.lib.lcx_synchronize(self.h))
+
+    # ---- exchange buffers ---------------------------------------------------------------------
+    def exchange_tensors(self):
+        """(ybuf, sbuf) as torch tensors on this GPU, bound as the handle's exchange buffers and
+        with the handle's work moved to torch's current stream (so that torch.distributed
+        collectives on those tensors are stream-ordered with the kernels)."""
+        if self._ex is None:
+            import torch
+            ye, se = C.c_int64(), C.c_int64()
+            _abi.check(self.lib.lcx_exchange_layout(self.h, C.byref(ye), C.byref(se), None, None))
+            dev = torch.device("cuda", self.device)
+            tdt = torch.float32 if self.dtype == np.float32 else torch.float64
+            y = torch.zeros(ye.value, dtype=tdt, device=dev)
+            s = torch.zeros(se.value, dtype=torch.float64, device=dev)
+            torch.cuda.synchronize(dev)
+            _abi.check(self.lib.lcx_bind_exchange(self.h, C.c_void_p(y.data_ptr()), C.c_void_p(s.data_ptr())))
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream().cuda_stream
+            _abi.check(self.lib.lcx_set_stream(self.h, C.c_void_p(stream)))
+            self._ex = (y, s)
+        return self._ex
+
+    def read_sbuf(self, count):
+        out = np.empty(int(count), dtype=np.float64)
+        _abi.check(self.lib.lcx_read_sbuf(self.h, int(count), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    # ---- data ---------------------------------------------------------------------------------
+    def upload_x(self, x):
+        x, p = self._a(x)
+        assert x.shape == (self.n_samples, self.nv), x.shape
+        _abi.check(self.lib.lcx_upload_x(self.h, p, x.shape[1]))
+
+    def generate_x(self, seed, kind=0, n_groups=1, col_offset=0):
+        _abi.check(self.lib.lcx_generate_x(self.h, int(seed), int(kind), int(n_groups), int(col_offset)))
+
+    def download_x(self):
+        out = np.empty((self.n_samples, self.nv), dtype=self.dtype)
+        _abi.check(self.lib.lcx_download_x(self.h, _abi.np_ptr(out), self.nv))
+        return out
+
+    def set_ws(self, w):
+        w, p = self._a(w)
+        assert w.shape == (self.m, self.nv), w.shape
+        _abi.check(self.lib.lcx_set_ws(self.h, p))
+        self.generation += 1
+
+    def get_ws(self, which=0):
+        out = np.empty((self.m, self.nv), dtype=self.dtype)
+        _abi.check(self.lib.lcx_get_ws(self.h, which, _abi.np_ptr(out)))
+        return out
+
+    def permute_factors(self, order):
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        _abi.check(self.lib.lcx_permute_factors(self.h, order.ctypes.data_as(C.POINTER(C.c_int32))))
+        self.generation += 1
+
+    # ---- moments (linearcorex.py:236-288) -------------------------------------------------------
+    def moments_a(self, which):
+        _abi.check(self.lib.lcx_moments_a(self.h, which))
+
+    def moments_b(self, which, eps, quick):
+        _abi.check(self.lib.lcx_moments_b(self.h, which, float(eps), 1 if quick else 0))
+        if which == 0:
+            self.generation += 1
+
+    def moments_c(self, which):
+        _abi.check(self.lib.lcx_moments_c(self.h, which))
+
+    def moments_detail(self, which):
+        _abi.check(self.lib.lcx_moments_detail(self.h, which))
+
+    # ---- update (linearcorex.py:290-334) ---------------------------------------------------------
+    def update_a(self):
+        _abi.check(self.lib.lcx_update_a(self.h))
+
+    def update_b(self, eps):
+        _abi.check(self.lib.lcx_update_b(self.h, float(eps)))
+
+    def update_c(self, eps):
+        _abi.check(self.lib.lcx_update_c(self.h, float(eps)))
+
+    def update_d(self):
+        _abi.check(self.lib.lcx_update_d(self.h))
+
+    def make_trial(self, eta):
+        _abi.check(self.lib.lcx_make_trial(self.h, float(eta)))
+
+    def accept_trial(self):
+        _abi.check(self.lib.lcx_accept_trial(self.h))
+        self.generation += 1
+
+    def rescale_ws(self, eps_old, eps_new):
+        _abi.check(self.lib.lcx_rescale_ws(self.h, float(eps_old), float(eps_new)))
+        self.generation += 1
+
+    def init_scale_ws(self):
+        _abi.check(self.lib.lcx_init_scale_ws(self.h))
+        self.generation += 1
+
+    # ---- readback ---------------------------------------------------------------------------------
+    def read_state(self, which):
+        out = np.empty(_abi.S_COUNT, dtype=np.float64)
+        _abi.check(self.lib.lcx_read_state(self.h, which, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def moment_shape(self, name):
+        m, nv, n = self.m, self.nv, self.n_samples
+        return {"uj": (m,), "ry": (m, m), "H": (m, m), "Si": (nv,), "Qi-Si^2": (nv,),
+                "X_i^2 | Y": (nv,), "X_i Z_j": (nv, m), "Y": (n, m)}.get(name, (m, nv))
+
+    def get_moment(self, which, name, eps=0.0):
+        out = np.empty(self.moment_shape(name), dtype=self.dtype)
+        _abi.check(self.lib.lcx_get_moment(self.h, which, MOMENT_KEYS[name], float(eps), _abi.np_ptr(out)))
+        return out
+
+    def set_moment(self, which, name, value):
+        value, p = self._a(value)
+        assert value.shape == self.moment_shape(name)
+        _abi.check(self.lib.lcx_set_moment(self.h, which, MOMENT_KEYS[name], p))
+
+    # ---- outputs ------------------------------------------------------------------------------------
+    def covariance(self, eps, std, max_block_bytes=1 << 28):
+        """get_covariance (linearcorex.py:443-451) for this shard, assembled from row blocks."""
+        std, ps = self._a(std)
+        nv = self.nv
+        out = np.empty((nv, nv), dtype=self.dtype)
+        rows = max(64, int(max_block_bytes // (nv * self.dtype.itemsize)) // 64 * 64)
+        for r0 in range(0, nv, rows):
+            nr = min(rows, nv - r0)
+            blk = out[r0:r0 + nr]
+            _abi.check(self.lib.lcx_covariance_rows(self.h, float(eps), ps, r0, nr, _abi.np_ptr(blk)))
+        return out
+
+    def project(self, x):
+        x, p = self._a(x)
+        assert x.ndim == 2 and x.shape[1] == self.nv
+        out = np.empty((x.shape[0], self.m), dtype=self.dtype)
+        _abi.check(self.lib.lcx_project(self.h, p, x.shape[0], x.shape[1], _abi.np_ptr(out)))
+        return out
+
+
+def gemm_nt_check(a, b_km, m_pad, dtype, device=0, split=1, waves=4):
+    """Isolated run of the X.B^T kernel: a (n x k), b_km (k x m_pad) -> (n x m_pad)."""
+    lib = _abi.load()
+    a = np.ascontiguousarray(a, dtype=dtype)
+    b = np.ascontiguousarray(b_km, dtype=dtype)
+    out = np.empty((a.shape[0], m_pad), dtype=dtype)
+    _abi.check(lib.lcx_test_gemm_nt(_abi.dtype_code(dtype), device, _abi.np_ptr(a), a.shape[0], a.shape[1],
+                                    a.shape[1], _abi.np_ptr(b), m_pad, _abi.np_ptr(out), split, waves))
+    return out
+
+
+def gemm_tn_check(a, b_km, m_pad, dtype, device=0, rowscale=None, split=1, waves=4):
+    """Isolated run of the A^T.B kernel: a (k x v), b_km (k x m_pad) -> (v x m_pad)."""
+    lib = _abi.load()
+    a = np.ascontiguousarray(a, dtype=dtype)
+    b = np.ascontiguousarray(b_km, dtype=dtype)
+    rs = None if rowscale is None else np.ascontiguousarray(rowscale, dtype=dtype)
+    out = np.empty((a.shape[1], m_pad), dtype=dtype)
+    _abi.check(lib.lcx_test_gemm_tn(_abi.dtype_code(dtype), device, _abi.np_ptr(a), a.shape[0], a.shape[1],
+                                    a.shape[1], _abi.np_ptr(b), m_pad,
+                                    None if rs is None else _abi.np_ptr(rs), _abi.np_ptr(out), split, waves))
+    return out

@@ -1,0 +1,66 @@
+"""Sharding of the n_variables axis across ranks (one process per GPU) and the exchange steps.
+
+torch.distributed is used as plumbing only: backend "nccl" is RCCL over xGMI on the GPU box, "gloo"
+in the CPU tests.  The algorithm needs, per moment evaluation:
+    L1  all-reduce(sum) of  [ Y_partial (n_samples x m) | W_p.W_p^T (m x m) ]   -> `allreduce_y`
+    L2  all-reduce(sum) of 2 scalars                                             -> `allreduce_s(2)`
+and per update: H (m x m), [Y_g | Bj], and the tangent scalar.  With one rank every call is a no-op.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class Comm:
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    # contiguous, balanced column ranges
+    def shard(self, nv, rank=None):
+        r = self.rank if rank is None else rank
+        return (nv * r) // self.world, (nv * (r + 1)) // self.world
+
+    def allreduce(self, tensor):
+        if self.world > 1:
+            self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM, group=self.group)
+
+    def barrier(self):
+        if self.world > 1:
+            self._dist.barrier(group=self.group)
+
+    def gather_columns(self, local, nv, like):
+        """All-gather per-rank column blocks (last axis) into the full array on every rank.
+        `like` is a tensor on the device the group communicates on."""
+        import torch
+        if self.world == 1:
+            return local
+        widths = [self.shard(nv, r)[1] - self.shard(nv, r)[0] for r in range(self.world)]
+        wmax = max(widths)
+        lead = local.shape[:-1]
+        pad = np.zeros(lead + (wmax,), dtype=local.dtype)
+        pad[..., :local.shape[-1]] = local
+        mine = torch.from_numpy(pad).to(like.device)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self._dist.all_gather(parts, mine, group=self.group)
+        return np.concatenate([p.cpu().numpy()[..., :w] for p, w in zip(parts, widths)], axis=-1)
+
+
+class SingleComm:
+    """world size 1: no torch import, no collectives."""
+    rank, world = 0, 1
+
+    def shard(self, nv, rank=None):
+        return 0, nv
+
+    def allreduce(self, tensor):
+        pass
+
+    def barrier(self):
+        pass
+
+    def gather_columns(self, local, nv, like=None):
+        return local

@@ -1,0 +1,464 @@
+"""Drop-in `Corex` for the non-synergistic Linear CorEx fit path, executed on MI355X.
+
+Public surface = the reference's (linearcorex/linearcorex.py:72-74 constructor, :103-107 fit /
+fit_transform, :386 transform, :440 predict, :431 invert, :397 preprocess, :443 get_covariance,
+:193 clusters, properties tc/tcs/mis, attributes ws/moments/theta/history ...).  What differs is
+where the work happens: X, W and every moment live in HBM for the whole fit and this class only
+sequences the dependency levels of `_calculate_moments_ns` / `_update_ns` (:236-334) through the
+C ABI (include/lcx.h), reading back a few scalars per line-search trial for control flow.
+
+There is no NumPy fallback: without liblcx_hip.so and a GPU `fit` raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .comm import SingleComm
+from .preprocess import g, g_inv, mean_impute   # noqa: F401  (re-exported like the reference module)
+
+_DETAIL_KEYS = ("MI", "X_i Y_j", "X_i Z_j", "X_i^2 | Y", "I(Y_j ; X)", "I(X_i ; Y)", "TCs",
+                "TC_no_overlap", "TC_direct", "additivity")
+_DEVICE_KEYS = ("uj", "rho", "ry", "invrho", "rhoinvrho", "Qij", "Si", "Qi-Si^2", "MI", "X_i Z_j",
+                "X_i^2 | Y")
+
+
+class DeviceMoments(dict):
+    """`self.moments`: same keys as the reference dict (linearcorex.py:249-287).  Scalars and
+    per-factor vectors are stored eagerly; the m x nv arrays stay on the GPU and are copied out on
+    first access (they are only valid while the fit state they describe is still resident)."""
+
+    def __init__(self, owner, generation, eps, eager):
+        super().__init__(eager)
+        self._owner, self._gen, self._eps = owner, generation, eps
+        self._lazy = set(_DEVICE_KEYS) | {"Y_j^2", "X_i Y_j", "I(X_i ; Y)"}
+
+    def _fetch(self, key):
+        be = self._owner._backend if self._owner is not None else None
+        if be is None or be.generation != self._gen:
+            raise KeyError("%r: these moments are no longer resident on the device" % key)
+        o = self._owner
+        if key == "Y_j^2":
+            return o.yscale ** 2 / (1.0 - self["uj"])                      # :262
+        if key == "X_i Y_j":
+            return self["rho"].T * np.sqrt(self["Y_j^2"])                  # :279
+        if key == "I(X_i ; Y)":
+            return -0.5 * np.log(self["X_i^2 | Y"])                        # :283
+        val = be.get_moment(0, key, self._eps)
+        if key not in ("uj", "ry"):
+            val = o._gather(val, key)
+        return val
+
+    def __missing__(self, key):
+        if key in self._lazy:
+            val = self._fetch(key)
+            dict.__setitem__(self, key, val)
+            return val
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def materialize(self, keys=None):
+        for k in (keys or sorted(self._lazy)):
+            try:
+                self[k]
+            except KeyError:
+                pass
+        return dict(self)
+
+    def __reduce__(self):
+        return (dict, (self.materialize(),))
+
+
+class Corex(object):
+    """Linear Total Correlation Explanation on MI355X (reference docstring: linearcorex.py:22-70).
+
+    Parameters are the reference's.  Keyword-only extras:
+      dtype   working precision on the device: np.float32 (what the reference computes, :108) or
+              np.float64 (the precision the 1e-6 get_covariance tolerance is defined in);
+      device  HIP device index (default: LOCAL_RANK or 0);
+      comm    a `linearcorex_amd.comm.Comm` to shard n_variables over ranks;
+      eliminate_synergy  alias of discourage_overlap (the name used by the reference docstring).
+    """
+
+    def __init__(self, n_hidden=10, max_iter=10000, tol=1e-5, anneal=True, missing_values=None,
+                 discourage_overlap=True, gaussianize='standard', gpu=False,
+                 verbose=False, seed=None, *, dtype=np.float32, device=None, comm=None,
+                 eliminate_synergy=None, _backend_factory=None):
+        if eliminate_synergy is not None:
+            discourage_overlap = bool(eliminate_synergy)
+        self.m = n_hidden
+        self.max_iter = max_iter
+        self.tol = tol
+        self.anneal = anneal
+        self.eps = 0
+        self.missing_values = missing_values
+        self.discourage_overlap = discourage_overlap
+        self.gaussianize = gaussianize
+        self.gpu = gpu                      # kept for signature compatibility; the device path is the only path
+        self.yscale = 1.
+        np.random.seed(seed)                # same global-RNG side effect as the reference (:89)
+        self.verbose = verbose
+        if verbose:
+            np.set_printoptions(precision=3, suppress=True, linewidth=160)
+            print('Linear CorEx with {:d} latent factors'.format(n_hidden))
+        self.n_samples, self.nv = 0, 0
+        self.ws = np.zeros((0, 0))
+        self.moments = {}
+        self.theta = None
+        self.history = {}
+        self.last_update = 0
+        self.n_obs = 0
+        # device side
+        self.dtype = np.dtype(dtype)
+        self.device = device
+        self._comm = comm if comm is not None else SingleComm()
+        self._backend_factory = _backend_factory
+        self._backend = None
+        self._cols = (0, 0)
+        self._tc_cur = np.nan
+        self.stats = {"iterations": 0, "moment_evals": 0, "trials": 0, "invalid_trials": 0}
+
+    # ------------------------------------------------------------------------------------------
+    # backend plumbing
+    # ------------------------------------------------------------------------------------------
+    def _make_backend(self, n_samples, nv_local):
+        if self._backend is not None:
+            self._backend.close()
+        if self._backend_factory is not None:
+            be = self._backend_factory(n_samples, nv_local, self.m, self.dtype)
+        else:
+            from .backend import HipBackend
+            dev = self.device
+            if dev is None:
+                import os
+                dev = int(os.environ.get("LOCAL_RANK", "0"))
+            be = HipBackend(n_samples, nv_local, self.m, self.dtype, dev)
+        self._backend = be
+        self._ex = be.exchange_tensors() if self._comm.world > 1 else None
+        return be
+
+    def _xy(self):
+        if self._ex is not None:
+            self._comm.allreduce(self._ex[0])
+
+    def _xs(self, count):
+        if self._ex is not None:
+            self._comm.allreduce(self._ex[1][:count])
+
+    def _gather(self, local, key=None):
+        """Per-variable arrays are sharded on the last (m x nv, nv) or first (nv x m) axis."""
+        if self._comm.world == 1:
+            return local
+        if key == "X_i Z_j":
+            return self._comm.gather_columns(np.ascontiguousarray(local.T), self.nv, self._ex[1]).T
+        return self._comm.gather_columns(local, self.nv, self._ex[1])
+
+    # ------------------------------------------------------------------------------------------
+    # public API
+    # ------------------------------------------------------------------------------------------
+    def fit_transform(self, x):
+        self.fit(x)
+        return self.transform(x)
+
+    def fit(self, x):
+        x = np.asarray(x, dtype=self.dtype)                    # reference casts to float32 (:108)
+        x = self.preprocess(x, fit=True)
+        self.n_samples, self.nv = x.shape
+        c0, c1 = self._comm.shard(self.nv)
+        self._cols = (c0, c1)
+        be = self._make_backend(self.n_samples, c1 - c0)
+        be.upload_x(np.ascontiguousarray(x[:, c0:c1]))
+        del x
+        return self._fit_resident()
+
+    def fit_generated(self, n_samples, n_variables, seed=1, kind=0, n_groups=1):
+        """Fit on synthetic data generated and standardised on the device (sizes that cannot be
+        staged on the host: BASELINE.json configs 3-4).  kind 0 = iid N(0,1), 1 = planted groups."""
+        self.n_samples, self.nv = int(n_samples), int(n_variables)
+        c0, c1 = self._comm.shard(self.nv)
+        self._cols = (c0, c1)
+        be = self._make_backend(self.n_samples, c1 - c0)
+        be.generate_x(seed, kind, n_groups, c0)
+        self.theta = (np.zeros(self.nv, self.dtype), np.ones(self.nv, self.dtype))
+        self.n_obs = self.n_samples
+        return self._fit_resident()
+
+    def _fit_resident(self, max_total_iter=None):
+        if self.m is None:
+            raise NotImplementedError("n_hidden=None (pick_n_hidden) is broken in the reference (SURVEY.md §2 #14)")
+        if not self.discourage_overlap:
+            raise NotImplementedError("discourage_overlap=False (the synergistic branch, linearcorex.py:336-384) "
+                                      "is outside the accelerated path")
+        be, (c0, c1) = self._backend, self._cols
+        anneal_schedule = [0.]
+        if self.ws.size == 0:
+            w = np.random.randn(self.m, self.nv).astype(self.dtype)          # :116
+            be.set_ws(np.ascontiguousarray(w[:, c0:c1]))
+            del w
+            be.moments_a(0)
+            self._xy()
+            be.init_scale_ws()                                                # ws /= 10*_norm (:117)
+            if self.anneal:
+                anneal_schedule = [0.6 ** k for k in range(1, 7)] + [0]
+        else:
+            be.set_ws(np.ascontiguousarray(np.asarray(self.ws, dtype=self.dtype)[:, c0:c1]))
+        self.eps = 0
+        self.moments = self._calculate_moments(quick=True)                    # :122
+
+        for i_eps, eps in enumerate(anneal_schedule):
+            eps0 = self.eps
+            self.eps = eps
+            if i_eps > 0:
+                be.rescale_ws(eps0, eps)                                      # :129-133
+            self.moments = self._calculate_moments(quick=False, details=False)   # :134
+            delta = 0.
+            for i_loop in range(self.max_iter):
+                last_tc = self.tc
+                self.moments = self._update_ns()                              # :139
+                if not self.moments or not np.isfinite(self.tc):              # :144-149
+                    try:
+                        print("Error: TC is no longer finite: {}".format(self.tc))
+                    except Exception:
+                        print("Error... updates giving invalid solutions?")
+                        self.ws = self._gather(be.get_ws(0))
+                        return self
+                delta = np.abs(self.tc - last_tc)
+                self.update_records(self.moments, delta)
+                self.stats["iterations"] += 1
+                if delta < self.tol:
+                    if self.verbose:
+                        print('{:d} iterations to tol: {:f}, TC={:f}'.format(i_loop, self.tol, self.tc))
+                    break
+                if max_total_iter is not None and self.stats["iterations"] >= max_total_iter:
+                    break
+            else:
+                if self.verbose:
+                    print("Warning: Convergence not achieved in {:d} iterations. "
+                          "Final delta: {:f}".format(self.max_iter, float(delta)))
+        self.moments = self._calculate_moments(quick=False, details=True)     # :160
+        order = np.argsort(-self.moments["TCs"])                              # :161
+        be.permute_factors(order)                                             # :162
+        self.moments = self._calculate_moments(quick=False, details=True)     # :163
+        self.ws = self._gather(be.get_ws(0))
+        return self
+
+    def update_records(self, moments, delta):
+        """History book-keeping (linearcorex.py:166-175)."""
+        self.history.setdefault("TC", []).append(moments["TC"])
+        if self.verbose > 1:
+            print("TC={:.3f}\tadd={:.3f}\tdelta={:.6f}".format(moments["TC"], moments.get("additivity", 0), delta))
+        if self.verbose:
+            self.history.setdefault("additivity", []).append(moments.get("additivity", 0))
+            self.history.setdefault("TCs", []).append(moments.get("TCs", np.zeros(self.m)))
+
+    @property
+    def tc(self):
+        return self.moments["TC"]
+
+    @property
+    def tcs(self):
+        return self.moments["TCs"]
+
+    @property
+    def mis(self):
+        return - 0.5 * np.log1p(-self.moments["rho"] ** 2)
+
+    def clusters(self):
+        return np.argmax(np.abs(self.ws), axis=0)
+
+    # ------------------------------------------------------------------------------------------
+    # hot path: the reference's private methods, re-expressed as device levels + exchanges
+    # ------------------------------------------------------------------------------------------
+    def _moments_levels(self, which, quick):
+        be = self._backend
+        be.moments_a(which)                 # Y_partial = X.W^T (:247), W.W^T partial
+        self._xy()
+        be.moments_b(which, self.eps, quick)  # uj, early exit, X^T.Y, rho ... Qi-Si^2, TC partial sums
+        self._xs(2)
+        be.moments_c(which)                 # TC
+        self.stats["moment_evals"] += 1
+
+    def _scalar(self, x):
+        return self.dtype.type(x)
+
+    def _calculate_moments(self, quick=False, details=False):
+        """`_calculate_moments_ns(x, self.ws, quick)` (:236-288) on the current weights."""
+        be = self._backend
+        self._moments_levels(0, quick)
+        st = be.read_state(0)
+        if st[2] != 0:
+            return False                                                       # :250-251
+        self._tc_cur = st[0]
+        eager = {"TC": self._scalar(st[0])}
+        if details:
+            be.moments_detail(0)
+            self._xs(self.m + 3)
+            sums = be.read_sbuf(self.m + 3)
+            uj = be.get_moment(0, "uj")
+            eager["uj"] = uj
+            ysq = self.yscale ** 2 / (1.0 - uj)
+            # note: under NumPy >= 2 the reference gets float64 here (np.log of a Python float, :282)
+            iyx = 0.5 * np.log(ysq) - 0.5 * np.log(self.yscale ** 2)
+            eager["I(Y_j ; X)"] = iyx
+            eager["TCs"] = sums[:self.m] - iyx                                 # :284
+            eager["TC_no_overlap"] = sums[self.m] - iyx.sum()                  # :285
+            eager["TC_direct"] = sums[self.m + 1] - iyx                        # :286
+            eager["additivity"] = self._scalar(sums[self.m + 2] - sums[self.m + 1])   # :287
+        return DeviceMoments(self, be.generation, self.eps, eager)
+
+    def _calculate_moments_ns(self, x=None, ws=None, quick=False):
+        if x is not None or ws is not None:
+            raise NotImplementedError("moments are evaluated on the resident X / ws only")
+        return self._calculate_moments(quick=quick, details=not quick)
+
+    def _update_ns(self, x=None):
+        """One fixed-point iteration with back-tracking (:290-334).  Returns the new moments (the
+        new weights stay on the device)."""
+        be = self._backend
+        m = self.moments
+        be.update_a()                        # H partial (:294)
+        self._xs(be_mp2(be))
+        be.update_b(self.eps)                # grad (:296-300), Bj partial, Y_g partial
+        self._xy()
+        be.update_c(self.eps)                # X^T.Y_g, sig_grad, update, tangent partial (:301-305)
+        self._xs(1)
+        be.update_d()
+        tc_cur = self._tc_cur
+        update_tangent = None
+        eta = 1.
+        last = None                          # (invalid?, tc) of the last evaluated trial
+        while True:
+            if eta < min(self.tol, 1e-10):                                     # :316-319
+                if self.verbose:
+                    print('Warning: step size becoming too small')
+                break
+            be.make_trial(eta)                                                 # :320
+            self._moments_levels(1, True)                                      # :321
+            self.stats["trials"] += 1
+            st = be.read_state(1)
+            if update_tangent is None:
+                update_tangent = be.read_state(0)[3]
+                if update_tangent >= 0:                                        # :306-311
+                    print('Warning: covariance is nearly singular and this causes a loss of numerical precision.'
+                          'For this reason, we can no longer find an update that increases the objective. '
+                          'Hopefully this is a good solution. If not, this is caused by having many variables that are '
+                          'near duplicates. You could try again with the duplicates removed to look for other structure.')
+                    return m
+            invalid, tc_new = st[2] != 0, st[0]
+            last = (invalid, tc_new)
+            if invalid:                                                        # :322-326
+                self.stats["invalid_trials"] += 1
+                eta *= 0.5
+                if self.verbose > 1:
+                    print('back:{:.7f}'.format(eta))
+                continue
+            wolfe1 = -tc_new <= -tc_cur + 0.1 * eta * update_tangent           # :327
+            if not wolfe1:
+                eta *= 0.5
+                if self.verbose > 1:
+                    print('wolfe1:{:.7f}'.format(eta))
+                continue
+            break
+        if last is None or last[0]:
+            # step size underflow right after an invalid trial: the reference returns
+            # (w_update, False) here and `fit` reports it (:144-149)
+            be.accept_trial()
+            return False
+        be.accept_trial()                                                      # :334 / :139
+        self._tc_cur = last[1]
+        return DeviceMoments(self, be.generation, self.eps, {"TC": self._scalar(last[1])})
+
+    # ------------------------------------------------------------------------------------------
+    # outputs
+    # ------------------------------------------------------------------------------------------
+    def transform(self, x, details=False):
+        """x -> latent factors Y = x~ . ws^T (:386-395)."""
+        x = self.preprocess(np.asarray(x, dtype=self.dtype))
+        ns, nv = x.shape
+        assert self.nv == nv, "Incorrect number of variables in input, %d instead of %d" % (nv, self.nv)
+        be = self._resident_backend()
+        c0, c1 = self._cols
+        y = be.project(np.ascontiguousarray(x[:, c0:c1]))
+        if self._comm.world > 1:
+            import torch
+            t = torch.from_numpy(y).to(self._ex[1].device)
+            self._comm.allreduce(t)
+            y = t.cpu().numpy()
+        if details:
+            if ns != self.n_samples:
+                raise NotImplementedError("transform(details=True) is supported on the fitted data only")
+            return y, self._calculate_moments(quick=False, details=True)
+        return y
+
+    def preprocess(self, x, fit=False):
+        """Per-marginal standardisation (:397-429); host side (a one-off O(ns*nv) pass)."""
+        from .preprocess import preprocess as _pp
+        x, self.theta, self.n_obs = _pp(x, self.theta if not fit else None, self.gaussianize,
+                                        self.missing_values, verbose=self.verbose)
+        return x
+
+    def invert(self, x):
+        """Undo the preprocessing (:431-438)."""
+        if self.gaussianize == 'standard':
+            return self.theta[1] * x + self.theta[0]
+        elif self.gaussianize == 'outliers':
+            return self.theta[1] * g_inv(x) + self.theta[0]
+        return x
+
+    def predict(self, y):
+        """:440-441."""
+        return self.invert(np.dot(self.moments["X_i Z_j"], np.asarray(y).T).T)
+
+    def get_covariance(self):
+        """Covariance estimate of the non-synergistic model (:443-451), nv x nv."""
+        if self._comm.world > 1:
+            raise NotImplementedError("get_covariance() needs all variables on one GPU (nv x nv output)")
+        be = self._resident_backend(need_moments=True)
+        return be.covariance(self.eps, np.asarray(self.theta[1], dtype=self.dtype))
+
+    # ------------------------------------------------------------------------------------------
+    # persistence (vis_corex.py:549 pickles the model)
+    # ------------------------------------------------------------------------------------------
+    def _resident_backend(self, need_moments=False):
+        if self._backend is None:
+            if self.ws.size == 0:
+                raise RuntimeError("model is not fitted")
+            # restored from a pickle: bring W (and what get_covariance needs) back to the device
+            self._cols = self._comm.shard(self.nv)
+            be = self._make_backend(max(int(self.n_samples), 1), self.nv)
+            be.set_ws(np.asarray(self.ws, dtype=self.dtype))
+            self._moments_restored = False
+        if need_moments and getattr(self, "_moments_restored", True) is False:
+            self._backend.set_moment(0, "rhoinvrho", self.moments["rhoinvrho"])
+            self._backend.set_moment(0, "Si", self.moments["Si"])
+            self._moments_restored = True
+        return self._backend
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        if isinstance(d.get("moments"), DeviceMoments):
+            d["moments"] = d["moments"].materialize()
+        for k in ("_backend", "_ex", "_backend_factory"):
+            d[k] = None
+        if not isinstance(d.get("_comm"), SingleComm):
+            d["_comm"] = SingleComm()
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+
+
+def be_mp2(be):
+    """number of doubles of H in the scalar exchange buffer (m_pad^2)."""
+    mp = getattr(be, "m_pad", None)
+    if mp is None:
+        mp = be.geometry()["m_pad"]
+        be.m_pad = mp
+    return mp * mp

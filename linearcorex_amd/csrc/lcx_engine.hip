@@ -1,0 +1,1013 @@
+// lcx_engine.hip - host side of the C ABI declared in include/lcx.h.
+//
+// Owns the device state of one n_variables shard of a Linear CorEx fit (X, W and two moment sets,
+// all resident in HBM) and enqueues the kernels of each dependency level of the reference's
+// _calculate_moments_ns / _update_ns (linearcorex.py:236-334) on one HIP stream.  No torch types,
+// no callbacks; multi-GPU exchange happens between the *_a/_b/_c entry points, outside.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/lcx.h"
+#include "gemm_kernels.hpp"
+#include "moment_kernels.hpp"
+
+using namespace lcx;
+
+// -------------------------------------------------------------------------------------------------
+// error plumbing
+// -------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHECK(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(LCX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + \
+                                         __FILE__ + ":" + std::to_string(__LINE__) + ")");     \
+    } while (0)
+#define LCXCHECK(expr)              \
+    do {                            \
+        int s_ = (expr);            \
+        if (s_ != LCX_OK) return s_; \
+    } while (0)
+#define KCHECK() HIPCHECK(hipGetLastError())
+
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// -------------------------------------------------------------------------------------------------
+// context
+// -------------------------------------------------------------------------------------------------
+struct MomentSet {
+    void *rho, *rir, *qij;      // [Vp][Mp]
+    void *si, *q2, *hscale;     // [Vp]
+    double *uj, *ry, *wmag;     // small
+    SetState* st;               // device
+};
+
+struct TimingPair {
+    hipEvent_t a, b;
+    int kind;
+};
+
+struct lcx_ctx {
+    int device, dtype;
+    size_t es;
+    int64_t N, V, Npad, ldx;    // ldx == Vp
+    int M, Mp, CT;
+    hipStream_t own_stream, stream;
+    void* X;
+    void* Wt[2];
+    MomentSet set[2];
+    void *grad, *update, *sgrad, *scratch;
+    void *ybuf_own, *ybuf;
+    double *sbuf_own, *sbuf;
+    int64_t ybuf_elems, sbuf_elems;
+    void *ypart, *dpart, *gpart;
+    double *tcpart, *bjpart, *tanpart, *detpart, *ryinv, *invwork;
+    SetState* states;           // device [2]
+    SetState* host_states;      // pinned [2]
+    int* order_dev;
+    // launch geometry
+    int nt_S, nt_KW, tn_S, tn_KW, gn_S, gv_S, pv_grid, target_waves;
+    // timing
+    bool timing;
+    std::vector<TimingPair> pending;
+    std::vector<TimingPair> pool;
+    int64_t t_launch[2];
+    double t_ms[2];
+    bool have_direction;
+};
+
+template <typename T> static inline T* P(void* p) { return reinterpret_cast<T*>(p); }
+
+// -------------------------------------------------------------------------------------------------
+// GEMM launchers
+// -------------------------------------------------------------------------------------------------
+static int timing_begin(lcx_ctx* h, int kind, TimingPair* tp) {
+    if (!h || !h->timing || kind < 0) return LCX_OK;
+    if (h->pool.empty()) {
+        HIPCHECK(hipEventCreate(&tp->a));
+        HIPCHECK(hipEventCreate(&tp->b));
+    } else {
+        *tp = h->pool.back();
+        h->pool.pop_back();
+    }
+    tp->kind = kind;
+    HIPCHECK(hipEventRecord(tp->a, h->stream));
+    return LCX_OK;
+}
+static int timing_end(lcx_ctx* h, int kind, TimingPair* tp) {
+    if (!h || !h->timing || kind < 0) return LCX_OK;
+    HIPCHECK(hipEventRecord(tp->b, h->stream));
+    h->pending.push_back(*tp);
+    return LCX_OK;
+}
+static int timing_collect(lcx_ctx* h) {
+    for (auto& tp : h->pending) {
+        float ms = 0.f;
+        HIPCHECK(hipEventSynchronize(tp.b));
+        HIPCHECK(hipEventElapsedTime(&ms, tp.a, tp.b));
+        h->t_launch[tp.kind] += 1;
+        h->t_ms[tp.kind] += ms;
+        h->pool.push_back(tp);
+    }
+    h->pending.clear();
+    return LCX_OK;
+}
+
+template <typename T, int CT>
+static int launch_nt(hipStream_t st, const T* X, int64_t ldx, int64_t rows_pad, const T* B, T* out,
+                     int S, int KW, const int* skip) {
+    constexpr int RT = NtShape<T, CT>::RT;
+    constexpr int CH = 4 * (32 / (int)sizeof(T));
+    const int nchunks = (int)(ldx / CH);
+    dim3 grid((unsigned)(rows_pad / (16 * RT)), (unsigned)S);
+    const size_t lds = (size_t)KW * 16 * RT * 16 * CT * sizeof(T);
+    switch (KW) {
+        case 1: hipLaunchKernelGGL((gemm_nt_kernel<T, CT, RT, 1>), grid, dim3(64), lds, st, X, ldx, B, out, rows_pad, nchunks, S, skip); break;
+        case 2: hipLaunchKernelGGL((gemm_nt_kernel<T, CT, RT, 2>), grid, dim3(128), lds, st, X, ldx, B, out, rows_pad, nchunks, S, skip); break;
+        case 4: hipLaunchKernelGGL((gemm_nt_kernel<T, CT, RT, 4>), grid, dim3(256), lds, st, X, ldx, B, out, rows_pad, nchunks, S, skip); break;
+        default: hipLaunchKernelGGL((gemm_nt_kernel<T, CT, RT, 8>), grid, dim3(512), lds, st, X, ldx, B, out, rows_pad, nchunks, S, skip); break;
+    }
+    KCHECK();
+    return LCX_OK;
+}
+
+// out rows (padded "v" count) must be a multiple of 16*RT; K a multiple of 16.
+template <typename T, int CT, int RT, bool SCALE>
+static int launch_tn(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t vcols_pad, const T* B,
+                     const T* rowscale, T* out, int S, int KW, const int* skip) {
+    const int kgroups = (int)(K / 16);
+    dim3 grid((unsigned)(vcols_pad / (16 * RT)), (unsigned)S);
+    const size_t lds = (size_t)KW * 16 * RT * 16 * CT * sizeof(T);
+    switch (KW) {
+        case 1: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 1, SCALE>), grid, dim3(64), lds, st, A, lda, B, rowscale, out, vcols_pad, kgroups, S, skip); break;
+        case 2: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 2, SCALE>), grid, dim3(128), lds, st, A, lda, B, rowscale, out, vcols_pad, kgroups, S, skip); break;
+        case 4: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 4, SCALE>), grid, dim3(256), lds, st, A, lda, B, rowscale, out, vcols_pad, kgroups, S, skip); break;
+        default: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 8, SCALE>), grid, dim3(512), lds, st, A, lda, B, rowscale, out, vcols_pad, kgroups, S, skip); break;
+    }
+    KCHECK();
+    return LCX_OK;
+}
+
+static int pick_split(int64_t tiles, int kw, int64_t kunits, int target_waves, int cap) {
+    int64_t s = cdiv(target_waves, tiles * kw);
+    const int64_t by_work = kunits / ((int64_t)kw * 4);   // keep >= 4 contraction units per wave
+    if (s > by_work) s = by_work;
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+static int pick_kw(int64_t kunits) { return kunits >= 32 ? 4 : (kunits >= 8 ? 2 : 1); }
+
+template <typename T, int CT> struct Geo {
+    static constexpr int NT_RT = NtShape<T, CT>::RT;
+    static constexpr int TN_RT = TnShape<T, CT>::RT;
+    // Gram matrices contract a [K][Mp] array with itself: the column tile must fit in Mp
+    static constexpr int G_RT = TnShape<T, CT>::RT < CT ? TnShape<T, CT>::RT : CT;
+    static constexpr int CH = 4 * (32 / (int)sizeof(T));
+};
+
+// dynamic LDS above 64 KiB needs an explicit opt-in per kernel
+template <typename F> static int allow_lds(F* f, size_t bytes) {
+    if (bytes > 48 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return LCX_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// typed implementation
+// -------------------------------------------------------------------------------------------------
+template <typename T, int CT> struct Impl {
+    static constexpr int Mp = 16 * CT;
+    static constexpr int VPB = PV_THREADS / Mp;
+
+    static int geometry(lcx_ctx* h) {
+        const int64_t nchunks = h->ldx / Geo<T, CT>::CH;
+        h->nt_KW = pick_kw(nchunks);
+        h->nt_S = pick_split(h->Npad / (16 * Geo<T, CT>::NT_RT), h->nt_KW, nchunks, h->target_waves, 16);
+        const int64_t kgn = h->Npad / 16, kgv = h->ldx / 16;
+        h->tn_KW = pick_kw(kgn);
+        h->tn_S = pick_split(h->ldx / (16 * Geo<T, CT>::TN_RT), h->tn_KW, kgn, h->target_waves, 32);
+        h->gn_S = pick_split(Mp / (16 * Geo<T, CT>::G_RT), pick_kw(kgn), kgn, h->target_waves / 2, 128);
+        h->gv_S = pick_split(Mp / (16 * Geo<T, CT>::G_RT), pick_kw(kgv), kgv, h->target_waves / 2, 128);
+        int64_t groups = cdiv(h->V, VPB);
+        h->pv_grid = (int)(groups < 2048 ? (groups < 1 ? 1 : groups) : 2048);
+        return LCX_OK;
+    }
+
+    // ---- Gram matrix of a [K][Mp] array (K multiple of 16): partials -> gpart[S][Mp][Mp] ------
+    static int gram(lcx_ctx* h, const T* A, int64_t K, const T* scale, int S, const int* skip) {
+        const int kw = pick_kw(K / 16);
+        constexpr int RT = Geo<T, CT>::G_RT;
+        if (scale)
+            return launch_tn<T, CT, RT, true>(h->stream, A, Mp, K, Mp, A, scale, P<T>(h->gpart), S, kw, skip);
+        return launch_tn<T, CT, RT, false>(h->stream, A, Mp, K, Mp, A, nullptr, P<T>(h->gpart), S, kw, skip);
+    }
+
+    static int nt_big(lcx_ctx* h, const T* B, const int* skip) {
+        TimingPair tp;
+        LCXCHECK(timing_begin(h, 0, &tp));
+        T* dst = h->nt_S > 1 ? P<T>(h->ypart) : P<T>(h->ybuf);
+        LCXCHECK((launch_nt<T, CT>(h->stream, P<T>(h->X), h->ldx, h->Npad, B, dst, h->nt_S, h->nt_KW, skip)));
+        LCXCHECK(timing_end(h, 0, &tp));
+        if (h->nt_S > 1) {
+            const int64_t n = h->Npad * Mp;
+            hipLaunchKernelGGL((reduce_partials_kernel<T, T>), dim3((unsigned)(cdiv(n, 256) < 1024 ? cdiv(n, 256) : 1024)), dim3(256), 0,
+                               h->stream, P<T>(h->ypart), h->nt_S, n, n, P<T>(h->ybuf), skip);
+            KCHECK();
+        }
+        return LCX_OK;
+    }
+    static int tn_big(lcx_ctx* h, const int* skip) {
+        TimingPair tp;
+        LCXCHECK(timing_begin(h, 1, &tp));
+        LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false>(h->stream, P<T>(h->X), h->ldx, h->Npad, h->ldx, P<T>(h->ybuf), nullptr,
+                                           P<T>(h->dpart), h->tn_S, h->tn_KW, skip)));
+        LCXCHECK(timing_end(h, 1, &tp));
+        return LCX_OK;
+    }
+
+    static int moments_a(lcx_ctx* h, int which) {
+        T* w = P<T>(h->Wt[which]);
+        LCXCHECK(nt_big(h, w, nullptr));
+        // W W^T partials over the shard -> tail of ybuf
+        LCXCHECK(gram(h, w, h->ldx, nullptr, h->gv_S, nullptr));
+        hipLaunchKernelGGL((reduce_partials_kernel<T, T>), dim3(cdiv(Mp * Mp, 256)), dim3(256), 0, h->stream,
+                           P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp,
+                           P<T>(h->ybuf) + h->Npad * Mp, (const int*)nullptr);
+        KCHECK();
+        return LCX_OK;
+    }
+
+    static int small(lcx_ctx* h, int which, double eps, int quick) {
+        MomentSet& s = h->set[which];
+        LCXCHECK(gram(h, P<T>(h->ybuf), h->Npad, nullptr, h->gn_S, nullptr));
+        SmallDesc sd{s.uj, s.ry, s.wmag};
+        hipLaunchKernelGGL((small_moments_kernel<T>), dim3(1), dim3(PV_THREADS), 0, h->stream, P<T>(h->gpart),
+                           h->gn_S, P<T>(h->ybuf) + h->Npad * Mp, Mp, h->M, (double)h->N, eps, quick, sd, s.st);
+        KCHECK();
+        return LCX_OK;
+    }
+
+    static int moments_b(lcx_ctx* h, int which, double eps, int quick) {
+        MomentSet& s = h->set[which];
+        LCXCHECK(small(h, which, eps, quick));
+        const int* skip = &s.st->invalid;
+        LCXCHECK(tn_big(h, skip));
+        const size_t lds = ((size_t)Mp * Mp + (size_t)VPB * Mp) * sizeof(T);
+        LCXCHECK(allow_lds(moments_epilogue_kernel<T, Mp>, lds));
+        hipLaunchKernelGGL((moments_epilogue_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream,
+                           P<T>(h->dpart), h->tn_S, h->ldx * Mp, P<T>(h->Wt[which]), s.ry, h->V, (double)h->N, eps,
+                           P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), P<T>(s.hscale),
+                           h->tcpart, skip);
+        KCHECK();
+        hipLaunchKernelGGL(tc_partials_kernel, dim3(1), dim3(64), 0, h->stream, h->tcpart, h->pv_grid, h->sbuf, 2, skip);
+        KCHECK();
+        return LCX_OK;
+    }
+
+    static int moments_c(lcx_ctx* h, int which) {
+        hipLaunchKernelGGL((tc_final_kernel<T>), dim3(1), dim3(1), 0, h->stream, h->sbuf, h->set[which].st);
+        KCHECK();
+        return LCX_OK;
+    }
+
+    static int update_a(lcx_ctx* h) {
+        MomentSet& s = h->set[0];
+        LCXCHECK(gram(h, P<T>(s.rir), h->ldx, P<T>(s.hscale), h->gv_S, nullptr));
+        hipLaunchKernelGGL((reduce_partials_kernel<T, double>), dim3(cdiv(Mp * Mp, 256)), dim3(256), 0, h->stream,
+                           P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, h->sbuf, (const int*)nullptr);
+        KCHECK();
+        return LCX_OK;
+    }
+
+    static int update_b(lcx_ctx* h, double eps) {
+        (void)eps;
+        MomentSet& s = h->set[0];
+        const size_t lds = ((size_t)Mp * (Mp + 1) + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
+        LCXCHECK(allow_lds(grad_kernel<T, Mp>, lds));
+        hipLaunchKernelGGL((grad_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(h->Wt[0]),
+                           P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), s.uj, h->sbuf, h->V,
+                           P<T>(h->grad), h->bjpart);
+        KCHECK();
+        LCXCHECK(nt_big(h, P<T>(h->grad), nullptr));
+        hipLaunchKernelGGL((bj_reduce_kernel<T>), dim3(1), dim3(128), 0, h->stream, h->bjpart, h->pv_grid, Mp,
+                           P<T>(h->ybuf) + h->Npad * Mp);
+        KCHECK();
+        return LCX_OK;
+    }
+
+    static int update_c(lcx_ctx* h, double eps) {
+        MomentSet& s = h->set[0];
+        LCXCHECK(tn_big(h, nullptr));
+        const int grid = (int)(cdiv(h->V * Mp, PV_THREADS) < 2048 ? cdiv(h->V * Mp, PV_THREADS) : 2048);
+        hipLaunchKernelGGL((update_kernel<T, Mp>), dim3(grid), dim3(PV_THREADS), 0, h->stream, P<T>(h->dpart), h->tn_S,
+                           h->ldx * Mp, P<T>(h->grad), P<T>(h->Wt[0]), s.uj, P<T>(h->ybuf) + h->Npad * Mp, h->V,
+                           (double)h->N, eps, P<T>(h->update), P<T>(h->sgrad), h->tanpart);
+        KCHECK();
+        hipLaunchKernelGGL(tc_partials_kernel, dim3(1), dim3(64), 0, h->stream, h->tanpart, grid, h->sbuf, 1,
+                           (const int*)nullptr);
+        KCHECK();
+        return LCX_OK;
+    }
+
+    static int make_trial(lcx_ctx* h, double eta) {
+        const int64_t n = h->V * Mp;
+        hipLaunchKernelGGL((axpy_kernel<T>), dim3((unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048)), dim3(256), 0,
+                           h->stream, P<T>(h->Wt[0]), P<T>(h->update), (T)eta, n, P<T>(h->Wt[1]));
+        KCHECK();
+        return LCX_OK;
+    }
+
+    static int rescale(lcx_ctx* h, double e0, double e1) {
+        const int64_t n = h->V * Mp;
+        hipLaunchKernelGGL((rescale_kernel<T>), dim3((unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048)), dim3(256), 0,
+                           h->stream, P<T>(h->Wt[0]), n, Mp, h->set[0].uj, h->set[0].wmag, e0, e1);
+        KCHECK();
+        return LCX_OK;
+    }
+
+    static int init_scale(lcx_ctx* h) {
+        LCXCHECK(small(h, 0, 0.0, 0));
+        const int64_t n = h->V * Mp;
+        hipLaunchKernelGGL((init_scale_kernel<T>), dim3((unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048)), dim3(256), 0,
+                           h->stream, P<T>(h->Wt[0]), n, Mp, h->M, h->set[0].uj);
+        KCHECK();
+        return LCX_OK;
+    }
+
+    static int permute(lcx_ctx* h, const int32_t* order) {
+        HIPCHECK(hipMemcpyAsync(h->order_dev, order, sizeof(int) * h->M, hipMemcpyHostToDevice, h->stream));
+        const int64_t n = h->V * Mp;
+        hipLaunchKernelGGL((permute_kernel<T>), dim3((unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048)), dim3(256), 0,
+                           h->stream, P<T>(h->Wt[0]), P<T>(h->Wt[1]), n, Mp, h->M, h->order_dev);
+        KCHECK();
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        std::swap(h->Wt[0], h->Wt[1]);
+        return LCX_OK;
+    }
+
+    // detail sums; optionally materialise MI / XiZj / Xi2|Y into scratch arrays
+    static int detail(lcx_ctx* h, int which, T* mi_o, T* xz_o, T* x2y_o) {
+        MomentSet& s = h->set[which];
+        hipLaunchKernelGGL(invert_kernel, dim3(1), dim3(256), 0, h->stream, s.ry, Mp, h->invwork, h->ryinv);
+        KCHECK();
+        const size_t lds = ((size_t)Mp * Mp + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
+        LCXCHECK(allow_lds(detail_kernel<T, Mp>, lds));
+        hipLaunchKernelGGL((detail_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(s.rho),
+                           h->ryinv, h->V, h->M, mi_o, xz_o, x2y_o, h->detpart);
+        KCHECK();
+        hipLaunchKernelGGL(tc_partials_kernel, dim3(1), dim3(192), 0, h->stream, h->detpart, h->pv_grid, h->sbuf,
+                           Mp + 3, (const int*)nullptr);
+        KCHECK();
+        return LCX_OK;
+    }
+
+    // [Vp][Mp] device -> (m, V) or (V, m) host
+    static int fetch_mv(lcx_ctx* h, const T* dev, T* host, bool as_m_by_v) {
+        std::vector<T> tmp((size_t)h->V * Mp);
+        HIPCHECK(hipMemcpyAsync(tmp.data(), dev, tmp.size() * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        for (int64_t v = 0; v < h->V; ++v)
+            for (int j = 0; j < h->M; ++j) {
+                if (as_m_by_v) host[(int64_t)j * h->V + v] = tmp[v * Mp + j];
+                else host[v * h->M + j] = tmp[v * Mp + j];
+            }
+        return LCX_OK;
+    }
+    static int fetch_v(lcx_ctx* h, const T* dev, T* host) {
+        HIPCHECK(hipMemcpyAsync(host, dev, (size_t)h->V * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        return LCX_OK;
+    }
+    static int fetch_small(lcx_ctx* h, const double* dev, int rows, int cols, T* host) {
+        std::vector<double> tmp((size_t)Mp * Mp);
+        HIPCHECK(hipMemcpyAsync(tmp.data(), dev, sizeof(double) * (rows == 1 ? Mp : Mp * Mp), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        for (int a = 0; a < rows; ++a)
+            for (int b = 0; b < cols; ++b) host[a * cols + b] = (T)tmp[(rows == 1 ? 0 : a * Mp) + b];
+        return LCX_OK;
+    }
+
+    static int get_moment(lcx_ctx* h, int which, int key, double eps, void* out) {
+        (void)eps;
+        MomentSet& s = h->set[which];
+        T* o = P<T>(out);
+        T* scr = P<T>(h->scratch);
+        const int64_t n = h->ldx * Mp;
+        switch (key) {
+            case LCX_M_UJ: return fetch_small(h, s.uj, 1, h->M, o);
+            case LCX_M_RY: return fetch_small(h, s.ry, h->M, h->M, o);
+            case LCX_M_H: {
+                LCXCHECK(fetch_small(h, h->sbuf, h->M, h->M, o));
+                for (int a = 0; a < h->M; ++a) o[a * h->M + a] = (T)0;
+                return LCX_OK;
+            }
+            case LCX_M_RHO: return fetch_mv(h, P<T>(s.rho), o, true);
+            case LCX_M_RHOINVRHO: return fetch_mv(h, P<T>(s.rir), o, true);
+            case LCX_M_QIJ: return fetch_mv(h, P<T>(s.qij), o, true);
+            case LCX_M_INVRHO: {
+                hipLaunchKernelGGL((invrho_kernel<T>), dim3(1024), dim3(256), 0, h->stream, P<T>(s.rho), n, scr);
+                KCHECK();
+                return fetch_mv(h, scr, o, true);
+            }
+            case LCX_M_SI: return fetch_v(h, P<T>(s.si), o);
+            case LCX_M_QISI2: return fetch_v(h, P<T>(s.q2), o);
+            case LCX_M_MI: LCXCHECK(detail(h, which, scr, nullptr, nullptr)); return fetch_mv(h, scr, o, true);
+            case LCX_M_XIZJ: LCXCHECK(detail(h, which, nullptr, scr, nullptr)); return fetch_mv(h, scr, o, false);
+            case LCX_M_XI2_GIVEN_Y: LCXCHECK(detail(h, which, nullptr, nullptr, scr)); return fetch_v(h, scr, o);
+            case LCX_M_GRAD: return fetch_mv(h, P<T>(h->grad), o, true);
+            case LCX_M_UPDATE: return fetch_mv(h, P<T>(h->update), o, true);
+            case LCX_M_SIG_GRAD: return fetch_mv(h, P<T>(h->sgrad), o, true);
+            case LCX_M_Y: {
+                std::vector<T> tmp((size_t)h->N * Mp);
+                HIPCHECK(hipMemcpyAsync(tmp.data(), h->ybuf, tmp.size() * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+                HIPCHECK(hipStreamSynchronize(h->stream));
+                for (int64_t r = 0; r < h->N; ++r)
+                    for (int j = 0; j < h->M; ++j) o[r * h->M + j] = tmp[r * Mp + j];
+                return LCX_OK;
+            }
+            default: return fail(LCX_ERR_ARG, "unknown moment key");
+        }
+    }
+
+    static int set_moment(lcx_ctx* h, int which, int key, const void* in) {
+        MomentSet& s = h->set[which];
+        const T* src = reinterpret_cast<const T*>(in);
+        if (key == LCX_M_SI) {
+            HIPCHECK(hipMemcpyAsync(s.si, src, sizeof(T) * h->V, hipMemcpyHostToDevice, h->stream));
+            HIPCHECK(hipStreamSynchronize(h->stream));
+            return LCX_OK;
+        }
+        if (key != LCX_M_RHOINVRHO) return fail(LCX_ERR_ARG, "lcx_set_moment: only RHOINVRHO and SI can be restored");
+        std::vector<T> tmp((size_t)h->ldx * Mp, (T)0);
+        for (int j = 0; j < h->M; ++j)
+            for (int64_t v = 0; v < h->V; ++v) tmp[v * Mp + j] = src[(int64_t)j * h->V + v];
+        HIPCHECK(hipMemcpyAsync(s.rir, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        return LCX_OK;
+    }
+
+    static int set_ws(lcx_ctx* h, const void* w_host) {
+        const T* w = reinterpret_cast<const T*>(w_host);
+        std::vector<T> tmp((size_t)h->ldx * Mp, (T)0);
+        for (int j = 0; j < h->M; ++j)
+            for (int64_t v = 0; v < h->V; ++v) tmp[v * Mp + j] = w[(int64_t)j * h->V + v];
+        HIPCHECK(hipMemcpyAsync(h->Wt[0], tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        return LCX_OK;
+    }
+
+    static int covariance(lcx_ctx* h, double eps, const void* std_host, int64_t row0, int64_t nrows, void* out_host) {
+        MomentSet& s = h->set[0];
+        T *std_dev = nullptr, *out_dev = nullptr;
+        HIPCHECK(hipMalloc((void**)&std_dev, sizeof(T) * h->V));
+        if (hipMalloc((void**)&out_dev, sizeof(T) * nrows * h->V) != hipSuccess) {
+            (void)hipFree(std_dev);
+            return fail(LCX_ERR_HIP, "covariance_rows: cannot allocate the output block on device");
+        }
+        HIPCHECK(hipMemcpyAsync(std_dev, std_host, sizeof(T) * h->V, hipMemcpyHostToDevice, h->stream));
+        dim3 grid((unsigned)cdiv(h->V, 64), (unsigned)cdiv(nrows, 64));
+        hipLaunchKernelGGL((covariance_kernel<T, Mp>), grid, dim3(256), 0, h->stream, P<T>(s.rir), P<T>(s.si), std_dev,
+                           h->V, row0, nrows, eps, out_dev);
+        KCHECK();
+        HIPCHECK(hipMemcpyAsync(out_host, out_dev, sizeof(T) * nrows * h->V, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        HIPCHECK(hipFree(std_dev));
+        HIPCHECK(hipFree(out_dev));
+        return LCX_OK;
+    }
+
+    static int project(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, void* out_host) {
+        const int64_t blk = 8192;      // rows per staged block
+        const int64_t rows_pad = round_up(n_rows < blk ? n_rows : blk, 64);
+        T *xd = nullptr, *yd = nullptr;
+        HIPCHECK(hipMalloc((void**)&xd, sizeof(T) * rows_pad * h->ldx));
+        HIPCHECK(hipMalloc((void**)&yd, sizeof(T) * rows_pad * Mp));
+        std::vector<T> tmp((size_t)rows_pad * Mp);
+        T* out = P<T>(out_host);
+        for (int64_t r0 = 0; r0 < n_rows; r0 += blk) {
+            const int64_t nr = (n_rows - r0) < blk ? (n_rows - r0) : blk;
+            HIPCHECK(hipMemsetAsync(xd, 0, sizeof(T) * rows_pad * h->ldx, h->stream));
+            HIPCHECK(hipMemcpy2DAsync(xd, h->ldx * sizeof(T), reinterpret_cast<const T*>(x_host) + r0 * ld, ld * sizeof(T),
+                                      h->V * sizeof(T), nr, hipMemcpyHostToDevice, h->stream));
+            LCXCHECK((launch_nt<T, CT>(h->stream, xd, h->ldx, rows_pad, P<T>(h->Wt[0]), yd, 1, h->nt_KW, nullptr)));
+            HIPCHECK(hipMemcpyAsync(tmp.data(), yd, sizeof(T) * rows_pad * Mp, hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(hipStreamSynchronize(h->stream));
+            for (int64_t r = 0; r < nr; ++r)
+                for (int j = 0; j < h->M; ++j) out[(r0 + r) * h->M + j] = tmp[r * Mp + j];
+        }
+        HIPCHECK(hipFree(xd));
+        HIPCHECK(hipFree(yd));
+        return LCX_OK;
+    }
+
+    static int generate(lcx_ctx* h, uint64_t seed, int kind, int n_groups, int64_t col_offset) {
+        hipLaunchKernelGGL((generate_kernel<T>), dim3(4096), dim3(256), 0, h->stream, P<T>(h->X), h->N, h->V, h->ldx,
+                           seed, kind, n_groups < 1 ? 1 : n_groups, col_offset);
+        KCHECK();
+        double *mean = nullptr, *istd = nullptr;
+        HIPCHECK(hipMalloc((void**)&mean, sizeof(double) * h->V));
+        HIPCHECK(hipMalloc((void**)&istd, sizeof(double) * h->V));
+        hipLaunchKernelGGL((colstats_kernel<T>), dim3((unsigned)cdiv(h->V, 64)), dim3(64), 0, h->stream, P<T>(h->X), h->N,
+                           h->V, h->ldx, mean, istd);
+        KCHECK();
+        hipLaunchKernelGGL((standardize_kernel<T>), dim3(4096), dim3(256), 0, h->stream, P<T>(h->X), h->N, h->V, h->ldx,
+                           mean, istd);
+        KCHECK();
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        HIPCHECK(hipFree(mean));
+        HIPCHECK(hipFree(istd));
+        return LCX_OK;
+    }
+};
+
+// runtime (dtype, CT) -> Impl<T, CT>::fn(args...)
+#define DISPATCH(h, fn, ...)                                                        \
+    do {                                                                            \
+        if ((h)->dtype == LCX_F32) {                                                \
+            switch ((h)->CT) {                                                      \
+                case 1: return Impl<float, 1>::fn(__VA_ARGS__);                     \
+                case 2: return Impl<float, 2>::fn(__VA_ARGS__);                     \
+                case 4: return Impl<float, 4>::fn(__VA_ARGS__);                     \
+                case 8: return Impl<float, 8>::fn(__VA_ARGS__);                     \
+            }                                                                       \
+        } else {                                                                    \
+            switch ((h)->CT) {                                                      \
+                case 1: return Impl<double, 1>::fn(__VA_ARGS__);                    \
+                case 2: return Impl<double, 2>::fn(__VA_ARGS__);                    \
+                case 4: return Impl<double, 4>::fn(__VA_ARGS__);                    \
+                case 8: return Impl<double, 8>::fn(__VA_ARGS__);                    \
+            }                                                                       \
+        }                                                                           \
+        return fail(LCX_ERR_ARG, "unsupported n_hidden padding");                   \
+    } while (0)
+
+static int ct_for(int m) {
+    if (m <= 16) return 1;
+    if (m <= 32) return 2;
+    if (m <= 64) return 4;
+    if (m <= 128) return 8;
+    return 0;
+}
+
+#define NEED(h)                                            \
+    if (!(h)) return fail(LCX_ERR_ARG, "null handle");     \
+    HIPCHECK(hipSetDevice((h)->device));
+
+// ---- isolated GEMM checks -------------------------------------------------------------------------
+template <typename T, int CT>
+static int test_nt(const void* a_host, int64_t n_rows, int64_t k, int64_t lda, const void* b_host, void* out_host,
+                   int force_split, int force_kw) {
+    constexpr int Mp = 16 * CT;
+    const int64_t rows_pad = round_up(n_rows, 64), ldx = round_up(k, 64);
+    T *xd, *bd, *od, *pd;
+    hipStream_t st = 0;
+    HIPCHECK(hipMalloc((void**)&xd, sizeof(T) * rows_pad * ldx));
+    HIPCHECK(hipMalloc((void**)&bd, sizeof(T) * ldx * Mp));
+    const int S = force_split > 0 ? force_split : 1, KW = force_kw > 0 ? force_kw : 4;
+    HIPCHECK(hipMalloc((void**)&pd, sizeof(T) * S * rows_pad * Mp));
+    HIPCHECK(hipMalloc((void**)&od, sizeof(T) * rows_pad * Mp));
+    HIPCHECK(hipMemset(xd, 0, sizeof(T) * rows_pad * ldx));
+    HIPCHECK(hipMemset(bd, 0, sizeof(T) * ldx * Mp));
+    HIPCHECK(hipMemcpy2D(xd, ldx * sizeof(T), a_host, lda * sizeof(T), k * sizeof(T), n_rows, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(bd, b_host, sizeof(T) * k * Mp, hipMemcpyHostToDevice));
+    LCXCHECK((launch_nt<T, CT>(st, xd, ldx, rows_pad, bd, pd, S, KW, nullptr)));
+    const int64_t n = rows_pad * Mp;
+    hipLaunchKernelGGL((reduce_partials_kernel<T, T>), dim3(256), dim3(256), 0, st, pd, S, n, n, od, (const int*)nullptr);
+    KCHECK();
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(out_host, od, sizeof(T) * n_rows * Mp, hipMemcpyDeviceToHost));
+    HIPCHECK(hipFree(xd)); HIPCHECK(hipFree(bd)); HIPCHECK(hipFree(od)); HIPCHECK(hipFree(pd));
+    return LCX_OK;
+}
+
+template <typename T, int CT>
+static int test_tn(const void* a_host, int64_t k, int64_t v, int64_t lda, const void* b_host, const void* rs_host,
+                   void* out_host, int force_split, int force_kw) {
+    constexpr int Mp = 16 * CT;
+    const int64_t kpad = round_up(k, 64), ldv = round_up(v, 64);
+    T *ad, *bd, *od, *pd, *sd = nullptr;
+    hipStream_t st = 0;
+    HIPCHECK(hipMalloc((void**)&ad, sizeof(T) * kpad * ldv));
+    HIPCHECK(hipMalloc((void**)&bd, sizeof(T) * kpad * Mp));
+    HIPCHECK(hipMalloc((void**)&sd, sizeof(T) * kpad));
+    const int S = force_split > 0 ? force_split : 1, KW = force_kw > 0 ? force_kw : 4;
+    HIPCHECK(hipMalloc((void**)&pd, sizeof(T) * S * ldv * Mp));
+    HIPCHECK(hipMalloc((void**)&od, sizeof(T) * ldv * Mp));
+    HIPCHECK(hipMemset(ad, 0, sizeof(T) * kpad * ldv));
+    HIPCHECK(hipMemset(bd, 0, sizeof(T) * kpad * Mp));
+    HIPCHECK(hipMemset(sd, 0, sizeof(T) * kpad));
+    HIPCHECK(hipMemcpy2D(ad, ldv * sizeof(T), a_host, lda * sizeof(T), v * sizeof(T), k, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(bd, b_host, sizeof(T) * k * Mp, hipMemcpyHostToDevice));
+    if (rs_host) {
+        HIPCHECK(hipMemcpy(sd, rs_host, sizeof(T) * k, hipMemcpyHostToDevice));
+        LCXCHECK((launch_tn<T, CT, TnShape<T, CT>::RT, true>(st, ad, ldv, kpad, ldv, bd, sd, pd, S, KW, nullptr)));
+    } else {
+        LCXCHECK((launch_tn<T, CT, TnShape<T, CT>::RT, false>(st, ad, ldv, kpad, ldv, bd, nullptr, pd, S, KW, nullptr)));
+    }
+    const int64_t n = ldv * Mp;
+    hipLaunchKernelGGL((reduce_partials_kernel<T, T>), dim3(256), dim3(256), 0, st, pd, S, n, n, od, (const int*)nullptr);
+    KCHECK();
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(out_host, od, sizeof(T) * v * Mp, hipMemcpyDeviceToHost));
+    HIPCHECK(hipFree(ad)); HIPCHECK(hipFree(bd)); HIPCHECK(hipFree(od)); HIPCHECK(hipFree(pd)); HIPCHECK(hipFree(sd));
+    return LCX_OK;
+}
+
+
+// -------------------------------------------------------------------------------------------------
+// C ABI
+// -------------------------------------------------------------------------------------------------
+extern "C" {
+
+int lcx_abi_version(void) { return 1; }
+const char* lcx_last_error(void) { return g_err.c_str(); }
+
+int lcx_device_count(int* out_count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    if (out_count) *out_count = n;
+    return LCX_OK;
+}
+
+static int dev_alloc(void** p, size_t bytes, hipStream_t st) {
+    HIPCHECK(hipMalloc(p, bytes ? bytes : 16));
+    HIPCHECK(hipMemsetAsync(*p, 0, bytes ? bytes : 16, st));
+    return LCX_OK;
+}
+
+int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden, int dtype, int device) {
+    if (!out || n_samples < 1 || nv_local < 1 || n_hidden < 1) return fail(LCX_ERR_ARG, "lcx_create: bad sizes");
+    if (dtype != LCX_F32 && dtype != LCX_F64) return fail(LCX_ERR_ARG, "lcx_create: dtype must be LCX_F32 or LCX_F64");
+    const int ct = ct_for(n_hidden);
+    if (!ct) return fail(LCX_ERR_ARG, "lcx_create: n_hidden > 128 is not supported by this build");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(LCX_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(LCX_ERR_ARG, "lcx_create: device index out of range");
+    HIPCHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, device));
+
+    lcx_ctx* h = new lcx_ctx();
+    h->device = device;
+    h->dtype = dtype;
+    h->es = dtype == LCX_F32 ? 4 : 8;
+    h->N = n_samples;
+    h->V = nv_local;
+    h->M = n_hidden;
+    h->CT = ct;
+    h->Mp = 16 * ct;
+    h->Npad = round_up(n_samples, 64);
+    h->ldx = round_up(nv_local, 64);        // 64 elements: whole 128 B chunks and whole tn column tiles
+    h->timing = false;
+    h->t_launch[0] = h->t_launch[1] = 0;
+    h->t_ms[0] = h->t_ms[1] = 0.0;
+    h->have_direction = false;
+    h->target_waves = prop.multiProcessorCount * 12;
+    HIPCHECK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    hipStream_t st = h->stream;
+
+    int rc = LCX_OK;
+    {
+        lcx_ctx* hh = h;
+        auto geo = [&]() -> int { DISPATCH(hh, geometry, hh); };
+        rc = geo();
+        if (rc != LCX_OK) { delete h; return rc; }
+    }
+    const size_t es = h->es;
+    const size_t mv = (size_t)h->ldx * h->Mp * es;
+    const size_t vv = (size_t)h->ldx * es;
+    const int Mp = h->Mp;
+#define A_(ptr, bytes) do { int r_ = dev_alloc((void**)&(ptr), (bytes), st); if (r_ != LCX_OK) return r_; } while (0)
+    A_(h->X, (size_t)h->Npad * h->ldx * es);
+    for (int k = 0; k < 2; ++k) {
+        A_(h->Wt[k], mv);
+        A_(h->set[k].rho, mv);
+        A_(h->set[k].rir, mv);
+        A_(h->set[k].qij, mv);
+        A_(h->set[k].si, vv);
+        A_(h->set[k].q2, vv);
+        A_(h->set[k].hscale, vv);
+        A_(h->set[k].uj, sizeof(double) * Mp);
+        A_(h->set[k].ry, sizeof(double) * Mp * Mp);
+        A_(h->set[k].wmag, sizeof(double) * Mp);
+    }
+    A_(h->grad, mv);
+    A_(h->update, mv);
+    A_(h->sgrad, mv);
+    A_(h->scratch, mv);
+    h->ybuf_elems = h->Npad * Mp + (int64_t)Mp * Mp;
+    h->sbuf_elems = (int64_t)Mp * Mp + 8;
+    A_(h->ybuf_own, (size_t)h->ybuf_elems * es);
+    A_(h->sbuf_own, sizeof(double) * h->sbuf_elems);
+    h->ybuf = h->ybuf_own;
+    h->sbuf = h->sbuf_own;
+    A_(h->ypart, h->nt_S > 1 ? (size_t)h->nt_S * h->Npad * Mp * es : 16);
+    A_(h->dpart, (size_t)h->tn_S * mv);
+    {
+        const int gs = h->gn_S > h->gv_S ? h->gn_S : h->gv_S;
+        A_(h->gpart, (size_t)gs * Mp * Mp * es);
+    }
+    A_(h->tcpart, sizeof(double) * 2 * 2048);
+    A_(h->bjpart, sizeof(double) * Mp * 2048);
+    A_(h->tanpart, sizeof(double) * 2048);
+    A_(h->detpart, sizeof(double) * (Mp + 3) * 2048);
+    A_(h->ryinv, sizeof(double) * Mp * Mp);
+    A_(h->invwork, sizeof(double) * Mp * 2 * Mp);
+    A_(h->states, sizeof(SetState) * 2);
+    A_(h->order_dev, sizeof(int) * Mp);
+#undef A_
+    h->set[0].st = h->states;
+    h->set[1].st = h->states + 1;
+    HIPCHECK(hipHostMalloc((void**)&h->host_states, sizeof(SetState) * 2, hipHostMallocDefault));
+    HIPCHECK(hipStreamSynchronize(st));
+    *out = h;
+    return LCX_OK;
+}
+
+int lcx_destroy(lcx_ctx* h) {
+    if (!h) return LCX_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    void* ptrs[] = {h->X, h->Wt[0], h->Wt[1], h->grad, h->update, h->sgrad, h->scratch, h->ybuf_own, h->sbuf_own,
+                    h->ypart, h->dpart, h->gpart, h->tcpart, h->bjpart, h->tanpart, h->detpart, h->ryinv, h->invwork,
+                    h->states, h->order_dev};
+    for (void* p : ptrs) (void)hipFree(p);
+    for (int k = 0; k < 2; ++k) {
+        MomentSet& s = h->set[k];
+        void* q[] = {s.rho, s.rir, s.qij, s.si, s.q2, s.hscale, s.uj, s.ry, s.wmag};
+        for (void* p : q) (void)hipFree(p);
+    }
+    (void)hipHostFree(h->host_states);
+    for (auto& tp : h->pool) { (void)hipEventDestroy(tp.a); (void)hipEventDestroy(tp.b); }
+    for (auto& tp : h->pending) { (void)hipEventDestroy(tp.a); (void)hipEventDestroy(tp.b); }
+    (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return LCX_OK;
+}
+
+int lcx_set_stream(lcx_ctx* h, void* s) {
+    NEED(h);
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return LCX_OK;
+}
+
+int lcx_synchronize(lcx_ctx* h) {
+    NEED(h);
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    return LCX_OK;
+}
+
+int lcx_exchange_layout(lcx_ctx* h, int64_t* ye, int64_t* se, void** yd, void** sd) {
+    NEED(h);
+    if (ye) *ye = h->ybuf_elems;
+    if (se) *se = h->sbuf_elems;
+    if (yd) *yd = h->ybuf;
+    if (sd) *sd = h->sbuf;
+    return LCX_OK;
+}
+
+int lcx_bind_exchange(lcx_ctx* h, void* y, void* s) {
+    NEED(h);
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    h->ybuf = y ? y : h->ybuf_own;
+    h->sbuf = s ? (double*)s : h->sbuf_own;
+    if (y) HIPCHECK(hipMemsetAsync(y, 0, (size_t)h->ybuf_elems * h->es, h->stream));
+    if (s) HIPCHECK(hipMemsetAsync(s, 0, sizeof(double) * h->sbuf_elems, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    return LCX_OK;
+}
+
+int lcx_upload_x(lcx_ctx* h, const void* x, int64_t ld) {
+    NEED(h);
+    if (!x || ld < h->V) return fail(LCX_ERR_ARG, "lcx_upload_x: bad leading dimension");
+    HIPCHECK(hipMemcpy2DAsync(h->X, h->ldx * h->es, x, ld * h->es, h->V * h->es, h->N, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    return LCX_OK;
+}
+
+int lcx_download_x(lcx_ctx* h, void* x, int64_t ld) {
+    NEED(h);
+    if (!x || ld < h->V) return fail(LCX_ERR_ARG, "lcx_download_x: bad leading dimension");
+    HIPCHECK(hipMemcpy2DAsync(x, ld * h->es, h->X, h->ldx * h->es, h->V * h->es, h->N, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    return LCX_OK;
+}
+
+int lcx_generate_x(lcx_ctx* h, uint64_t seed, int kind, int n_groups, int64_t col_offset) {
+    NEED(h);
+    DISPATCH(h, generate, h, seed, kind, n_groups, col_offset);
+}
+
+int lcx_set_ws(lcx_ctx* h, const void* w) {
+    NEED(h);
+    if (!w) return fail(LCX_ERR_ARG, "lcx_set_ws: null");
+    DISPATCH(h, set_ws, h, w);
+}
+
+static int get_ws_impl(lcx_ctx* h, int which, void* w) {
+    if (h->dtype == LCX_F32) {
+        switch (h->CT) { case 1: return Impl<float,1>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
+                         case 2: return Impl<float,2>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
+                         case 4: return Impl<float,4>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
+                         case 8: return Impl<float,8>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true); }
+    } else {
+        switch (h->CT) { case 1: return Impl<double,1>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
+                         case 2: return Impl<double,2>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
+                         case 4: return Impl<double,4>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
+                         case 8: return Impl<double,8>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true); }
+    }
+    return fail(LCX_ERR_ARG, "bad CT");
+}
+int lcx_get_ws(lcx_ctx* h, int which, void* w) {
+    NEED(h);
+    if (!w || which < 0 || which > 1) return fail(LCX_ERR_ARG, "lcx_get_ws: bad argument");
+    return get_ws_impl(h, which, w);
+}
+
+int lcx_permute_factors(lcx_ctx* h, const int32_t* order) {
+    NEED(h);
+    if (!order) return fail(LCX_ERR_ARG, "lcx_permute_factors: null");
+    for (int j = 0; j < h->M; ++j)
+        if (order[j] < 0 || order[j] >= h->M) return fail(LCX_ERR_ARG, "lcx_permute_factors: index out of range");
+    DISPATCH(h, permute, h, order);
+}
+
+#define WHICH_OK(w) if ((w) < 0 || (w) > 1) return fail(LCX_ERR_ARG, "which must be 0 or 1")
+
+int lcx_moments_a(lcx_ctx* h, int which) { NEED(h); WHICH_OK(which); DISPATCH(h, moments_a, h, which); }
+int lcx_moments_b(lcx_ctx* h, int which, double eps, int quick) { NEED(h); WHICH_OK(which); DISPATCH(h, moments_b, h, which, eps, quick); }
+int lcx_moments_c(lcx_ctx* h, int which) { NEED(h); WHICH_OK(which); DISPATCH(h, moments_c, h, which); }
+
+static int detail_entry(lcx_ctx* h, int which) {
+    if (h->dtype == LCX_F32) {
+        switch (h->CT) { case 1: return Impl<float,1>::detail(h, which, nullptr, nullptr, nullptr);
+                         case 2: return Impl<float,2>::detail(h, which, nullptr, nullptr, nullptr);
+                         case 4: return Impl<float,4>::detail(h, which, nullptr, nullptr, nullptr);
+                         case 8: return Impl<float,8>::detail(h, which, nullptr, nullptr, nullptr); }
+    } else {
+        switch (h->CT) { case 1: return Impl<double,1>::detail(h, which, nullptr, nullptr, nullptr);
+                         case 2: return Impl<double,2>::detail(h, which, nullptr, nullptr, nullptr);
+                         case 4: return Impl<double,4>::detail(h, which, nullptr, nullptr, nullptr);
+                         case 8: return Impl<double,8>::detail(h, which, nullptr, nullptr, nullptr); }
+    }
+    return fail(LCX_ERR_ARG, "bad CT");
+}
+int lcx_moments_detail(lcx_ctx* h, int which) { NEED(h); WHICH_OK(which); return detail_entry(h, which); }
+
+int lcx_update_a(lcx_ctx* h) { NEED(h); DISPATCH(h, update_a, h); }
+int lcx_update_b(lcx_ctx* h, double eps) { NEED(h); DISPATCH(h, update_b, h, eps); }
+int lcx_update_c(lcx_ctx* h, double eps) { NEED(h); DISPATCH(h, update_c, h, eps); }
+int lcx_update_d(lcx_ctx* h) {
+    NEED(h);
+    hipLaunchKernelGGL(tangent_store_kernel, dim3(1), dim3(1), 0, h->stream, h->sbuf, h->set[0].st);
+    KCHECK();
+    h->have_direction = true;
+    return LCX_OK;
+}
+int lcx_make_trial(lcx_ctx* h, double eta) {
+    NEED(h);
+    if (!h->have_direction) return fail(LCX_ERR_STATE, "lcx_make_trial before lcx_update_a..d");
+    DISPATCH(h, make_trial, h, eta);
+}
+int lcx_accept_trial(lcx_ctx* h) {
+    NEED(h);
+    std::swap(h->Wt[0], h->Wt[1]);
+    std::swap(h->set[0], h->set[1]);
+    h->have_direction = false;
+    return LCX_OK;
+}
+
+int lcx_rescale_ws(lcx_ctx* h, double e0, double e1) { NEED(h); DISPATCH(h, rescale, h, e0, e1); }
+int lcx_init_scale_ws(lcx_ctx* h) { NEED(h); DISPATCH(h, init_scale, h); }
+
+int lcx_read_state(lcx_ctx* h, int which, double* out) {
+    NEED(h);
+    WHICH_OK(which);
+    if (!out) return fail(LCX_ERR_ARG, "lcx_read_state: null");
+    HIPCHECK(hipMemcpyAsync(h->host_states + which, h->set[which].st, sizeof(SetState), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    const SetState& s = h->host_states[which];
+    out[LCX_S_TC] = s.tc;
+    out[LCX_S_MAX_UJ] = s.max_uj;
+    out[LCX_S_INVALID] = (double)s.invalid;
+    out[LCX_S_TANGENT] = s.tangent;
+    out[LCX_S_SUM_LOG_RJ] = s.sum_log_rj;
+    out[5] = out[6] = out[7] = 0.0;
+    if (h->timing) LCXCHECK(timing_collect(h));
+    return LCX_OK;
+}
+
+int lcx_get_moment(lcx_ctx* h, int which, int key, double eps, void* out) {
+    NEED(h);
+    WHICH_OK(which);
+    if (!out) return fail(LCX_ERR_ARG, "lcx_get_moment: null");
+    DISPATCH(h, get_moment, h, which, key, eps, out);
+}
+
+int lcx_set_moment(lcx_ctx* h, int which, int key, const void* in) {
+    NEED(h);
+    WHICH_OK(which);
+    if (!in) return fail(LCX_ERR_ARG, "lcx_set_moment: null");
+    DISPATCH(h, set_moment, h, which, key, in);
+}
+
+int lcx_read_sbuf(lcx_ctx* h, int64_t count, double* out) {
+    NEED(h);
+    if (!out || count < 1 || count > h->sbuf_elems) return fail(LCX_ERR_ARG, "lcx_read_sbuf: bad count");
+    HIPCHECK(hipMemcpyAsync(out, h->sbuf, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    return LCX_OK;
+}
+
+int lcx_covariance_rows(lcx_ctx* h, double eps, const void* std_host, int64_t row0, int64_t nrows, void* out) {
+    NEED(h);
+    if (!std_host || !out || row0 < 0 || nrows < 1 || row0 + nrows > h->V) return fail(LCX_ERR_ARG, "lcx_covariance_rows: bad range");
+    DISPATCH(h, covariance, h, eps, std_host, row0, nrows, out);
+}
+
+int lcx_project(lcx_ctx* h, const void* x, int64_t n_rows, int64_t ld, void* out) {
+    NEED(h);
+    if (!x || !out || n_rows < 1 || ld < h->V) return fail(LCX_ERR_ARG, "lcx_project: bad argument");
+    DISPATCH(h, project, h, x, n_rows, ld, out);
+}
+
+int lcx_timing_enable(lcx_ctx* h, int enable) {
+    NEED(h);
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    LCXCHECK(timing_collect(h));
+    h->timing = enable != 0;
+    return LCX_OK;
+}
+int lcx_timing_read(lcx_ctx* h, int kind, int64_t* launches, double* total_ms) {
+    NEED(h);
+    if (kind < 0 || kind > 1) return fail(LCX_ERR_ARG, "kind must be 0 or 1");
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    LCXCHECK(timing_collect(h));
+    if (launches) *launches = h->t_launch[kind];
+    if (total_ms) *total_ms = h->t_ms[kind];
+    return LCX_OK;
+}
+int lcx_timing_reset(lcx_ctx* h) {
+    NEED(h);
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    LCXCHECK(timing_collect(h));
+    h->t_launch[0] = h->t_launch[1] = 0;
+    h->t_ms[0] = h->t_ms[1] = 0.0;
+    return LCX_OK;
+}
+
+int lcx_geometry(lcx_ctx* h, int64_t* n_pad, int64_t* ldx, int* m_pad, int64_t* info8) {
+    NEED(h);
+    if (n_pad) *n_pad = h->Npad;
+    if (ldx) *ldx = h->ldx;
+    if (m_pad) *m_pad = h->Mp;
+    if (info8) {
+        info8[0] = h->nt_S; info8[1] = h->nt_KW; info8[2] = h->tn_S; info8[3] = h->tn_KW;
+        info8[4] = h->gn_S; info8[5] = h->gv_S; info8[6] = h->pv_grid; info8[7] = h->target_waves;
+    }
+    return LCX_OK;
+}
+
+int lcx_test_gemm_nt(int dtype, int device, const void* a, int64_t n_rows, int64_t k, int64_t lda, const void* b,
+                     int m_pad, void* out, int fs, int fk) {
+    HIPCHECK(hipSetDevice(device));
+    const int ct = m_pad / 16;
+    if (dtype == LCX_F32) {
+        switch (ct) { case 1: return test_nt<float,1>(a,n_rows,k,lda,b,out,fs,fk); case 2: return test_nt<float,2>(a,n_rows,k,lda,b,out,fs,fk);
+                      case 4: return test_nt<float,4>(a,n_rows,k,lda,b,out,fs,fk); case 8: return test_nt<float,8>(a,n_rows,k,lda,b,out,fs,fk); }
+    } else {
+        switch (ct) { case 1: return test_nt<double,1>(a,n_rows,k,lda,b,out,fs,fk); case 2: return test_nt<double,2>(a,n_rows,k,lda,b,out,fs,fk);
+                      case 4: return test_nt<double,4>(a,n_rows,k,lda,b,out,fs,fk); case 8: return test_nt<double,8>(a,n_rows,k,lda,b,out,fs,fk); }
+    }
+    return fail(LCX_ERR_ARG, "m_pad must be 16, 32, 64 or 128");
+}
+
+int lcx_test_gemm_tn(int dtype, int device, const void* a, int64_t k, int64_t v, int64_t lda, const void* b, int m_pad,
+                     const void* rs, void* out, int fs, int fk) {
+    HIPCHECK(hipSetDevice(device));
+    const int ct = m_pad / 16;
+    if (dtype == LCX_F32) {
+        switch (ct) { case 1: return test_tn<float,1>(a,k,v,lda,b,rs,out,fs,fk); case 2: return test_tn<float,2>(a,k,v,lda,b,rs,out,fs,fk);
+                      case 4: return test_tn<float,4>(a,k,v,lda,b,rs,out,fs,fk); case 8: return test_tn<float,8>(a,k,v,lda,b,rs,out,fs,fk); }
+    } else {
+        switch (ct) { case 1: return test_tn<double,1>(a,k,v,lda,b,rs,out,fs,fk); case 2: return test_tn<double,2>(a,k,v,lda,b,rs,out,fs,fk);
+                      case 4: return test_tn<double,4>(a,k,v,lda,b,rs,out,fs,fk); case 8: return test_tn<double,8>(a,k,v,lda,b,rs,out,fs,fk); }
+    }
+    return fail(LCX_ERR_ARG, "m_pad must be 16, 32, 64 or 128");
+}
+
+}  // extern "C"

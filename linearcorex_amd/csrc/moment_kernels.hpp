@@ -1,0 +1,612 @@
+// moment_kernels.hpp - per-variable / per-factor kernels of the Linear CorEx fit loop (gfx950).
+//
+// Every "m by nv" array of the reference (W, rho, rhoinvrho, Qij, grad, update ...) is stored
+// variable-major on the device: [Vp][Mp], Mp = n_hidden padded to a multiple of 16, so that
+//   * a variable's Mp-vector is contiguous (coalesced per-variable math, natural nv-sharding),
+//   * the array is directly the "B" operand of gemm_nt and the output layout of gemm_tn.
+// Padded factors (j >= m) carry W = 0 and stay exactly 0 through every formula; padded variables
+// (v >= V) are never written and stay 0.
+//
+// These kernels are HBM-bound on M x V arrays (SURVEY.md 8a "K3-K5"): one thread per (variable,
+// factor), Mp consecutive threads per variable, wavefront shuffle reductions over the factor axis,
+// the m x m operators (ry, H) staged in LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lcx {
+
+constexpr int PV_THREADS = 256;
+
+// state scalars per moment set (mirrors LCX_S_* in include/lcx.h)
+struct SetState {
+    double tc, max_uj, invalid_d, tangent, sum_log_rj, r5, r6, r7;
+    int invalid;  // read by the GEMM kernels as skip flag
+    int pad[15];
+};
+
+// replicated per-factor quantities of a moment set
+struct SmallDesc {
+    double* uj;    // [Mp]
+    double* ry;    // [Mp*Mp], diagonal forced to 1 (linearcorex.py:263)
+    double* wmag;  // [Mp]  sum_i W_ji^2 (linearcorex.py:130, :249)
+};
+
+// sum over the Mp consecutive threads that share a variable. Mp in {16,32,64,128}.
+template <int Mp, typename R>
+__device__ __forceinline__ R group_sum(R v, R* scratch /* [PV_THREADS/64] per use */, int tid) {
+    constexpr int W = Mp < 64 ? Mp : 64;
+#pragma unroll
+    for (int off = W / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, W);
+    if (Mp > 64) {
+        // two waves per variable: combine through LDS in a fixed order
+        __syncthreads();
+        if ((tid & 63) == 0) scratch[tid >> 6] = v;
+        __syncthreads();
+        const int base = (tid >> 6) & ~1;
+        v = scratch[base] + scratch[base + 1];
+    }
+    return v;
+}
+
+template <typename R>
+__device__ __forceinline__ R block_sum(R v, R* scratch /* [PV_THREADS/64] */, int tid) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) scratch[tid >> 6] = v;
+    __syncthreads();
+    R s = scratch[0];
+    for (int w = 1; w < PV_THREADS / 64; ++w) s += scratch[w];
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sum grid-level partials: out[i] = sum_s in[s][i]   (OUT may be double for the exchange buffer)
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename OUT>
+__global__ void reduce_partials_kernel(const T* __restrict__ in, int nsplit, int64_t n, int64_t stride,
+                                       OUT* __restrict__ out, const int* __restrict__ skip_flag) {
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        T s = in[i];
+        for (int k = 1; k < nsplit; ++k) s += in[k * stride + i];
+        out[i] = (OUT)s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-factor moments from the Gram matrices (one block):
+//   ry = (1-eps^2) Y^T Y / N + eps^2 W W^T   (== ws.dot(rho.T), linearcorex.py:261)
+//   uj = diag(ry) before the diagonal is set to 1 (:249, :263); early-exit flag (:250-251)
+// gy: [nsplit][Mp][Mp] partials of Y^T Y; gw: [Mp][Mp] (already summed over shards)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void small_moments_kernel(const T* __restrict__ gy, int nsplit, const T* __restrict__ gw,
+                                     int Mp, int m, double n_samples, double eps, int quick,
+                                     SmallDesc sm, SetState* st) {
+    __shared__ double red_max[PV_THREADS / 64];
+    __shared__ double red_sum[PV_THREADS / 64];
+    const int tid = threadIdx.x;
+    const T c1 = (T)(1.0 - eps * eps), c2 = (T)(eps * eps), ns = (T)n_samples;
+    double mx = -1e300, slog = 0.0;
+    for (int idx = tid; idx < Mp * Mp; idx += blockDim.x) {
+        T g = gy[idx];
+        for (int k = 1; k < nsplit; ++k) g += gy[(int64_t)k * Mp * Mp + idx];
+        const T val = c1 * g / ns + c2 * gw[idx];
+        const int j = idx / Mp, k2 = idx % Mp;
+        if (j == k2) {
+            sm.uj[j] = (double)val;
+            sm.wmag[j] = (double)gw[idx];
+            sm.ry[idx] = 1.0;
+            if (j < m) {
+                mx = fmax(mx, (double)val);
+                slog += (double)log((T)1 - val);   // sum_j log(1-uj), in working precision (:274)
+            }
+        } else {
+            sm.ry[idx] = (double)val;
+        }
+    }
+    // block max / sum
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = fmax(mx, __shfl_xor(mx, off, 64));
+        slog += __shfl_xor(slog, off, 64);
+    }
+    if ((tid & 63) == 0) { red_max[tid >> 6] = mx; red_sum[tid >> 6] = slog; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < (int)(blockDim.x / 64); ++w) { mx = fmax(mx, red_max[w]); slog += red_sum[w]; }
+        st->max_uj = mx;
+        st->sum_log_rj = slog;
+        const int inv = (quick && mx >= 1.0) ? 1 : 0;
+        st->invalid = inv;
+        st->invalid_d = (double)inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// moments epilogue: from D = X^T Y partials to rho, rhoinvrho, Qij, Si, Qi-Si^2 and the two log sums
+// (linearcorex.py:260, :264-269, :272-273).  grid-stride over variable groups.
+// dynamic LDS: ry_s[Mp*Mp] (T) + rir_s[VPB*Mp] (T)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int Mp>
+__global__ void __launch_bounds__(PV_THREADS)
+moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride,
+                        const T* __restrict__ W, const double* __restrict__ ry, int64_t V,
+                        double n_samples, double eps, T* __restrict__ rho_o, T* __restrict__ rir_o,
+                        T* __restrict__ qij_o, T* __restrict__ si_o, T* __restrict__ q2_o,
+                        T* __restrict__ hscale_o, double* __restrict__ tcpart,
+                        const int* __restrict__ skip_flag) {
+    constexpr int VPB = PV_THREADS / Mp;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* ry_s = reinterpret_cast<T*>(smem_raw);
+    T* rir_s = ry_s + Mp * Mp;
+    __shared__ T gs_scratch[PV_THREADS / 64];
+    __shared__ double bs_scratch[PV_THREADS / 64];
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+
+    const int tid = threadIdx.x, vl = tid / Mp, j = tid % Mp;
+    for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) ry_s[idx] = (T)ry[idx];
+    __syncthreads();
+
+    const T c1 = (T)(1.0 - eps * eps), c2 = (T)(eps * eps), ns = (T)n_samples;
+    double s1 = 0.0, s2 = 0.0;
+    const int64_t ngroups = (V + VPB - 1) / VPB;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t v = grp * VPB + vl;
+        const bool ok = v < V;
+        const int64_t o = (ok ? v : 0) * Mp + j;
+        T d = dpart[o];
+        for (int k = 1; k < nsplit; ++k) d += dpart[k * pstride + o];
+        const T rho = ok ? (c1 * d / ns + c2 * W[o]) : (T)0;
+        const T inv = (T)1 / ((T)1 - rho * rho);
+        const T rir = rho * inv;
+        __syncthreads();                       // rir_s reuse across iterations
+        rir_s[vl * Mp + j] = rir;
+        const T si = group_sum<Mp, T>(rho * rir, gs_scratch, tid);
+        __syncthreads();
+        T qv = (T)0;
+#pragma unroll 8
+        for (int k = 0; k < Mp; ++k) qv += ry_s[k * Mp + j] * rir_s[vl * Mp + k];   // ry symmetric
+        const T q2 = group_sum<Mp, T>(rir * (qv - si * rho), gs_scratch, tid);
+        if (ok) {
+            rho_o[o] = rho;
+            rir_o[o] = rir;
+            qij_o[o] = qv;
+            if (j == 0) {
+                si_o[v] = si;
+                q2_o[v] = q2;
+                hscale_o[v] = (T)1 / ((T)1 + q2);
+                s1 += (double)log((T)1 + si);
+                s2 += (double)log((T)1 + q2);
+            }
+        }
+    }
+    s1 = block_sum<double>(s1, bs_scratch, tid);
+    s2 = block_sum<double>(s2, bs_scratch, tid);
+    if (tid == 0) { tcpart[2 * blockIdx.x] = s1; tcpart[2 * blockIdx.x + 1] = s2; }
+}
+
+// sum the per-block pairs into the exchange buffer: sbuf[0], sbuf[1]
+__global__ void tc_partials_kernel(const double* __restrict__ tcpart, int nblocks,
+                                   double* __restrict__ sbuf, int nvals,
+                                   const int* __restrict__ skip_flag) {
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+    const int k = threadIdx.x;
+    if (k < nvals) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += tcpart[(int64_t)b * nvals + k];
+        sbuf[k] = s;
+    }
+}
+
+// TC = sum log(1+Si) - 1/2 sum log(1+QiSi2) + 1/2 sum log(1-uj), rounded to the working precision
+template <typename T>
+__global__ void tc_final_kernel(const double* __restrict__ sbuf, SetState* st) {
+    if (st->invalid) { st->tc = __builtin_nan(""); return; }
+    const T tc = (T)sbuf[0] - (T)0.5 * (T)sbuf[1] + (T)0.5 * (T)st->sum_log_rj;
+    st->tc = (double)tc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gradient (linearcorex.py:293-300) and the per-block partial of Bj (:302).
+// dynamic LDS: h_s[Mp*(Mp+1)] (T) + w_s[VPB*Mp] (T) + bj_s[VPB*Mp] (double)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int Mp>
+__global__ void __launch_bounds__(PV_THREADS)
+grad_kernel(const T* __restrict__ W, const T* __restrict__ rho_i, const T* __restrict__ rir_i,
+            const T* __restrict__ qij_i, const T* __restrict__ si_i, const T* __restrict__ q2_i,
+            const double* __restrict__ uj, const double* __restrict__ H /* sbuf, diag ignored */,
+            int64_t V, T* __restrict__ grad_o, double* __restrict__ bjpart) {
+    constexpr int VPB = PV_THREADS / Mp;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* h_s = reinterpret_cast<T*>(smem_raw);        // [Mp][Mp+1]
+    T* w_s = h_s + Mp * (Mp + 1);                   // [VPB][Mp]
+    double* bj_s = reinterpret_cast<double*>(w_s + VPB * Mp + (((VPB * Mp) & 1) ? 1 : 0));
+    const int tid = threadIdx.x, vl = tid / Mp, j = tid % Mp;
+    for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) {
+        const int a = idx / Mp, b = idx % Mp;
+        h_s[a * (Mp + 1) + b] = (a == b) ? (T)0 : (T)H[idx];       // fill_diagonal(H, 0), :295
+    }
+    const T rj = (T)1 - (T)uj[j];
+    __syncthreads();
+    double bj = 0.0;
+    const int64_t ngroups = (V + VPB - 1) / VPB;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t v = grp * VPB + vl;
+        const bool ok = v < V;
+        const int64_t o = (ok ? v : 0) * Mp + j;
+        const T w = ok ? W[o] : (T)0;
+        __syncthreads();
+        w_s[vl * Mp + j] = w;
+        __syncthreads();
+        const T rho = rho_i[o], rir = rir_i[o], qij = qij_i[o];
+        const T si = si_i[ok ? v : 0], q2 = q2_i[ok ? v : 0];
+        const T inv = (T)1 / ((T)1 - rho * rho);
+        T g = w / rj;                                                           // :296
+        g -= (T)2 * inv * rir / ((T)1 + si);                                    // :297
+        g += inv * inv * (((T)1 + rho * rho) * qij - (T)2 * rho * si) / ((T)1 + q2);   // :298-299
+        T hw = (T)0;
+#pragma unroll 8
+        for (int k = 0; k < Mp; ++k) hw += h_s[j * (Mp + 1) + k] * w_s[vl * Mp + k];
+        g += hw;                                                                // :300
+        if (ok) {
+            grad_o[o] = g;
+            bj += (double)(rho * g);
+        }
+    }
+    bj_s[vl * Mp + j] = bj;
+    __syncthreads();
+    if (tid < Mp) {
+        double s = bj_s[tid];
+        for (int k = 1; k < VPB; ++k) s += bj_s[k * Mp + tid];
+        bjpart[(int64_t)blockIdx.x * Mp + tid] = s;
+    }
+}
+
+// Bj partials -> tail of the Y exchange buffer (working dtype)
+template <typename T>
+__global__ void bj_reduce_kernel(const double* __restrict__ bjpart, int nblocks, int Mp,
+                                 T* __restrict__ tail) {
+    const int j = threadIdx.x;
+    if (j < Mp) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += bjpart[(int64_t)b * Mp + j];
+        tail[j] = (T)s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// second half of _sig (:212), update (:303) and the per-block partial of update_tangent (:305)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int Mp>
+__global__ void __launch_bounds__(PV_THREADS)
+update_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, const T* __restrict__ grad,
+              const T* __restrict__ W, const double* __restrict__ uj, const T* __restrict__ bj_tail,
+              int64_t V, double n_samples, double eps, T* __restrict__ update_o,
+              T* __restrict__ sgrad_o, double* __restrict__ tanpart) {
+    __shared__ double bs_scratch[PV_THREADS / 64];
+    const int tid = threadIdx.x;
+    const T c1 = (T)(1.0 - eps * eps), c2 = (T)(eps * eps), ns = (T)n_samples;
+    double tan = 0.0;
+    const int64_t total = V * Mp;
+    for (int64_t o = (int64_t)blockIdx.x * PV_THREADS + tid; o < total;
+         o += (int64_t)gridDim.x * PV_THREADS) {
+        const int j = (int)(o % Mp);
+        T d = dpart[o];
+        for (int k = 1; k < nsplit; ++k) d += dpart[k * pstride + o];
+        const T g = grad[o];
+        const T sg = c1 * d / ns + c2 * g;                                      // :212
+        const T rj = (T)1 - (T)uj[j];
+        const T up = -rj * (g - (T)2 * W[o] / ((T)2 - rj) * bj_tail[j]);         // :303
+        update_o[o] = up;
+        sgrad_o[o] = sg;
+        tan += (double)(sg * up);
+    }
+    tan = block_sum<double>(tan, bs_scratch, tid);
+    if (tid == 0) tanpart[blockIdx.x] = tan;
+}
+
+__global__ void tangent_store_kernel(const double* __restrict__ sbuf, SetState* st) {
+    st->tangent = sbuf[0];
+}
+
+// w_update = ws + eta * update (:320)
+template <typename T>
+__global__ void axpy_kernel(const T* __restrict__ w, const T* __restrict__ up, T eta, int64_t n,
+                            T* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = w[i] + eta * up[i];
+}
+
+// stage change (:130-133): ws *= 0.001*floor(1000*a_j)
+template <typename T>
+__global__ void rescale_kernel(T* __restrict__ w, int64_t n, int Mp, const double* __restrict__ uj,
+                               const double* __restrict__ wmag, double eps_old, double eps_new) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % Mp);
+        const T u = (T)uj[j];
+        T f = (T)1;
+        if (u > (T)0) {
+            const T delta = (T)((eps_new * eps_new - eps_old * eps_old) / (1.0 - eps_new * eps_new)) *
+                            (T)wmag[j] / u;
+            const T a = sqrt((T)((1.0 - eps_old * eps_old)) /
+                             ((T)(1.0 - eps_new * eps_new) * ((T)1 + delta)));
+            f = (T)0.001 * floor((T)1000 * a);
+        }
+        w[i] *= f;
+    }
+}
+
+// ws /= 10*sqrt(uj) (:117)
+template <typename T>
+__global__ void init_scale_kernel(T* __restrict__ w, int64_t n, int Mp, int m,
+                                  const double* __restrict__ uj) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % Mp);
+        if (j < m) w[i] = w[i] / ((T)10 * sqrt((T)uj[j]));
+    }
+}
+
+// ws[order] (:162): out[v][j] = in[v][order[j]] for j < m
+template <typename T>
+__global__ void permute_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t n, int Mp,
+                               int m, const int* __restrict__ order) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % Mp);
+        out[i] = (j < m) ? in[i - j + order[j]] : (T)0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// detail moments (:277-287)
+// ------------------------------------------------------------------------------------------------
+// inverse of ry by Gauss-Jordan with partial pivoting; one block; work: [Mp][2*Mp] doubles (global)
+__global__ void invert_kernel(const double* __restrict__ a, int Mp, double* __restrict__ work,
+                              double* __restrict__ inv) {
+    __shared__ int piv_s;
+    __shared__ double pval_s;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int W2 = 2 * Mp;
+    for (int idx = tid; idx < Mp * W2; idx += nt) {
+        const int r = idx / W2, c = idx % W2;
+        work[idx] = (c < Mp) ? a[r * Mp + c] : ((c - Mp == r) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    for (int col = 0; col < Mp; ++col) {
+        if (tid == 0) {
+            int p = col;
+            double best = fabs(work[col * W2 + col]);
+            for (int r = col + 1; r < Mp; ++r) {
+                const double x = fabs(work[r * W2 + col]);
+                if (x > best) { best = x; p = r; }
+            }
+            piv_s = p;
+        }
+        __syncthreads();
+        const int p = piv_s;
+        if (p != col) {
+            for (int c = tid; c < W2; c += nt) {
+                const double t = work[col * W2 + c];
+                work[col * W2 + c] = work[p * W2 + c];
+                work[p * W2 + c] = t;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) pval_s = work[col * W2 + col];
+        __syncthreads();
+        const double pv = pval_s;
+        for (int c = tid; c < W2; c += nt) work[col * W2 + c] /= pv;
+        __syncthreads();
+        for (int idx = tid; idx < Mp * W2; idx += nt) {
+            const int r = idx / W2, c = idx % W2;
+            if (r != col && c != col) work[idx] -= work[r * W2 + col] * work[col * W2 + c];
+        }
+        __syncthreads();
+        for (int r = tid; r < Mp; r += nt)
+            if (r != col) work[r * W2 + col] = 0.0;
+        __syncthreads();
+    }
+    for (int idx = tid; idx < Mp * Mp; idx += nt) inv[idx] = work[(idx / Mp) * W2 + Mp + idx % Mp];
+}
+
+// X_i Z_j = solve(ry, rho)^T (:280), X_i^2|Y (:281), MI (:278) and the sums behind TCs,
+// TC_no_overlap, TC_direct, additivity (:284-287).
+// partial sums per block: [0..Mp) sum_i MI_ji ; [Mp] sum_i max_j MI ; [Mp+1] sum_i I(X_i;Y) ; [Mp+2] sum_ij MI
+// optional outputs (may be null): mi_o, xz_o [Vp][Mp], x2y_o [Vp]
+// dynamic LDS: ri_s[Mp*Mp] (T) + rho_s[VPB*Mp] (T) + acc_s[VPB*Mp] (double)
+template <typename T, int Mp>
+__global__ void __launch_bounds__(PV_THREADS)
+detail_kernel(const T* __restrict__ rho_i, const double* __restrict__ ryinv, int64_t V, int m,
+              T* __restrict__ mi_o, T* __restrict__ xz_o, T* __restrict__ x2y_o,
+              double* __restrict__ dpart_sums) {
+    constexpr int VPB = PV_THREADS / Mp;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* ri_s = reinterpret_cast<T*>(smem_raw);
+    T* rho_s = ri_s + Mp * Mp;
+    double* acc_s = reinterpret_cast<double*>(rho_s + VPB * Mp + (((VPB * Mp) & 1) ? 1 : 0));
+    __shared__ T gs_scratch[PV_THREADS / 64];
+    __shared__ double bs_scratch[PV_THREADS / 64];
+    const int tid = threadIdx.x, vl = tid / Mp, j = tid % Mp;
+    for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) ri_s[idx] = (T)ryinv[idx];
+    __syncthreads();
+    double col_mi = 0.0, s_max = 0.0, s_ixy = 0.0;
+    const int64_t ngroups = (V + VPB - 1) / VPB;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t v = grp * VPB + vl;
+        const bool ok = v < V;
+        const int64_t o = (ok ? v : 0) * Mp + j;
+        const T rho = ok ? rho_i[o] : (T)0;
+        __syncthreads();
+        rho_s[vl * Mp + j] = rho;
+        __syncthreads();
+        T xz = (T)0;
+#pragma unroll 8
+        for (int k = 0; k < Mp; ++k) xz += ri_s[j * Mp + k] * rho_s[vl * Mp + k];   // (ry^-1 rho)_j
+        const T mi = (T)-0.5 * log1p(-rho * rho);
+        const T dot = group_sum<Mp, T>(xz * rho, gs_scratch, tid);
+        // max over factors of MI (padded factors have MI = 0 <= every real MI)
+        T mx = mi;
+        {
+            constexpr int Wd = Mp < 64 ? Mp : 64;
+#pragma unroll
+            for (int off = Wd / 2; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, Wd));
+            if (Mp > 64) {
+                __syncthreads();
+                if ((tid & 63) == 0) gs_scratch[tid >> 6] = mx;
+                __syncthreads();
+                const int base = (tid >> 6) & ~1;
+                mx = fmax(gs_scratch[base], gs_scratch[base + 1]);
+            }
+        }
+        T x2y = (T)1 - dot;
+        x2y = x2y < (T)1e-6 ? (T)1e-6 : x2y;                                       // clip, :281
+        if (ok) {
+            if (mi_o) mi_o[o] = mi;
+            if (xz_o) xz_o[o] = xz;
+            if (j < m) col_mi += (double)mi;
+            if (j == 0) {
+                if (x2y_o) x2y_o[v] = x2y;
+                s_max += (double)mx;
+                s_ixy += (double)((T)-0.5 * log(x2y));
+            }
+        }
+    }
+    acc_s[vl * Mp + j] = col_mi;
+    __syncthreads();
+    double* outp = dpart_sums + (int64_t)blockIdx.x * (Mp + 3);
+    double colsum = 0.0;
+    if (tid < Mp) {
+        for (int k = 0; k < VPB; ++k) colsum += acc_s[k * Mp + tid];
+        outp[tid] = colsum;
+    }
+    const double tot = block_sum<double>(tid < Mp ? colsum : 0.0, bs_scratch, tid);
+    s_max = block_sum<double>(s_max, bs_scratch, tid);
+    s_ixy = block_sum<double>(s_ixy, bs_scratch, tid);
+    if (tid == 0) { outp[Mp] = s_max; outp[Mp + 1] = s_ixy; outp[Mp + 2] = tot; }
+}
+
+// derived arrays for readback
+template <typename T>
+__global__ void invrho_kernel(const T* __restrict__ rho, int64_t n, T* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (T)1 / ((T)1 - rho[i] * rho[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// get_covariance rows (:446-451): out[r][c] = std_r std_c * (r==c ? 1 : z_r . z_c / (1-eps^2)),
+// z_i = rhoinvrho_i / (1 + Si_i).  64x64 output tile per block, 256 threads, 4x4 per thread.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int Mp>
+__global__ void __launch_bounds__(256)
+covariance_kernel(const T* __restrict__ rir, const T* __restrict__ si, const T* __restrict__ stdv,
+                  int64_t V, int64_t row0, int64_t nrows, double eps, T* __restrict__ out) {
+    constexpr int KC = Mp < 32 ? Mp : 32;      // factor chunk staged in LDS
+    __shared__ T zr[64][KC + 1];
+    __shared__ T zc[64][KC + 1];
+    const int tid = threadIdx.x;
+    const int64_t rb = row0 + (int64_t)blockIdx.y * 64, cb = (int64_t)blockIdx.x * 64;
+    const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;
+    T acc[4][4] = {};
+    for (int j0 = 0; j0 < Mp; j0 += KC) {
+        __syncthreads();
+        for (int idx = tid; idx < 64 * KC; idx += 256) {
+            const int a = idx / KC, j = idx % KC;
+            const int64_t vr = rb + a, vc = cb + a;
+            zr[a][j] = (vr < V && vr < row0 + nrows) ? rir[vr * Mp + j0 + j] / ((T)1 + si[vr]) : (T)0;
+            zc[a][j] = (vc < V) ? rir[vc * Mp + j0 + j] / ((T)1 + si[vc]) : (T)0;
+        }
+        __syncthreads();
+        for (int j = 0; j < KC; ++j) {
+            T a[4], b[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { a[x] = zr[tr + x][j]; b[x] = zc[tc + x][j]; }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[x][y] += a[x] * b[y];
+        }
+    }
+    const T denom = (T)(1.0 - eps * eps);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const int64_t r = rb + tr + x;
+        if (r >= V || r >= row0 + nrows) continue;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const int64_t c = cb + tc + y;
+            if (c >= V) continue;
+            T val = acc[x][y] / denom;
+            if (r == c) val = (T)1;
+            out[(r - row0) * V + c] = stdv[r] * stdv[c] * val;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic data on device: counter-based N(0,1), keyed by (seed, row, global col)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double gauss_at(uint64_t seed, uint64_t a, uint64_t b) {
+    const uint64_t h1 = mix64(seed ^ mix64(a * 0xD1342543DE82EF95ull + b));
+    const uint64_t h2 = mix64(h1 ^ 0xA0761D6478BD642Full);
+    const double u1 = ((double)(h1 >> 11) + 1.0) * (1.0 / 9007199254740993.0);
+    const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925 * u2);
+}
+
+template <typename T>
+__global__ void generate_kernel(T* __restrict__ X, int64_t N, int64_t V, int64_t ldx, uint64_t seed,
+                                int kind, int n_groups, int64_t col_offset) {
+    const int64_t total = N * V;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / V, c = i % V, gc = c + col_offset;
+        double x = gauss_at(seed, (uint64_t)r, (uint64_t)gc);
+        if (kind == 1) {
+            const uint64_t grp = mix64(seed * 31 + (uint64_t)gc) % (uint64_t)n_groups;
+            x += gauss_at(seed ^ 0x5851F42D4C957F2Dull, (uint64_t)r, (1ull << 40) + grp);
+        }
+        X[r * ldx + c] = (T)x;
+    }
+}
+
+// column mean / inverse std over samples, then normalise in place (preprocess 'standard', :409-415)
+template <typename T>
+__global__ void colstats_kernel(const T* __restrict__ X, int64_t N, int64_t V, int64_t ldx,
+                                double* __restrict__ mean, double* __restrict__ istd) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= V) return;
+    double s = 0.0;
+    for (int64_t r = 0; r < N; ++r) s += (double)X[r * ldx + c];
+    const double mu = s / (double)N;
+    double ss = 0.0;
+    for (int64_t r = 0; r < N; ++r) { const double d = (double)X[r * ldx + c] - mu; ss += d * d; }
+    double sd = sqrt(ss / (double)N);
+    if (sd < 1e-10) sd = 1e-10;
+    mean[c] = mu;
+    istd[c] = 1.0 / sd;
+}
+template <typename T>
+__global__ void standardize_kernel(T* __restrict__ X, int64_t N, int64_t V, int64_t ldx,
+                                   const double* __restrict__ mean, const double* __restrict__ istd) {
+    const int64_t total = N * V;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / V, c = i % V;
+        X[r * ldx + c] = (T)(((double)X[r * ldx + c] - mean[c]) * istd[c]);
+    }
+}
+
+}  // namespace lcx

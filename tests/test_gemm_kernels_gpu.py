@@ -1,0 +1,79 @@
+"""Parity of the two X-streaming MFMA kernels in isolation (through the C ABI test entry points)
+against NumPy float64, for every padded n_hidden, both dtypes, ragged sizes and forced splits."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.float32: 2e-5, np.float64: 1e-12}
+
+
+def _asym(n, k, seed):
+    rng = np.random.RandomState(seed)
+    return rng.randn(n, k) + 0.01 * np.arange(k)[None, :] + 0.1 * np.arange(n)[:, None] / max(n, 1)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("m_pad", [16, 32, 64, 128])
+@pytest.mark.parametrize("shape,split,waves", [((70, 45), 1, 1), ((257, 300), 1, 4), ((1000, 1111), 3, 4),
+                                               ((64, 2048), 2, 8), ((333, 64), 1, 2)])
+def test_gemm_nt(dtype, m_pad, shape, split, waves):
+    from linearcorex_amd.backend import gemm_nt_check
+    n, k = shape
+    a = _asym(n, k, 1).astype(dtype)
+    b = _asym(k, m_pad, 2).astype(dtype)          # asymmetric: catches row/col swaps
+    got = gemm_nt_check(a, b, m_pad, dtype, split=split, waves=waves)
+    ref = a.astype(np.float64) @ b.astype(np.float64)
+    scale = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+    assert np.max(np.abs(got - ref) / scale) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("m_pad", [16, 32, 64, 128])
+@pytest.mark.parametrize("shape,split,waves", [((70, 45), 1, 1), ((300, 257), 1, 4), ((1111, 1000), 3, 4),
+                                               ((2048, 64), 2, 8), ((64, 333), 1, 2)])
+def test_gemm_tn(dtype, m_pad, shape, split, waves):
+    from linearcorex_amd.backend import gemm_tn_check
+    k, v = shape
+    a = _asym(k, v, 3).astype(dtype)
+    b = _asym(k, m_pad, 4).astype(dtype)
+    got = gemm_tn_check(a, b, m_pad, dtype, split=split, waves=waves)
+    ref = a.astype(np.float64).T @ b.astype(np.float64)
+    scale = np.abs(a).astype(np.float64).T @ np.abs(b).astype(np.float64)
+    assert np.max(np.abs(got - ref) / scale) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gemm_tn_rowscale(dtype):
+    from linearcorex_amd.backend import gemm_tn_check
+    k, v, m_pad = 500, 200, 32
+    a = _asym(k, v, 5).astype(dtype)
+    b = _asym(k, m_pad, 6).astype(dtype)
+    s = np.random.RandomState(7).rand(k).astype(dtype) + 0.5
+    got = gemm_tn_check(a, b, m_pad, dtype, rowscale=s, split=2, waves=4)
+    ref = (a.astype(np.float64) * s.astype(np.float64)[:, None]).T @ b.astype(np.float64)
+    scale = np.abs(a).astype(np.float64).T @ np.abs(b).astype(np.float64) * 1.5
+    assert np.max(np.abs(got - ref) / scale) < TOL[dtype] * 2
+
+
+def test_gemm_linearity_at_config2_size():
+    """Size-independent property at BASELINE.json config-2 shape (10k x 5k, m=32, f64):
+    (X.(B1+B2)^T) == X.B1^T + X.B2^T and X^T.(Y1+Y2) == X^T.Y1 + X^T.Y2 up to rounding."""
+    from linearcorex_amd.backend import gemm_nt_check, gemm_tn_check
+    rng = np.random.RandomState(0)
+    n, v, m_pad = 10000, 5000, 32
+    x = rng.randn(n, v)
+    b1, b2 = rng.randn(v, m_pad), rng.randn(v, m_pad)
+    y1 = gemm_nt_check(x, b1, m_pad, np.float64, split=3)
+    y2 = gemm_nt_check(x, b2, m_pad, np.float64, split=3)
+    y12 = gemm_nt_check(x, b1 + b2, m_pad, np.float64, split=3)
+    assert np.max(np.abs(y12 - (y1 + y2))) < 1e-10 * np.sqrt(v)
+    # spot check a few rows against NumPy
+    rows = [0, 1, 4999, 9999]
+    assert np.allclose(y1[rows], x[rows] @ b1, rtol=0, atol=1e-10)
+    d1 = gemm_tn_check(x, y1, m_pad, np.float64, split=5)
+    d2 = gemm_tn_check(x, y2, m_pad, np.float64, split=5)
+    d12 = gemm_tn_check(x, y12, m_pad, np.float64, split=5)
+    assert np.max(np.abs(d12 - (d1 + d2)) / np.abs(d12).max()) < 1e-12
+    cols = [0, 17, 4999]
+    assert np.allclose(d1[cols], x[:, cols].T @ y1, rtol=1e-11, atol=1e-7)

@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py - fit iterations/sec of the Linear CorEx hot path on MI355X (BASELINE.json metric).
+
+A "step" is one fixed-point iteration of the fit loop (reference `_update_ns` + its book-keeping,
+linearcorex.py:137-151) inside the reference's 7-stage annealing schedule (:119-134); stage changes
+that fall in the timed window are part of it.  Workload at N=1: BASELINE.json configs[1] -
+synthetic Gaussian X, 10k samples x 5k variables, n_hidden=32, float64.  With N>1 ranks the
+n_variables axis is sharded, 5k variables per GPU (weak scaling): the unit counted in `value` is
+"one iteration over a 10k x 5k x 32 block", so N ranks finish N units per iteration.
+
+    python bench.py --gpus 1 --steps 70 --warmup 7
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_MFMA_PEAK_TFLOPS = 78.6
+FP32_MFMA_PEAK_TFLOPS = 157.3
+
+WORKLOADS = {
+    # name: (n_samples, n_variables per GPU, n_hidden, dtype)
+    "c2": (10000, 5000, 32, "f64"),      # BASELINE.json configs[1]
+    "c3": (50000, 100000, 64, "f32"),    # configs[2] (MFMA roofline run; X generated on device)
+    "c4shard": (50000, 125000, 128, "f32"),  # configs[3], one GPU's shard
+    "tiny": (2000, 640, 8, "f64"),       # plumbing check
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=70)
+    ap.add_argument("--warmup", type=int, default=7)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-iters-per-stage", type=int, default=8,
+                    help="bounded CPU-baseline sample: oracle iterations per annealing stage (0 = skip)")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(x, m, dtype, iters_per_stage):
+    """The NumPy oracle (a port of the reference path, pinned to it bit for bit) on the host cores,
+    same X, same schedule, bounded to iters_per_stage iterations per annealing stage."""
+    from oracle import corex_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    xt = O.preprocess(np.asarray(x, dtype=dtype))[0]
+    stamps = []
+    t0 = time.perf_counter()
+    res = O.fit_ns_preprocessed(xt, m, seed=0, dtype=dtype, max_iter=iters_per_stage, tol=0.0,
+                                on_iteration=lambda *a: stamps.append(time.perf_counter()), finish=False)
+    t1 = time.perf_counter()
+    n_it = len(res.history_tc)
+    return {"value": n_it / (t1 - t0), "unit": "iterations/s", "cores": int(threads), "kind": "port",
+            "sample": "%d iterations (%d per annealing stage x 7) of the same workload, NumPy %s/BLAS threads=%d, "
+                      "%.1f s" % (n_it, iters_per_stage, np.__version__, threads, t1 - t0),
+            "trials_per_iteration": res.n_trials / max(1, n_it)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path is the only product path)")
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from linearcorex_amd.comm import Comm
+        comm = Comm()
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    import __graft_entry__ as ge
+    ge.build()
+    from linearcorex_amd import Corex
+
+    n, v_per, m, tag = WORKLOADS[args.workload]
+    dtype = np.float64 if tag == "f64" else np.float32
+    v_total = v_per * world
+    total_steps = args.warmup + args.steps
+    per_stage = int(math.ceil(total_steps / 7.0))
+
+    model = Corex(n_hidden=m, seed=0, dtype=dtype, tol=0.0, max_iter=10 ** 9, device=local_rank, comm=comm)
+    x_host = None
+    if n * v_per * 8 <= (4 << 30):
+        # Gen-A: iid N(0,1); rank r draws its own 5k columns from RandomState(1 + r)
+        from linearcorex_amd.preprocess import preprocess as pp
+        x_host = np.random.RandomState(1 + rank).randn(n, v_per)
+        xt = pp(x_host.astype(dtype), None, "standard", None)[0]
+        be = model._attach_shard(xt, v_total)
+        del xt
+    else:
+        model.n_samples, model.nv = n, v_total
+        model._cols = model._comm.shard(v_total)
+        be = model._make_backend(n, v_per)
+        be.generate_x(1, 0, 1, model._cols[0])
+        model.theta = (np.zeros(1), np.ones(1))
+
+    def sync():
+        be.synchronize()
+        torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier()
+            torch.cuda.synchronize()
+
+    state = {"step": 0, "t0": None, "t1": None}
+    sched = model._init_weights()
+
+    def one_step():
+        if state["step"] == args.warmup:
+            sync()
+            if not args.no_kernel_timing:
+                be.timing_reset()
+                be.timing_enable(True)
+            model.stats.update(trials=0, invalid_trials=0, moment_evals=0)
+            state["t0"] = time.perf_counter()
+        model._iterate()
+        state["step"] += 1
+        if state["step"] == total_steps:
+            sync()
+            state["t1"] = time.perf_counter()
+            be.timing_enable(False)
+
+    for i_eps, eps in enumerate(sched):
+        if state["step"] >= total_steps:
+            break
+        model._begin_stage(i_eps, eps)
+        for _ in range(per_stage):
+            if state["step"] >= total_steps:
+                break
+            one_step()
+    elapsed = state["t1"] - state["t0"]
+    if comm is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    its_per_s = args.steps / elapsed
+    geo = be.geometry()
+    es = np.dtype(dtype).itemsize
+    timing = be.timing_read() if not args.no_kernel_timing else {}
+    trials = model.stats["trials"] / max(1, args.steps)
+    invalid = model.stats["invalid_trials"] / max(1, args.steps)
+
+    # algorithmic bytes / flops of ONE launch of an X-streaming GEMM on this rank:
+    alg_bytes = es * (n * v_per + m * v_per + n * m)
+    alg_flops = 2.0 * n * v_per * m
+    kernels = {}
+    for name, (cnt, ms) in timing.items():
+        if cnt:
+            avg = ms / cnt * 1e-3
+            kernels[name] = {"launches": cnt, "avg_us": avg * 1e6, "GBps": alg_bytes / avg / 1e9,
+                             "TFLOPs": alg_flops / avg / 1e12}
+    roofline = None
+    if kernels:
+        dom = max(kernels, key=lambda k: kernels[k]["launches"] * kernels[k]["avg_us"])
+        intensity = alg_flops / alg_bytes
+        mfma_peak = FP64_MFMA_PEAK_TFLOPS if tag == "f64" else FP32_MFMA_PEAK_TFLOPS
+        if intensity < mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9):
+            roofline = {"bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None}
+        else:
+            roofline = {"bound": "mfma", "achieved": kernels[dom]["TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s",
+                        "frac": kernels[dom]["TFLOPs"] / mfma_peak, "traffic": None}
+        roofline.update(kernel=dom, avg_launch_us=kernels[dom]["avg_us"], launches=kernels[dom]["launches"],
+                        algorithmic_bytes_per_launch=alg_bytes, algorithmic_flops_per_launch=alg_flops,
+                        all_kernels=kernels)
+
+    out = {
+        "metric": "corex_fit_iterations_per_sec",
+        "value": its_per_s * world,
+        "unit": "iterations/s (10k x 5k x 32 block-iterations; = fit iterations/s at 1 GPU)" if args.workload == "c2"
+                else "iterations/s x GPUs",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": tag, "data": "synthetic",
+        "config": {"workload": "%s: synthetic Gaussian X %d samples x %d variables%s, n_hidden=%d, %s, "
+                               "7-stage annealing, %d iterations per stage"
+                               % (args.workload, n, v_total, " (%d per GPU, variable-sharded)" % v_per if world > 1 else "",
+                                  m, tag, per_stage),
+                   "n_samples": n, "n_variables_total": v_total, "n_variables_per_gpu": v_per, "n_hidden": m,
+                   "fit_iterations_per_sec": its_per_s,
+                   "line_search_trials_per_iteration": trials, "invalid_trials_per_iteration": invalid,
+                   "x_passes_per_iteration": 2 + 2 * trials - invalid,
+                   "launch_geometry": geo, "final_TC": float(model.tc)},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and args.cpu_iters_per_stage > 0 and x_host is not None:
+        out["cpu_baseline"] = cpu_baseline(x_host, m, dtype, args.cpu_iters_per_stage)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -190,7 +190,20 @@ class Corex(object):
         self.n_obs = self.n_samples
         return self._fit_resident()
 
-    def _fit_resident(self, max_total_iter=None):
+    def _attach_shard(self, x_local, nv_total):
+        """Make an already preprocessed column block resident as this rank's shard (bench / tests):
+        x_local is n_samples x (c1-c0) for (c0, c1) = comm.shard(nv_total)."""
+        self.n_samples, self.nv = int(x_local.shape[0]), int(nv_total)
+        self._cols = self._comm.shard(self.nv)
+        assert x_local.shape[1] == self._cols[1] - self._cols[0]
+        be = self._make_backend(self.n_samples, x_local.shape[1])
+        be.upload_x(np.ascontiguousarray(x_local, dtype=self.dtype))
+        if self.theta is None:
+            self.theta = (np.zeros(self.nv, self.dtype), np.ones(self.nv, self.dtype))
+        return be
+
+    def _init_weights(self):
+        """Random start, normalised so that uj = 0.01 (:113-122).  Returns the annealing schedule."""
         if self.m is None:
             raise NotImplementedError("n_hidden=None (pick_n_hidden) is broken in the reference (SURVEY.md §2 #14)")
         if not self.discourage_overlap:
@@ -211,43 +224,59 @@ class Corex(object):
             be.set_ws(np.ascontiguousarray(np.asarray(self.ws, dtype=self.dtype)[:, c0:c1]))
         self.eps = 0
         self.moments = self._calculate_moments(quick=True)                    # :122
+        return anneal_schedule
 
-        for i_eps, eps in enumerate(anneal_schedule):
-            eps0 = self.eps
-            self.eps = eps
-            if i_eps > 0:
-                be.rescale_ws(eps0, eps)                                      # :129-133
-            self.moments = self._calculate_moments(quick=False, details=False)   # :134
-            delta = 0.
-            for i_loop in range(self.max_iter):
-                last_tc = self.tc
-                self.moments = self._update_ns()                              # :139
-                if not self.moments or not np.isfinite(self.tc):              # :144-149
-                    try:
-                        print("Error: TC is no longer finite: {}".format(self.tc))
-                    except Exception:
-                        print("Error... updates giving invalid solutions?")
-                        self.ws = self._gather(be.get_ws(0))
-                        return self
-                delta = np.abs(self.tc - last_tc)
-                self.update_records(self.moments, delta)
-                self.stats["iterations"] += 1
-                if delta < self.tol:
-                    if self.verbose:
-                        print('{:d} iterations to tol: {:f}, TC={:f}'.format(i_loop, self.tol, self.tc))
-                    break
-                if max_total_iter is not None and self.stats["iterations"] >= max_total_iter:
-                    break
-            else:
-                if self.verbose:
-                    print("Warning: Convergence not achieved in {:d} iterations. "
-                          "Final delta: {:f}".format(self.max_iter, float(delta)))
+    def _begin_stage(self, i_eps, eps):
+        """Change the annealing parameter and rescale so that uj < 1 still holds (:127-134)."""
+        eps0 = self.eps
+        self.eps = eps
+        if i_eps > 0:
+            self._backend.rescale_ws(eps0, eps)                               # :129-133
+        self.moments = self._calculate_moments(quick=False, details=False)    # :134
+
+    def _iterate(self):
+        """One pass of the loop body (:137-151).  Returns delta, or None if the solution went invalid."""
+        last_tc = self.tc
+        self.moments = self._update_ns()                                      # :139
+        if not self.moments or not np.isfinite(self.tc):                      # :144-149
+            try:
+                print("Error: TC is no longer finite: {}".format(self.tc))
+            except Exception:
+                print("Error... updates giving invalid solutions?")
+                return None
+        delta = np.abs(self.tc - last_tc)
+        self.update_records(self.moments, delta)
+        self.stats["iterations"] += 1
+        return delta
+
+    def _finish(self):
+        """Detail moments, sort factors by TC, recompute (:160-163)."""
+        be = self._backend
         self.moments = self._calculate_moments(quick=False, details=True)     # :160
         order = np.argsort(-self.moments["TCs"])                              # :161
         be.permute_factors(order)                                             # :162
         self.moments = self._calculate_moments(quick=False, details=True)     # :163
         self.ws = self._gather(be.get_ws(0))
         return self
+
+    def _fit_resident(self):
+        for i_eps, eps in enumerate(self._init_weights()):
+            self._begin_stage(i_eps, eps)
+            delta = 0.
+            for i_loop in range(self.max_iter):
+                delta = self._iterate()
+                if delta is None:
+                    self.ws = self._gather(self._backend.get_ws(0))
+                    return self
+                if delta < self.tol:
+                    if self.verbose:
+                        print('{:d} iterations to tol: {:f}, TC={:f}'.format(i_loop, self.tol, self.tc))
+                    break
+            else:
+                if self.verbose:
+                    print("Warning: Convergence not achieved in {:d} iterations. "
+                          "Final delta: {:f}".format(self.max_iter, float(delta)))
+        return self._finish()
 
     def update_records(self, moments, delta):
         """History book-keeping (linearcorex.py:166-175)."""
@@ -346,6 +375,7 @@ class Corex(object):
             if update_tangent is None:
                 update_tangent = be.read_state(0)[3]
                 if update_tangent >= 0:                                        # :306-311
+                    self.stats["trials"] -= 1      # the speculative trial is discarded
                     print('Warning: covariance is nearly singular and this causes a loss of numerical precision.'
                           'For this reason, we can no longer find an update that increases the objective. '
                           'Hopefully this is a good solution. If not, this is caused by having many variables that are '

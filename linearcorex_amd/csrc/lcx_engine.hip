@@ -367,7 +367,7 @@ template <typename T, int CT> struct Impl {
                            h->ryinv, h->V, h->M, mi_o, xz_o, x2y_o, h->detpart);
         KCHECK();
         hipLaunchKernelGGL(tc_partials_kernel, dim3(1), dim3(192), 0, h->stream, h->detpart, h->pv_grid, h->sbuf,
-                           Mp + 3, (const int*)nullptr);
+                           h->M + 3, (const int*)nullptr);
         KCHECK();
         return LCX_OK;
     }

@@ -417,7 +417,7 @@ __global__ void invert_kernel(const double* __restrict__ a, int Mp, double* __re
 
 // X_i Z_j = solve(ry, rho)^T (:280), X_i^2|Y (:281), MI (:278) and the sums behind TCs,
 // TC_no_overlap, TC_direct, additivity (:284-287).
-// partial sums per block: [0..Mp) sum_i MI_ji ; [Mp] sum_i max_j MI ; [Mp+1] sum_i I(X_i;Y) ; [Mp+2] sum_ij MI
+// partial sums per block: [0..m) sum_i MI_ji ; [m] sum_i max_j MI ; [m+1] sum_i I(X_i;Y) ; [m+2] sum_ij MI
 // optional outputs (may be null): mi_o, xz_o [Vp][Mp], x2y_o [Vp]
 // dynamic LDS: ri_s[Mp*Mp] (T) + rho_s[VPB*Mp] (T) + acc_s[VPB*Mp] (double)
 template <typename T, int Mp>
@@ -479,16 +479,16 @@ detail_kernel(const T* __restrict__ rho_i, const double* __restrict__ ryinv, int
     }
     acc_s[vl * Mp + j] = col_mi;
     __syncthreads();
-    double* outp = dpart_sums + (int64_t)blockIdx.x * (Mp + 3);
+    double* outp = dpart_sums + (int64_t)blockIdx.x * (m + 3);      // compact: m sums + 3 scalars
     double colsum = 0.0;
-    if (tid < Mp) {
+    if (tid < m) {
         for (int k = 0; k < VPB; ++k) colsum += acc_s[k * Mp + tid];
         outp[tid] = colsum;
     }
-    const double tot = block_sum<double>(tid < Mp ? colsum : 0.0, bs_scratch, tid);
+    const double tot = block_sum<double>(tid < m ? colsum : 0.0, bs_scratch, tid);
     s_max = block_sum<double>(s_max, bs_scratch, tid);
     s_ixy = block_sum<double>(s_ixy, bs_scratch, tid);
-    if (tid == 0) { outp[Mp] = s_max; outp[Mp + 1] = s_ixy; outp[Mp + 2] = tot; }
+    if (tid == 0) { outp[m] = s_max; outp[m + 1] = s_ixy; outp[m + 2] = tot; }
 }
 
 // derived arrays for readback

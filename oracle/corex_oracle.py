@@ -261,9 +261,18 @@ def fit_ns(x, n_hidden, seed=0, max_iter=10000, tol=1e-5, anneal=True, dtype=np.
 
     w0 != None reproduces the warm-start path (skip init, schedule [0.], ref :113-119).
     on_iteration(stage, it, w, mo, info) is a test hook."""
-    out = OracleFit()
     x = np.asarray(x, dtype=dtype)                                          # ref :108
-    x, out.theta, _ = preprocess(x, None, gaussianize, missing_values)
+    x, theta, _ = preprocess(x, None, gaussianize, missing_values)
+    out = fit_ns_preprocessed(x, n_hidden, seed, max_iter, tol, anneal, dtype, w0, keep_x, on_iteration)
+    out.theta = theta
+    return out
+
+
+def fit_ns_preprocessed(x, n_hidden, seed=0, max_iter=10000, tol=1e-5, anneal=True, dtype=np.float32,
+                        w0=None, keep_x=False, on_iteration=None, finish=True):
+    """The loop of ref :110-164 on an already preprocessed x (finish=False stops before the
+    final detail moments / factor sort of ref :160-163 - the region bench.py times)."""
+    out = OracleFit()
     ns, nv = x.shape
     if w0 is None:
         w = initial_weights(seed, n_hidden, nv, dtype)
@@ -298,6 +307,9 @@ def fit_ns(x, n_hidden, seed=0, max_iter=10000, tol=1e-5, anneal=True, dtype=np.
             if delta < tol:                                                 # ref :152
                 break
         out.stage_iters.append(n_it)
+    if not finish:
+        out.ws, out.moments, out.eps = w, mo, eps
+        return out
     mo = moments_ns(x, w, eps, quick=False)                                 # ref :160
     order = np.argsort(-mo["TCs"])                                          # ref :161
     w = w[order]

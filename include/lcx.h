@@ -181,6 +181,9 @@ int lcx_project(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, void
 int lcx_timing_enable(lcx_ctx* h, int enable);
 int lcx_timing_read(lcx_ctx* h, int kind, int64_t* launches, double* total_ms);
 int lcx_timing_reset(lcx_ctx* h);
+/* micro-benchmark: `iters` back-to-back launches of one X-streaming GEMM (kind as above, with its
+ * partial-sum reduction) on the resident X; returns the average wall time per launch from HIP events */
+int lcx_bench_gemm(lcx_ctx* h, int kind, int iters, double* avg_ms);
 /* geometry actually used (for the roofline arithmetic): padded sizes and launch shapes */
 int lcx_geometry(lcx_ctx* h, int64_t* n_pad, int64_t* ldx, int* m_pad, int64_t* info8);
 

@@ -57,8 +57,8 @@ class HipBackend:
         n_pad, ldx, mp = C.c_int64(), C.c_int64(), C.c_int()
         info = (C.c_int64 * 8)()
         _abi.check(self.lib.lcx_geometry(self.h, C.byref(n_pad), C.byref(ldx), C.byref(mp), info))
-        names = ["nt_split", "nt_waves", "tn_split", "tn_waves", "gram_n_split", "gram_v_split",
-                 "pv_grid", "target_waves"]
+        names = ["nt_split", "nt_waves", "tn_split", "tn_waves", "nt_blocks_per_cu", "tn_blocks_per_cu",
+                 "pv_grid", "n_cus"]
         g = dict(zip(names, [int(v) for v in info]))
         g.update(n_pad=n_pad.value, ldx=ldx.value, m_pad=mp.value)
         return g
@@ -76,6 +76,11 @@ class HipBackend:
             _abi.check(self.lib.lcx_timing_read(self.h, kind, C.byref(n), C.byref(ms)))
             out[name] = (n.value, ms.value)
         return out
+
+    def bench_gemm(self, kind, iters=20):
+        ms = C.c_double()
+        _abi.check(self.lib.lcx_bench_gemm(self.h, int(kind), int(iters), C.byref(ms)))
+        return ms.value
 
     def synchronize(self):
         _abi.check(self.lib.lcx_synchronize(self.h))

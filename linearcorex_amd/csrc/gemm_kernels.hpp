@@ -148,16 +148,18 @@ gemm_nt_kernel(const T* __restrict__ X, int64_t ldx, const T* __restrict__ B, T*
 // ------------------------------------------------------------------------------------------------
 // gemm_tn: columns of A (contraction over rows) times B[k][Mp].
 // grid = (column tiles of 16*RT, nsplit); block = 64*KW threads.
-// A: [K][lda] with K a multiple of 16 and the tile columns in bounds (zero padded);
+// A: [K][lda] (or panel-major, see below) with K a multiple of 64 and the tile columns in bounds;
 // optional per-row scale of A (used for H, linearcorex.py:294).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int CT, int RT, int KW, bool SCALE>
+// MODE is for ablation probes only (tools/gemm_probe.hip): 0 = real kernel, 1 = loads without MFMA,
+// 2 = MFMA without loads (registers loaded once).
+template <typename T, int CT, int RT, int KW, bool SCALE, int MODE = 0, int U = 4>
 __global__ void __launch_bounds__(64 * KW)
-gemm_tn_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+gemm_tn_kernel(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const T* __restrict__ B,
                const T* __restrict__ rowscale, T* __restrict__ out, int64_t out_rows, int kgroups,
                int nsplit, const int* __restrict__ skip_flag) {
     constexpr int Mp = 16 * CT;
-    constexpr int U = 4;                      // MFMA steps per group; a group is 16 rows of A
+    // U = MFMA steps per group; a group is 4*U rows of A (kgroups counts 16-row units)
     typedef typename MF<T>::acc_t acc_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* red = reinterpret_cast<T*>(smem_raw);  // [KW][16*RT][Mp]
@@ -168,8 +170,9 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
     const int i = lane & 15, q = lane >> 4;
     const int64_t v0 = (int64_t)blockIdx.x * (16 * RT);
     const int part = blockIdx.y * KW + wave, nparts = nsplit * KW;
-    const int g0 = (int)((int64_t)kgroups * part / nparts);
-    const int g1 = (int)((int64_t)kgroups * (part + 1) / nparts);
+    const int ng = kgroups * 4 / U;           // groups of 4*U rows (K is a multiple of 64)
+    const int g0 = (int)((int64_t)ng * part / nparts);
+    const int g1 = (int)((int64_t)ng * (part + 1) / nparts);
 
     acc_t acc[RT][CT];
 #pragma unroll
@@ -177,7 +180,10 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
 #pragma unroll
         for (int u = 0; u < CT; ++u) acc[t][u] = (acc_t){0, 0, 0, 0};
 
-    const T* ap = A + (int64_t)q * lda + v0 + i * RT;
+    // plain row-major A: tile_stride = 16*RT, lda = row length.  Panel-major A (each column tile
+    // stored as its own contiguous [K][16*RT] slab): tile_stride = K*16*RT, lda = 16*RT, so a
+    // wave streams one contiguous region of HBM.
+    const T* ap = A + (int64_t)blockIdx.x * tile_stride + (int64_t)q * lda + i * RT;
     const T* bp = B + (int64_t)q * Mp + i * CT;
 
     Pk<T, RT> a0[U], a1[U];
@@ -185,8 +191,8 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
     T s0[U], s1[U];
 
 #define LCX_TN_LOAD(G, AA, BB, SS)                                                    \
-    {                                                                                 \
-        const int64_t rb = (int64_t)(G) * 16;                                         \
+    if (MODE != 2 || (G) == g0) {                                                     \
+        const int64_t rb = (int64_t)(G) * (4 * U);                                    \
         _Pragma("unroll") for (int st = 0; st < U; ++st) {                            \
             AA[st] = ldg<T, RT>(ap + (rb + 4 * st) * lda);                            \
             BB[st] = ldg<T, CT>(bp + (rb + 4 * st) * Mp);                             \
@@ -198,13 +204,16 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
         _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
         _Pragma("unroll") for (int t = 0; t < RT; ++t) {                              \
             const T av = SCALE ? AA[st].v[t] * SS[st] : AA[st].v[t];                  \
-            _Pragma("unroll") for (int u = 0; u < CT; ++u)                            \
-                acc[t][u] = MF<T>::mma(av, BB[st].v[u], acc[t][u]);                   \
+            _Pragma("unroll") for (int u = 0; u < CT; ++u) {                          \
+                if (MODE == 1) { asm volatile("" ::"v"(av), "v"(BB[st].v[u])); }      \
+                else acc[t][u] = MF<T>::mma(av, BB[st].v[u], acc[t][u]);              \
+            }                                                                         \
         }                                                                             \
     }
 
     if (g0 < g1) {
         LCX_TN_LOAD(g0, a0, b0, s0);
+        if (MODE == 2) { LCX_TN_LOAD(g0, a1, b1, s1); }
         int g = g0;
         while (true) {
             int gn = (g + 1 < g1) ? g + 1 : g1 - 1;
@@ -241,8 +250,10 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
 
 // tile shapes per (dtype, CT): chosen so accumulators + two register sets stay under ~200 VGPRs
 template <typename T, int CT> struct NtShape { static constexpr int RT = (sizeof(T) == 8 && CT >= 8) ? 1 : 2; };
+// tn: wave tile = 16*RT columns of A.  Measured on MI355X (tools/gemm_probe, 10k x 5k f64, Mp=32):
+// 64-column tiles (512 B per row per wave) stream ~8 % faster than 32-column ones.
 template <typename T, int CT> struct TnShape {
-    static constexpr int RT = (sizeof(T) == 8) ? (CT >= 8 ? 1 : 2) : (CT >= 8 ? 2 : 4);
+    static constexpr int RT = (sizeof(T) == 8) ? (CT >= 8 ? 1 : (CT >= 4 ? 2 : 4)) : (CT >= 8 ? 2 : 4);
 };
 
 }  // namespace lcx

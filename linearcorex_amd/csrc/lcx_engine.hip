@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -64,20 +65,21 @@ struct lcx_ctx {
     int64_t N, V, Npad, ldx;    // ldx == Vp
     int M, Mp, CT;
     hipStream_t own_stream, stream;
-    void* X;
+    void* X;                    // [Npad][ldx]
+    void* XT;                   // [ldx][Npad] transposed copy
     void* Wt[2];
     MomentSet set[2];
     void *grad, *update, *sgrad, *scratch;
     void *ybuf_own, *ybuf;
     double *sbuf_own, *sbuf;
     int64_t ybuf_elems, sbuf_elems;
-    void *ypart, *dpart, *gpart;
+    void *ypart, *dpart, *gpart, *gsum;
     double *tcpart, *bjpart, *tanpart, *detpart, *ryinv, *invwork;
     SetState* states;           // device [2]
     SetState* host_states;      // pinned [2]
     int* order_dev;
     // launch geometry
-    int nt_S, nt_KW, tn_S, tn_KW, gn_S, gv_S, pv_grid, target_waves;
+    int nt_S, nt_KW, tn_S, tn_KW, gn_S, gv_S, pv_grid, target_waves, n_cus, nt_bpc, tn_bpc;
     // timing
     bool timing;
     std::vector<TimingPair> pending;
@@ -150,10 +152,10 @@ static int launch_tn(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t
     dim3 grid((unsigned)(vcols_pad / (16 * RT)), (unsigned)S);
     const size_t lds = (size_t)KW * 16 * RT * 16 * CT * sizeof(T);
     switch (KW) {
-        case 1: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 1, SCALE>), grid, dim3(64), lds, st, A, lda, B, rowscale, out, vcols_pad, kgroups, S, skip); break;
-        case 2: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 2, SCALE>), grid, dim3(128), lds, st, A, lda, B, rowscale, out, vcols_pad, kgroups, S, skip); break;
-        case 4: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 4, SCALE>), grid, dim3(256), lds, st, A, lda, B, rowscale, out, vcols_pad, kgroups, S, skip); break;
-        default: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 8, SCALE>), grid, dim3(512), lds, st, A, lda, B, rowscale, out, vcols_pad, kgroups, S, skip); break;
+        case 1: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 1, SCALE>), grid, dim3(64), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
+        case 2: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 2, SCALE>), grid, dim3(128), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
+        case 4: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 4, SCALE>), grid, dim3(256), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
+        default: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 8, SCALE>), grid, dim3(512), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
     }
     KCHECK();
     return LCX_OK;
@@ -190,17 +192,74 @@ template <typename T, int CT> struct Impl {
     static constexpr int Mp = 16 * CT;
     static constexpr int VPB = PV_THREADS / Mp;
 
+    // resident blocks per CU of a kernel at a given block size / dynamic LDS
+    template <typename F> static int blocks_per_cu(F* f, int threads, size_t lds) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)f, threads, lds) != hipSuccess || n < 1) n = 1;
+        return n;
+    }
+    static int env_int(const char* name, int dflt) {
+        const char* v = getenv(name);
+        return (v && *v) ? atoi(v) : dflt;
+    }
+    // Split of the contraction.  These launches are HBM-bound and every block lives for the whole
+    // launch, so what matters is how full the last "round" of resident blocks is: 1.03 rounds cost
+    // almost 2 (measured: 632 blocks on 512 slots 102 us vs 474 blocks 79 us).  Pick the split that
+    // fills whole rounds best, with a small penalty per extra split (partial tiles to write + sum).
+    static int single_round_split(int64_t tiles, int64_t capacity_blocks, int64_t kunits, int kw, int cap) {
+        if (tiles < 1) tiles = 1;
+        if (capacity_blocks < 1) capacity_blocks = 1;
+        int64_t by_work = kunits / ((int64_t)kw * 4);
+        if (by_work > cap) by_work = cap;
+        if (by_work < 1) by_work = 1;
+        int best = 1;
+        double best_score = -1.0;
+        for (int s = 1; s <= by_work; ++s) {
+            const int64_t blocks = tiles * s;
+            const int64_t rounds = (blocks + capacity_blocks - 1) / capacity_blocks;
+            const double score = (double)blocks / (double)(rounds * capacity_blocks) - 0.015 * s;
+            if (score > best_score + 1e-9) { best_score = score; best = s; }
+        }
+        return best;
+    }
+
     static int geometry(lcx_ctx* h) {
+        constexpr int NT_RT = Geo<T, CT>::NT_RT, TN_RT = Geo<T, CT>::TN_RT;
         const int64_t nchunks = h->ldx / Geo<T, CT>::CH;
-        h->nt_KW = pick_kw(nchunks);
-        h->nt_S = pick_split(h->Npad / (16 * Geo<T, CT>::NT_RT), h->nt_KW, nchunks, h->target_waves, 16);
         const int64_t kgn = h->Npad / 16, kgv = h->ldx / 16;
-        h->tn_KW = pick_kw(kgn);
-        h->tn_S = pick_split(h->ldx / (16 * Geo<T, CT>::TN_RT), h->tn_KW, kgn, h->target_waves, 32);
-        h->gn_S = pick_split(Mp / (16 * Geo<T, CT>::G_RT), pick_kw(kgn), kgn, h->target_waves / 2, 128);
-        h->gv_S = pick_split(Mp / (16 * Geo<T, CT>::G_RT), pick_kw(kgv), kgv, h->target_waves / 2, 128);
+        const int cus = h->n_cus;
+        // X . B^T, computed as XT^T . B with the tn kernel: tiles over n, contraction over v
+        h->nt_KW = env_int("LCX_NT_KW", pick_kw(kgv));
+        {
+            const size_t lds = (size_t)h->nt_KW * 16 * TN_RT * Mp * sizeof(T);
+            int bpc = 1;
+            switch (h->nt_KW) {
+                case 1: bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, 1, false>, 64, lds); break;
+                case 2: bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, 2, false>, 128, lds); break;
+                case 4: bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, 4, false>, 256, lds); break;
+                default: h->nt_KW = 8; bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, 8, false>, 512, lds); break;
+            }
+            h->nt_bpc = bpc;
+            h->nt_S = env_int("LCX_NT_S", single_round_split(h->Npad / (16 * TN_RT), (int64_t)bpc * cus, kgv, h->nt_KW, 16));
+        }
+        // X^T . Y
+        h->tn_KW = env_int("LCX_TN_KW", pick_kw(kgn));
+        {
+            const size_t lds = (size_t)h->tn_KW * 16 * TN_RT * Mp * sizeof(T);
+            int bpc = 1;
+            switch (h->tn_KW) {
+                case 1: bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, 1, false>, 64, lds); break;
+                case 2: bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, 2, false>, 128, lds); break;
+                case 4: bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, 4, false>, 256, lds); break;
+                default: h->tn_KW = 8; bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, 8, false>, 512, lds); break;
+            }
+            h->tn_bpc = bpc;
+            h->tn_S = env_int("LCX_TN_S", single_round_split(h->ldx / (16 * TN_RT), (int64_t)bpc * cus, kgn, h->tn_KW, 32));
+        }
+        h->gn_S = pick_split(Mp / (16 * Geo<T, CT>::G_RT), pick_kw(kgn), kgn, h->target_waves / 4, 64);
+        h->gv_S = pick_split(Mp / (16 * Geo<T, CT>::G_RT), pick_kw(kgv), kgv, h->target_waves / 4, 64);
         int64_t groups = cdiv(h->V, VPB);
-        h->pv_grid = (int)(groups < 2048 ? (groups < 1 ? 1 : groups) : 2048);
+        h->pv_grid = (int)(groups < 1024 ? (groups < 1 ? 1 : groups) : 1024);
         return LCX_OK;
     }
 
@@ -213,11 +272,14 @@ template <typename T, int CT> struct Impl {
         return launch_tn<T, CT, RT, false>(h->stream, A, Mp, K, Mp, A, nullptr, P<T>(h->gpart), S, kw, skip);
     }
 
-    static int nt_big(lcx_ctx* h, const T* B, const int* skip) {
+    // Y(_partial) = X . B^T (linearcorex.py:247 / :210) as a contraction over the rows of XT
+    static int nt_big(lcx_ctx* h, const void* Bv, const int* skip) {
+        const T* B = reinterpret_cast<const T*>(Bv);
         TimingPair tp;
         LCXCHECK(timing_begin(h, 0, &tp));
         T* dst = h->nt_S > 1 ? P<T>(h->ypart) : P<T>(h->ybuf);
-        LCXCHECK((launch_nt<T, CT>(h->stream, P<T>(h->X), h->ldx, h->Npad, B, dst, h->nt_S, h->nt_KW, skip)));
+        LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, B, nullptr,
+                                                               dst, h->nt_S, h->nt_KW, skip)));
         LCXCHECK(timing_end(h, 0, &tp));
         if (h->nt_S > 1) {
             const int64_t n = h->Npad * Mp;
@@ -225,6 +287,13 @@ template <typename T, int CT> struct Impl {
                                h->stream, P<T>(h->ypart), h->nt_S, n, n, P<T>(h->ybuf), skip);
             KCHECK();
         }
+        return LCX_OK;
+    }
+    static int make_xt(lcx_ctx* h) {
+        dim3 grid((unsigned)(h->ldx / 64), (unsigned)(h->Npad / 64));
+        hipLaunchKernelGGL((transpose_kernel<T>), grid, dim3(256), 0, h->stream, P<T>(h->X), h->ldx, P<T>(h->XT), h->Npad);
+        KCHECK();
+        HIPCHECK(hipStreamSynchronize(h->stream));
         return LCX_OK;
     }
     static int tn_big(lcx_ctx* h, const int* skip) {
@@ -241,7 +310,7 @@ template <typename T, int CT> struct Impl {
         LCXCHECK(nt_big(h, w, nullptr));
         // W W^T partials over the shard -> tail of ybuf
         LCXCHECK(gram(h, w, h->ldx, nullptr, h->gv_S, nullptr));
-        hipLaunchKernelGGL((reduce_partials_kernel<T, T>), dim3(cdiv(Mp * Mp, 256)), dim3(256), 0, h->stream,
+        hipLaunchKernelGGL((reduce_wide_kernel<T, T>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
                            P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp,
                            P<T>(h->ybuf) + h->Npad * Mp, (const int*)nullptr);
         KCHECK();
@@ -252,8 +321,11 @@ template <typename T, int CT> struct Impl {
         MomentSet& s = h->set[which];
         LCXCHECK(gram(h, P<T>(h->ybuf), h->Npad, nullptr, h->gn_S, nullptr));
         SmallDesc sd{s.uj, s.ry, s.wmag};
-        hipLaunchKernelGGL((small_moments_kernel<T>), dim3(1), dim3(PV_THREADS), 0, h->stream, P<T>(h->gpart),
-                           h->gn_S, P<T>(h->ybuf) + h->Npad * Mp, Mp, h->M, (double)h->N, eps, quick, sd, s.st);
+        hipLaunchKernelGGL((reduce_wide_kernel<T, T>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
+                           P<T>(h->gpart), h->gn_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, P<T>(h->gsum), (const int*)nullptr);
+        KCHECK();
+        hipLaunchKernelGGL((small_moments_kernel<T>), dim3(1), dim3(PV_THREADS), 0, h->stream, P<T>(h->gsum),
+                           1, P<T>(h->ybuf) + h->Npad * Mp, Mp, h->M, (double)h->N, eps, quick, sd, s.st);
         KCHECK();
         return LCX_OK;
     }
@@ -270,7 +342,7 @@ template <typename T, int CT> struct Impl {
                            P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), P<T>(s.hscale),
                            h->tcpart, skip);
         KCHECK();
-        hipLaunchKernelGGL(tc_partials_kernel, dim3(1), dim3(64), 0, h->stream, h->tcpart, h->pv_grid, h->sbuf, 2, skip);
+        hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(2), dim3(PV_THREADS), 0, h->stream, h->tcpart, h->pv_grid, 2, h->sbuf, skip);
         KCHECK();
         return LCX_OK;
     }
@@ -284,7 +356,7 @@ template <typename T, int CT> struct Impl {
     static int update_a(lcx_ctx* h) {
         MomentSet& s = h->set[0];
         LCXCHECK(gram(h, P<T>(s.rir), h->ldx, P<T>(s.hscale), h->gv_S, nullptr));
-        hipLaunchKernelGGL((reduce_partials_kernel<T, double>), dim3(cdiv(Mp * Mp, 256)), dim3(256), 0, h->stream,
+        hipLaunchKernelGGL((reduce_wide_kernel<T, double>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
                            P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, h->sbuf, (const int*)nullptr);
         KCHECK();
         return LCX_OK;
@@ -300,8 +372,8 @@ template <typename T, int CT> struct Impl {
                            P<T>(h->grad), h->bjpart);
         KCHECK();
         LCXCHECK(nt_big(h, P<T>(h->grad), nullptr));
-        hipLaunchKernelGGL((bj_reduce_kernel<T>), dim3(1), dim3(128), 0, h->stream, h->bjpart, h->pv_grid, Mp,
-                           P<T>(h->ybuf) + h->Npad * Mp);
+        hipLaunchKernelGGL((sum_partials_kernel<T>), dim3(Mp), dim3(PV_THREADS), 0, h->stream, h->bjpart, h->pv_grid, Mp,
+                           P<T>(h->ybuf) + h->Npad * Mp, (const int*)nullptr);
         KCHECK();
         return LCX_OK;
     }
@@ -314,7 +386,7 @@ template <typename T, int CT> struct Impl {
                            h->ldx * Mp, P<T>(h->grad), P<T>(h->Wt[0]), s.uj, P<T>(h->ybuf) + h->Npad * Mp, h->V,
                            (double)h->N, eps, P<T>(h->update), P<T>(h->sgrad), h->tanpart);
         KCHECK();
-        hipLaunchKernelGGL(tc_partials_kernel, dim3(1), dim3(64), 0, h->stream, h->tanpart, grid, h->sbuf, 1,
+        hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(1), dim3(PV_THREADS), 0, h->stream, h->tanpart, grid, 1, h->sbuf,
                            (const int*)nullptr);
         KCHECK();
         return LCX_OK;
@@ -366,8 +438,8 @@ template <typename T, int CT> struct Impl {
         hipLaunchKernelGGL((detail_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(s.rho),
                            h->ryinv, h->V, h->M, mi_o, xz_o, x2y_o, h->detpart);
         KCHECK();
-        hipLaunchKernelGGL(tc_partials_kernel, dim3(1), dim3(192), 0, h->stream, h->detpart, h->pv_grid, h->sbuf,
-                           h->M + 3, (const int*)nullptr);
+        hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(h->M + 3), dim3(PV_THREADS), 0, h->stream, h->detpart, h->pv_grid,
+                           h->M + 3, h->sbuf, (const int*)nullptr);
         KCHECK();
         return LCX_OK;
     }
@@ -500,7 +572,7 @@ template <typename T, int CT> struct Impl {
             HIPCHECK(hipMemsetAsync(xd, 0, sizeof(T) * rows_pad * h->ldx, h->stream));
             HIPCHECK(hipMemcpy2DAsync(xd, h->ldx * sizeof(T), reinterpret_cast<const T*>(x_host) + r0 * ld, ld * sizeof(T),
                                       h->V * sizeof(T), nr, hipMemcpyHostToDevice, h->stream));
-            LCXCHECK((launch_nt<T, CT>(h->stream, xd, h->ldx, rows_pad, P<T>(h->Wt[0]), yd, 1, h->nt_KW, nullptr)));
+            LCXCHECK((launch_nt<T, CT>(h->stream, xd, h->ldx, rows_pad, P<T>(h->Wt[0]), yd, 1, 4, nullptr)));
             HIPCHECK(hipMemcpyAsync(tmp.data(), yd, sizeof(T) * rows_pad * Mp, hipMemcpyDeviceToHost, h->stream));
             HIPCHECK(hipStreamSynchronize(h->stream));
             for (int64_t r = 0; r < nr; ++r)
@@ -527,7 +599,7 @@ template <typename T, int CT> struct Impl {
         HIPCHECK(hipStreamSynchronize(h->stream));
         HIPCHECK(hipFree(mean));
         HIPCHECK(hipFree(istd));
-        return LCX_OK;
+        return make_xt(h);
     }
 };
 
@@ -675,6 +747,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     h->t_ms[0] = h->t_ms[1] = 0.0;
     h->have_direction = false;
     h->target_waves = prop.multiProcessorCount * 12;
+    h->n_cus = prop.multiProcessorCount;
     HIPCHECK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     hipStream_t st = h->stream;
@@ -692,6 +765,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     const int Mp = h->Mp;
 #define A_(ptr, bytes) do { int r_ = dev_alloc((void**)&(ptr), (bytes), st); if (r_ != LCX_OK) return r_; } while (0)
     A_(h->X, (size_t)h->Npad * h->ldx * es);
+    A_(h->XT, (size_t)h->Npad * h->ldx * es);
     for (int k = 0; k < 2; ++k) {
         A_(h->Wt[k], mv);
         A_(h->set[k].rho, mv);
@@ -719,6 +793,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     {
         const int gs = h->gn_S > h->gv_S ? h->gn_S : h->gv_S;
         A_(h->gpart, (size_t)gs * Mp * Mp * es);
+        A_(h->gsum, (size_t)Mp * Mp * es);
     }
     A_(h->tcpart, sizeof(double) * 2 * 2048);
     A_(h->bjpart, sizeof(double) * Mp * 2048);
@@ -741,8 +816,8 @@ int lcx_destroy(lcx_ctx* h) {
     if (!h) return LCX_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->X, h->Wt[0], h->Wt[1], h->grad, h->update, h->sgrad, h->scratch, h->ybuf_own, h->sbuf_own,
-                    h->ypart, h->dpart, h->gpart, h->tcpart, h->bjpart, h->tanpart, h->detpart, h->ryinv, h->invwork,
+    void* ptrs[] = {h->X, h->XT, h->Wt[0], h->Wt[1], h->grad, h->update, h->sgrad, h->scratch, h->ybuf_own, h->sbuf_own,
+                    h->ypart, h->dpart, h->gpart, h->gsum, h->tcpart, h->bjpart, h->tanpart, h->detpart, h->ryinv, h->invwork,
                     h->states, h->order_dev};
     for (void* p : ptrs) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) {
@@ -796,7 +871,7 @@ int lcx_upload_x(lcx_ctx* h, const void* x, int64_t ld) {
     if (!x || ld < h->V) return fail(LCX_ERR_ARG, "lcx_upload_x: bad leading dimension");
     HIPCHECK(hipMemcpy2DAsync(h->X, h->ldx * h->es, x, ld * h->es, h->V * h->es, h->N, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
-    return LCX_OK;
+    DISPATCH(h, make_xt, h);
 }
 
 int lcx_download_x(lcx_ctx* h, void* x, int64_t ld) {
@@ -970,6 +1045,29 @@ int lcx_timing_reset(lcx_ctx* h) {
     return LCX_OK;
 }
 
+int lcx_bench_gemm(lcx_ctx* h, int kind, int iters, double* avg_ms) {
+    NEED(h);
+    if (kind < 0 || kind > 1 || iters < 1 || !avg_ms) return fail(LCX_ERR_ARG, "lcx_bench_gemm: bad argument");
+    hipEvent_t a, b;
+    HIPCHECK(hipEventCreate(&a));
+    HIPCHECK(hipEventCreate(&b));
+    auto once = [&]() -> int {
+        if (kind == 0) { DISPATCH(h, nt_big, h, (const void*)h->Wt[0], nullptr); }
+        DISPATCH(h, tn_big, h, nullptr);
+    };
+    for (int i = 0; i < 3; ++i) LCXCHECK(once());
+    HIPCHECK(hipEventRecord(a, h->stream));
+    for (int i = 0; i < iters; ++i) LCXCHECK(once());
+    HIPCHECK(hipEventRecord(b, h->stream));
+    HIPCHECK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, a, b));
+    *avg_ms = ms / iters;
+    HIPCHECK(hipEventDestroy(a));
+    HIPCHECK(hipEventDestroy(b));
+    return LCX_OK;
+}
+
 int lcx_geometry(lcx_ctx* h, int64_t* n_pad, int64_t* ldx, int* m_pad, int64_t* info8) {
     NEED(h);
     if (n_pad) *n_pad = h->Npad;
@@ -977,7 +1075,7 @@ int lcx_geometry(lcx_ctx* h, int64_t* n_pad, int64_t* ldx, int* m_pad, int64_t* 
     if (m_pad) *m_pad = h->Mp;
     if (info8) {
         info8[0] = h->nt_S; info8[1] = h->nt_KW; info8[2] = h->tn_S; info8[3] = h->tn_KW;
-        info8[4] = h->gn_S; info8[5] = h->gv_S; info8[6] = h->pv_grid; info8[7] = h->target_waves;
+        info8[4] = h->nt_bpc; info8[5] = h->tn_bpc; info8[6] = h->pv_grid; info8[7] = h->n_cus;
     }
     return LCX_OK;
 }

@@ -188,16 +188,39 @@ moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride
     if (tid == 0) { tcpart[2 * blockIdx.x] = s1; tcpart[2 * blockIdx.x + 1] = s2; }
 }
 
-// sum the per-block pairs into the exchange buffer: sbuf[0], sbuf[1]
-__global__ void tc_partials_kernel(const double* __restrict__ tcpart, int nblocks,
-                                   double* __restrict__ sbuf, int nvals,
-                                   const int* __restrict__ skip_flag) {
+// out[k] = sum_b part[b][k], one block per output value k, fixed summation order (deterministic)
+template <typename OUT>
+__global__ void __launch_bounds__(PV_THREADS)
+sum_partials_kernel(const double* __restrict__ part, int nblocks, int nvals, OUT* __restrict__ out,
+                    const int* __restrict__ skip_flag) {
+    __shared__ double bs_scratch[PV_THREADS / 64];
     if (skip_flag != nullptr && *skip_flag != 0) return;
-    const int k = threadIdx.x;
-    if (k < nvals) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += tcpart[(int64_t)b * nvals + k];
-        sbuf[k] = s;
+    const int k = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0;
+    for (int b = tid; b < nblocks; b += PV_THREADS) s += part[(int64_t)b * nvals + k];
+    s = block_sum<double>(s, bs_scratch, tid);
+    if (tid == 0) out[k] = (OUT)s;
+}
+
+// out[i] = sum_s in[s][i] for many splits: 8 threads share an element, fixed order
+template <typename T, typename OUT>
+__global__ void __launch_bounds__(256)
+reduce_wide_kernel(const T* __restrict__ in, int nsplit, int64_t n, int64_t stride,
+                   OUT* __restrict__ out, const int* __restrict__ skip_flag) {
+    __shared__ T sh[8][32];
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + e;
+    T s = (T)0;
+    if (i < n)
+        for (int k = g; k < nsplit; k += 8) s += in[k * stride + i];
+    sh[g][e] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        T t = sh[0][e];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += sh[k][e];
+        out[i] = (OUT)t;
     }
 }
 
@@ -262,18 +285,6 @@ grad_kernel(const T* __restrict__ W, const T* __restrict__ rho_i, const T* __res
         double s = bj_s[tid];
         for (int k = 1; k < VPB; ++k) s += bj_s[k * Mp + tid];
         bjpart[(int64_t)blockIdx.x * Mp + tid] = s;
-    }
-}
-
-// Bj partials -> tail of the Y exchange buffer (working dtype)
-template <typename T>
-__global__ void bj_reduce_kernel(const double* __restrict__ bjpart, int nblocks, int Mp,
-                                 T* __restrict__ tail) {
-    const int j = threadIdx.x;
-    if (j < Mp) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += bjpart[(int64_t)b * Mp + j];
-        tail[j] = (T)s;
     }
 }
 
@@ -547,6 +558,23 @@ covariance_kernel(const T* __restrict__ rir, const T* __restrict__ si, const T* 
             out[(r - row0) * V + c] = stdv[r] * stdv[c] * val;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// second resident copy of the shard, transposed: XT[v][n] = X[n][v]  ([Vp][Npad], zero padded).
+// With 288 GB of HBM both layouts fit, and both X-streaming contractions then read their big
+// operand with 16 consecutive lanes on 256 contiguous bytes (gemm_tn's pattern).
+// 64x64 tiles through LDS; grid = (Vp/64, Npad/64), 256 threads.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+transpose_kernel(const T* __restrict__ X, int64_t ldx, T* __restrict__ XT, int64_t ldt) {
+    __shared__ T tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t v0 = (int64_t)blockIdx.x * 64, n0 = (int64_t)blockIdx.y * 64;
+    for (int r = ty; r < 64; r += 4) tile[r][tx] = X[(n0 + r) * ldx + v0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) XT[(v0 + r) * ldt + n0 + tx] = tile[tx][r];
 }
 
 // ------------------------------------------------------------------------------------------------

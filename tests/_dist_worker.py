@@ -1,0 +1,43 @@
+"""Worker of tests/test_distributed_cpu.py: one rank of a world_size-N gloo group running the
+product's `Corex` driver over the NumPy backend double.  argv: out_dir n v m"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch.distributed as dist  # noqa: E402
+
+from linearcorex_amd import Corex  # noqa: E402
+from linearcorex_amd.comm import Comm  # noqa: E402
+from oracle import corex_oracle as O  # noqa: E402
+from tests.shard_double import ShardDouble  # noqa: E402
+
+
+def main():
+    out_dir, n, v, m = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    dist.init_process_group("gloo")
+    comm = Comm()
+    x, _ = O.gen_planted(n, v, m, seed=2)
+    model = Corex(n_hidden=m, seed=0, dtype=np.float64, comm=comm,
+                  _backend_factory=lambda ns, nv, mm, dt: ShardDouble(ns, nv, mm, dt))
+    model.fit(x)
+    c0, c1 = comm.shard(v)
+    assert model._backend.nv == c1 - c0
+    y = model.transform(x)
+    rho = model.moments["rho"]              # lazily gathered: every rank must ask (collective)
+    xz = model.moments["X_i Z_j"]
+    si = model.moments["Si"]
+    if comm.rank == 0:
+        np.savez(os.path.join(out_dir, "dist_result.npz"), history=np.asarray(model.history["TC"], np.float64),
+                 ws=model.ws, clusters=model.clusters(), transform=y, rho=rho, xz=xz, si=si,
+                 tcs=model.tcs, world=comm.world, trials=model.stats["trials"],
+                 calls=np.array(len(model._backend.calls)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,212 @@
+"""NumPy test double of the backend interface (`linearcorex_amd.backend.HipBackend`).
+
+TEST INFRASTRUCTURE ONLY - it lets the CPU suite exercise the product's *host* logic (the `Corex`
+driver: line search, annealing stages, warm start, pickling, and the n_variables sharding with its
+all-reduce exchange steps over gloo) without a GPU.  The arithmetic is the oracle's, regrouped at
+the same dependency levels as the C ABI (include/lcx.h): every quantity that needs a sum over all
+variables is written to an exchange buffer between the *_a/_b/_c calls, exactly like the HIP path.
+The product never imports this module.
+"""
+import numpy as np
+import torch
+
+
+class ShardDouble:
+    def __init__(self, n_samples, nv_local, n_hidden, dtype=np.float64):
+        self.n, self.nv, self.m = int(n_samples), int(nv_local), int(n_hidden)
+        self.dtype = np.dtype(dtype)
+        self.m_pad = self.m
+        self.generation = 0
+        self.x = None
+        self.w = [np.zeros((self.m, self.nv), self.dtype), np.zeros((self.m, self.nv), self.dtype)]
+        self.mo = [dict(), dict()]
+        self.state = [np.zeros(8), np.zeros(8)]
+        self.ybuf = np.zeros(self.n * self.m + self.m * self.m, self.dtype)
+        self.sbuf = np.zeros(self.m * self.m + 8, np.float64)
+        self.grad = self.update = self.sig_grad = None
+        self.calls = []
+
+    # ---- plumbing ----------------------------------------------------------------------------
+    def close(self):
+        pass
+
+    def geometry(self):
+        return {"m_pad": self.m}
+
+    def synchronize(self):
+        pass
+
+    def exchange_tensors(self):
+        return torch.from_numpy(self.ybuf), torch.from_numpy(self.sbuf)
+
+    def read_sbuf(self, count):
+        return self.sbuf[:count].copy()
+
+    def upload_x(self, x):
+        assert x.shape == (self.n, self.nv)
+        self.x = np.ascontiguousarray(x, self.dtype)
+
+    def set_ws(self, w):
+        self.w[0] = np.array(w, self.dtype)
+        self.generation += 1
+
+    def get_ws(self, which=0):
+        return self.w[which].copy()
+
+    def permute_factors(self, order):
+        self.w[0] = self.w[0][np.asarray(order)]
+        self.generation += 1
+
+    def _y(self):
+        return self.ybuf[:self.n * self.m].reshape(self.n, self.m)
+
+    def _tail(self):
+        return self.ybuf[self.n * self.m:]
+
+    # ---- moments (ref :236-275) -----------------------------------------------------------------
+    def moments_a(self, which):
+        w = self.w[which]
+        self._y()[:] = self.x.dot(w.T)
+        self._tail()[:] = w.dot(w.T).ravel()
+        self.calls.append("moments_a")
+
+    def moments_b(self, which, eps, quick):
+        w, n = self.w[which], self.n
+        y = self._y().copy()
+        gw = self._tail().reshape(self.m, self.m).copy()
+        dt = self.dtype.type
+        c1, c2 = dt(1 - eps ** 2), dt(eps ** 2)
+        ry = c1 * y.T.dot(y) / dt(n) + c2 * gw
+        uj = np.diag(ry).copy()
+        np.fill_diagonal(ry, 1)
+        st = self.state[which]
+        st[1] = uj.max()
+        st[4] = np.sum(np.log(1 - uj)) if np.all(uj < 1) else np.nan
+        invalid = bool(quick and uj.max() >= 1.0)
+        st[2] = 1.0 if invalid else 0.0
+        mo = {"uj": uj, "ry": ry, "wmag": np.diag(gw).copy(), "Y": y}
+        if not invalid:
+            rho = c1 * self.x.T.dot(y).T / dt(n) + c2 * w
+            inv = 1.0 / (1.0 - rho ** 2)
+            rir = rho * inv
+            qij = ry.dot(rir)
+            si = np.sum(rho * rir, axis=0)
+            q2 = np.einsum("ki,ki->i", rir, qij - si * rho)
+            mo.update(rho=rho, invrho=inv, rhoinvrho=rir, Qij=qij, Si=si)
+            mo["Qi-Si^2"] = q2
+            with np.errstate(all="ignore"):
+                self.sbuf[0] = np.sum(np.log(1 + si).astype(np.float64))
+                self.sbuf[1] = np.sum(np.log(1 + q2).astype(np.float64))
+        self.mo[which] = mo
+        if which == 0:
+            self.generation += 1
+        self.calls.append("moments_b")
+
+    def moments_c(self, which):
+        st = self.state[which]
+        if st[2] != 0:
+            st[0] = np.nan
+        else:
+            st[0] = float(self.dtype.type(self.sbuf[0] - 0.5 * self.sbuf[1] + 0.5 * st[4]))
+        self.calls.append("moments_c")
+
+    def moments_detail(self, which):
+        mo, m = self.mo[which], self.m
+        rho = mo["rho"]
+        mi = -0.5 * np.log1p(-rho ** 2)
+        xz = np.linalg.solve(mo["ry"], rho).T
+        x2y = (1.0 - np.einsum("ij,ji->i", xz, rho)).clip(1e-6)
+        mo.update(MI=mi)
+        mo["X_i Z_j"] = xz
+        mo["X_i^2 | Y"] = x2y
+        self.sbuf[:m] = mi.sum(axis=1)
+        self.sbuf[m] = mi.max(axis=0).sum()
+        self.sbuf[m + 1] = (-0.5 * np.log(x2y)).sum()
+        self.sbuf[m + 2] = mi.sum()
+
+    # ---- update (ref :290-305) -------------------------------------------------------------------
+    def update_a(self):
+        mo = self.mo[0]
+        rir = mo["rhoinvrho"]
+        self.sbuf[:self.m * self.m] = np.dot(rir / (1 + mo["Qi-Si^2"]), rir.T).ravel()
+        self.calls.append("update_a")
+
+    def update_b(self, eps):
+        mo, w = self.mo[0], self.w[0]
+        h = self.sbuf[:self.m * self.m].reshape(self.m, self.m).astype(self.dtype)
+        np.fill_diagonal(h, 0)
+        rj = 1.0 - mo["uj"][:, np.newaxis]
+        rho, inv, rir = mo["rho"], mo["invrho"], mo["rhoinvrho"]
+        grad = w / rj
+        grad -= 2 * inv * rir / (1 + mo["Si"])
+        grad += inv ** 2 * ((1 + rho ** 2) * mo["Qij"] - 2 * rho * mo["Si"]) / (1 + mo["Qi-Si^2"])
+        grad += np.dot(h, w)
+        self.grad = grad
+        self._y()[:] = self.x.dot(grad.T)
+        self._tail()[:self.m] = np.sum(rho * grad, axis=1)
+        mo["H"] = h
+        self.calls.append("update_b")
+
+    def update_c(self, eps):
+        mo, w = self.mo[0], self.w[0]
+        dt = self.dtype.type
+        yg = self._y().copy()
+        bj = self._tail()[:self.m].copy()[:, np.newaxis]
+        sg = dt(1 - eps ** 2) * self.x.T.dot(yg).T / dt(self.n) + dt(eps ** 2) * self.grad
+        rj = 1.0 - mo["uj"][:, np.newaxis]
+        self.update = -rj * (self.grad - 2.0 * w / (2 - rj) * bj)
+        self.sig_grad = sg
+        self.sbuf[0] = float(np.einsum("ji,ji", sg.astype(np.float64), self.update.astype(np.float64)))
+        self.calls.append("update_c")
+
+    def update_d(self):
+        self.state[0][3] = self.sbuf[0]
+
+    def make_trial(self, eta):
+        self.w[1] = self.w[0] + self.dtype.type(eta) * self.update
+
+    def accept_trial(self):
+        self.w.reverse()
+        self.mo.reverse()
+        self.state.reverse()
+        self.generation += 1
+
+    def rescale_ws(self, eps_old, eps_new):
+        mo, w = self.mo[0], self.w[0]
+        wmag = mo["wmag"][:, np.newaxis]
+        delta = (eps_new ** 2 - eps_old ** 2) / (1.0 - eps_new ** 2) * wmag / mo["uj"].reshape((-1, 1))
+        a = np.sqrt((1.0 - eps_old ** 2) / ((1.0 - eps_new ** 2) * (1.0 + delta)))
+        self.w[0] = w * (0.001 * np.floor(1000.0 * a)).astype(self.dtype)
+        self.generation += 1
+
+    def init_scale_ws(self):
+        y = self._y()
+        uj = np.einsum("lj,lj->j", y, y) / self.n
+        self.w[0] = self.w[0] / (10.0 * np.sqrt(uj))[:, np.newaxis].astype(self.dtype)
+        self.generation += 1
+
+    # ---- readback / outputs ---------------------------------------------------------------------
+    def read_state(self, which):
+        return self.state[which].copy()
+
+    def get_moment(self, which, name, eps=0.0):
+        if name in ("grad", "update", "sig_grad"):
+            return getattr(self, name).copy()
+        if name in ("MI", "X_i Z_j", "X_i^2 | Y") and name not in self.mo[which]:
+            keep = self.sbuf.copy()
+            self.moments_detail(which)
+            self.sbuf[:] = keep
+        return np.array(self.mo[which][name], copy=True)
+
+    def set_moment(self, which, name, value):
+        self.mo[which][name] = np.array(value, self.dtype)
+
+    def covariance(self, eps, std):
+        mo = self.mo[0]
+        z = mo["rhoinvrho"] / (1 + mo["Si"])
+        cov = np.dot(z.T, z) / (1.0 - eps ** 2)
+        np.fill_diagonal(cov, 1)
+        return std[:, np.newaxis] * std * cov
+
+    def project(self, x):
+        return np.asarray(x, self.dtype).dot(self.w[0].T)

@@ -1,0 +1,67 @@
+"""N>1 path on CPU: world_size-2 (and 3) gloo groups running the product's host driver with the
+n_variables axis sharded, exchange steps as torch.distributed all-reduces.  The result must equal
+the single-process oracle (same iteration count; float64 agreement to ~1e-10: only the summation
+order of the all-reduced quantities changes)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import corex_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(world, out_dir, n, v, m):
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(out_dir),
+                                       str(n), str(v), str(m)], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode(errors="replace"))
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_fit_matches_oracle(world, tmp_path):
+    n, v, m = 300, 203, 4               # 203 variables: uneven shards
+    launch(world, tmp_path, n, v, m)
+    got = np.load(os.path.join(tmp_path, "dist_result.npz"))
+    assert int(got["world"]) == world
+    x, _ = O.gen_planted(n, v, m, seed=2)
+    ref = O.fit_ns(x, m, seed=0, dtype=np.float64, keep_x=True)
+    h, h_ref = got["history"], np.asarray(ref.history_tc)
+    assert len(h) == len(h_ref)
+    assert np.max(np.abs(h - h_ref) / np.maximum(1, np.abs(h_ref))) < 1e-9
+    assert np.array_equal(got["clusters"], ref.clusters())
+    assert got["ws"].shape == (m, v)
+    assert np.max(np.abs(got["ws"] - ref.ws)) < 1e-8
+    assert np.max(np.abs(got["transform"] - ref.transform(ref.x_tilde))) < 1e-8
+    assert np.max(np.abs(got["rho"] - ref.moments["rho"])) < 1e-8
+    assert np.max(np.abs(got["xz"] - ref.moments["X_i Z_j"])) < 1e-8
+    assert np.max(np.abs(got["si"] - ref.moments["Si"])) < 1e-8
+    assert np.max(np.abs(got["tcs"] - ref.moments["TCs"])) < 1e-8
+    assert int(got["trials"]) == ref.n_trials

@@ -1,0 +1,161 @@
+"""Host logic of the product on CPU: the `Corex` driver (control flow of fit / _update_ns, stages,
+warm start, lazy moments, pickling) over the NumPy backend double, checked against the golden
+fixtures generated from the reference; the C-ABI library's exports; loud failure without a GPU."""
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+from linearcorex_amd import Corex, _abi
+from oracle import corex_oracle as O
+from tests.shard_double import ShardDouble
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FACTORY = lambda ns, nv, m, dt: ShardDouble(ns, nv, m, dt)   # noqa: E731
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(1e-300, float(np.max(np.abs(b)))))
+
+
+@pytest.mark.parametrize("tag,dt", [("f64", np.float64), ("f32", np.float32)])
+def test_driver_reproduces_reference_on_big5(g1, tag, dt):
+    x = g1["x_raw"].astype(np.float64)
+    out = Corex(n_hidden=5, seed=0, dtype=dt, _backend_factory=FACTORY).fit(x)
+    h_ref = g1[tag + "_history_tc"]
+    h = np.asarray(out.history["TC"], np.float64)
+    assert np.array_equal(out.clusters(), g1[tag + "_clusters"])
+    if tag == "f64":
+        assert len(h) == len(h_ref)
+        assert relerr(h, h_ref) < 1e-9
+        assert relerr(out.ws, g1["f64_ws"]) < 1e-7
+        assert relerr(out.get_covariance(), g1["f64_cov"]) < 1e-7
+        assert relerr(out.transform(x), g1["f64_transform"]) < 1e-7
+        for key, name in (("rho", "rho"), ("MI", "MI"), ("X_i Z_j", "X_i_Z_j"), ("X_i Y_j", "X_i_Y_j"),
+                          ("TCs", "TCs"), ("TC_direct", "TC_direct"), ("I(Y_j ; X)", "IY_j_s_X"),
+                          ("I(X_i ; Y)", "IX_i_s_Y"), ("Y_j^2", "Y_jp2"), ("X_i^2 | Y", "X_ip2_g_Y")):
+            assert relerr(out.moments[key], g1["f64_mom_" + name]) < 1e-7, key
+        assert abs(out.moments["additivity"] - float(g1["f64_mom_additivity"])) < 1e-7
+        assert abs(out.moments["TC_no_overlap"] - float(g1["f64_mom_TC_no_overlap"])) < 1e-7
+        assert out.stats["trials"] + 10 == int(g1["f64_n_moment_calls"])
+    else:
+        assert abs(len(h) - len(h_ref)) <= 0.1 * len(h_ref)
+        assert abs(float(out.tc) - float(g1["f32_tc"])) < 1e-3 * float(g1["f32_tc"])
+
+
+def test_api_surface_and_conventions(g1):
+    import inspect
+    sig = inspect.signature(Corex.__init__)
+    names = list(sig.parameters)[1:11]
+    assert names == ["n_hidden", "max_iter", "tol", "anneal", "missing_values", "discourage_overlap",
+                     "gaussianize", "gpu", "verbose", "seed"]                 # linearcorex.py:72-74
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert (d["n_hidden"], d["max_iter"], d["tol"], d["anneal"], d["discourage_overlap"], d["gaussianize"]) == \
+           (10, 10000, 1e-5, True, True, "standard")
+    for meth in ("fit", "fit_transform", "transform", "predict", "invert", "preprocess", "get_covariance",
+                 "clusters", "update_records"):
+        assert callable(getattr(Corex, meth))
+    for prop in ("tc", "tcs", "mis"):
+        assert isinstance(getattr(Corex, prop), property)
+    c = Corex(n_hidden=3, eliminate_synergy=True)
+    assert c.discourage_overlap is True and c.ws.size == 0 and c.moments == {} and c.history == {}
+    with pytest.raises(NotImplementedError):
+        Corex(n_hidden=2, discourage_overlap=False, _backend_factory=FACTORY).fit(np.random.randn(50, 6))
+    # global RNG side effect of the constructor (linearcorex.py:89)
+    Corex(n_hidden=2, seed=123)
+    a = np.random.rand()
+    np.random.seed(123)
+    assert a == np.random.rand()
+
+
+def test_pickle_warm_start_and_predict(g1):
+    x = g1["x_raw"].astype(np.float64)
+    out = Corex(n_hidden=5, seed=0, dtype=np.float64, _backend_factory=FACTORY).fit(x)
+    blob = pickle.dumps(out)
+    back = pickle.loads(blob)
+    assert isinstance(back.moments, dict) and "rho" in back.moments and "X_i Z_j" in back.moments
+    assert np.array_equal(back.ws, out.ws)
+    y = out.transform(x)
+    xr = out.predict(y)
+    assert xr.shape == x.shape
+    # predict = invert(X_i Z_j . y) (linearcorex.py:440-441)
+    assert np.allclose(xr, out.theta[1] * np.dot(out.moments["X_i Z_j"], y.T).T + out.theta[0])
+    # warm start: non-empty ws -> no re-init, schedule [0.] (linearcorex.py:113-119)
+    back._backend_factory = FACTORY
+    n0 = len(back.history["TC"])
+    back.fit(x)
+    assert 1 <= len(back.history["TC"]) - n0 <= 5
+    assert abs(float(back.tc) - float(out.tc)) < 1e-4
+    # stale lazy moments are refused rather than silently wrong
+    fresh = Corex(n_hidden=5, seed=0, dtype=np.float64, max_iter=3, _backend_factory=FACTORY).fit(x)
+    m_old = fresh.moments
+    assert m_old["Qij"].shape == (5, 50)          # resident: fetched on demand
+    fresh._backend.generation += 1
+    with pytest.raises(KeyError):
+        m_old["invrho"]
+
+
+def test_missing_values_and_outliers_through_driver(g5, g6):
+    out = Corex(n_hidden=6, seed=0, dtype=np.float64, missing_values=-1e6, max_iter=60,
+                _backend_factory=FACTORY).fit(g6["x_raw"])
+    assert np.array_equal(out.n_obs, g6["f64_n_obs"])
+    assert len(out.history["TC"]) == len(g6["f64_history_tc"])
+    assert relerr(out.history["TC"], g6["f64_history_tc"]) < 1e-8
+    assert np.array_equal(out.clusters(), g6["f64_clusters"])
+    n, v, m = (int(t) for t in g5["shape"])
+    x, grp = O.gen_planted(n, v, m, seed=3)
+    heavy = np.arange(v) % 20 == 0
+    x[:, heavy] = np.sign(x[:, heavy]) * np.abs(x[:, heavy]) ** 1.5
+    out = Corex(n_hidden=m, seed=0, dtype=np.float64, gaussianize="outliers", _backend_factory=FACTORY).fit(x)
+    assert len(out.history["TC"]) == len(g5["f64_history_tc"])
+    assert np.array_equal(out.clusters(), g5["f64_clusters"])
+    assert relerr(out.get_covariance()[:128, :128], g5["f64_cov_block"]) < 1e-7
+
+
+# ---- the C ABI -------------------------------------------------------------------------------------
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "lcx.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(lcx_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    return out
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()                                    # hipcc cross-compiles gfx950 without a GPU
+    decl = header_functions()
+    assert len(decl) >= 35
+    assert set(decl) == set(_abi.SIGNATURES), set(decl) ^ set(_abi.SIGNATURES)
+    lib = _abi.load()
+    for name, nargs in decl.items():
+        assert hasattr(lib, name), name
+        assert len(_abi.SIGNATURES[name]) == nargs, name
+    assert lib.lcx_abi_version() == 1
+
+
+def test_product_fails_loudly_without_its_library_or_gpu(monkeypatch, tmp_path):
+    import ctypes as C
+    lib = _abi.load()
+    n = C.c_int()
+    lib.lcx_device_count(C.byref(n))
+    if n.value == 0:
+        with pytest.raises(_abi.LcxError):
+            Corex(n_hidden=2, seed=0).fit(np.random.randn(40, 8))      # no CPU fallback
+    monkeypatch.setattr(_abi, "_lib", None)
+    monkeypatch.setattr(_abi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_abi.LcxError):
+        _abi.load()
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "linearcorex_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# ", ""), fn

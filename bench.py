@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--cpu-iters-per-stage", type=int, default=8,
                     help="bounded CPU-baseline sample: oracle iterations per annealing stage (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--line-search", default="linear", choices=["linear", "exact"],
+                    help="linear: trials cost no pass over X (default); exact: reference-shaped, 2 passes per trial")
     return ap.parse_args()
 
 
@@ -99,7 +101,8 @@ def main():
     total_steps = args.warmup + args.steps
     per_stage = int(math.ceil(total_steps / 7.0))
 
-    model = Corex(n_hidden=m, seed=0, dtype=dtype, tol=0.0, max_iter=10 ** 9, device=local_rank, comm=comm)
+    model = Corex(n_hidden=m, seed=0, dtype=dtype, tol=0.0, max_iter=10 ** 9, device=local_rank, comm=comm,
+                  line_search=args.line_search)
     x_host = None
     if n * v_per * 8 <= (4 << 30):
         # Gen-A: iid N(0,1); rank r draws its own 5k columns from RandomState(1 + r)
@@ -131,7 +134,7 @@ def main():
             if not args.no_kernel_timing:
                 be.timing_reset()
                 be.timing_enable(True)
-            model.stats.update(trials=0, invalid_trials=0, moment_evals=0)
+            model.stats.update(trials=0, invalid_trials=0, moment_evals=0, refreshes=0)
             state["t0"] = time.perf_counter()
         model._iterate()
         state["step"] += 1
@@ -202,7 +205,10 @@ def main():
                    "n_samples": n, "n_variables_total": v_total, "n_variables_per_gpu": v_per, "n_hidden": m,
                    "fit_iterations_per_sec": its_per_s,
                    "line_search_trials_per_iteration": trials, "invalid_trials_per_iteration": invalid,
-                   "x_passes_per_iteration": 2 + 2 * trials - invalid,
+                   "line_search": args.line_search,
+                   "x_passes_per_iteration": (sum(c for c, _ in timing.values()) / max(1, args.steps)) if timing
+                   else None,
+                   "x_passes_per_iteration_reference_shaped": 2 + 2 * trials - invalid,
                    "launch_geometry": geo, "final_TC": float(model.tc)},
         "roofline": roofline,
     }

@@ -148,6 +148,14 @@ int lcx_update_c(lcx_ctx* h, double eps);
 int lcx_update_d(lcx_ctx* h);
 /* w_update = ws + eta*update (:320) into set 1                                                   */
 int lcx_make_trial(lcx_ctx* h, double eta);
+/* Linear trial mode (optional).  X^T.(X.u^T) is linear in u and acts per factor, and
+ * update_j is a per-factor combination of grad_j and ws_j, so Y and X^T.Y of ws + eta*update follow
+ * from quantities lcx_update_c already has - a trial then costs no pass over X.  Same outputs as
+ * lcx_make_trial + lcx_moments_a/_b (set 1) up to rounding.
+ * a: w_update (:320), W.W^T partial -> tail of ybuf, Y' = Y + eta*Y(update)
+ * b: (tail of ybuf global) uj, early-exit flag, rho ... Qi-Si^2, TC partial sums -> sbuf[0..1]   */
+int lcx_trial_linear_a(lcx_ctx* h, double eta);
+int lcx_trial_linear_b(lcx_ctx* h, double eps, double eta);
 /* self.ws, self.moments = w_update, m_update (:139,:334): swap sets                              */
 int lcx_accept_trial(lcx_ctx* h);
 

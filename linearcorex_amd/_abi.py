@@ -49,6 +49,8 @@ SIGNATURES = {
     "lcx_update_c": [_vp, _dbl],
     "lcx_update_d": [_vp],
     "lcx_make_trial": [_vp, _dbl],
+    "lcx_trial_linear_a": [_vp, _dbl],
+    "lcx_trial_linear_b": [_vp, _dbl, _dbl],
     "lcx_accept_trial": [_vp],
     "lcx_rescale_ws": [_vp, _dbl, _dbl],
     "lcx_init_scale_ws": [_vp],

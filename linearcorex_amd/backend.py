@@ -172,6 +172,12 @@ class HipBackend:
     def make_trial(self, eta):
         _abi.check(self.lib.lcx_make_trial(self.h, float(eta)))
 
+    def trial_linear_a(self, eta):
+        _abi.check(self.lib.lcx_trial_linear_a(self.h, float(eta)))
+
+    def trial_linear_b(self, eps, eta):
+        _abi.check(self.lib.lcx_trial_linear_b(self.h, float(eps), float(eta)))
+
     def accept_trial(self):
         _abi.check(self.lib.lcx_accept_trial(self.h))
         self.generation += 1

@@ -84,13 +84,18 @@ class Corex(object):
               np.float64 (the precision the 1e-6 get_covariance tolerance is defined in);
       device  HIP device index (default: LOCAL_RANK or 0);
       comm    a `linearcorex_amd.comm.Comm` to shard n_variables over ranks;
-      eliminate_synergy  alias of discourage_overlap (the name used by the reference docstring).
+      eliminate_synergy  alias of discourage_overlap (the name used by the reference docstring);
+      line_search  "exact": every back-tracking trial re-evaluates the moments with two passes over
+              X, as the reference does (:321); "linear": X^T.(X.u^T) is linear in u, so the trial
+              moments follow from the direction already computed for `_sig` (:301) and cost no pass
+              over X - same mathematics, different rounding; the solution is re-evaluated exactly
+              every `refresh_every` iterations and at every annealing stage.
     """
 
     def __init__(self, n_hidden=10, max_iter=10000, tol=1e-5, anneal=True, missing_values=None,
                  discourage_overlap=True, gaussianize='standard', gpu=False,
                  verbose=False, seed=None, *, dtype=np.float32, device=None, comm=None,
-                 eliminate_synergy=None, _backend_factory=None):
+                 eliminate_synergy=None, line_search="exact", refresh_every=8, _backend_factory=None):
         if eliminate_synergy is not None:
             discourage_overlap = bool(eliminate_synergy)
         self.m = n_hidden
@@ -123,6 +128,11 @@ class Corex(object):
         self._backend = None
         self._cols = (0, 0)
         self._tc_cur = np.nan
+        if line_search not in ("exact", "linear"):
+            raise ValueError("line_search must be 'exact' or 'linear'")
+        self.line_search = line_search
+        self.refresh_every = int(refresh_every)
+        self._since_exact = 0
         self.stats = {"iterations": 0, "moment_evals": 0, "trials": 0, "invalid_trials": 0}
 
     # ------------------------------------------------------------------------------------------
@@ -151,6 +161,11 @@ class Corex(object):
     def _xs(self, count):
         if self._ex is not None:
             self._comm.allreduce(self._ex[1][:count])
+
+    def _xtail(self):
+        """all-reduce only the m_pad^2 tail of the Y exchange buffer (W.W^T partials)."""
+        if self._ex is not None:
+            self._comm.allreduce(self._ex[0][-be_mp2(self._backend):])
 
     def _gather(self, local, key=None):
         """Per-variable arrays are sharded on the last (m x nv, nv) or first (nv x m) axis."""
@@ -321,6 +336,7 @@ class Corex(object):
         """`_calculate_moments_ns(x, self.ws, quick)` (:236-288) on the current weights."""
         be = self._backend
         self._moments_levels(0, quick)
+        self._since_exact = 0
         st = be.read_state(0)
         if st[2] != 0:
             return False                                                       # :250-251
@@ -360,6 +376,7 @@ class Corex(object):
         self._xs(1)
         be.update_d()
         tc_cur = self._tc_cur
+        linear = self.line_search == "linear"
         update_tangent = None
         eta = 1.
         last = None                          # (invalid?, tc) of the last evaluated trial
@@ -368,8 +385,16 @@ class Corex(object):
                 if self.verbose:
                     print('Warning: step size becoming too small')
                 break
-            be.make_trial(eta)                                                 # :320
-            self._moments_levels(1, True)                                      # :321
+            if linear:
+                be.trial_linear_a(eta)                                         # :320, Y' = Y + eta*Y(update)
+                self._xtail()
+                be.trial_linear_b(self.eps, eta)                               # D' = D + eta*D(update) ... TC sums
+                self._xs(2)
+                be.moments_c(1)
+                self.stats["moment_evals"] += 1
+            else:
+                be.make_trial(eta)                                             # :320
+                self._moments_levels(1, True)                                  # :321
             self.stats["trials"] += 1
             st = be.read_state(1)
             if update_tangent is None:
@@ -403,6 +428,13 @@ class Corex(object):
             return False
         be.accept_trial()                                                      # :334 / :139
         self._tc_cur = last[1]
+        if linear:
+            self._since_exact += 1
+            if self._since_exact >= self.refresh_every:
+                # re-anchor the recurrences Y += eta*Y(update), D += eta*D(update) on a fresh evaluation
+                fresh = self._calculate_moments(quick=False, details=False)
+                self.stats["refreshes"] = self.stats.get("refreshes", 0) + 1
+                return fresh
         return DeviceMoments(self, be.generation, self.eps, {"TC": self._scalar(last[1])})
 
     # ------------------------------------------------------------------------------------------

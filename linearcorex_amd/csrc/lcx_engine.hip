@@ -48,6 +48,8 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // context
 // -------------------------------------------------------------------------------------------------
 struct MomentSet {
+    void *Y;                    // [Npad][Mp]  X.W^T (all-reduced), kept for the linear trial mode
+    void *D;                    // [Vp][Mp]    X^T.Y of the shard
     void *rho, *rir, *qij;      // [Vp][Mp]
     void *si, *q2, *hscale;     // [Vp]
     double *uj, *ry, *wmag;     // small
@@ -70,6 +72,8 @@ struct lcx_ctx {
     void* Wt[2];
     MomentSet set[2];
     void *grad, *update, *sgrad, *scratch;
+    void *ydir, *ddir;          // Y(update) [Npad][Mp], D(update) [Vp][Mp]
+    bool have_linear;
     void *ybuf_own, *ybuf;
     double *sbuf_own, *sbuf;
     int64_t ybuf_elems, sbuf_elems;
@@ -317,9 +321,9 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
 
-    static int small(lcx_ctx* h, int which, double eps, int quick) {
+    static int small(lcx_ctx* h, int which, double eps, int quick, const T* ysrc) {
         MomentSet& s = h->set[which];
-        LCXCHECK(gram(h, P<T>(h->ybuf), h->Npad, nullptr, h->gn_S, nullptr));
+        LCXCHECK(gram(h, ysrc, h->Npad, nullptr, h->gn_S, nullptr));
         SmallDesc sd{s.uj, s.ry, s.wmag};
         hipLaunchKernelGGL((reduce_wide_kernel<T, T>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
                            P<T>(h->gpart), h->gn_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, P<T>(h->gsum), (const int*)nullptr);
@@ -330,21 +334,52 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
 
-    static int moments_b(lcx_ctx* h, int which, double eps, int quick) {
+    static int epilogue(lcx_ctx* h, int which, double eps, bool linear, double eta) {
         MomentSet& s = h->set[which];
-        LCXCHECK(small(h, which, eps, quick));
         const int* skip = &s.st->invalid;
-        LCXCHECK(tn_big(h, skip));
         const size_t lds = ((size_t)Mp * Mp + (size_t)VPB * Mp) * sizeof(T);
         LCXCHECK(allow_lds(moments_epilogue_kernel<T, Mp>, lds));
         hipLaunchKernelGGL((moments_epilogue_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream,
-                           P<T>(h->dpart), h->tn_S, h->ldx * Mp, P<T>(h->Wt[which]), s.ry, h->V, (double)h->N, eps,
+                           P<T>(h->dpart), h->tn_S, h->ldx * Mp,
+                           linear ? P<T>(h->set[0].D) : (const T*)nullptr, P<T>(h->ddir), (T)eta, P<T>(s.D),
+                           P<T>(h->Wt[which]), s.ry, h->V, (double)h->N, eps,
                            P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), P<T>(s.hscale),
                            h->tcpart, skip);
         KCHECK();
         hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(2), dim3(PV_THREADS), 0, h->stream, h->tcpart, h->pv_grid, 2, h->sbuf, skip);
         KCHECK();
         return LCX_OK;
+    }
+
+    static int moments_b(lcx_ctx* h, int which, double eps, int quick) {
+        MomentSet& s = h->set[which];
+        // keep the (all-reduced) Y of this set: the linear trial mode starts from it
+        HIPCHECK(hipMemcpyAsync(s.Y, h->ybuf, (size_t)h->Npad * Mp * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+        LCXCHECK(small(h, which, eps, quick, P<T>(h->ybuf)));
+        LCXCHECK(tn_big(h, &s.st->invalid));
+        return epilogue(h, which, eps, false, 0.0);
+    }
+
+    // ---- linear trial mode: moments of ws + eta*update without touching X ----------------------
+    // a: w_update (:320), its W.W^T partial -> ybuf tail, and Y' = Y + eta*Y(update) -> set 1
+    static int trial_linear_a(lcx_ctx* h, double eta) {
+        LCXCHECK(make_trial(h, eta));
+        T* w = P<T>(h->Wt[1]);
+        LCXCHECK(gram(h, w, h->ldx, nullptr, h->gv_S, nullptr));
+        hipLaunchKernelGGL((reduce_wide_kernel<T, T>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
+                           P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp,
+                           P<T>(h->ybuf) + h->Npad * Mp, (const int*)nullptr);
+        KCHECK();
+        const int64_t n = h->Npad * Mp;
+        hipLaunchKernelGGL((axpy_kernel<T>), dim3((unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048)), dim3(256), 0,
+                           h->stream, P<T>(h->set[0].Y), P<T>(h->ydir), (T)eta, n, P<T>(h->set[1].Y));
+        KCHECK();
+        return LCX_OK;
+    }
+    // b: (W.W^T tail global) uj, flag, D' = D + eta*D(update), rho ... TC partial sums
+    static int trial_linear_b(lcx_ctx* h, double eps, double eta) {
+        LCXCHECK(small(h, 1, eps, 1, P<T>(h->set[1].Y)));
+        return epilogue(h, 1, eps, true, eta);
     }
 
     static int moments_c(lcx_ctx* h, int which) {
@@ -384,8 +419,15 @@ template <typename T, int CT> struct Impl {
         const int grid = (int)(cdiv(h->V * Mp, PV_THREADS) < 2048 ? cdiv(h->V * Mp, PV_THREADS) : 2048);
         hipLaunchKernelGGL((update_kernel<T, Mp>), dim3(grid), dim3(PV_THREADS), 0, h->stream, P<T>(h->dpart), h->tn_S,
                            h->ldx * Mp, P<T>(h->grad), P<T>(h->Wt[0]), s.uj, P<T>(h->ybuf) + h->Npad * Mp, h->V,
-                           (double)h->N, eps, P<T>(h->update), P<T>(h->sgrad), h->tanpart);
+                           (double)h->N, eps, P<T>(h->update), P<T>(h->sgrad), h->tanpart,
+                           P<T>(s.D), P<T>(h->ddir));
         KCHECK();
+        {
+            const int64_t n = h->Npad * Mp;
+            hipLaunchKernelGGL((ydir_kernel<T>), dim3((unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048)), dim3(256), 0,
+                               h->stream, P<T>(h->ybuf), P<T>(s.Y), s.uj, P<T>(h->ybuf) + h->Npad * Mp, Mp, n, P<T>(h->ydir));
+            KCHECK();
+        }
         hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(1), dim3(PV_THREADS), 0, h->stream, h->tanpart, grid, 1, h->sbuf,
                            (const int*)nullptr);
         KCHECK();
@@ -409,7 +451,7 @@ template <typename T, int CT> struct Impl {
     }
 
     static int init_scale(lcx_ctx* h) {
-        LCXCHECK(small(h, 0, 0.0, 0));
+        LCXCHECK(small(h, 0, 0.0, 0, P<T>(h->ybuf)));
         const int64_t n = h->V * Mp;
         hipLaunchKernelGGL((init_scale_kernel<T>), dim3((unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048)), dim3(256), 0,
                            h->stream, P<T>(h->Wt[0]), n, Mp, h->M, h->set[0].uj);
@@ -768,6 +810,8 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     A_(h->XT, (size_t)h->Npad * h->ldx * es);
     for (int k = 0; k < 2; ++k) {
         A_(h->Wt[k], mv);
+        A_(h->set[k].Y, (size_t)h->Npad * Mp * es);
+        A_(h->set[k].D, mv);
         A_(h->set[k].rho, mv);
         A_(h->set[k].rir, mv);
         A_(h->set[k].qij, mv);
@@ -782,6 +826,9 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     A_(h->update, mv);
     A_(h->sgrad, mv);
     A_(h->scratch, mv);
+    A_(h->ydir, (size_t)h->Npad * Mp * es);
+    A_(h->ddir, mv);
+    h->have_linear = false;
     h->ybuf_elems = h->Npad * Mp + (int64_t)Mp * Mp;
     h->sbuf_elems = (int64_t)Mp * Mp + 8;
     A_(h->ybuf_own, (size_t)h->ybuf_elems * es);
@@ -816,13 +863,13 @@ int lcx_destroy(lcx_ctx* h) {
     if (!h) return LCX_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->X, h->XT, h->Wt[0], h->Wt[1], h->grad, h->update, h->sgrad, h->scratch, h->ybuf_own, h->sbuf_own,
+    void* ptrs[] = {h->X, h->XT, h->Wt[0], h->Wt[1], h->grad, h->update, h->sgrad, h->scratch, h->ydir, h->ddir, h->ybuf_own, h->sbuf_own,
                     h->ypart, h->dpart, h->gpart, h->gsum, h->tcpart, h->bjpart, h->tanpart, h->detpart, h->ryinv, h->invwork,
                     h->states, h->order_dev};
     for (void* p : ptrs) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) {
         MomentSet& s = h->set[k];
-        void* q[] = {s.rho, s.rir, s.qij, s.si, s.q2, s.hscale, s.uj, s.ry, s.wmag};
+        void* q[] = {s.Y, s.D, s.rho, s.rir, s.qij, s.si, s.q2, s.hscale, s.uj, s.ry, s.wmag};
         for (void* p : q) (void)hipFree(p);
     }
     (void)hipHostFree(h->host_states);
@@ -957,6 +1004,16 @@ int lcx_make_trial(lcx_ctx* h, double eta) {
     NEED(h);
     if (!h->have_direction) return fail(LCX_ERR_STATE, "lcx_make_trial before lcx_update_a..d");
     DISPATCH(h, make_trial, h, eta);
+}
+int lcx_trial_linear_a(lcx_ctx* h, double eta) {
+    NEED(h);
+    if (!h->have_direction) return fail(LCX_ERR_STATE, "lcx_trial_linear_a before lcx_update_a..d");
+    DISPATCH(h, trial_linear_a, h, eta);
+}
+int lcx_trial_linear_b(lcx_ctx* h, double eps, double eta) {
+    NEED(h);
+    if (!h->have_direction) return fail(LCX_ERR_STATE, "lcx_trial_linear_b before lcx_update_a..d");
+    DISPATCH(h, trial_linear_b, h, eps, eta);
 }
 int lcx_accept_trial(lcx_ctx* h) {
     NEED(h);

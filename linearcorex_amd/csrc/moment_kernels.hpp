@@ -133,6 +133,8 @@ __global__ void small_moments_kernel(const T* __restrict__ gy, int nsplit, const
 template <typename T, int Mp>
 __global__ void __launch_bounds__(PV_THREADS)
 moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride,
+                        const T* __restrict__ d_base, const T* __restrict__ d_dir, T eta,
+                        T* __restrict__ d_out,
                         const T* __restrict__ W, const double* __restrict__ ry, int64_t V,
                         double n_samples, double eps, T* __restrict__ rho_o, T* __restrict__ rir_o,
                         T* __restrict__ qij_o, T* __restrict__ si_o, T* __restrict__ q2_o,
@@ -157,8 +159,16 @@ moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride
         const int64_t v = grp * VPB + vl;
         const bool ok = v < V;
         const int64_t o = (ok ? v : 0) * Mp + j;
-        T d = dpart[o];
-        for (int k = 1; k < nsplit; ++k) d += dpart[k * pstride + o];
+        // D = X^T.Y of this weight matrix: either the partial sums of a fresh pass over X, or - X^T.Y
+        // being linear in W - D(W) + eta*D(update) from the current solution
+        T d;
+        if (d_base != nullptr) {
+            d = d_base[o] + eta * d_dir[o];
+        } else {
+            d = dpart[o];
+            for (int k = 1; k < nsplit; ++k) d += dpart[k * pstride + o];
+        }
+        if (ok) d_out[o] = d;
         const T rho = ok ? (c1 * d / ns + c2 * W[o]) : (T)0;
         const T inv = (T)1 / ((T)1 - rho * rho);
         const T rir = rho * inv;
@@ -296,7 +306,8 @@ __global__ void __launch_bounds__(PV_THREADS)
 update_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, const T* __restrict__ grad,
               const T* __restrict__ W, const double* __restrict__ uj, const T* __restrict__ bj_tail,
               int64_t V, double n_samples, double eps, T* __restrict__ update_o,
-              T* __restrict__ sgrad_o, double* __restrict__ tanpart) {
+              T* __restrict__ sgrad_o, double* __restrict__ tanpart,
+              const T* __restrict__ d_cur, T* __restrict__ d_dir_o) {
     __shared__ double bs_scratch[PV_THREADS / 64];
     const int tid = threadIdx.x;
     const T c1 = (T)(1.0 - eps * eps), c2 = (T)(eps * eps), ns = (T)n_samples;
@@ -313,6 +324,9 @@ update_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, const T*
         const T up = -rj * (g - (T)2 * W[o] / ((T)2 - rj) * bj_tail[j]);         // :303
         update_o[o] = up;
         sgrad_o[o] = sg;
+        // update_j = -rj (grad_j - c_j W_j), c_j = 2 Bj / (2 - rj), is a per-factor combination of
+        // grad and W, and X^T.(X.u^T) acts row-wise and linearly, so D(update) needs no pass over X
+        if (d_dir_o != nullptr) d_dir_o[o] = -rj * (d - (T)2 * bj_tail[j] / ((T)2 - rj) * d_cur[o]);
         tan += (double)(sg * up);
     }
     tan = block_sum<double>(tan, bs_scratch, tid);
@@ -323,6 +337,19 @@ __global__ void tangent_store_kernel(const double* __restrict__ sbuf, SetState* 
     st->tangent = sbuf[0];
 }
 
+// Y(update) = -rj (Y_g - c Y) on [Npad][Mp]  (same per-factor combination as above)
+template <typename T>
+__global__ void ydir_kernel(const T* __restrict__ yg, const T* __restrict__ ycur, const double* __restrict__ uj,
+                            const T* __restrict__ bj_tail, int Mp, int64_t n, T* __restrict__ ydir) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % Mp);
+        const T rj = (T)1 - (T)uj[j];
+        ydir[i] = -rj * (yg[i] - (T)2 * bj_tail[j] / ((T)2 - rj) * ycur[i]);
+    }
+}
+
+// out = a + eta * b  (Y of a line-search trial from Y and Y(update))
 // w_update = ws + eta * update (:320)
 template <typename T>
 __global__ void axpy_kernel(const T* __restrict__ w, const T* __restrict__ up, T eta, int64_t n,

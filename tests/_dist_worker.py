@@ -18,10 +18,11 @@ from tests.shard_double import ShardDouble  # noqa: E402
 
 def main():
     out_dir, n, v, m = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    mode = sys.argv[5] if len(sys.argv) > 5 else "exact"
     dist.init_process_group("gloo")
     comm = Comm()
     x, _ = O.gen_planted(n, v, m, seed=2)
-    model = Corex(n_hidden=m, seed=0, dtype=np.float64, comm=comm,
+    model = Corex(n_hidden=m, seed=0, dtype=np.float64, comm=comm, line_search=mode,
                   _backend_factory=lambda ns, nv, mm, dt: ShardDouble(ns, nv, mm, dt))
     model.fit(x)
     c0, c1 = comm.shard(v)

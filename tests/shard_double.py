@@ -71,8 +71,13 @@ class ShardDouble:
         self.calls.append("moments_a")
 
     def moments_b(self, which, eps, quick):
-        w, n = self.w[which], self.n
         y = self._y().copy()
+        self._finish_moments(which, eps, quick, y, None)
+        self.calls.append("moments_b")
+
+    def _finish_moments(self, which, eps, quick, y, d):
+        """d = X^T.Y of the shard (nv x m); None -> one pass over X."""
+        w, n = self.w[which], self.n
         gw = self._tail().reshape(self.m, self.m).copy()
         dt = self.dtype.type
         c1, c2 = dt(1 - eps ** 2), dt(eps ** 2)
@@ -86,7 +91,10 @@ class ShardDouble:
         st[2] = 1.0 if invalid else 0.0
         mo = {"uj": uj, "ry": ry, "wmag": np.diag(gw).copy(), "Y": y}
         if not invalid:
-            rho = c1 * self.x.T.dot(y).T / dt(n) + c2 * w
+            if d is None:
+                d = self.x.T.dot(y)
+            mo["D"] = d
+            rho = c1 * d.T / dt(n) + c2 * w
             inv = 1.0 / (1.0 - rho ** 2)
             rir = rho * inv
             qij = ry.dot(rir)
@@ -100,7 +108,19 @@ class ShardDouble:
         self.mo[which] = mo
         if which == 0:
             self.generation += 1
-        self.calls.append("moments_b")
+
+    # linear trial mode (include/lcx.h lcx_trial_linear_a/_b)
+    def trial_linear_a(self, eta):
+        self.make_trial(eta)
+        w = self.w[1]
+        self._tail()[:] = w.dot(w.T).ravel()
+        self._ytrial = self.mo[0]["Y"] + self.dtype.type(eta) * self.ydir
+        self.calls.append("trial_linear_a")
+
+    def trial_linear_b(self, eps, eta):
+        d = self.mo[0]["D"] + self.dtype.type(eta) * self.ddir
+        self._finish_moments(1, eps, True, self._ytrial, d)
+        self.calls.append("trial_linear_b")
 
     def moments_c(self, which):
         st = self.state[which]
@@ -156,6 +176,9 @@ class ShardDouble:
         rj = 1.0 - mo["uj"][:, np.newaxis]
         self.update = -rj * (self.grad - 2.0 * w / (2 - rj) * bj)
         self.sig_grad = sg
+        c = 2.0 * bj / (2 - rj)                                   # (m, 1)
+        self.ydir = (-rj * (yg.T - c * mo["Y"].T)).T                # Y(update), n x m
+        self.ddir = (-rj * (self.x.T.dot(yg).T - c * mo["D"].T)).T  # D(update), nv x m
         self.sbuf[0] = float(np.einsum("ji,ji", sg.astype(np.float64), self.update.astype(np.float64)))
         self.calls.append("update_c")
 

@@ -23,14 +23,14 @@ def free_port():
     return p
 
 
-def launch(world, out_dir, n, v, m):
+def launch(world, out_dir, n, v, m, mode="exact"):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(out_dir),
-                                       str(n), str(v), str(m)], env=env, cwd=ROOT,
+                                       str(n), str(v), str(m), mode], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:
@@ -45,10 +45,10 @@ def launch(world, out_dir, n, v, m):
         assert p.returncode == 0, o[-3000:]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_fit_matches_oracle(world, tmp_path):
+@pytest.mark.parametrize("world,mode", [(2, "exact"), (3, "exact"), (2, "linear")])
+def test_sharded_fit_matches_oracle(world, mode, tmp_path):
     n, v, m = 300, 203, 4               # 203 variables: uneven shards
-    launch(world, tmp_path, n, v, m)
+    launch(world, tmp_path, n, v, m, mode)
     got = np.load(os.path.join(tmp_path, "dist_result.npz"))
     assert int(got["world"]) == world
     x, _ = O.gen_planted(n, v, m, seed=2)

@@ -46,6 +46,28 @@ def test_driver_reproduces_reference_on_big5(g1, tag, dt):
         assert abs(float(out.tc) - float(g1["f32_tc"])) < 1e-3 * float(g1["f32_tc"])
 
 
+@pytest.mark.parametrize("refresh", [1, 8, 10 ** 9])
+def test_linear_line_search_matches_exact(g1, refresh):
+    """line_search='linear' evaluates trials without passes over X (linearity of X^T.(X.u^T));
+    in float64 it must reproduce the reference trajectory to rounding, whatever the refresh period."""
+    x = g1["x_raw"].astype(np.float64)
+    out = Corex(n_hidden=5, seed=0, dtype=np.float64, line_search="linear", refresh_every=refresh,
+                _backend_factory=FACTORY).fit(x)
+    h_ref = g1["f64_history_tc"]
+    h = np.asarray(out.history["TC"], np.float64)
+    assert len(h) == len(h_ref)
+    assert relerr(h, h_ref) < 1e-9
+    assert relerr(out.get_covariance(), g1["f64_cov"]) < 1e-7
+    assert np.array_equal(out.clusters(), g1["f64_clusters"])
+    calls = out._backend.calls
+    assert calls.count("trial_linear_b") == out.stats["trials"]
+    # X is streamed by moments_a/_b (2 passes) and update_b/_c (2 passes) only
+    n_exact = calls.count("moments_b")
+    assert n_exact == 1 + 7 + 2 + out.stats.get("refreshes", 0)
+    if refresh == 10 ** 9:
+        assert out.stats.get("refreshes", 0) == 0
+
+
 def test_api_surface_and_conventions(g1):
     import inspect
     sig = inspect.signature(Corex.__init__)

@@ -97,6 +97,11 @@ int lcx_destroy(lcx_ctx* h);
 int lcx_set_stream(lcx_ctx* h, void* hip_stream);
 int lcx_synchronize(lcx_ctx* h);
 
+/* Number of ranks that share the n_variables axis (default 1).  With 1 the *_a/_b/_c halves of a
+ * level need no exchange in between, and the engine folds their tiny tail kernels together
+ * (lcx_moments_c and lcx_update_d then launch nothing). */
+int lcx_set_world(lcx_ctx* h, int world);
+
 /* Exchange buffers (device pointers).  ybuf: n_samples_padded*m_padded + m_padded*m_padded
  * elements of the working dtype; sbuf: lcx_sbuf_count doubles.  lcx_exchange_layout reports
  * element counts; lcx_bind_exchange(NULL, NULL) restores the handle's own buffers. */
@@ -165,7 +170,8 @@ int lcx_rescale_ws(lcx_ctx* h, double eps_old, double eps_new);
 int lcx_init_scale_ws(lcx_ctx* h);
 
 /* ---- readback -------------------------------------------------------------------------------- */
-/* synchronises the stream and copies the LCX_S_COUNT scalars of a set */
+/* the LCX_S_COUNT scalars of a set; waits (polling a pinned host mirror the last kernel of a level
+ * writes) until the work enqueued so far for that set has published them */
 int lcx_read_state(lcx_ctx* h, int which, double* out);
 /* host_out: the reference-shaped array, working dtype (see lcx_moment_key) */
 int lcx_get_moment(lcx_ctx* h, int which, int key, double eps, void* host_out);

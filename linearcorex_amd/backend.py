@@ -82,6 +82,9 @@ class HipBackend:
         _abi.check(self.lib.lcx_bench_gemm(self.h, int(kind), int(iters), C.byref(ms)))
         return ms.value
 
+    def set_world(self, world):
+        _abi.check(self.lib.lcx_set_world(self.h, int(world)))
+
     def synchronize(self):
         _abi.check(self.lib.lcx_synchronize(self.h))
 

@@ -95,7 +95,7 @@ class Corex(object):
     def __init__(self, n_hidden=10, max_iter=10000, tol=1e-5, anneal=True, missing_values=None,
                  discourage_overlap=True, gaussianize='standard', gpu=False,
                  verbose=False, seed=None, *, dtype=np.float32, device=None, comm=None,
-                 eliminate_synergy=None, line_search="exact", refresh_every=8, _backend_factory=None):
+                 eliminate_synergy=None, line_search="exact", refresh_every=16, _backend_factory=None):
         if eliminate_synergy is not None:
             discourage_overlap = bool(eliminate_synergy)
         self.m = n_hidden
@@ -151,6 +151,7 @@ class Corex(object):
                 dev = int(os.environ.get("LOCAL_RANK", "0"))
             be = HipBackend(n_samples, nv_local, self.m, self.dtype, dev)
         self._backend = be
+        be.set_world(self._comm.world)
         self._ex = be.exchange_tensors() if self._comm.world > 1 else None
         return be
 

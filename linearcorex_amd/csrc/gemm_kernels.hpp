@@ -153,23 +153,21 @@ gemm_nt_kernel(const T* __restrict__ X, int64_t ldx, const T* __restrict__ B, T*
 // ------------------------------------------------------------------------------------------------
 // MODE is for ablation probes only (tools/gemm_probe.hip): 0 = real kernel, 1 = loads without MFMA,
 // 2 = MFMA without loads (registers loaded once).
-template <typename T, int CT, int RT, int KW, bool SCALE, int MODE = 0, int U = 4>
-__global__ void __launch_bounds__(64 * KW)
-gemm_tn_kernel(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const T* __restrict__ B,
-               const T* __restrict__ rowscale, T* __restrict__ out, int64_t out_rows, int kgroups,
-               int nsplit, const int* __restrict__ skip_flag) {
+template <typename T, int CT, int RT, int KW, bool SCALE, int MODE, int U>
+__device__ __forceinline__ void
+tn_body(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const T* __restrict__ B,
+        const T* __restrict__ rowscale, T* __restrict__ out, int64_t out_rows, int kgroups,
+        int nsplit, const int tile_x, const int split_y) {
     constexpr int Mp = 16 * CT;
     // U = MFMA steps per group; a group is 4*U rows of A (kgroups counts 16-row units)
     typedef typename MF<T>::acc_t acc_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* red = reinterpret_cast<T*>(smem_raw);  // [KW][16*RT][Mp]
 
-    if (skip_flag != nullptr && *skip_flag != 0) return;
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int64_t v0 = (int64_t)blockIdx.x * (16 * RT);
-    const int part = blockIdx.y * KW + wave, nparts = nsplit * KW;
+    const int64_t v0 = (int64_t)tile_x * (16 * RT);
+    const int part = split_y * KW + wave, nparts = nsplit * KW;
     const int ng = kgroups * 4 / U;           // groups of 4*U rows (K is a multiple of 64)
     const int g0 = (int)((int64_t)ng * part / nparts);
     const int g1 = (int)((int64_t)ng * (part + 1) / nparts);
@@ -183,7 +181,7 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const 
     // plain row-major A: tile_stride = 16*RT, lda = row length.  Panel-major A (each column tile
     // stored as its own contiguous [K][16*RT] slab): tile_stride = K*16*RT, lda = 16*RT, so a
     // wave streams one contiguous region of HBM.
-    const T* ap = A + (int64_t)blockIdx.x * tile_stride + (int64_t)q * lda + i * RT;
+    const T* ap = A + (int64_t)tile_x * tile_stride + (int64_t)q * lda + i * RT;
     const T* bp = B + (int64_t)q * Mp + i * CT;
 
     Pk<T, RT> a0[U], a1[U];
@@ -239,13 +237,39 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const 
             for (int g = 0; g < 4; ++g)
                 mine[(MF<T>::row(lane, g) * RT + t) * Mp + i * CT + u] = acc[t][u][g];
     __syncthreads();
-    T* dst = out + ((int64_t)blockIdx.y * out_rows + v0) * Mp;
+    T* dst = out + ((int64_t)split_y * out_rows + v0) * Mp;
     for (int idx = threadIdx.x; idx < TILE; idx += 64 * KW) {
         T s = red[idx];
 #pragma unroll
         for (int w = 1; w < KW; ++w) s += red[w * TILE + idx];
         dst[idx] = s;
     }
+}
+
+template <typename T, int CT, int RT, int KW, bool SCALE, int MODE = 0, int U = 4>
+__global__ void __launch_bounds__(64 * KW)
+gemm_tn_kernel(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const T* __restrict__ B,
+               const T* __restrict__ rowscale, T* __restrict__ out, int64_t out_rows, int kgroups,
+               int nsplit, const int* __restrict__ skip_flag) {
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+    tn_body<T, CT, RT, KW, SCALE, MODE, U>(A, lda, tile_stride, B, rowscale, out, out_rows, kgroups, nsplit,
+                                            blockIdx.x, blockIdx.y);
+}
+
+// Two independent Gram contractions (A^T.A of two [K][Mp] arrays) in one launch: blockIdx.z picks
+// the problem, grid.y = max of the two split counts.
+template <typename T> struct GramProblem {
+    const T* A;
+    T* out;
+    int kgroups, nsplit;
+};
+template <typename T, int CT, int RT, int KW>
+__global__ void __launch_bounds__(64 * KW)
+gram_pair_kernel(GramProblem<T> p0, GramProblem<T> p1) {
+    const GramProblem<T> p = blockIdx.z ? p1 : p0;
+    if ((int)blockIdx.y >= p.nsplit) return;
+    tn_body<T, CT, RT, KW, false, 0, 4>(p.A, 16 * CT, 16 * RT, p.A, nullptr, p.out, 16 * CT, p.kgroups, p.nsplit,
+                                         blockIdx.x, blockIdx.y);
 }
 
 // tile shapes per (dtype, CT): chosen so accumulators + two register sets stay under ~200 VGPRs

@@ -54,6 +54,9 @@ struct MomentSet {
     void *si, *q2, *hscale;     // [Vp]
     double *uj, *ry, *wmag;     // small
     SetState* st;               // device
+    SetState* hst;              // pinned host mirror (host address)
+    SetState* hst_dev;          // same memory, device-visible address
+    unsigned int seq_expect;    // sequence number of the last publication enqueued for this set
 };
 
 struct TimingPair {
@@ -77,11 +80,12 @@ struct lcx_ctx {
     void *ybuf_own, *ybuf;
     double *sbuf_own, *sbuf;
     int64_t ybuf_elems, sbuf_elems;
-    void *ypart, *dpart, *gpart, *gsum;
+    void *ypart, *dpart, *gpart, *gpartw;
     double *tcpart, *bjpart, *tanpart, *detpart, *ryinv, *invwork;
     SetState* states;           // device [2]
     SetState* host_states;      // pinned [2]
     int* order_dev;
+    unsigned int* ticket;       // arrival counter of small_moments_kernel
     // launch geometry
     int nt_S, nt_KW, tn_S, tn_KW, gn_S, gv_S, pv_grid, target_waves, n_cus, nt_bpc, tn_bpc;
     // timing
@@ -91,6 +95,8 @@ struct lcx_ctx {
     int64_t t_launch[2];
     double t_ms[2];
     bool have_direction;
+    int world;                  // ranks sharing the variables axis (1: no exchange between levels)
+    unsigned int seq_next;
 };
 
 template <typename T> static inline T* P(void* p) { return reinterpret_cast<T*>(p); }
@@ -268,16 +274,16 @@ template <typename T, int CT> struct Impl {
     }
 
     // ---- Gram matrix of a [K][Mp] array (K multiple of 16): partials -> gpart[S][Mp][Mp] ------
-    static int gram(lcx_ctx* h, const T* A, int64_t K, const T* scale, int S, const int* skip) {
+    static int gram(lcx_ctx* h, const T* A, int64_t K, const T* scale, int S, const int* skip, T* dst) {
         const int kw = pick_kw(K / 16);
         constexpr int RT = Geo<T, CT>::G_RT;
         if (scale)
-            return launch_tn<T, CT, RT, true>(h->stream, A, Mp, K, Mp, A, scale, P<T>(h->gpart), S, kw, skip);
-        return launch_tn<T, CT, RT, false>(h->stream, A, Mp, K, Mp, A, nullptr, P<T>(h->gpart), S, kw, skip);
+            return launch_tn<T, CT, RT, true>(h->stream, A, Mp, K, Mp, A, scale, dst, S, kw, skip);
+        return launch_tn<T, CT, RT, false>(h->stream, A, Mp, K, Mp, A, nullptr, dst, S, kw, skip);
     }
 
     // Y(_partial) = X . B^T (linearcorex.py:247 / :210) as a contraction over the rows of XT
-    static int nt_big(lcx_ctx* h, const void* Bv, const int* skip) {
+    static int nt_big(lcx_ctx* h, const void* Bv, const int* skip, bool with_bj = false) {
         const T* B = reinterpret_cast<const T*>(Bv);
         TimingPair tp;
         LCXCHECK(timing_begin(h, 0, &tp));
@@ -285,8 +291,14 @@ template <typename T, int CT> struct Impl {
         LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, B, nullptr,
                                                                dst, h->nt_S, h->nt_KW, skip)));
         LCXCHECK(timing_end(h, 0, &tp));
-        if (h->nt_S > 1) {
-            const int64_t n = h->Npad * Mp;
+        const int64_t n = h->Npad * Mp;
+        if (with_bj) {
+            // partial tiles of Y (if split) and the Bj partials of grad_kernel, one launch
+            const int yblocks = h->nt_S > 1 ? (int)(cdiv(n, PV_THREADS) < 1024 ? cdiv(n, PV_THREADS) : 1024) : 0;
+            hipLaunchKernelGGL((reduce_y_bj_kernel<T>), dim3(yblocks + Mp), dim3(PV_THREADS), 0, h->stream, P<T>(h->ypart),
+                               h->nt_S, n, P<T>(h->ybuf), yblocks, h->bjpart, h->pv_grid, Mp, P<T>(h->ybuf) + n);
+            KCHECK();
+        } else if (h->nt_S > 1) {
             hipLaunchKernelGGL((reduce_partials_kernel<T, T>), dim3((unsigned)(cdiv(n, 256) < 1024 ? cdiv(n, 256) : 1024)), dim3(256), 0,
                                h->stream, P<T>(h->ypart), h->nt_S, n, n, P<T>(h->ybuf), skip);
             KCHECK();
@@ -309,28 +321,58 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
 
+    // W.W^T partials of the shard -> gpartw; with several ranks also summed into the ybuf tail, which
+    // is what gets all-reduced
+    static int gram_w(lcx_ctx* h, const T* w) {
+        LCXCHECK(gram(h, w, h->ldx, nullptr, h->gv_S, nullptr, P<T>(h->gpartw)));
+        if (h->world > 1) {
+            hipLaunchKernelGGL((reduce_wide_kernel<T, T>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
+                               P<T>(h->gpartw), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp,
+                               P<T>(h->ybuf) + h->Npad * Mp, (const int*)nullptr);
+            KCHECK();
+        }
+        return LCX_OK;
+    }
+
     static int moments_a(lcx_ctx* h, int which) {
         T* w = P<T>(h->Wt[which]);
         LCXCHECK(nt_big(h, w, nullptr));
-        // W W^T partials over the shard -> tail of ybuf
-        LCXCHECK(gram(h, w, h->ldx, nullptr, h->gv_S, nullptr));
-        hipLaunchKernelGGL((reduce_wide_kernel<T, T>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
-                           P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp,
-                           P<T>(h->ybuf) + h->Npad * Mp, (const int*)nullptr);
+        return gram_w(h, w);
+    }
+
+    // per-factor moments; ysrc != null: first form the Y^T.Y partials of that Y
+    static int small(lcx_ctx* h, int which, double eps, int quick, const T* ysrc) {
+        MomentSet& s = h->set[which];
+        if (ysrc) LCXCHECK(gram(h, ysrc, h->Npad, nullptr, h->gn_S, nullptr, P<T>(h->gpart)));
+        SmallDesc sd{s.uj, s.ry, s.wmag};
+        const T* gw = h->world > 1 ? P<T>(h->ybuf) + h->Npad * Mp : P<T>(h->gpartw);
+        hipLaunchKernelGGL((small_moments_kernel<T>), dim3(Mp * Mp / 32), dim3(256), 0, h->stream, P<T>(h->gpart),
+                           h->gn_S, gw, h->world > 1 ? 1 : h->gv_S, Mp, h->M, (double)h->N, eps, quick, sd, s.st,
+                           h->ticket);
         KCHECK();
         return LCX_OK;
     }
 
-    static int small(lcx_ctx* h, int which, double eps, int quick, const T* ysrc) {
-        MomentSet& s = h->set[which];
-        LCXCHECK(gram(h, ysrc, h->Npad, nullptr, h->gn_S, nullptr));
-        SmallDesc sd{s.uj, s.ry, s.wmag};
-        hipLaunchKernelGGL((reduce_wide_kernel<T, T>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
-                           P<T>(h->gpart), h->gn_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, P<T>(h->gsum), (const int*)nullptr);
+    // W'^T-Gram and Y'^T-Gram of a trial in one launch
+    static int gram_pair(lcx_ctx* h, const T* w, const T* y) {
+        constexpr int RT = Geo<T, CT>::G_RT;
+        const int kgv = (int)(h->ldx / 16), kgn = (int)(h->Npad / 16);
+        const int kw = pick_kw(kgv < kgn ? kgv : kgn);
+        GramProblem<T> p0{w, P<T>(h->gpartw), kgv, h->gv_S}, p1{y, P<T>(h->gpart), kgn, h->gn_S};
+        dim3 grid((unsigned)(Mp / (16 * RT)), (unsigned)(h->gv_S > h->gn_S ? h->gv_S : h->gn_S), 2);
+        const size_t lds = (size_t)kw * 16 * RT * Mp * sizeof(T);
+        switch (kw) {
+            case 1: hipLaunchKernelGGL((gram_pair_kernel<T, CT, RT, 1>), grid, dim3(64), lds, h->stream, p0, p1); break;
+            case 2: hipLaunchKernelGGL((gram_pair_kernel<T, CT, RT, 2>), grid, dim3(128), lds, h->stream, p0, p1); break;
+            default: hipLaunchKernelGGL((gram_pair_kernel<T, CT, RT, 4>), grid, dim3(256), lds, h->stream, p0, p1); break;
+        }
         KCHECK();
-        hipLaunchKernelGGL((small_moments_kernel<T>), dim3(1), dim3(PV_THREADS), 0, h->stream, P<T>(h->gsum),
-                           1, P<T>(h->ybuf) + h->Npad * Mp, Mp, h->M, (double)h->N, eps, quick, sd, s.st);
-        KCHECK();
+        if (h->world > 1) {
+            hipLaunchKernelGGL((reduce_wide_kernel<T, T>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
+                               P<T>(h->gpartw), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp,
+                               P<T>(h->ybuf) + h->Npad * Mp, (const int*)nullptr);
+            KCHECK();
+        }
         return LCX_OK;
     }
 
@@ -346,8 +388,12 @@ template <typename T, int CT> struct Impl {
                            P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), P<T>(s.hscale),
                            h->tcpart, skip);
         KCHECK();
-        hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(2), dim3(PV_THREADS), 0, h->stream, h->tcpart, h->pv_grid, 2, h->sbuf, skip);
+        const int single = h->world == 1;
+        const unsigned int seq = ++h->seq_next;
+        hipLaunchKernelGGL((tc_finalize_kernel<T>), dim3(1), dim3(PV_THREADS), 0, h->stream, h->tcpart, h->pv_grid, h->sbuf,
+                           s.st, s.hst_dev, seq, single);
         KCHECK();
+        if (single) s.seq_expect = seq;
         return LCX_OK;
     }
 
@@ -363,34 +409,32 @@ template <typename T, int CT> struct Impl {
     // ---- linear trial mode: moments of ws + eta*update without touching X ----------------------
     // a: w_update (:320), its W.W^T partial -> ybuf tail, and Y' = Y + eta*Y(update) -> set 1
     static int trial_linear_a(lcx_ctx* h, double eta) {
-        LCXCHECK(make_trial(h, eta));
-        T* w = P<T>(h->Wt[1]);
-        LCXCHECK(gram(h, w, h->ldx, nullptr, h->gv_S, nullptr));
-        hipLaunchKernelGGL((reduce_wide_kernel<T, T>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
-                           P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp,
-                           P<T>(h->ybuf) + h->Npad * Mp, (const int*)nullptr);
+        const int64_t n1 = h->V * Mp, n2 = h->Npad * Mp;
+        hipLaunchKernelGGL((axpy2_kernel<T>), dim3((unsigned)(cdiv(n1 + n2, 256) < 2048 ? cdiv(n1 + n2, 256) : 2048)), dim3(256), 0,
+                           h->stream, P<T>(h->Wt[0]), P<T>(h->update), P<T>(h->Wt[1]), n1,
+                           P<T>(h->set[0].Y), P<T>(h->ydir), P<T>(h->set[1].Y), n2, (T)eta);
         KCHECK();
-        const int64_t n = h->Npad * Mp;
-        hipLaunchKernelGGL((axpy_kernel<T>), dim3((unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048)), dim3(256), 0,
-                           h->stream, P<T>(h->set[0].Y), P<T>(h->ydir), (T)eta, n, P<T>(h->set[1].Y));
-        KCHECK();
-        return LCX_OK;
+        return gram_pair(h, P<T>(h->Wt[1]), P<T>(h->set[1].Y));
     }
     // b: (W.W^T tail global) uj, flag, D' = D + eta*D(update), rho ... TC partial sums
     static int trial_linear_b(lcx_ctx* h, double eps, double eta) {
-        LCXCHECK(small(h, 1, eps, 1, P<T>(h->set[1].Y)));
+        LCXCHECK(small(h, 1, eps, 1, nullptr));
         return epilogue(h, 1, eps, true, eta);
     }
 
     static int moments_c(lcx_ctx* h, int which) {
-        hipLaunchKernelGGL((tc_final_kernel<T>), dim3(1), dim3(1), 0, h->stream, h->sbuf, h->set[which].st);
+        if (h->world == 1) return LCX_OK;            // tc_finalize_kernel already did it
+        MomentSet& s = h->set[which];
+        const unsigned int seq = ++h->seq_next;
+        hipLaunchKernelGGL((tc_final_kernel<T>), dim3(1), dim3(1), 0, h->stream, h->sbuf, s.st, s.hst_dev, seq);
         KCHECK();
+        s.seq_expect = seq;
         return LCX_OK;
     }
 
     static int update_a(lcx_ctx* h) {
         MomentSet& s = h->set[0];
-        LCXCHECK(gram(h, P<T>(s.rir), h->ldx, P<T>(s.hscale), h->gv_S, nullptr));
+        LCXCHECK(gram(h, P<T>(s.rir), h->ldx, P<T>(s.hscale), h->gv_S, nullptr, P<T>(h->gpart)));
         hipLaunchKernelGGL((reduce_wide_kernel<T, double>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
                            P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, h->sbuf, (const int*)nullptr);
         KCHECK();
@@ -406,31 +450,26 @@ template <typename T, int CT> struct Impl {
                            P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), s.uj, h->sbuf, h->V,
                            P<T>(h->grad), h->bjpart);
         KCHECK();
-        LCXCHECK(nt_big(h, P<T>(h->grad), nullptr));
-        hipLaunchKernelGGL((sum_partials_kernel<T>), dim3(Mp), dim3(PV_THREADS), 0, h->stream, h->bjpart, h->pv_grid, Mp,
-                           P<T>(h->ybuf) + h->Npad * Mp, (const int*)nullptr);
-        KCHECK();
-        return LCX_OK;
+        return nt_big(h, P<T>(h->grad), nullptr, true);
     }
 
     static int update_c(lcx_ctx* h, double eps) {
         MomentSet& s = h->set[0];
         LCXCHECK(tn_big(h, nullptr));
-        const int grid = (int)(cdiv(h->V * Mp, PV_THREADS) < 2048 ? cdiv(h->V * Mp, PV_THREADS) : 2048);
-        hipLaunchKernelGGL((update_kernel<T, Mp>), dim3(grid), dim3(PV_THREADS), 0, h->stream, P<T>(h->dpart), h->tn_S,
+        const int grid = (int)(cdiv(h->V * Mp, PV_THREADS) < 1536 ? cdiv(h->V * Mp, PV_THREADS) : 1536);
+        const int64_t ny = h->Npad * Mp;
+        const int gridy = (int)(cdiv(ny, PV_THREADS) < 512 ? cdiv(ny, PV_THREADS) : 512);
+        hipLaunchKernelGGL((update_kernel<T, Mp>), dim3(grid + gridy), dim3(PV_THREADS), 0, h->stream, P<T>(h->dpart), h->tn_S,
                            h->ldx * Mp, P<T>(h->grad), P<T>(h->Wt[0]), s.uj, P<T>(h->ybuf) + h->Npad * Mp, h->V,
                            (double)h->N, eps, P<T>(h->update), P<T>(h->sgrad), h->tanpart,
-                           P<T>(s.D), P<T>(h->ddir));
+                           P<T>(s.D), P<T>(h->ddir), grid, P<T>(h->ybuf), P<T>(s.Y), ny, P<T>(h->ydir));
         KCHECK();
-        {
-            const int64_t n = h->Npad * Mp;
-            hipLaunchKernelGGL((ydir_kernel<T>), dim3((unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048)), dim3(256), 0,
-                               h->stream, P<T>(h->ybuf), P<T>(s.Y), s.uj, P<T>(h->ybuf) + h->Npad * Mp, Mp, n, P<T>(h->ydir));
-            KCHECK();
-        }
-        hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(1), dim3(PV_THREADS), 0, h->stream, h->tanpart, grid, 1, h->sbuf,
-                           (const int*)nullptr);
+        const int single = h->world == 1;
+        const unsigned int seq = ++h->seq_next;
+        hipLaunchKernelGGL(tan_finalize_kernel, dim3(1), dim3(PV_THREADS), 0, h->stream, h->tanpart, grid, h->sbuf, s.st,
+                           s.hst_dev, seq, single);
         KCHECK();
+        if (single) s.seq_expect = seq;
         return LCX_OK;
     }
 
@@ -840,7 +879,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     {
         const int gs = h->gn_S > h->gv_S ? h->gn_S : h->gv_S;
         A_(h->gpart, (size_t)gs * Mp * Mp * es);
-        A_(h->gsum, (size_t)Mp * Mp * es);
+        A_(h->gpartw, (size_t)gs * Mp * Mp * es);
     }
     A_(h->tcpart, sizeof(double) * 2 * 2048);
     A_(h->bjpart, sizeof(double) * Mp * 2048);
@@ -850,10 +889,23 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     A_(h->invwork, sizeof(double) * Mp * 2 * Mp);
     A_(h->states, sizeof(SetState) * 2);
     A_(h->order_dev, sizeof(int) * Mp);
+    A_(h->ticket, 64);
 #undef A_
     h->set[0].st = h->states;
     h->set[1].st = h->states + 1;
-    HIPCHECK(hipHostMalloc((void**)&h->host_states, sizeof(SetState) * 2, hipHostMallocDefault));
+    HIPCHECK(hipHostMalloc((void**)&h->host_states, sizeof(SetState) * 2, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(h->host_states, 0, sizeof(SetState) * 2);
+    {
+        SetState* dv = nullptr;
+        HIPCHECK(hipHostGetDevicePointer((void**)&dv, h->host_states, 0));
+        for (int k = 0; k < 2; ++k) {
+            h->set[k].hst = h->host_states + k;
+            h->set[k].hst_dev = dv + k;
+            h->set[k].seq_expect = 0;
+        }
+    }
+    h->world = 1;
+    h->seq_next = 0;
     HIPCHECK(hipStreamSynchronize(st));
     *out = h;
     return LCX_OK;
@@ -864,8 +916,8 @@ int lcx_destroy(lcx_ctx* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->X, h->XT, h->Wt[0], h->Wt[1], h->grad, h->update, h->sgrad, h->scratch, h->ydir, h->ddir, h->ybuf_own, h->sbuf_own,
-                    h->ypart, h->dpart, h->gpart, h->gsum, h->tcpart, h->bjpart, h->tanpart, h->detpart, h->ryinv, h->invwork,
-                    h->states, h->order_dev};
+                    h->ypart, h->dpart, h->gpart, h->gpartw, h->tcpart, h->bjpart, h->tanpart, h->detpart, h->ryinv, h->invwork,
+                    h->states, h->order_dev, h->ticket};
     for (void* p : ptrs) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) {
         MomentSet& s = h->set[k];
@@ -995,8 +1047,13 @@ int lcx_update_b(lcx_ctx* h, double eps) { NEED(h); DISPATCH(h, update_b, h, eps
 int lcx_update_c(lcx_ctx* h, double eps) { NEED(h); DISPATCH(h, update_c, h, eps); }
 int lcx_update_d(lcx_ctx* h) {
     NEED(h);
-    hipLaunchKernelGGL(tangent_store_kernel, dim3(1), dim3(1), 0, h->stream, h->sbuf, h->set[0].st);
-    KCHECK();
+    if (h->world > 1) {
+        MomentSet& s = h->set[0];
+        const unsigned int seq = ++h->seq_next;
+        hipLaunchKernelGGL(tangent_store_kernel, dim3(1), dim3(1), 0, h->stream, h->sbuf, s.st, s.hst_dev, seq);
+        KCHECK();
+        s.seq_expect = seq;
+    }
     h->have_direction = true;
     return LCX_OK;
 }
@@ -1026,20 +1083,52 @@ int lcx_accept_trial(lcx_ctx* h) {
 int lcx_rescale_ws(lcx_ctx* h, double e0, double e1) { NEED(h); DISPATCH(h, rescale, h, e0, e1); }
 int lcx_init_scale_ws(lcx_ctx* h) { NEED(h); DISPATCH(h, init_scale, h); }
 
+// Wait until the pinned mirror of a set carries the last publication enqueued for it.
+static int wait_published(lcx_ctx* h, MomentSet& s) {
+    if (s.seq_expect == 0) {                 // nothing published yet: plain copy
+        HIPCHECK(hipMemcpyAsync(s.hst, s.st, sizeof(SetState), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        return LCX_OK;
+    }
+    volatile unsigned int* p = &s.hst->seq;
+    int spins = 0;
+    while (*p != s.seq_expect) {
+        if (++spins >= 4096) {
+            spins = 0;
+            hipError_t q = hipStreamQuery(h->stream);
+            if (q == hipSuccess) {
+                if (*p == s.seq_expect) break;
+                return fail(LCX_ERR_STATE, "stream drained but the state mirror was not published");
+            }
+            if (q != hipErrorNotReady) HIPCHECK(q);
+        }
+        __builtin_ia32_pause();
+    }
+    __sync_synchronize();
+    return LCX_OK;
+}
+
 int lcx_read_state(lcx_ctx* h, int which, double* out) {
     NEED(h);
     WHICH_OK(which);
     if (!out) return fail(LCX_ERR_ARG, "lcx_read_state: null");
-    HIPCHECK(hipMemcpyAsync(h->host_states + which, h->set[which].st, sizeof(SetState), hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    const SetState& s = h->host_states[which];
+    MomentSet& ms = h->set[which];
+    LCXCHECK(wait_published(h, ms));
+    const SetState& s = *ms.hst;
     out[LCX_S_TC] = s.tc;
     out[LCX_S_MAX_UJ] = s.max_uj;
     out[LCX_S_INVALID] = (double)s.invalid;
     out[LCX_S_TANGENT] = s.tangent;
     out[LCX_S_SUM_LOG_RJ] = s.sum_log_rj;
     out[5] = out[6] = out[7] = 0.0;
-    if (h->timing) LCXCHECK(timing_collect(h));
+    return LCX_OK;
+}
+
+int lcx_set_world(lcx_ctx* h, int world) {
+    NEED(h);
+    if (world < 1) return fail(LCX_ERR_ARG, "lcx_set_world: world must be >= 1");
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    h->world = world;
     return LCX_OK;
 }
 
@@ -1109,7 +1198,7 @@ int lcx_bench_gemm(lcx_ctx* h, int kind, int iters, double* avg_ms) {
     HIPCHECK(hipEventCreate(&a));
     HIPCHECK(hipEventCreate(&b));
     auto once = [&]() -> int {
-        if (kind == 0) { DISPATCH(h, nt_big, h, (const void*)h->Wt[0], nullptr); }
+        if (kind == 0) { DISPATCH(h, nt_big, h, (const void*)h->Wt[0], nullptr, false); }
         DISPATCH(h, tn_big, h, nullptr);
     };
     for (int i = 0; i < 3; ++i) LCXCHECK(once());

@@ -21,9 +21,23 @@ constexpr int PV_THREADS = 256;
 // state scalars per moment set (mirrors LCX_S_* in include/lcx.h)
 struct SetState {
     double tc, max_uj, invalid_d, tangent, sum_log_rj, r5, r6, r7;
-    int invalid;  // read by the GEMM kernels as skip flag
-    int pad[15];
+    int invalid;          // read by the GEMM kernels as skip flag
+    unsigned int seq;     // publication counter of the pinned host mirror
+    int pad[14];
 };
+
+// Copy a set's scalars to its pinned host mirror and bump the mirror's sequence number last, so
+// that the host can poll the mirror instead of issuing a device-to-host copy + stream sync.
+__device__ __forceinline__ void publish_state(const SetState* st, SetState* host, unsigned int seq) {
+    host->tc = st->tc;
+    host->max_uj = st->max_uj;
+    host->invalid_d = st->invalid_d;
+    host->tangent = st->tangent;
+    host->sum_log_rj = st->sum_log_rj;
+    host->invalid = st->invalid;
+    __threadfence_system();
+    __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // replicated per-factor quantities of a moment set
 struct SmallDesc {
@@ -83,45 +97,74 @@ __global__ void reduce_partials_kernel(const T* __restrict__ in, int nsplit, int
 // gy: [nsplit][Mp][Mp] partials of Y^T Y; gw: [Mp][Mp] (already summed over shards)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void small_moments_kernel(const T* __restrict__ gy, int nsplit, const T* __restrict__ gw,
-                                     int Mp, int m, double n_samples, double eps, int quick,
-                                     SmallDesc sm, SetState* st) {
-    __shared__ double red_max[PV_THREADS / 64];
-    __shared__ double red_sum[PV_THREADS / 64];
-    const int tid = threadIdx.x;
-    const T c1 = (T)(1.0 - eps * eps), c2 = (T)(eps * eps), ns = (T)n_samples;
-    double mx = -1e300, slog = 0.0;
-    for (int idx = tid; idx < Mp * Mp; idx += blockDim.x) {
-        T g = gy[idx];
-        for (int k = 1; k < nsplit; ++k) g += gy[(int64_t)k * Mp * Mp + idx];
-        const T val = c1 * g / ns + c2 * gw[idx];
-        const int j = idx / Mp, k2 = idx % Mp;
+__global__ void __launch_bounds__(256)
+small_moments_kernel(const T* __restrict__ gy, int nsplit, const T* __restrict__ gw, int nsplit_w,
+                     int Mp, int m, double n_samples, double eps, int quick, SmallDesc sm,
+                     SetState* st, unsigned int* ticket) {
+    // Each block sums the partial Gram tiles of 32 matrix elements (8 threads per element, fixed
+    // order) and writes ry / uj; the block that draws the last ticket then derives the per-factor
+    // scalars.  One launch instead of reduce + finish; deterministic (no floating-point atomics).
+    __shared__ T shy[8][32];
+    __shared__ T shw[8][32];
+    __shared__ double lg[128];
+    __shared__ double uu[128];
+    __shared__ int last_s;
+    const int tid = threadIdx.x, e = tid & 31, g = tid >> 5;
+    const int64_t mm = (int64_t)Mp * Mp;
+    const int64_t idx = (int64_t)blockIdx.x * 32 + e;
+    T a = (T)0, b = (T)0;
+    for (int k = g; k < nsplit; k += 8) a += gy[k * mm + idx];
+    for (int k = g; k < nsplit_w; k += 8) b += gw[k * mm + idx];
+    shy[g][e] = a;
+    shw[g][e] = b;
+    __syncthreads();
+    if (g == 0) {
+        T gyv = shy[0][e], gwv = shw[0][e];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { gyv += shy[k][e]; gwv += shw[k][e]; }
+        const T c1 = (T)(1.0 - eps * eps), c2 = (T)(eps * eps), ns = (T)n_samples;
+        const T val = c1 * gyv / ns + c2 * gwv;
+        const int j = (int)(idx / Mp), k2 = (int)(idx % Mp);
         if (j == k2) {
             sm.uj[j] = (double)val;
-            sm.wmag[j] = (double)gw[idx];
+            sm.wmag[j] = (double)gwv;
             sm.ry[idx] = 1.0;
-            if (j < m) {
-                mx = fmax(mx, (double)val);
-                slog += (double)log((T)1 - val);   // sum_j log(1-uj), in working precision (:274)
-            }
         } else {
             sm.ry[idx] = (double)val;
         }
     }
-    // block max / sum
-    for (int off = 32; off > 0; off >>= 1) {
-        mx = fmax(mx, __shfl_xor(mx, off, 64));
-        slog += __shfl_xor(slog, off, 64);
-    }
-    if ((tid & 63) == 0) { red_max[tid >> 6] = mx; red_sum[tid >> 6] = slog; }
+    // hand-off to the last block: release (agent scope) -> ticket; last block acquires
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < (int)(blockDim.x / 64); ++w) { mx = fmax(mx, red_max[w]); slog += red_sum[w]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == gridDim.x - 1);
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        last_s = last;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    if (tid < 128) {
+        double u = -1e300, l = 0.0;
+        if (tid < m) {
+            u = __hip_atomic_load(&sm.uj[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            l = (double)log((T)1 - (T)u);          // log(1-uj) in working precision (:274)
+        }
+        uu[tid] = u;
+        lg[tid] = l;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double mx = -1e300, slog = 0.0;
+        for (int j = 0; j < m; ++j) { mx = fmax(mx, uu[j]); slog += lg[j]; }
         st->max_uj = mx;
         st->sum_log_rj = slog;
         const int inv = (quick && mx >= 1.0) ? 1 : 0;
         st->invalid = inv;
         st->invalid_d = (double)inv;
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -212,6 +255,30 @@ sum_partials_kernel(const double* __restrict__ part, int nblocks, int nvals, OUT
     if (tid == 0) out[k] = (OUT)s;
 }
 
+// One launch for the two reductions that follow the X.grad^T pass: blocks [0, yblocks) sum the
+// grid-level partial tiles of Y (skipped when nsplit == 1), the next nvals blocks sum the per-block
+// Bj partials into the tail of the exchange buffer.
+template <typename T>
+__global__ void __launch_bounds__(PV_THREADS)
+reduce_y_bj_kernel(const T* __restrict__ ypart, int nsplit, int64_t n, T* __restrict__ yout, int yblocks,
+                   const double* __restrict__ part, int nblocks, int nvals, T* __restrict__ tail) {
+    __shared__ double bs_scratch[PV_THREADS / 64];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < yblocks) {
+        for (int64_t i = (int64_t)blockIdx.x * PV_THREADS + tid; i < n; i += (int64_t)yblocks * PV_THREADS) {
+            T s = ypart[i];
+            for (int k = 1; k < nsplit; ++k) s += ypart[k * n + i];
+            yout[i] = s;
+        }
+        return;
+    }
+    const int k = blockIdx.x - yblocks;
+    double s = 0.0;
+    for (int b = tid; b < nblocks; b += PV_THREADS) s += part[(int64_t)b * nvals + k];
+    s = block_sum<double>(s, bs_scratch, tid);
+    if (tid == 0) tail[k] = (T)s;
+}
+
 // out[i] = sum_s in[s][i] for many splits: 8 threads share an element, fixed order
 template <typename T, typename OUT>
 __global__ void __launch_bounds__(256)
@@ -236,10 +303,50 @@ reduce_wide_kernel(const T* __restrict__ in, int nsplit, int64_t n, int64_t stri
 
 // TC = sum log(1+Si) - 1/2 sum log(1+QiSi2) + 1/2 sum log(1-uj), rounded to the working precision
 template <typename T>
-__global__ void tc_final_kernel(const double* __restrict__ sbuf, SetState* st) {
+__device__ __forceinline__ void tc_store(const double* sbuf, SetState* st) {
     if (st->invalid) { st->tc = __builtin_nan(""); return; }
     const T tc = (T)sbuf[0] - (T)0.5 * (T)sbuf[1] + (T)0.5 * (T)st->sum_log_rj;
     st->tc = (double)tc;
+}
+template <typename T>
+__global__ void tc_final_kernel(const double* __restrict__ sbuf, SetState* st, SetState* host, unsigned int seq) {
+    tc_store<T>(sbuf, st);
+    publish_state(st, host, seq);
+}
+// per-block pairs -> sbuf[0..1]; with one GPU (single != 0) also TC and the host mirror, so that
+// lcx_moments_c has nothing left to launch
+template <typename T>
+__global__ void __launch_bounds__(PV_THREADS)
+tc_finalize_kernel(const double* __restrict__ tcpart, int nblocks, double* __restrict__ sbuf, SetState* st,
+                   SetState* host, unsigned int seq, int single) {
+    __shared__ double bs_scratch[PV_THREADS / 64];
+    const int tid = threadIdx.x;
+    if (!st->invalid) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int b = tid; b < nblocks; b += PV_THREADS) { s1 += tcpart[2 * b]; s2 += tcpart[2 * b + 1]; }
+        s1 = block_sum<double>(s1, bs_scratch, tid);
+        s2 = block_sum<double>(s2, bs_scratch, tid);
+        if (tid == 0) { sbuf[0] = s1; sbuf[1] = s2; }
+    }
+    if (tid == 0 && single) {
+        __threadfence();
+        tc_store<T>(sbuf, st);
+        publish_state(st, host, seq);
+    }
+}
+// tangent partials -> sbuf[0]; with one GPU also the state scalar + host mirror
+__global__ void __launch_bounds__(PV_THREADS)
+tan_finalize_kernel(const double* __restrict__ tanpart, int nblocks, double* __restrict__ sbuf, SetState* st,
+                    SetState* host, unsigned int seq, int single) {
+    __shared__ double bs_scratch[PV_THREADS / 64];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int b = tid; b < nblocks; b += PV_THREADS) s += tanpart[b];
+    s = block_sum<double>(s, bs_scratch, tid);
+    if (tid == 0) {
+        sbuf[0] = s;
+        if (single) { st->tangent = s; publish_state(st, host, seq); }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -307,14 +414,26 @@ update_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, const T*
               const T* __restrict__ W, const double* __restrict__ uj, const T* __restrict__ bj_tail,
               int64_t V, double n_samples, double eps, T* __restrict__ update_o,
               T* __restrict__ sgrad_o, double* __restrict__ tanpart,
-              const T* __restrict__ d_cur, T* __restrict__ d_dir_o) {
+              const T* __restrict__ d_cur, T* __restrict__ d_dir_o,
+              int update_blocks, const T* __restrict__ yg, const T* __restrict__ ycur, int64_t ny,
+              T* __restrict__ ydir_o) {
     __shared__ double bs_scratch[PV_THREADS / 64];
     const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= update_blocks) {
+        // the blocks past `update_blocks` form Y(update) = -rj (Y_g - c Y) on [Npad][Mp]
+        const int nb = gridDim.x - update_blocks;
+        for (int64_t i = (int64_t)(blockIdx.x - update_blocks) * PV_THREADS + tid; i < ny; i += (int64_t)nb * PV_THREADS) {
+            const int j = (int)(i % Mp);
+            const T rj = (T)1 - (T)uj[j];
+            ydir_o[i] = -rj * (yg[i] - (T)2 * bj_tail[j] / ((T)2 - rj) * ycur[i]);
+        }
+        return;
+    }
     const T c1 = (T)(1.0 - eps * eps), c2 = (T)(eps * eps), ns = (T)n_samples;
     double tan = 0.0;
     const int64_t total = V * Mp;
     for (int64_t o = (int64_t)blockIdx.x * PV_THREADS + tid; o < total;
-         o += (int64_t)gridDim.x * PV_THREADS) {
+         o += (int64_t)update_blocks * PV_THREADS) {
         const int j = (int)(o % Mp);
         T d = dpart[o];
         for (int k = 1; k < nsplit; ++k) d += dpart[k * pstride + o];
@@ -333,20 +452,9 @@ update_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, const T*
     if (tid == 0) tanpart[blockIdx.x] = tan;
 }
 
-__global__ void tangent_store_kernel(const double* __restrict__ sbuf, SetState* st) {
+__global__ void tangent_store_kernel(const double* __restrict__ sbuf, SetState* st, SetState* host, unsigned int seq) {
     st->tangent = sbuf[0];
-}
-
-// Y(update) = -rj (Y_g - c Y) on [Npad][Mp]  (same per-factor combination as above)
-template <typename T>
-__global__ void ydir_kernel(const T* __restrict__ yg, const T* __restrict__ ycur, const double* __restrict__ uj,
-                            const T* __restrict__ bj_tail, int Mp, int64_t n, T* __restrict__ ydir) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int j = (int)(i % Mp);
-        const T rj = (T)1 - (T)uj[j];
-        ydir[i] = -rj * (yg[i] - (T)2 * bj_tail[j] / ((T)2 - rj) * ycur[i]);
-    }
+    publish_state(st, host, seq);
 }
 
 // out = a + eta * b  (Y of a line-search trial from Y and Y(update))
@@ -357,6 +465,18 @@ __global__ void axpy_kernel(const T* __restrict__ w, const T* __restrict__ up, T
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x)
         out[i] = w[i] + eta * up[i];
+}
+
+// two axpys in one launch: w_update = ws + eta*update (:320) and Y' = Y + eta*Y(update)
+template <typename T>
+__global__ void axpy2_kernel(const T* __restrict__ a1, const T* __restrict__ b1, T* __restrict__ o1, int64_t n1,
+                             const T* __restrict__ a2, const T* __restrict__ b2, T* __restrict__ o2, int64_t n2,
+                             T eta) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n1) o1[i] = a1[i] + eta * b1[i];
+        else o2[i - n1] = a2[i - n1] + eta * b2[i - n1];
+    }
 }
 
 // stage change (:130-133): ws *= 0.001*floor(1000*a_j)

@@ -36,6 +36,9 @@ class ShardDouble:
     def synchronize(self):
         pass
 
+    def set_world(self, world):
+        self.world = world
+
     def exchange_tensors(self):
         return torch.from_numpy(self.ybuf), torch.from_numpy(self.sbuf)
 

@@ -44,11 +44,14 @@ def parse():
     ap.add_argument("--steps", type=int, default=70)
     ap.add_argument("--warmup", type=int, default=7)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-iters-per-stage", type=int, default=8,
+    ap.add_argument("--cpu-iters-per-stage", type=int, default=40,
                     help="bounded CPU-baseline sample: oracle iterations per annealing stage (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--line-search", default="linear", choices=["linear", "exact"],
-                    help="linear: trials cost no pass over X (default); exact: reference-shaped, 2 passes per trial")
+    ap.add_argument("--line-search", default="exact", choices=["linear", "exact"],
+                    help="exact (default, the headline): reference-shaped, every trial makes 2 passes over X "
+                         "(linearcorex.py:321); linear: trials cost no pass over X")
+    ap.add_argument("--no-also-linear", dest="also_linear", action="store_false",
+                    help="skip the second measurement in linear trial mode (reported under config.linear_trial_mode)")
     return ap.parse_args()
 
 
@@ -74,27 +77,23 @@ def cpu_baseline(x, m, dtype, iters_per_stage):
             "trials_per_iteration": res.n_trials / max(1, n_it)}
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+def load_pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of this same command
+    (tools/pmc_traffic.py writes profiles/pmc_traffic_<workload>.json on the GPU box; FETCH_SIZE is
+    doubled there as MI355X_MICROARCH.md prescribes for gfx950).  None if no such profile is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % workload)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d["kernels"][kernel]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
+
+
+def measure(args, comm, world, rank, local_rank, line_search, keep_x=False):
+    """Warm up, then time exactly args.steps fit iterations (barrier + synchronize on both sides)."""
     import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path is the only product path)")
-    torch.cuda.set_device(local_rank)
-    comm = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        from linearcorex_amd.comm import Comm
-        comm = Comm()
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
-
-    import __graft_entry__ as ge
-    ge.build()
     from linearcorex_amd import Corex
-
     n, v_per, m, tag = WORKLOADS[args.workload]
     dtype = np.float64 if tag == "f64" else np.float32
     v_total = v_per * world
@@ -102,10 +101,10 @@ def main():
     per_stage = int(math.ceil(total_steps / 7.0))
 
     model = Corex(n_hidden=m, seed=0, dtype=dtype, tol=0.0, max_iter=10 ** 9, device=local_rank, comm=comm,
-                  line_search=args.line_search)
+                  line_search=line_search)
     x_host = None
     if n * v_per * 8 <= (4 << 30):
-        # Gen-A: iid N(0,1); rank r draws its own 5k columns from RandomState(1 + r)
+        # Gen-A: iid N(0,1); rank r draws its own columns from RandomState(1 + r)
         from linearcorex_amd.preprocess import preprocess as pp
         x_host = np.random.RandomState(1 + rank).randn(n, v_per)
         xt = pp(x_host.astype(dtype), None, "standard", None)[0]
@@ -153,17 +152,51 @@ def main():
             one_step()
     elapsed = state["t1"] - state["t0"]
     if comm is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    res = {"elapsed": elapsed, "its_per_s": args.steps / elapsed, "geo": be.geometry(),
+           "timing": be.timing_read() if not args.no_kernel_timing else {},
+           "trials": model.stats["trials"] / max(1, args.steps),
+           "invalid": model.stats["invalid_trials"] / max(1, args.steps),
+           "final_tc": float(model.tc), "per_stage": per_stage, "x_host": x_host if keep_x else None,
+           "kernel_names": {"gemm_nt": be.kernel_name(0), "gemm_tn": be.kernel_name(1)}}
+    be.close()
+    model._backend = None
+    return res
 
-    its_per_s = args.steps / elapsed
-    geo = be.geometry()
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path is the only product path)")
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from linearcorex_amd.comm import Comm
+        comm = Comm()
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    import __graft_entry__ as ge
+    ge.build()
+
+    n, v_per, m, tag = WORKLOADS[args.workload]
+    dtype = np.float64 if tag == "f64" else np.float32
+    v_total = v_per * world
     es = np.dtype(dtype).itemsize
-    timing = be.timing_read() if not args.no_kernel_timing else {}
-    trials = model.stats["trials"] / max(1, args.steps)
-    invalid = model.stats["invalid_trials"] / max(1, args.steps)
+
+    # headline: the reference-shaped iteration (every line-search trial re-evaluates the moments
+    # with two passes over X, linearcorex.py:321)
+    r = measure(args, comm, world, rank, local_rank, args.line_search, keep_x=True)
+    elapsed, its_per_s, timing, geo = r["elapsed"], r["its_per_s"], r["timing"], r["geo"]
+    trials, invalid, per_stage = r["trials"], r["invalid"], r["per_stage"]
 
     # algorithmic bytes / flops of ONE launch of an X-streaming GEMM on this rank:
     alg_bytes = es * (n * v_per + m * v_per + n * m)
@@ -174,20 +207,44 @@ def main():
             avg = ms / cnt * 1e-3
             kernels[name] = {"launches": cnt, "avg_us": avg * 1e6, "GBps": alg_bytes / avg / 1e9,
                              "TFLOPs": alg_flops / avg / 1e12}
+    # use sites -> kernel function (rocprofv3 row).  X.B^T ("gemm_nt", :247/:210) and X^T.Y ("gemm_tn",
+    # :259/:211) usually run the same instantiation (the first one on the transposed copy of X).
+    by_fn = {}
+    for name, k in kernels.items():
+        fn = r["kernel_names"][name]
+        d = by_fn.setdefault(fn, {"launches": 0, "total_us": 0.0, "use_sites": []})
+        d["launches"] += k["launches"]
+        d["total_us"] += k["launches"] * k["avg_us"]
+        d["use_sites"].append(name)
+    for fn, d in by_fn.items():
+        avg = d["total_us"] / d["launches"] * 1e-6
+        d.update(avg_us=avg * 1e6, GBps=alg_bytes / avg / 1e9, TFLOPs=alg_flops / avg / 1e12)
     roofline = None
     if kernels:
-        dom = max(kernels, key=lambda k: kernels[k]["launches"] * kernels[k]["avg_us"])
+        dom = max(by_fn, key=lambda k: by_fn[k]["total_us"])
+        use_sites = kernels
+        kernels = by_fn
         intensity = alg_flops / alg_bytes
         mfma_peak = FP64_MFMA_PEAK_TFLOPS if tag == "f64" else FP32_MFMA_PEAK_TFLOPS
+        traffic, traffic_src = load_pmc_traffic(args.workload, dom)
         if intensity < mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9):
             roofline = {"bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None}
+                        "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic}
         else:
             roofline = {"bound": "mfma", "achieved": kernels[dom]["TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s",
-                        "frac": kernels[dom]["TFLOPs"] / mfma_peak, "traffic": None}
+                        "frac": kernels[dom]["TFLOPs"] / mfma_peak, "traffic": traffic}
         roofline.update(kernel=dom, avg_launch_us=kernels[dom]["avg_us"], launches=kernels[dom]["launches"],
                         algorithmic_bytes_per_launch=alg_bytes, algorithmic_flops_per_launch=alg_flops,
-                        all_kernels=kernels)
+                        traffic_source=traffic_src, use_sites=use_sites)
+
+    extra = None
+    if args.also_linear and args.line_search == "exact":
+        # same iterations with the linear trial mode: reported beside the headline, never as it
+        r2 = measure(args, comm, world, rank, local_rank, "linear")
+        extra = {"fit_iterations_per_sec": r2["its_per_s"], "ms_per_step": r2["elapsed"] / args.steps * 1e3,
+                 "x_passes_per_iteration": (sum(c for c, _ in r2["timing"].values()) / max(1, args.steps))
+                 if r2["timing"] else None,
+                 "line_search_trials_per_iteration": r2["trials"], "final_TC": r2["final_tc"]}
 
     out = {
         "metric": "corex_fit_iterations_per_sec",
@@ -209,9 +266,11 @@ def main():
                    "x_passes_per_iteration": (sum(c for c, _ in timing.values()) / max(1, args.steps)) if timing
                    else None,
                    "x_passes_per_iteration_reference_shaped": 2 + 2 * trials - invalid,
-                   "launch_geometry": geo, "final_TC": float(model.tc)},
+                   "launch_geometry": geo, "final_TC": r["final_tc"],
+                   "linear_trial_mode": extra},
         "roofline": roofline,
     }
+    x_host = r["x_host"]
     if rank == 0 and world == 1 and args.cpu_iters_per_stage > 0 and x_host is not None:
         out["cpu_baseline"] = cpu_baseline(x_host, m, dtype, args.cpu_iters_per_stage)
     elif rank == 0:

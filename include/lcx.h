@@ -201,6 +201,10 @@ int lcx_bench_gemm(lcx_ctx* h, int kind, int iters, double* avg_ms);
 /* geometry actually used (for the roofline arithmetic): padded sizes and launch shapes */
 int lcx_geometry(lcx_ctx* h, int64_t* n_pad, int64_t* ldx, int* m_pad, int64_t* info8);
 
+/* name of the kernel function behind pass `kind` as rocprofv3 prints it (without "void " and the
+ * argument list), so that bench.py's roofline line and the committed rocprof summary name the same row */
+int lcx_kernel_name(lcx_ctx* h, int kind, char* buf, int64_t len);
+
 /* ---- kernel unit tests (parity of the two GEMM kernels in isolation) -------------------------- */
 /* out (n_rows x m_pad) = A (n_rows x k, ld=lda) . B^T with B given as (k x m_pad) row-major     */
 int lcx_test_gemm_nt(int dtype, int device, const void* a_host, int64_t n_rows, int64_t k, int64_t lda,

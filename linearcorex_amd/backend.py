@@ -77,6 +77,11 @@ class HipBackend:
             out[name] = (n.value, ms.value)
         return out
 
+    def kernel_name(self, kind):
+        buf = C.create_string_buffer(256)
+        _abi.check(self.lib.lcx_kernel_name(self.h, int(kind), buf, 256))
+        return buf.value.decode()
+
     def bench_gemm(self, kind, iters=20):
         ms = C.c_double()
         _abi.check(self.lib.lcx_bench_gemm(self.h, int(kind), int(iters), C.byref(ms)))

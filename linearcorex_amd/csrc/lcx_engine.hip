@@ -664,6 +664,14 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
 
+    // Name of the kernel instantiation behind the two X-streaming passes, as rocprofv3 prints it (both
+    // passes run the same function: X.B^T contracts over the rows of the transposed copy).
+    static int kernel_name(lcx_ctx* h, int kind, char* buf, int64_t len) {
+        snprintf(buf, (size_t)len, "lcx::gemm_tn_kernel<%s, %d, %d, %d, false, 0, 4>", sizeof(T) == 8 ? "double" : "float", CT,
+                 Geo<T, CT>::TN_RT, kind == 0 ? h->nt_KW : h->tn_KW);
+        return LCX_OK;
+    }
+
     static int generate(lcx_ctx* h, uint64_t seed, int kind, int n_groups, int64_t col_offset) {
         hipLaunchKernelGGL((generate_kernel<T>), dim3(4096), dim3(256), 0, h->stream, P<T>(h->X), h->N, h->V, h->ldx,
                            seed, kind, n_groups < 1 ? 1 : n_groups, col_offset);
@@ -1224,6 +1232,12 @@ int lcx_geometry(lcx_ctx* h, int64_t* n_pad, int64_t* ldx, int* m_pad, int64_t* 
         info8[4] = h->nt_bpc; info8[5] = h->tn_bpc; info8[6] = h->pv_grid; info8[7] = h->n_cus;
     }
     return LCX_OK;
+}
+
+int lcx_kernel_name(lcx_ctx* h, int kind, char* buf, int64_t len) {
+    if (!h) return fail(LCX_ERR_ARG, "null handle");
+    if (kind < 0 || kind > 1 || !buf || len < 16) return fail(LCX_ERR_ARG, "lcx_kernel_name: bad argument");
+    DISPATCH(h, kernel_name, h, kind, buf, len);
 }
 
 int lcx_test_gemm_nt(int dtype, int device, const void* a, int64_t n_rows, int64_t k, int64_t lda, const void* b,

@@ -272,6 +272,194 @@ gram_pair_kernel(GramProblem<T> p0, GramProblem<T> p1) {
                                          blockIdx.x, blockIdx.y);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// gemm_ct: the same contraction D[v][j] = sum_n A[n][v] B[n][j] for MANY column tiles (large shards).
+//
+// Measured on MI355X (tools/gemm_probe2/4): when every wave fetches its own rows of B from L2 the
+// B stream is Mp/(16*RT) times the A stream in bytes (1x at n_hidden 64, 4x at 128 in float32) and
+// the kernel stalls at ~80 TF/s; with B staged once per block through LDS it reaches 115-125 TF/s.
+//   * a block's KW waves own KW ADJACENT column tiles (a "super tile" of KW*16*RT columns) and walk
+//     the SAME contraction range, so one copy of B serves the block: global -> VGPR -> LDS, double
+//     buffered, one barrier per group of 4*U rows;
+//   * A still goes global -> VGPR directly, 16 bytes per lane, contiguous 256 B per 16-lane row;
+//   * the contraction split moves to the grid, balanced stream-K style: the work is the list of
+//     (super tile, group) units in super-tile-major order, every block takes the same number of
+//     units (+-1), so a launch is one full round of resident blocks whatever the shape;
+//   * a block that covers only part of a super tile writes a partial tile into slot
+//     (block - first block of that super tile); the last contributor zero-fills the unused slots, so
+//     consumers sum a fixed number of slots (`maxslots`) in a fixed order: deterministic, no atomics.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int sk_owner(int64_t unit, int64_t total, int nb) {
+    return (int)(((unit + 1) * nb - 1) / total);      // the block b with start(b) <= unit < start(b+1), start(b) = total*b/nb
+}
+
+template <typename T, int N> struct VecT;
+template <> struct VecT<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct VecT<double, 1> { typedef double type; };
+template <> struct VecT<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct VecT<float, 2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct VecT<float, 1> { typedef float type; };
+
+// elements per 16-byte piece (capped by the tile count)
+template <typename T, int RT> struct Epl { static constexpr int v = (16 / (int)sizeof(T)) < RT ? (16 / (int)sizeof(T)) : RT; };
+
+// RT elements of one row for lane i: piece p sits at column p*16*EPL + i*EPL, so that every load
+// instruction covers 16 lanes x 16 B = 256 contiguous bytes of the row
+template <typename T, int RT>
+__device__ __forceinline__ void load_row_pieces(const T* rowp, int i, T (&dst)[RT]) {
+    constexpr int EPL = Epl<T, RT>::v;
+    typedef typename VecT<T, EPL>::type V;
+#pragma unroll
+    for (int p = 0; p < RT / EPL; ++p) {
+        const V v = *reinterpret_cast<const V*>(rowp + p * 16 * EPL + i * EPL);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            if constexpr (EPL == 1) dst[p] = v; else dst[p * EPL + e] = v[e];
+        }
+    }
+}
+// column (within the wave's 16*RT tile) that accumulator (tile t, MFMA output row r) belongs to
+template <typename T, int RT>
+__device__ __forceinline__ int piece_col(int t, int r) {
+    constexpr int EPL = Epl<T, RT>::v;
+    return (t / EPL) * 16 * EPL + r * EPL + (t % EPL);
+}
+
+template <typename T, int CT, int RT, int KW, int U>
+__global__ void __launch_bounds__(64 * KW)
+gemm_ct_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T* __restrict__ out,
+               int64_t out_rows, int64_t vcols, int ng /* groups of 4*U rows */, int nsuper, int maxslots,
+               const int* __restrict__ skip_flag) {
+    constexpr int Mp = 16 * CT;
+    constexpr int CHUNK = 4 * U * Mp;                        // elements of B per group
+    constexpr int PCS = CHUNK * (int)sizeof(T) / 16;         // 16-byte pieces per group
+    constexpr int NTH = 64 * KW;
+    constexpr int PPT = (PCS + NTH - 1) / NTH;               // pieces per thread
+    typedef typename MF<T>::acc_t acc_t;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) T Bs[2][CHUNK];
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t total = (int64_t)nsuper * ng;
+    const int nb = gridDim.x;
+    int64_t L0 = total * blockIdx.x / nb;
+    const int64_t L1 = total * (blockIdx.x + 1) / nb;
+
+    while (L0 < L1) {
+        const int st_ = (int)(L0 / ng);                      // super tile
+        const int s0 = (int)(L0 - (int64_t)st_ * ng);
+        const int s1 = (L1 - L0) < (int64_t)(ng - s0) ? s0 + (int)(L1 - L0) : ng;
+        const int cnt = s1 - s0;
+        const int64_t v0 = ((int64_t)st_ * KW + wave) * (16 * RT);
+        const bool active = v0 < vcols;
+
+        acc_t acc[RT][CT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int u = 0; u < CT; ++u) acc[t][u] = (acc_t){0, 0, 0, 0};
+        const T* ap = A + (active ? v0 : 0) + (int64_t)q * lda;
+        T a0[U][RT], a1[U][RT];
+        f4 bst[PPT];
+
+#define LCX_CT_LOADA(R, AA)                                                               \
+        if (active) {                                                                     \
+            const int64_t rb = (int64_t)(s0 + (R)) * (4 * U);                             \
+            _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
+                load_row_pieces<T, RT>(ap + (rb + 4 * st) * lda, i, AA[st]);              \
+        }
+#define LCX_CT_LOADB(R)                                                                   \
+        {                                                                                 \
+            const f4* src = reinterpret_cast<const f4*>(B + (int64_t)(s0 + (R)) * CHUNK); \
+            _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                             \
+                const int pc = p * NTH + (int)threadIdx.x;                                \
+                if (PCS % NTH == 0 || pc < PCS) bst[p] = src[pc];                         \
+            }                                                                             \
+        }
+#define LCX_CT_STOREB(BUF)                                                                \
+        {                                                                                 \
+            f4* dstp = reinterpret_cast<f4*>(&Bs[BUF][0]);                                \
+            _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                             \
+                const int pc = p * NTH + (int)threadIdx.x;                                \
+                if (PCS % NTH == 0 || pc < PCS) dstp[pc] = bst[p];                        \
+            }                                                                             \
+        }
+#define LCX_CT_MMA(AA, BUF)                                                               \
+        if (active) {                                                                     \
+            Pk<T, CT> bb[U];                                                              \
+            _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
+                bb[st] = *reinterpret_cast<const Pk<T, CT>*>(&Bs[BUF][(4 * st + q) * Mp + i * CT]); \
+            _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
+            _Pragma("unroll") for (int t = 0; t < RT; ++t)                                \
+            _Pragma("unroll") for (int u = 0; u < CT; ++u)                                \
+                acc[t][u] = MF<T>::mma(AA[st][t], bb[st].v[u], acc[t][u]);                \
+        }
+
+        LCX_CT_LOADA(0, a0);
+        LCX_CT_LOADB(0);
+        int r = 0;
+        while (true) {
+            LCX_CT_STOREB(0);
+            if (r + 1 < cnt) { LCX_CT_LOADA(r + 1, a1); LCX_CT_LOADB(r + 1); }
+            __syncthreads();
+            LCX_CT_MMA(a0, 0);
+            if (++r >= cnt) break;
+            LCX_CT_STOREB(1);
+            if (r + 1 < cnt) { LCX_CT_LOADA(r + 1, a0); LCX_CT_LOADB(r + 1); }
+            __syncthreads();
+            LCX_CT_MMA(a1, 1);
+            if (++r >= cnt) break;
+        }
+#undef LCX_CT_LOADA
+#undef LCX_CT_LOADB
+#undef LCX_CT_STOREB
+#undef LCX_CT_MMA
+
+        // ---- the wave's tile goes straight from the accumulators to its slot ---------------------
+        const int fb = sk_owner((int64_t)st_ * ng, total, nb);
+        if (active) {
+            T* dst = out + ((int64_t)(blockIdx.x - fb) * out_rows + v0) * Mp;
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    Pk<T, CT> o;
+#pragma unroll
+                    for (int u = 0; u < CT; ++u) o.v[u] = acc[t][u][g];
+                    *reinterpret_cast<Pk<T, CT>*>(dst + piece_col<T, RT>(t, MF<T>::row(lane, g)) * Mp + i * CT) = o;
+                }
+            if (s1 == ng) {        // last contributor of this super tile: zero the slots nobody writes
+                const int lb = sk_owner((int64_t)st_ * ng + ng - 1, total, nb);
+                Pk<T, CT> z;
+#pragma unroll
+                for (int u = 0; u < CT; ++u) z.v[u] = (T)0;
+                for (int sl = lb - fb + 1; sl < maxslots; ++sl) {
+                    T* zd = out + ((int64_t)sl * out_rows + v0) * Mp;
+#pragma unroll
+                    for (int t = 0; t < RT; ++t)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<Pk<T, CT>*>(zd + (16 * t + 4 * g + q) * Mp + i * CT) = z;
+                }
+            }
+        }
+        __syncthreads();            // Bs is reused by the next segment
+        L0 += cnt;
+    }
+}
+
+// tile shapes of gemm_ct: 16-byte A loads wherever the accumulators fit (RT*CT*4 registers of T)
+template <typename T, int CT> struct CtShape {
+    static constexpr int RT = (sizeof(T) == 8) ? (CT >= 4 ? 2 : 4) : 4;
+    // measured (tools/gemm_probe4, 50k x 20k float32): KW=4, U=4 gives 122 TF/s at n_hidden 64 and 140 TF/s
+    // at 128; KW=8 or U=2 lose 10-20 %
+    static constexpr int KW = 4;
+    static constexpr int U = 4;
+};
+
 // tile shapes per (dtype, CT): chosen so accumulators + two register sets stay under ~200 VGPRs
 template <typename T, int CT> struct NtShape { static constexpr int RT = (sizeof(T) == 8 && CT >= 8) ? 1 : 2; };
 // tn: wave tile = 16*RT columns of A.  Measured on MI355X (tools/gemm_probe, 10k x 5k f64, Mp=32):

@@ -88,6 +88,9 @@ struct lcx_ctx {
     unsigned int* ticket;       // arrival counter of small_moments_kernel
     // launch geometry
     int nt_S, nt_KW, tn_S, tn_KW, gn_S, gv_S, pv_grid, target_waves, n_cus, nt_bpc, tn_bpc;
+    // column-tiled stream-K kernel (gemm_ct) per pass: used when the shard has enough column tiles
+    bool nt_ct, tn_ct;
+    int nt_nb, nt_nsuper, tn_nb, tn_nsuper;
     // timing
     bool timing;
     std::vector<TimingPair> pending;
@@ -169,6 +172,33 @@ static int launch_tn(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t
     }
     KCHECK();
     return LCX_OK;
+}
+
+// gemm_ct launch: nb balanced blocks over (super tile, group) units; partial tiles -> out[slot][out_rows][Mp]
+template <typename T, int CT>
+static int launch_ct(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* out, int nb,
+                     int nsuper, int maxslots, const int* skip) {
+    typedef CtShape<T, CT> S;
+    const int ng = (int)(K / (4 * S::U));
+    hipLaunchKernelGGL((gemm_ct_kernel<T, CT, S::RT, S::KW, S::U>), dim3((unsigned)nb), dim3(64 * S::KW), 0, st, A, lda, B, out,
+                       vcols, vcols, ng, nsuper, maxslots, skip);
+    KCHECK();
+    return LCX_OK;
+}
+// geometry of a gemm_ct launch over `vcols` columns and K contraction rows
+template <typename T, int CT>
+static void ct_geometry(int n_cus, int64_t K, int64_t vcols, int force_nb, int* nb_o, int* nsuper_o, int* slots_o) {
+    typedef CtShape<T, CT> S;
+    int bpc = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)gemm_ct_kernel<T, CT, S::RT, S::KW, S::U>, 64 * S::KW, 0) != hipSuccess || bpc < 1) bpc = 1;
+    const int nsuper = (int)cdiv(vcols, S::KW * 16 * S::RT);
+    const int64_t total = (int64_t)nsuper * (K / (4 * S::U));
+    int64_t nb = force_nb > 0 ? force_nb : (int64_t)n_cus * bpc;
+    if (nb > total) nb = total;
+    if (nb < 1) nb = 1;
+    *nb_o = (int)nb;
+    *nsuper_o = nsuper;
+    *slots_o = (int)cdiv(nb, nsuper) + 1;
 }
 
 static int pick_split(int64_t tiles, int kw, int64_t kunits, int target_waves, int cap) {
@@ -266,6 +296,19 @@ template <typename T, int CT> struct Impl {
             h->tn_bpc = bpc;
             h->tn_S = env_int("LCX_TN_S", single_round_split(h->ldx / (16 * TN_RT), (int64_t)bpc * cus, kgn, h->tn_KW, 32));
         }
+        // Large shards: column-tiled stream-K kernel with B staged through LDS (gemm_ct).  It writes
+        // ceil(blocks / super tiles) + 1 partial slots, so it only pays when there are many column tiles.
+        {
+            const char* force = getenv("LCX_GEMM");          // "ct" / "tn" force one kernel for both passes
+            const int max_slots = env_int("LCX_CT_MAX_SLOTS", 6);
+            int nb, ns, sl;
+            ct_geometry<T, CT>(cus, h->ldx, h->Npad, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
+            h->nt_ct = force ? !strcmp(force, "ct") : sl <= max_slots;
+            if (h->nt_ct) { h->nt_nb = nb; h->nt_nsuper = ns; h->nt_S = sl; h->nt_KW = CtShape<T, CT>::KW; }
+            ct_geometry<T, CT>(cus, h->Npad, h->ldx, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
+            h->tn_ct = force ? !strcmp(force, "ct") : sl <= max_slots;
+            if (h->tn_ct) { h->tn_nb = nb; h->tn_nsuper = ns; h->tn_S = sl; h->tn_KW = CtShape<T, CT>::KW; }
+        }
         h->gn_S = pick_split(Mp / (16 * Geo<T, CT>::G_RT), pick_kw(kgn), kgn, h->target_waves / 4, 64);
         h->gv_S = pick_split(Mp / (16 * Geo<T, CT>::G_RT), pick_kw(kgv), kgv, h->target_waves / 4, 64);
         int64_t groups = cdiv(h->V, VPB);
@@ -288,8 +331,11 @@ template <typename T, int CT> struct Impl {
         TimingPair tp;
         LCXCHECK(timing_begin(h, 0, &tp));
         T* dst = h->nt_S > 1 ? P<T>(h->ypart) : P<T>(h->ybuf);
-        LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, B, nullptr,
-                                                               dst, h->nt_S, h->nt_KW, skip)));
+        if (h->nt_ct)
+            LCXCHECK((launch_ct<T, CT>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, B, dst, h->nt_nb, h->nt_nsuper, h->nt_S, skip)));
+        else
+            LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, B, nullptr,
+                                                                   dst, h->nt_S, h->nt_KW, skip)));
         LCXCHECK(timing_end(h, 0, &tp));
         const int64_t n = h->Npad * Mp;
         if (with_bj) {
@@ -315,8 +361,12 @@ template <typename T, int CT> struct Impl {
     static int tn_big(lcx_ctx* h, const int* skip) {
         TimingPair tp;
         LCXCHECK(timing_begin(h, 1, &tp));
-        LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false>(h->stream, P<T>(h->X), h->ldx, h->Npad, h->ldx, P<T>(h->ybuf), nullptr,
-                                           P<T>(h->dpart), h->tn_S, h->tn_KW, skip)));
+        if (h->tn_ct)
+            LCXCHECK((launch_ct<T, CT>(h->stream, P<T>(h->X), h->ldx, h->Npad, h->ldx, P<T>(h->ybuf), P<T>(h->dpart), h->tn_nb, h->tn_nsuper,
+                                       h->tn_S, skip)));
+        else
+            LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false>(h->stream, P<T>(h->X), h->ldx, h->Npad, h->ldx, P<T>(h->ybuf), nullptr,
+                                                                   P<T>(h->dpart), h->tn_S, h->tn_KW, skip)));
         LCXCHECK(timing_end(h, 1, &tp));
         return LCX_OK;
     }
@@ -667,8 +717,12 @@ template <typename T, int CT> struct Impl {
     // Name of the kernel instantiation behind the two X-streaming passes, as rocprofv3 prints it (both
     // passes run the same function: X.B^T contracts over the rows of the transposed copy).
     static int kernel_name(lcx_ctx* h, int kind, char* buf, int64_t len) {
-        snprintf(buf, (size_t)len, "lcx::gemm_tn_kernel<%s, %d, %d, %d, false, 0, 4>", sizeof(T) == 8 ? "double" : "float", CT,
-                 Geo<T, CT>::TN_RT, kind == 0 ? h->nt_KW : h->tn_KW);
+        if (kind == 0 ? h->nt_ct : h->tn_ct)
+            snprintf(buf, (size_t)len, "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d>", sizeof(T) == 8 ? "double" : "float", CT,
+                     CtShape<T, CT>::RT, CtShape<T, CT>::KW, CtShape<T, CT>::U);
+        else
+            snprintf(buf, (size_t)len, "lcx::gemm_tn_kernel<%s, %d, %d, %d, false, 0, 4>", sizeof(T) == 8 ? "double" : "float", CT,
+                     Geo<T, CT>::TN_RT, kind == 0 ? h->nt_KW : h->tn_KW);
         return LCX_OK;
     }
 
@@ -762,15 +816,26 @@ static int test_tn(const void* a_host, int64_t k, int64_t v, int64_t lda, const 
     HIPCHECK(hipMalloc((void**)&ad, sizeof(T) * kpad * ldv));
     HIPCHECK(hipMalloc((void**)&bd, sizeof(T) * kpad * Mp));
     HIPCHECK(hipMalloc((void**)&sd, sizeof(T) * kpad));
-    const int S = force_split > 0 ? force_split : 1, KW = force_kw > 0 ? force_kw : 4;
+    int S = force_split > 0 ? force_split : 1, KW = force_kw > 0 ? force_kw : 4;
+    int ct_nb = 0, ct_ns = 0;
+    if (force_kw < 0) {          // column-tiled stream-K kernel; force_split = number of blocks (0: as in production)
+        if (rs_host) return fail(LCX_ERR_ARG, "gemm_ct has no row scale");
+        int ncu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, 0) == hipSuccess) ncu = prop.multiProcessorCount;
+        ct_geometry<T, CT>(ncu, kpad, ldv, force_split, &ct_nb, &ct_ns, &S);
+    }
     HIPCHECK(hipMalloc((void**)&pd, sizeof(T) * S * ldv * Mp));
     HIPCHECK(hipMalloc((void**)&od, sizeof(T) * ldv * Mp));
+    HIPCHECK(hipMemset(pd, 0xff, sizeof(T) * S * ldv * Mp));     // every slot must be written by the kernel
     HIPCHECK(hipMemset(ad, 0, sizeof(T) * kpad * ldv));
     HIPCHECK(hipMemset(bd, 0, sizeof(T) * kpad * Mp));
     HIPCHECK(hipMemset(sd, 0, sizeof(T) * kpad));
     HIPCHECK(hipMemcpy2D(ad, ldv * sizeof(T), a_host, lda * sizeof(T), v * sizeof(T), k, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(bd, b_host, sizeof(T) * k * Mp, hipMemcpyHostToDevice));
-    if (rs_host) {
+    if (force_kw < 0) {
+        LCXCHECK((launch_ct<T, CT>(st, ad, ldv, kpad, ldv, bd, pd, ct_nb, ct_ns, S, nullptr)));
+    } else if (rs_host) {
         HIPCHECK(hipMemcpy(sd, rs_host, sizeof(T) * k, hipMemcpyHostToDevice));
         LCXCHECK((launch_tn<T, CT, TnShape<T, CT>::RT, true>(st, ad, ldv, kpad, ldv, bd, sd, pd, S, KW, nullptr)));
     } else {

@@ -77,3 +77,34 @@ def test_gemm_linearity_at_config2_size():
     assert np.max(np.abs(d12 - (d1 + d2)) / np.abs(d12).max()) < 1e-12
     cols = [0, 17, 4999]
     assert np.allclose(d1[cols], x[:, cols].T @ y1, rtol=1e-11, atol=1e-7)
+
+
+# ---- gemm_ct: column-tiled waves, B through LDS, stream-K balanced blocks --------------------------
+# waves=-1 selects it in the test entry point; split = number of blocks (0: what production would launch).
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("m_pad", [16, 32, 64, 128])
+@pytest.mark.parametrize("shape,blocks", [((70, 45), 0), ((300, 257), 3), ((1111, 1000), 0), ((2048, 64), 7),
+                                          ((64, 333), 1), ((1000, 1984), 37), ((4096, 640), 512)])
+def test_gemm_ct(dtype, m_pad, shape, blocks):
+    """Ragged sizes (inactive trailing waves of a super tile), block counts that cut super tiles at
+    arbitrary groups (several partial slots + zero-filled ones), one block, more blocks than units."""
+    from linearcorex_amd.backend import gemm_tn_check
+    k, v = shape
+    a = _asym(k, v, 8).astype(dtype)
+    b = _asym(k, m_pad, 9).astype(dtype)
+    got = gemm_tn_check(a, b, m_pad, dtype, split=blocks, waves=-1)
+    ref = a.astype(np.float64).T @ b.astype(np.float64)
+    scale = np.abs(a).astype(np.float64).T @ np.abs(b).astype(np.float64)
+    assert np.max(np.abs(got - ref) / scale) < TOL[dtype]
+
+
+def test_gemm_ct_is_deterministic_and_matches_tn():
+    from linearcorex_amd.backend import gemm_tn_check
+    rng = np.random.RandomState(3)
+    k, v, m_pad = 5000, 3000, 64
+    a, b = rng.randn(k, v).astype(np.float32), rng.randn(k, m_pad).astype(np.float32)
+    c1 = gemm_tn_check(a, b, m_pad, np.float32, split=0, waves=-1)
+    c2 = gemm_tn_check(a, b, m_pad, np.float32, split=0, waves=-1)
+    assert np.array_equal(c1, c2)                       # fixed summation order, no atomics
+    t = gemm_tn_check(a, b, m_pad, np.float32, split=3, waves=4)
+    assert np.max(np.abs(c1 - t)) < 2e-5 * np.sqrt(k) * 4

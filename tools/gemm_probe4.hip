@@ -1,0 +1,142 @@
+// gemm_probe4.hip - production gemm_ct_kernel (column-tiled waves, B through LDS, stream-K) vs gemm_tn_kernel,
+// interleaved medians + correctness (GPU box only).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <algorithm>
+#include <functional>
+#include <string>
+#include <string.h>
+#include "../linearcorex_amd/csrc/gemm_kernels.hpp"
+using namespace lcx;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+struct Variant { std::string name; std::function<void()> launch; std::vector<float> ms; int maxslots; };
+
+template <typename T, int CT, int RT, int KW, int U>
+Variant mkct(const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* out, int bpc_use = 0) {
+    auto kern = gemm_ct_kernel<T, CT, RT, KW, U>;
+    int bpc = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, 0));
+    const int use = bpc_use > 0 ? bpc_use : bpc;
+    const int ng = (int)(K / (4 * U));
+    const int nsuper = (int)((vcols + KW * 16 * RT - 1) / (KW * 16 * RT));
+    int64_t total = (int64_t)nsuper * ng;
+    int nb = 256 * use;
+    if (nb > total) nb = (int)total;
+    const int maxslots = (nb + nsuper - 1) / nsuper + 1;
+    char buf[200];
+    snprintf(buf, 200, "ct RT=%d KW=%d U=%d bpc=%d(use %d) nb=%d nsuper=%d slots=%d", RT, KW, U, bpc, use, nb, nsuper, maxslots);
+    return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, A, lda, B, out, vcols, vcols, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
+}
+
+template <typename T, int CT, int RT, int KW>
+Variant mkprod(const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* out, int S) {
+    auto kern = gemm_tn_kernel<T, CT, RT, KW, false, 0, 4>;
+    size_t lds = (size_t)KW * 16 * RT * 16 * CT * sizeof(T);
+    if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    char buf[200];
+    snprintf(buf, 200, "tn RT=%d KW=%d S=%d blocks=%d", RT, KW, S, (int)(vcols / (16 * RT)) * S);
+    return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3((unsigned)(vcols / (16 * RT)), S), dim3(64 * KW), lds, 0, A, lda, (int64_t)(16 * RT), B, (const T*)nullptr, out, vcols, (int)(K / 16), S, (const int*)nullptr); }, {}, S};
+}
+
+static void bench(std::vector<Variant>& vs, double gbytes, double tflop, int rounds = 5, int iters = 5) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (auto& v : vs) v.launch();
+    CK(hipDeviceSynchronize());
+    for (int r = 0; r < rounds; ++r)
+        for (auto& v : vs) {
+            v.launch();
+            CK(hipEventRecord(a, 0));
+            for (int it = 0; it < iters; ++it) v.launch();
+            CK(hipEventRecord(b, 0));
+            CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b));
+            v.ms.push_back(ms / iters);
+        }
+    for (auto& v : vs) {
+        std::sort(v.ms.begin(), v.ms.end());
+        const float med = v.ms[v.ms.size() / 2];
+        printf("%-60s med %8.1f us (min %8.1f max %8.1f) %6.0f GB/s %6.1f TF/s\n", v.name.c_str(), med * 1e3, v.ms.front() * 1e3, v.ms.back() * 1e3,
+               gbytes / med * 1e3, tflop / med * 1e3);
+    }
+    fflush(stdout);
+}
+
+template <typename T>
+void check(const char* what, Variant& v, Variant& ref, T* out, T* refout, int64_t V, int Mp, double tol) {
+    // ref writes into the same `out`; run ref first, copy, then v
+    const size_t n1 = (size_t)V * Mp;
+    ref.launch();
+    CK(hipDeviceSynchronize());
+    std::vector<T> r2((size_t)ref.maxslots * n1);
+    CK(hipMemcpy(r2.data(), out, r2.size() * sizeof(T), hipMemcpyDeviceToHost));
+    CK(hipMemset(out, 0xff, sizeof(T) * v.maxslots * n1));
+    v.launch();
+    CK(hipDeviceSynchronize());
+    std::vector<T> o((size_t)v.maxslots * n1);
+    CK(hipMemcpy(o.data(), out, o.size() * sizeof(T), hipMemcpyDeviceToHost));
+    double md = 0, mx = 0;
+    for (size_t x = 0; x < n1; ++x) {
+        double so = 0, sr = 0;
+        for (int s2 = 0; s2 < v.maxslots; ++s2) so += o[s2 * n1 + x];
+        for (int s2 = 0; s2 < ref.maxslots; ++s2) sr += r2[s2 * n1 + x];
+        md = fmax(md, fabs(so - sr)); mx = fmax(mx, fabs(sr));
+    }
+    printf("check %-10s %-52s max |diff| = %.3e (max |ref| = %.3e) %s\n", what, v.name.c_str(), md, mx, md <= tol * mx ? "ok" : "FAIL");
+}
+
+template <typename T, int CT, int TNRT>
+void suite(const char* name, int64_t K, int64_t V, int tnS) {
+    T *A, *B, *out;
+    CK(hipMalloc(&A, sizeof(T) * K * V));
+    CK(hipMalloc(&B, sizeof(T) * K * 16 * CT));
+    CK(hipMalloc(&out, sizeof(T) * 140 * V * 16 * CT));
+    {
+        std::vector<T> h((size_t)K * V);
+        for (size_t x = 0; x < h.size(); ++x) h[x] = (T)((double)rand() / RAND_MAX - 0.5);
+        CK(hipMemcpy(A, h.data(), sizeof(T) * K * V, hipMemcpyHostToDevice));
+        CK(hipMemcpy(B, h.data(), sizeof(T) * K * 16 * CT, hipMemcpyHostToDevice));
+    }
+    const double gb = sizeof(T) * ((double)K * V + 16.0 * CT * (K + V)) / 1e9, tf = 2.0 * K * V * 16 * CT / 1e12;
+    printf("== %s: K=%ld V=%ld Mp=%d elt=%zu\n", name, (long)K, (long)V, 16 * CT, sizeof(T));
+    std::vector<Variant> vs;
+    vs.push_back(mkprod<T, CT, TNRT, 4>(A, V, K, V, B, out, tnS));
+    constexpr int R = CtShape<T, CT>::RT;
+    vs.push_back(mkct<T, CT, R, 8, 2>(A, V, K, V, B, out));
+    vs.push_back(mkct<T, CT, R, 8, 4>(A, V, K, V, B, out));
+    vs.push_back(mkct<T, CT, R, 4, 2>(A, V, K, V, B, out));
+    vs.push_back(mkct<T, CT, R, 4, 4>(A, V, K, V, B, out));
+    vs.push_back(mkct<T, CT, R, 8, 1>(A, V, K, V, B, out));
+    if (R > 2) { vs.push_back(mkct<T, CT, 2, 8, 2>(A, V, K, V, B, out)); vs.push_back(mkct<T, CT, 2, 8, 4>(A, V, K, V, B, out)); }
+    const double tol = sizeof(T) == 8 ? 1e-12 : 2e-5;
+    for (size_t k = 1; k < vs.size(); ++k) check<T>(name, vs[k], vs[0], out, out, V, 16 * CT, tol);
+    bench(vs, gb, tf);
+    CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(out));
+}
+
+int main(int argc, char** argv) {
+    const char* which = argc > 1 ? argv[1] : "all";
+    const bool all = !strcmp(which, "all");
+    if (all || !strcmp(which, "c3")) {
+        suite<float, 4, 4>("c3l_xty", 50048, 20032, 3);
+        suite<float, 4, 4>("c3l_xw", 20032, 50048, 2);
+    }
+    if (all || !strcmp(which, "c4")) {
+        suite<float, 8, 2>("c4l_xty", 50048, 20032, 2);
+        suite<float, 8, 2>("c4l_xw", 20032, 50048, 2);
+    }
+    if (all || !strcmp(which, "c2")) {
+        suite<double, 2, 4>("c2_xty", 10048, 5056, 6);
+        suite<double, 2, 4>("c2_xw", 5056, 10048, 3);
+    }
+    if (all || !strcmp(which, "odd")) {
+        suite<float, 1, 4>("odd_f32_m16", 2048, 1984, 4);      // ragged super tile (1984 = 31 x 64)
+        suite<double, 4, 2>("odd_f64_m64", 4096, 3008, 4);
+        suite<double, 8, 1>("odd_f64_m128", 4096, 3008, 4);
+        suite<float, 2, 4>("odd_f32_m32", 1024, 6464, 4);
+    }
+    return 0;
+}

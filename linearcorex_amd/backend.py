@@ -34,6 +34,7 @@ class HipBackend:
                                        _abi.dtype_code(self.dtype), self.device))
         self.h = h
         self._ex = None            # torch exchange tensors when sharded
+        self.torch_stream = None
         self.generation = 0        # bumps whenever moment set 0 changes (guards lazy readback)
 
     # ---- lifetime ---------------------------------------------------------------------------
@@ -108,11 +109,19 @@ class HipBackend:
             s = torch.zeros(se.value, dtype=torch.float64, device=dev)
             torch.cuda.synchronize(dev)
             _abi.check(self.lib.lcx_bind_exchange(self.h, C.c_void_p(y.data_ptr()), C.c_void_p(s.data_ptr())))
-            with torch.cuda.device(dev):
-                stream = torch.cuda.current_stream().cuda_stream
-            _abi.check(self.lib.lcx_set_stream(self.h, C.c_void_p(stream)))
+            # A stream of our own that torch knows about: torch's default stream is the null stream (handle
+            # 0), which the engine's non-blocking stream is NOT ordered with.  Every collective on the
+            # exchange tensors must be issued under `with torch.cuda.stream(self.torch_stream)`.
+            self.torch_stream = torch.cuda.Stream(device=dev)
+            assert self.torch_stream.cuda_stream != 0
+            _abi.check(self.lib.lcx_set_stream(self.h, C.c_void_p(self.torch_stream.cuda_stream)))
             self._ex = (y, s)
         return self._ex
+
+    def stream_context(self):
+        """Context under which torch work (collectives) is stream-ordered with the engine's kernels."""
+        import torch
+        return torch.cuda.stream(self.torch_stream)
 
     def read_sbuf(self, count):
         out = np.empty(int(count), dtype=np.float64)

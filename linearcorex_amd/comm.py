@@ -43,7 +43,9 @@ class Comm:
         lead = local.shape[:-1]
         pad = np.zeros(lead + (wmax,), dtype=local.dtype)
         pad[..., :local.shape[-1]] = local
-        mine = torch.from_numpy(pad).to(like.device)
+        # RCCL gathers device tensors; gloo (CPU tests, and two ranks sharing one GPU) gathers on the host
+        dev = like.device if self._dist.get_backend(self.group) == "nccl" else "cpu"
+        mine = torch.from_numpy(pad).to(dev)
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         self._dist.all_gather(parts, mine, group=self.group)
         return np.concatenate([p.cpu().numpy()[..., :w] for p, w in zip(parts, widths)], axis=-1)

@@ -155,18 +155,23 @@ class Corex(object):
         self._ex = be.exchange_tensors() if self._comm.world > 1 else None
         return be
 
+    def _allreduce(self, tensor):
+        """Exchange step: all-reduce on the stream the engine's kernels run on."""
+        with self._backend.stream_context():
+            self._comm.allreduce(tensor)
+
     def _xy(self):
         if self._ex is not None:
-            self._comm.allreduce(self._ex[0])
+            self._allreduce(self._ex[0])
 
     def _xs(self, count):
         if self._ex is not None:
-            self._comm.allreduce(self._ex[1][:count])
+            self._allreduce(self._ex[1][:count])
 
     def _xtail(self):
         """all-reduce only the m_pad^2 tail of the Y exchange buffer (W.W^T partials)."""
         if self._ex is not None:
-            self._comm.allreduce(self._ex[0][-be_mp2(self._backend):])
+            self._allreduce(self._ex[0][-be_mp2(self._backend):])
 
     def _gather(self, local, key=None):
         """Per-variable arrays are sharded on the last (m x nv, nv) or first (nv x m) axis."""
@@ -451,9 +456,10 @@ class Corex(object):
         y = be.project(np.ascontiguousarray(x[:, c0:c1]))
         if self._comm.world > 1:
             import torch
-            t = torch.from_numpy(y).to(self._ex[1].device)
-            self._comm.allreduce(t)
-            y = t.cpu().numpy()
+            with be.stream_context():
+                t = torch.from_numpy(y).to(self._ex[1].device)
+                self._comm.allreduce(t)
+                y = t.cpu().numpy()
         if details:
             if ns != self.n_samples:
                 raise NotImplementedError("transform(details=True) is supported on the fitted data only")

@@ -19,11 +19,18 @@ from tests.shard_double import ShardDouble  # noqa: E402
 def main():
     out_dir, n, v, m = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     mode = sys.argv[5] if len(sys.argv) > 5 else "exact"
+    backend = sys.argv[6] if len(sys.argv) > 6 else "double"
+    max_iter = int(sys.argv[7]) if len(sys.argv) > 7 else 10000
     dist.init_process_group("gloo")
     comm = Comm()
     x, _ = O.gen_planted(n, v, m, seed=2)
-    model = Corex(n_hidden=m, seed=0, dtype=np.float64, comm=comm, line_search=mode,
-                  _backend_factory=lambda ns, nv, mm, dt: ShardDouble(ns, nv, mm, dt))
+    if backend == "hip":
+        # every rank drives its own engine handle on GPU 0; the exchange tensors are CUDA tensors and the
+        # collectives go through gloo (RCCL refuses two ranks on one device) - same host code as bench.py
+        model = Corex(n_hidden=m, seed=0, dtype=np.float64, comm=comm, line_search=mode, device=0, max_iter=max_iter)
+    else:
+        model = Corex(n_hidden=m, seed=0, dtype=np.float64, comm=comm, line_search=mode, max_iter=max_iter,
+                      _backend_factory=lambda ns, nv, mm, dt: ShardDouble(ns, nv, mm, dt))
     model.fit(x)
     c0, c1 = comm.shard(v)
     assert model._backend.nv == c1 - c0
@@ -35,7 +42,7 @@ def main():
         np.savez(os.path.join(out_dir, "dist_result.npz"), history=np.asarray(model.history["TC"], np.float64),
                  ws=model.ws, clusters=model.clusters(), transform=y, rho=rho, xz=xz, si=si,
                  tcs=model.tcs, world=comm.world, trials=model.stats["trials"],
-                 calls=np.array(len(model._backend.calls)))
+                 calls=np.array(len(getattr(model._backend, "calls", []))))
     dist.barrier()
     dist.destroy_process_group()
 

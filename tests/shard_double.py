@@ -42,6 +42,10 @@ class ShardDouble:
     def exchange_tensors(self):
         return torch.from_numpy(self.ybuf), torch.from_numpy(self.sbuf)
 
+    def stream_context(self):
+        import contextlib
+        return contextlib.nullcontext()
+
     def read_sbuf(self, count):
         return self.sbuf[:count].copy()
 

@@ -1,0 +1,61 @@
+"""N>1 device path on one GPU: two ranks, each with its own engine handle on GPU 0 holding half of
+the variables, exchange tensors all-reduced through torch.distributed (gloo here: RCCL does not allow
+two ranks on one device).  Exercises the world>1 kernels of liblcx_hip.so (W.W^T tail reduction,
+tc_final / tangent_store, bound exchange buffers, the caller's stream) and the same host code bench.py
+runs with --gpus N.  The result must equal the single-process oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import corex_oracle as O
+from tests.test_distributed_cpu import ROOT, free_port  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+MAX_ITER = 25          # per annealing stage: gloo stages every CUDA all-reduce through the host (slow)
+
+
+def launch_hip(world, out_dir, n, v, m, mode):
+    import subprocess
+    import sys
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(out_dir),
+                                       str(n), str(v), str(m), mode, "hip", str(MAX_ITER)], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode(errors="replace"))
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+
+
+@pytest.mark.parametrize("world,mode", [(2, "exact"), (3, "exact"), (2, "linear")])
+def test_sharded_fit_on_device_matches_oracle(world, mode, tmp_path):
+    n, v, m = 400, 331, 5               # uneven shards, ragged padding
+    launch_hip(world, tmp_path, n, v, m, mode)
+    got = np.load(os.path.join(tmp_path, "dist_result.npz"))
+    assert int(got["world"]) == world
+    x, _ = O.gen_planted(n, v, m, seed=2)
+    ref = O.fit_ns(x, m, seed=0, dtype=np.float64, keep_x=True, max_iter=MAX_ITER)
+    h, h_ref = got["history"], np.asarray(ref.history_tc)
+    assert len(h) == len(h_ref)
+    assert np.max(np.abs(h - h_ref) / np.maximum(1, np.abs(h_ref))) < 1e-8
+    assert np.array_equal(got["clusters"], ref.clusters())
+    assert np.max(np.abs(got["ws"] - ref.ws)) < 1e-7
+    assert np.max(np.abs(got["transform"] - ref.transform(ref.x_tilde))) < 1e-7
+    assert np.max(np.abs(got["rho"] - ref.moments["rho"])) < 1e-7
+    assert np.max(np.abs(got["xz"] - ref.moments["X_i Z_j"])) < 1e-7
+    assert np.max(np.abs(got["tcs"] - ref.moments["TCs"])) < 1e-7
+    if mode == "exact":
+        assert int(got["trials"]) == ref.n_trials

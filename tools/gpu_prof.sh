@@ -1,0 +1,20 @@
+#!/bin/bash
+# rocprofv3 kernel stats + PMC HBM traffic of the bench command for one workload (GPU box).
+#   bash tools/gpu_prof.sh <tag> <workload> [extra bench args]
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=$1; WL=$2; shift 2
+ARGS="--workload $WL --cpu-iters-per-stage 0 --no-also-linear $*"
+mkdir -p $R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$WL -o $WL -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_$WL.log 2>&1
+tail -1 $R/gpurun_out/prof_$WL.log | cut -c1-200
+STATS=$(find $R/gpurun_out/prof_$WL -name "*kernel_stats.csv" | head -1)
+cp "$STATS" $R/gpurun_out/${TAG}_rocprof_kernel_stats_$WL.csv && head -8 $R/gpurun_out/${TAG}_rocprof_kernel_stats_$WL.csv | cut -c1-220
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_${C}_$WL -o $WL -- python3 $R/bench.py $ARGS > $R/gpurun_out/pmc_${C}_$WL.log 2>&1
+  tail -1 $R/gpurun_out/pmc_${C}_$WL.log | cut -c1-120
+done
+python3 $R/tools/pmc_traffic.py --workload $WL --fetch $R/gpurun_out/pmc_FETCH_SIZE_$WL --write $R/gpurun_out/pmc_WRITE_SIZE_$WL \
+  --command "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py $ARGS" --out $R/gpurun_out/pmc_traffic_$WL.json
+find $R/gpurun_out -name "*counter_collection.csv" -size +2M -delete
+find $R/gpurun_out -name "*kernel_trace.csv" -size +8M -delete

@@ -113,6 +113,16 @@ int lcx_bind_exchange(lcx_ctx* h, void* ybuf_dev, void* sbuf_dev);
 /* Replaces cm.CUDAMatrix(x) (:427-428): upload the preprocessed shard, row-major, leading
  * dimension ld (elements of the working dtype). */
 int lcx_upload_x(lcx_ctx* h, const void* x_host, int64_t ld);
+/* Replaces preprocess(x, fit) + cm.CUDAMatrix(x) (:397-429) for a RAW shard: upload, then on the device
+ * impute missing cells by the column mean of the observed cells (mean_impute, :497-510; a cell is missing if
+ * it is NaN or equals `missing`, only when has_missing != 0), estimate theta = (mean, std) (fit != 0;
+ * 'standard': std over the observed cells :411-413, 'outliers': np.std over all rows :420-421, both clipped
+ * at 1e-10) or take the given one (fit == 0), standardise, and for kind 2 squash the tails with g (:483-487).
+ * kind: 0 pass-through ('none' and any unknown name, :404-405), 1 'standard', 2 'outliers'.
+ * mean_io / std_io: nv_local values of the working dtype; n_obs_out: nv_local int64 or NULL;
+ * max_abs_out: max |x~| (for the "more than 6 stds" warning, :416-417) or NULL. */
+int lcx_upload_preprocess(lcx_ctx* h, const void* x_raw_host, int64_t ld, int kind, int has_missing, double missing,
+                          int fit, void* mean_io, void* std_io, int64_t* n_obs_out, double* max_abs_out);
 /* On-device synthetic shard for sizes that cannot be staged on the host (SURVEY.md 8d Gen-A/B):
  * element (row, col_offset+col) of a counter-based N(0,1) generator keyed by seed; kind 0 = iid,
  * kind 1 = planted groups (n_groups latent factors + unit noise).  Columns are standardised on
@@ -188,6 +198,11 @@ int lcx_covariance_rows(lcx_ctx* h, double eps, const void* std_host, int64_t ro
                         void* out_host);
 /* transform (:386-395): out (n_rows x m) = x (n_rows x nv_local, ld) . ws^T  (per-shard partial) */
 int lcx_project(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, void* out_host);
+
+/* transform (:386-395) of RAW rows without missing values: standardise with theta on the device (kind as
+ * above), then x~ . ws^T */
+int lcx_project_raw(lcx_ctx* h, const void* x_raw_host, int64_t n_rows, int64_t ld, int kind, const void* mean,
+                    const void* std, void* out_host);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* HIP-event timing of the two X-streaming GEMM kernels on the handle's stream.

@@ -36,6 +36,8 @@ SIGNATURES = {
     "lcx_exchange_layout": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_vp)],
     "lcx_bind_exchange": [_vp, _vp, _vp],
     "lcx_upload_x": [_vp, _vp, _i64],
+    "lcx_upload_preprocess": [_vp, _vp, _i64, _i32, _i32, _dbl, _i32, _vp, _vp, C.POINTER(_i64), C.POINTER(_dbl)],
+    "lcx_project_raw": [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp],
     "lcx_generate_x": [_vp, C.c_uint64, _i32, _i32, _i64],
     "lcx_download_x": [_vp, _vp, _i64],
     "lcx_set_ws": [_vp, _vp],

@@ -134,6 +134,38 @@ class HipBackend:
         assert x.shape == (self.n_samples, self.nv), x.shape
         _abi.check(self.lib.lcx_upload_x(self.h, p, x.shape[1]))
 
+    PP_KINDS = {"standard": 1, "outliers": 2}     # anything else passes through (reference :404-405)
+
+    def upload_preprocess(self, x_raw, gaussianize, missing_values=None, theta=None):
+        """preprocess(x, fit=theta is None) of the reference (:397-429) on the device for this shard.
+        Returns (theta, n_obs, max_abs): theta = (mean, std) in the working dtype, n_obs per column
+        (int64 array) when missing values are enabled, else n_samples."""
+        x, p = self._a(x_raw)
+        assert x.shape == (self.n_samples, self.nv), x.shape
+        kind = self.PP_KINDS.get(gaussianize, 0)
+        fit = theta is None
+        mean = np.zeros(self.nv, self.dtype) if fit else np.ascontiguousarray(theta[0], self.dtype)
+        std = np.ones(self.nv, self.dtype) if fit else np.ascontiguousarray(theta[1], self.dtype)
+        n_obs = np.zeros(self.nv, np.int64)
+        mx = C.c_double()
+        has_missing = missing_values is not None
+        _abi.check(self.lib.lcx_upload_preprocess(self.h, p, x.shape[1], kind, 1 if has_missing else 0,
+                                                  float(missing_values) if has_missing else 0.0, 1 if fit else 0,
+                                                  _abi.np_ptr(mean), _abi.np_ptr(std),
+                                                  n_obs.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(mx)))
+        return (mean, std), (n_obs if has_missing else self.n_samples), mx.value
+
+    def project_raw(self, x_raw, gaussianize, theta):
+        x, p = self._a(x_raw)
+        assert x.ndim == 2 and x.shape[1] == self.nv
+        kind = self.PP_KINDS.get(gaussianize, 0)
+        mean = np.ascontiguousarray(theta[0], self.dtype)
+        std = np.ascontiguousarray(theta[1], self.dtype)
+        out = np.empty((x.shape[0], self.m), dtype=self.dtype)
+        _abi.check(self.lib.lcx_project_raw(self.h, p, x.shape[0], x.shape[1], kind, _abi.np_ptr(mean), _abi.np_ptr(std),
+                                            _abi.np_ptr(out)))
+        return out
+
     def generate_x(self, seed, kind=0, n_groups=1, col_offset=0):
         _abi.check(self.lib.lcx_generate_x(self.h, int(seed), int(kind), int(n_groups), int(col_offset)))
 

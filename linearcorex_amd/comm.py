@@ -28,6 +28,10 @@ class Comm:
         if self.world > 1:
             self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM, group=self.group)
 
+    def allreduce_max(self, tensor):
+        if self.world > 1:
+            self._dist.all_reduce(tensor, op=self._dist.ReduceOp.MAX, group=self.group)
+
     def barrier(self):
         if self.world > 1:
             self._dist.barrier(group=self.group)
@@ -59,6 +63,9 @@ class SingleComm:
         return 0, nv
 
     def allreduce(self, tensor):
+        pass
+
+    def allreduce_max(self, tensor):
         pass
 
     def barrier(self):

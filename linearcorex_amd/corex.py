@@ -190,12 +190,30 @@ class Corex(object):
 
     def fit(self, x):
         x = np.asarray(x, dtype=self.dtype)                    # reference casts to float32 (:108)
-        x = self.preprocess(x, fit=True)
         self.n_samples, self.nv = x.shape
         c0, c1 = self._comm.shard(self.nv)
         self._cols = (c0, c1)
         be = self._make_backend(self.n_samples, c1 - c0)
-        be.upload_x(np.ascontiguousarray(x[:, c0:c1]))
+        if self.gaussianize == 'empirical':
+            # rank-based gaussianisation (:424-426) is a per-column sort: host side, then a plain upload
+            x = self.preprocess(x, fit=True)
+            be.upload_x(np.ascontiguousarray(x[:, c0:c1]))
+        else:
+            # preprocess(x, fit=True) (:109, :397-429) happens on the device, per shard, while uploading
+            theta, n_obs, max_abs = be.upload_preprocess(np.ascontiguousarray(x[:, c0:c1]), self.gaussianize,
+                                                         self.missing_values, None)
+            if self.gaussianize in ('standard', 'outliers'):
+                self.theta = (self._gather(theta[0]), self._gather(theta[1]))
+            self.n_obs = self._gather(n_obs) if self.missing_values is not None else len(x)
+            if self.gaussianize == 'standard' and self.verbose:
+                if self._comm.world > 1:
+                    import torch
+                    with be.stream_context():
+                        t = torch.tensor([max_abs], dtype=torch.float64, device=self._ex[1].device)
+                        self._comm.allreduce_max(t)
+                        max_abs = float(t.item())
+                if max_abs > 6:
+                    print("Warning: outliers more than 6 stds away from mean. Consider using gaussianize='outliers'")
         del x
         return self._fit_resident()
 
@@ -448,12 +466,21 @@ class Corex(object):
     # ------------------------------------------------------------------------------------------
     def transform(self, x, details=False):
         """x -> latent factors Y = x~ . ws^T (:386-395)."""
-        x = self.preprocess(np.asarray(x, dtype=self.dtype))
+        x = np.asarray(x, dtype=self.dtype)
         ns, nv = x.shape
         assert self.nv == nv, "Incorrect number of variables in input, %d instead of %d" % (nv, self.nv)
         be = self._resident_backend()
         c0, c1 = self._cols
-        y = be.project(np.ascontiguousarray(x[:, c0:c1]))
+        if self.missing_values is None and self.gaussianize != 'empirical':
+            theta = None
+            if self.gaussianize in ('standard', 'outliers'):
+                theta = (self.theta[0][c0:c1], self.theta[1][c0:c1])
+            else:
+                theta = (np.zeros(c1 - c0, self.dtype), np.ones(c1 - c0, self.dtype))
+            y = be.project_raw(np.ascontiguousarray(x[:, c0:c1]), self.gaussianize, theta)   # preprocess on the device
+        else:
+            x = self.preprocess(x)       # imputation needs the column means of the whole new batch: host side
+            y = be.project(np.ascontiguousarray(x[:, c0:c1]))
         if self._comm.world > 1:
             import torch
             with be.stream_context():

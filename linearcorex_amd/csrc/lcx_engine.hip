@@ -726,22 +726,147 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
 
+    // ---- preprocess on device (:397-429): stats + impute + standardise / tail squash, in place on X ----
+    // mean_io / std_io: host arrays of T (nv_local); nobs_out: int64 (may be null)
+    static int preprocess_resident(lcx_ctx* h, int kind, int has_missing, double sentinel, int fit, void* mean_io,
+                                   void* std_io, int64_t* nobs_out, double* maxabs_out) {
+        const int64_t V = h->V, N = h->N;
+        const int strips = (int)cdiv(V, 64);
+        int RS = (int)cdiv(4 * h->n_cus, strips);
+        if (RS > 64) RS = 64;
+        if ((int64_t)RS * 16 > N) RS = (int)(N / 16 > 0 ? N / 16 : 1);
+        if (RS < 1) RS = 1;
+        double *nobs = nullptr, *imp = nullptr, *mean = nullptr, *stdv = nullptr, *ps = nullptr, *pn = nullptr, *bmax = nullptr;
+        HIPCHECK(hipMalloc((void**)&nobs, sizeof(double) * V));
+        HIPCHECK(hipMalloc((void**)&imp, sizeof(double) * V));
+        HIPCHECK(hipMalloc((void**)&mean, sizeof(double) * V));
+        HIPCHECK(hipMalloc((void**)&stdv, sizeof(double) * V));
+        HIPCHECK(hipMalloc((void**)&ps, sizeof(double) * V * RS));
+        HIPCHECK(hipMalloc((void**)&pn, sizeof(double) * V * RS));
+        HIPCHECK(hipMalloc((void**)&bmax, sizeof(double) * strips * RS));
+        const dim3 grid((unsigned)strips, (unsigned)RS);
+        const unsigned fgrid = (unsigned)cdiv(V, 256);
+        T* X = P<T>(h->X);
+        const bool need_stats = kind != PP_KIND_NONE;
+        if (has_missing || (fit && need_stats)) {
+            hipLaunchKernelGGL((pp_colsum_kernel<T>), grid, dim3(256), 0, h->stream, X, N, V, h->ldx, has_missing, (T)sentinel,
+                               (const double*)nullptr, ps, pn);
+            KCHECK();
+            hipLaunchKernelGGL((pp_finalize_kernel<T>), dim3(fgrid), dim3(256), 0, h->stream, ps, pn, RS, V, (double)N, kind, 0, nobs, imp, stdv);
+            KCHECK();
+        }
+        std::vector<double> tmp((size_t)V);
+        if (need_stats) {
+            if (fit) {
+                HIPCHECK(hipMemcpyAsync(mean, imp, sizeof(double) * V, hipMemcpyDeviceToDevice, h->stream));
+                hipLaunchKernelGGL((pp_colsum_kernel<T>), grid, dim3(256), 0, h->stream, X, N, V, h->ldx, has_missing, (T)sentinel,
+                                   (const double*)mean, ps, (double*)nullptr);
+                KCHECK();
+                hipLaunchKernelGGL((pp_finalize_kernel<T>), dim3(fgrid), dim3(256), 0, h->stream, ps, (const double*)nullptr, RS, V, (double)N, kind,
+                                   1, nobs, mean, stdv);
+                KCHECK();
+            } else {
+                if (!mean_io || !std_io) return fail(LCX_ERR_ARG, "preprocess: theta required when fit == 0");
+                const T* mh = reinterpret_cast<const T*>(mean_io);
+                const T* sh = reinterpret_cast<const T*>(std_io);
+                for (int64_t c = 0; c < V; ++c) tmp[c] = (double)mh[c];
+                HIPCHECK(hipMemcpy(mean, tmp.data(), sizeof(double) * V, hipMemcpyHostToDevice));
+                for (int64_t c = 0; c < V; ++c) tmp[c] = (double)sh[c];
+                HIPCHECK(hipMemcpy(stdv, tmp.data(), sizeof(double) * V, hipMemcpyHostToDevice));
+            }
+        }
+        if (need_stats || has_missing) {
+            hipLaunchKernelGGL((pp_apply_kernel<T>), grid, dim3(256), 0, h->stream, X, N, V, h->ldx, has_missing, (T)sentinel, imp, mean, stdv,
+                               kind, bmax);
+            KCHECK();
+        }
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        if (fit && need_stats && mean_io && std_io) {
+            T* mh = reinterpret_cast<T*>(mean_io);
+            T* sh = reinterpret_cast<T*>(std_io);
+            HIPCHECK(hipMemcpy(tmp.data(), mean, sizeof(double) * V, hipMemcpyDeviceToHost));
+            for (int64_t c = 0; c < V; ++c) mh[c] = (T)tmp[c];
+            HIPCHECK(hipMemcpy(tmp.data(), stdv, sizeof(double) * V, hipMemcpyDeviceToHost));
+            for (int64_t c = 0; c < V; ++c) sh[c] = (T)tmp[c];
+        }
+        if (nobs_out) {
+            if (has_missing) {
+                HIPCHECK(hipMemcpy(tmp.data(), nobs, sizeof(double) * V, hipMemcpyDeviceToHost));
+                for (int64_t c = 0; c < V; ++c) nobs_out[c] = (int64_t)tmp[c];
+            } else {
+                for (int64_t c = 0; c < V; ++c) nobs_out[c] = N;
+            }
+        }
+        if (maxabs_out) {
+            *maxabs_out = 0.0;
+            if (need_stats || has_missing) {
+                std::vector<double> bm((size_t)strips * RS);
+                HIPCHECK(hipMemcpy(bm.data(), bmax, sizeof(double) * bm.size(), hipMemcpyDeviceToHost));
+                for (double v : bm) if (v > *maxabs_out) *maxabs_out = v;
+            }
+        }
+        void* fr[] = {nobs, imp, mean, stdv, ps, pn, bmax};
+        for (void* q : fr) HIPCHECK(hipFree(q));
+        return LCX_OK;
+    }
+
+    static int upload_preprocess(lcx_ctx* h, const void* x, int64_t ld, int kind, int has_missing, double sentinel, int fit,
+                                 void* mean_io, void* std_io, int64_t* nobs_out, double* maxabs_out) {
+        HIPCHECK(hipMemcpy2DAsync(h->X, h->ldx * sizeof(T), x, ld * sizeof(T), h->V * sizeof(T), h->N, hipMemcpyHostToDevice, h->stream));
+        LCXCHECK(preprocess_resident(h, kind, has_missing, sentinel, fit, mean_io, std_io, nobs_out, maxabs_out));
+        return make_xt(h);
+    }
+
+    // transform (:386-395) of raw rows: standardise with theta on the device, then x~ . ws^T
+    static int project_raw(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, int kind, const void* mean_h,
+                           const void* std_h, void* out_host) {
+        const int64_t blk = 8192;
+        const int64_t rows_pad = round_up(n_rows < blk ? n_rows : blk, 64);
+        T *xd = nullptr, *yd = nullptr;
+        double *mean = nullptr, *stdv = nullptr, *bmax = nullptr;
+        const int strips = (int)cdiv(h->V, 64);
+        const int RS = 8;
+        HIPCHECK(hipMalloc((void**)&xd, sizeof(T) * rows_pad * h->ldx));
+        HIPCHECK(hipMalloc((void**)&yd, sizeof(T) * rows_pad * Mp));
+        HIPCHECK(hipMalloc((void**)&mean, sizeof(double) * h->V));
+        HIPCHECK(hipMalloc((void**)&stdv, sizeof(double) * h->V));
+        HIPCHECK(hipMalloc((void**)&bmax, sizeof(double) * strips * RS));
+        if (kind != PP_KIND_NONE) {
+            std::vector<double> tmp((size_t)h->V);
+            for (int64_t c = 0; c < h->V; ++c) tmp[c] = (double)reinterpret_cast<const T*>(mean_h)[c];
+            HIPCHECK(hipMemcpy(mean, tmp.data(), sizeof(double) * h->V, hipMemcpyHostToDevice));
+            for (int64_t c = 0; c < h->V; ++c) tmp[c] = (double)reinterpret_cast<const T*>(std_h)[c];
+            HIPCHECK(hipMemcpy(stdv, tmp.data(), sizeof(double) * h->V, hipMemcpyHostToDevice));
+        }
+        std::vector<T> tmp((size_t)rows_pad * Mp);
+        T* out = P<T>(out_host);
+        for (int64_t r0 = 0; r0 < n_rows; r0 += blk) {
+            const int64_t nr = (n_rows - r0) < blk ? (n_rows - r0) : blk;
+            HIPCHECK(hipMemsetAsync(xd, 0, sizeof(T) * rows_pad * h->ldx, h->stream));
+            HIPCHECK(hipMemcpy2DAsync(xd, h->ldx * sizeof(T), reinterpret_cast<const T*>(x_host) + r0 * ld, ld * sizeof(T),
+                                      h->V * sizeof(T), nr, hipMemcpyHostToDevice, h->stream));
+            if (kind != PP_KIND_NONE) {
+                hipLaunchKernelGGL((pp_apply_kernel<T>), dim3((unsigned)strips, RS), dim3(256), 0, h->stream, xd, nr, h->V, h->ldx, 0, (T)0,
+                                   (const double*)nullptr, mean, stdv, kind, bmax);
+                KCHECK();
+            }
+            LCXCHECK((launch_nt<T, CT>(h->stream, xd, h->ldx, rows_pad, P<T>(h->Wt[0]), yd, 1, 4, nullptr)));
+            HIPCHECK(hipMemcpyAsync(tmp.data(), yd, sizeof(T) * rows_pad * Mp, hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(hipStreamSynchronize(h->stream));
+            for (int64_t r = 0; r < nr; ++r)
+                for (int j = 0; j < h->M; ++j) out[(r0 + r) * h->M + j] = tmp[r * Mp + j];
+        }
+        void* fr[] = {xd, yd, mean, stdv, bmax};
+        for (void* q : fr) HIPCHECK(hipFree(q));
+        return LCX_OK;
+    }
+
     static int generate(lcx_ctx* h, uint64_t seed, int kind, int n_groups, int64_t col_offset) {
         hipLaunchKernelGGL((generate_kernel<T>), dim3(4096), dim3(256), 0, h->stream, P<T>(h->X), h->N, h->V, h->ldx,
                            seed, kind, n_groups < 1 ? 1 : n_groups, col_offset);
         KCHECK();
-        double *mean = nullptr, *istd = nullptr;
-        HIPCHECK(hipMalloc((void**)&mean, sizeof(double) * h->V));
-        HIPCHECK(hipMalloc((void**)&istd, sizeof(double) * h->V));
-        hipLaunchKernelGGL((colstats_kernel<T>), dim3((unsigned)cdiv(h->V, 64)), dim3(64), 0, h->stream, P<T>(h->X), h->N,
-                           h->V, h->ldx, mean, istd);
-        KCHECK();
-        hipLaunchKernelGGL((standardize_kernel<T>), dim3(4096), dim3(256), 0, h->stream, P<T>(h->X), h->N, h->V, h->ldx,
-                           mean, istd);
-        KCHECK();
-        HIPCHECK(hipStreamSynchronize(h->stream));
-        HIPCHECK(hipFree(mean));
-        HIPCHECK(hipFree(istd));
+        // standardise like preprocess 'standard' (:409-415)
+        LCXCHECK(preprocess_resident(h, PP_KIND_STANDARD, 0, 0.0, 1, nullptr, nullptr, nullptr, nullptr));
         return make_xt(h);
     }
 };
@@ -1046,6 +1171,14 @@ int lcx_upload_x(lcx_ctx* h, const void* x, int64_t ld) {
     DISPATCH(h, make_xt, h);
 }
 
+int lcx_upload_preprocess(lcx_ctx* h, const void* x, int64_t ld, int kind, int has_missing, double missing, int fit, void* mean_io,
+                          void* std_io, int64_t* n_obs_out, double* max_abs_out) {
+    NEED(h);
+    if (!x || ld < h->V) return fail(LCX_ERR_ARG, "lcx_upload_preprocess: bad leading dimension");
+    if (kind < 0 || kind > 2) return fail(LCX_ERR_ARG, "lcx_upload_preprocess: kind must be 0 (none), 1 (standard) or 2 (outliers)");
+    DISPATCH(h, upload_preprocess, h, x, ld, kind, has_missing, missing, fit, mean_io, std_io, n_obs_out, max_abs_out);
+}
+
 int lcx_download_x(lcx_ctx* h, void* x, int64_t ld) {
     NEED(h);
     if (!x || ld < h->V) return fail(LCX_ERR_ARG, "lcx_download_x: bad leading dimension");
@@ -1237,6 +1370,13 @@ int lcx_project(lcx_ctx* h, const void* x, int64_t n_rows, int64_t ld, void* out
     NEED(h);
     if (!x || !out || n_rows < 1 || ld < h->V) return fail(LCX_ERR_ARG, "lcx_project: bad argument");
     DISPATCH(h, project, h, x, n_rows, ld, out);
+}
+
+int lcx_project_raw(lcx_ctx* h, const void* x, int64_t n_rows, int64_t ld, int kind, const void* mean, const void* stdv, void* out) {
+    NEED(h);
+    if (!x || !out || n_rows < 1 || ld < h->V) return fail(LCX_ERR_ARG, "lcx_project_raw: bad argument");
+    if (kind < 0 || kind > 2 || (kind != 0 && (!mean || !stdv))) return fail(LCX_ERR_ARG, "lcx_project_raw: bad kind / theta");
+    DISPATCH(h, project_raw, h, x, n_rows, ld, kind, mean, stdv, out);
 }
 
 int lcx_timing_enable(lcx_ctx* h, int enable) {

@@ -757,30 +757,121 @@ __global__ void generate_kernel(T* __restrict__ X, int64_t N, int64_t V, int64_t
     }
 }
 
-// column mean / inverse std over samples, then normalise in place (preprocess 'standard', :409-415)
+// ------------------------------------------------------------------------------------------------
+// preprocess on device (reference linearcorex.py:397-429, mean_impute :497-510, g :483-487).
+// Three coalesced passes over the resident shard, 64-column strips x row splits, double accumulators:
+//   A  observed count and sum per column          -> n_obs, imputation mean
+//   B  sum of (x - mean)^2 over observed cells    -> std  ('standard': / n_obs, 'outliers': / N; clip 1e-10)
+//   C  impute, (x - mean) / std, optional tail squash g, in place; max |x~| per block
+// A cell is missing if it is NaN or equals the sentinel (only when missing values are enabled, as in
+// the reference); infinities are neither observed nor imputed (:505-507).
+// ------------------------------------------------------------------------------------------------
+constexpr int PP_KIND_NONE = 0, PP_KIND_STANDARD = 1, PP_KIND_OUTLIERS = 2;
+
 template <typename T>
-__global__ void colstats_kernel(const T* __restrict__ X, int64_t N, int64_t V, int64_t ldx,
-                                double* __restrict__ mean, double* __restrict__ istd) {
+__device__ __forceinline__ bool pp_missing(T x, int has_missing, T sentinel) {
+    return has_missing && (x != x || x == sentinel);
+}
+
+// pass A (center == nullptr): part_s = sum of observed, part_n = count of observed
+// pass B (center != nullptr): part_s = sum of (x - center)^2 over observed cells
+template <typename T>
+__global__ void __launch_bounds__(256)
+pp_colsum_kernel(const T* __restrict__ X, int64_t N, int64_t V, int64_t ldx, int has_missing, T sentinel,
+                 const double* __restrict__ center, double* __restrict__ part_s, double* __restrict__ part_n) {
+    __shared__ double sh_s[4][64];
+    __shared__ double sh_n[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * 64 + c;
+    const int RS = gridDim.y;
+    const int64_t r0 = N * blockIdx.y / RS, r1 = N * (blockIdx.y + 1) / RS;
+    double s = 0.0, n = 0.0;
+    if (col < V) {
+        const double mu = center ? center[col] : 0.0;
+        for (int64_t r = r0 + rl; r < r1; r += 4) {
+            const T x = X[r * ldx + col];
+            const bool obs = has_missing ? (!pp_missing(x, 1, sentinel) && isfinite((double)x)) : true;
+            if (obs) {
+                if (center) { const double d = (double)x - mu; s += d * d; }
+                else { s += (double)x; n += 1.0; }
+            }
+        }
+    }
+    sh_s[rl][c] = s;
+    sh_n[rl][c] = n;
+    __syncthreads();
+    if (rl == 0 && col < V) {
+        part_s[(int64_t)blockIdx.y * V + col] = sh_s[0][c] + sh_s[1][c] + sh_s[2][c] + sh_s[3][c];
+        if (part_n) part_n[(int64_t)blockIdx.y * V + col] = sh_n[0][c] + sh_n[1][c] + sh_n[2][c] + sh_n[3][c];
+    }
+}
+
+// after pass A: nobs, imputation mean (= mean of the observed cells); after pass B: std
+template <typename T>
+__global__ void pp_finalize_kernel(const double* __restrict__ part_s, const double* __restrict__ part_n, int RS,
+                                   int64_t V, double n_rows, int kind, int pass, double* __restrict__ nobs,
+                                   double* __restrict__ mean, double* __restrict__ stdv) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= V) return;
-    double s = 0.0;
-    for (int64_t r = 0; r < N; ++r) s += (double)X[r * ldx + c];
-    const double mu = s / (double)N;
-    double ss = 0.0;
-    for (int64_t r = 0; r < N; ++r) { const double d = (double)X[r * ldx + c] - mu; ss += d * d; }
-    double sd = sqrt(ss / (double)N);
-    if (sd < 1e-10) sd = 1e-10;
-    mean[c] = mu;
-    istd[c] = 1.0 / sd;
+    double s = 0.0, n = 0.0;
+    for (int k = 0; k < RS; ++k) {
+        s += part_s[(int64_t)k * V + c];
+        if (part_n) n += part_n[(int64_t)k * V + c];
+    }
+    if (pass == 0) {
+        nobs[c] = n;
+        mean[c] = (double)(T)(s / n);                       // the reference holds theta in the working dtype
+    } else {
+        const double denom = kind == PP_KIND_OUTLIERS ? n_rows : nobs[c];
+        double sd = (double)(T)sqrt(s / denom);
+        if (sd < 1e-10) sd = 1e-10;
+        stdv[c] = sd;
+    }
 }
+
 template <typename T>
-__global__ void standardize_kernel(T* __restrict__ X, int64_t N, int64_t V, int64_t ldx,
-                                   const double* __restrict__ mean, const double* __restrict__ istd) {
-    const int64_t total = N * V;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / V, c = i % V;
-        X[r * ldx + c] = (T)(((double)X[r * ldx + c] - mean[c]) * istd[c]);
+__device__ __forceinline__ T pp_g(T x) {                      // :483-487, t = 4
+    const T core = x < (T)-4 ? (T)-4 : (x > (T)4 ? (T)4 : x);
+    return core + tanh(x - core);
+}
+
+// pass C, in place.  impute[c] = mean of the observed cells of THIS data (what mean_impute writes),
+// mean/stdv = theta (of the fitted data).  blockmax[b] = max |x~| seen by block b.
+template <typename T>
+__global__ void __launch_bounds__(256)
+pp_apply_kernel(T* __restrict__ X, int64_t N, int64_t V, int64_t ldx, int has_missing, T sentinel,
+                const double* __restrict__ impute, const double* __restrict__ mean,
+                const double* __restrict__ stdv, int kind, double* __restrict__ blockmax) {
+    __shared__ double sh[4];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * 64 + c;
+    const int RS = gridDim.y;
+    const int64_t r0 = N * blockIdx.y / RS, r1 = N * (blockIdx.y + 1) / RS;
+    double mx = 0.0;
+    if (col < V) {
+        const T mu = kind == PP_KIND_NONE ? (T)0 : (T)mean[col];
+        const T sd = kind == PP_KIND_NONE ? (T)1 : (T)stdv[col];
+        const T imp = has_missing ? (T)impute[col] : (T)0;
+        for (int64_t r = r0 + rl; r < r1; r += 4) {
+            T x = X[r * ldx + col];
+            if (pp_missing(x, has_missing, sentinel)) x = imp;
+            if (kind != PP_KIND_NONE) {
+                x = (x - mu) / sd;
+                if (kind == PP_KIND_OUTLIERS) x = pp_g(x);
+            }
+            X[r * ldx + col] = x;
+            const double ax = fabs((double)x);
+            mx = ax > mx ? ax : mx;                             // NaN never wins, like np.max would propagate - only used for a warning
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; }
+    if ((threadIdx.x & 63) == 0) sh[rl] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = sh[0];
+        for (int k = 1; k < 4; ++k) m = sh[k] > m ? sh[k] : m;
+        blockmax[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = m;
     }
 }
 

@@ -53,6 +53,19 @@ class ShardDouble:
         assert x.shape == (self.n, self.nv)
         self.x = np.ascontiguousarray(x, self.dtype)
 
+    def upload_preprocess(self, x_raw, gaussianize, missing_values=None, theta=None):
+        from linearcorex_amd.preprocess import preprocess as pp
+        x, th, n_obs = pp(np.asarray(x_raw, self.dtype), theta, gaussianize, missing_values)
+        if th is None:
+            th = (np.zeros(self.nv, self.dtype), np.ones(self.nv, self.dtype))
+        self.upload_x(np.asarray(x, self.dtype))
+        return th, n_obs, float(np.max(np.abs(x)))
+
+    def project_raw(self, x_raw, gaussianize, theta):
+        from linearcorex_amd.preprocess import preprocess as pp
+        x = pp(np.asarray(x_raw, self.dtype), theta, gaussianize, None)[0]
+        return self.project(x)
+
     def set_ws(self, w):
         self.w[0] = np.array(w, self.dtype)
         self.generation += 1

@@ -40,7 +40,8 @@ def launch_hip(world, out_dir, n, v, m, mode):
         assert p.returncode == 0, o[-3000:]
 
 
-@pytest.mark.parametrize("world,mode", [(2, "exact"), (3, "exact"), (2, "linear")])
+# world 3 runs in the CPU suite; on the GPU box gloo needs ~4 minutes for it
+@pytest.mark.parametrize("world,mode", [(2, "exact"), (2, "linear")])
 def test_sharded_fit_on_device_matches_oracle(world, mode, tmp_path):
     n, v, m = 400, 331, 5               # uneven shards, ragged padding
     launch_hip(world, tmp_path, n, v, m, mode)

@@ -79,7 +79,13 @@ typedef enum {
     LCX_M_UPDATE = 12,     /* (m, nv)  last update        (:303)     */
     LCX_M_SIG_GRAD = 13,   /* (m, nv)  last _sig(grad)    (:301)     */
     LCX_M_H = 14,          /* (m, m)   last H             (:294-295) */
-    LCX_M_Y = 15           /* (n_samples, m)  X.W^T of the set (:247); all-reduced if sharded */
+    LCX_M_Y = 15,          /* (n_samples, m)  X.W^T of the set (:247); all-reduced if sharded */
+    /* synergistic branch (_calculate_moments_syn, :336-373) */
+    LCX_M_SYN_XIZJ = 16,   /* (nv, m)  X_i Z_j = solve(cy, X_i Y_j^T)^T   (:367) */
+    LCX_M_SYN_X2Y = 17,    /* (nv,)    X_i^2 | Y                          (:368) */
+    LCX_M_SYN_XIYJ = 18,   /* (nv, m)  X_i Y_j = X^T.Y / N                (:355) */
+    LCX_M_CY = 19,         /* (m, m)   cov(y)                             (:356) */
+    LCX_M_YJ2 = 20         /* (m,)     Y_j^2 = diag(cy)                   (:357) */
 } lcx_moment_key;
 
 /* ---- library ------------------------------------------------------------------------------ */
@@ -173,6 +179,26 @@ int lcx_trial_linear_a(lcx_ctx* h, double eta);
 int lcx_trial_linear_b(lcx_ctx* h, double eps, double eta);
 /* self.ws, self.moments = w_update, m_update (:139,:334): swap sets                              */
 int lcx_accept_trial(lcx_ctx* h);
+
+/* ---- synergistic branch: discourage_overlap=False (:336-384) -------------------------------------
+ * One evaluation of _calculate_moments_syn on set `which`:
+ *   lcx_moments_a(which)              Y_partial = X_shard . W_shard^T (:347)            -> ybuf     | all-reduce ybuf
+ *   lcx_syn_moments_b(which, yscale)  cy, Y_j^2, ry (:356-358; cy = Y^T.Y/N + yscale^2 I, which equals
+ *                                     ws.dot(X_i Y_j) + yscale^2 I because W.X^T = Y^T - no extra collective),
+ *                                     X^T.Y (:355), rho (:359), X_i Z_j (:367), X_i^2|Y (:368), per-shard sums
+ *                                     [0..m) sum_i MI_ji, [m] -, [m+1] sum_i I(X_i;Y), [m+2] sum_ij MI -> sbuf   | all-reduce sbuf[0..m+3)
+ *   lcx_syn_moments_c(which)          TC = sum_i I(X_i;Y) - sum_j I(Y_j;X) (:373) -> state scalars
+ * One _update_syn (:375-383) from set 0 into the weights of set 1 (then the moments above with which=1 and
+ * lcx_accept_trial):
+ *   lcx_syn_update_a()                H partial (:378) -> sbuf[0..m_padded^2)                       | all-reduce
+ *   lcx_syn_update_b(eta)             ws' = (1-eta) ws + eta (X_i Z_j^T / X_i^2|Y - H ws) (:380-382)          */
+int lcx_syn_moments_b(lcx_ctx* h, int which, double yscale);
+int lcx_syn_moments_c(lcx_ctx* h, int which);
+int lcx_syn_update_a(lcx_ctx* h);
+int lcx_syn_update_b(lcx_ctx* h, double eta);
+/* get_covariance, synergistic branch (:452-455): rows [row0, row0+nrows) of X_i Z_j . X_i Y_j^T, diagonal 1,
+ * scaled by std_i std_k */
+int lcx_covariance_rows_syn(lcx_ctx* h, const void* std_host, int64_t row0, int64_t nrows, void* out_host);
 
 /* ---- stage change (:129-133) ---------------------------------------------------------------- */
 int lcx_rescale_ws(lcx_ctx* h, double eps_old, double eps_new);

@@ -19,7 +19,7 @@ S_TC, S_MAX_UJ, S_INVALID, S_TANGENT, S_SUM_LOG_RJ, S_COUNT = 0, 1, 2, 3, 4, 8
 
 # lcx_moment_key
 M_UJ, M_RHO, M_RY, M_INVRHO, M_RHOINVRHO, M_QIJ, M_SI, M_QISI2, M_MI, M_XIZJ, M_XI2_GIVEN_Y, \
-    M_GRAD, M_UPDATE, M_SIG_GRAD, M_H, M_Y = range(16)
+    M_GRAD, M_UPDATE, M_SIG_GRAD, M_H, M_Y, M_SYN_XIZJ, M_SYN_X2Y, M_SYN_XIYJ, M_CY, M_YJ2 = range(21)
 
 _i64, _i32, _dbl, _vp = C.c_int64, C.c_int, C.c_double, C.c_void_p
 
@@ -55,6 +55,11 @@ SIGNATURES = {
     "lcx_trial_linear_a": [_vp, _dbl],
     "lcx_trial_linear_b": [_vp, _dbl, _dbl],
     "lcx_accept_trial": [_vp],
+    "lcx_syn_moments_b": [_vp, _i32, _dbl],
+    "lcx_syn_moments_c": [_vp, _i32],
+    "lcx_syn_update_a": [_vp],
+    "lcx_syn_update_b": [_vp, _dbl],
+    "lcx_covariance_rows_syn": [_vp, _vp, _i64, _i64, _vp],
     "lcx_rescale_ws": [_vp, _dbl, _dbl],
     "lcx_init_scale_ws": [_vp],
     "lcx_read_state": [_vp, _i32, C.POINTER(_dbl)],

@@ -20,6 +20,9 @@ MOMENT_KEYS = {
     "MI": _abi.M_MI, "X_i Z_j": _abi.M_XIZJ, "X_i^2 | Y": _abi.M_XI2_GIVEN_Y,
     "grad": _abi.M_GRAD, "update": _abi.M_UPDATE, "sig_grad": _abi.M_SIG_GRAD, "H": _abi.M_H,
     "Y": _abi.M_Y,
+    # synergistic branch (:336-373)
+    "syn X_i Z_j": _abi.M_SYN_XIZJ, "syn X_i^2 | Y": _abi.M_SYN_X2Y, "syn X_i Y_j": _abi.M_SYN_XIYJ,
+    "cy": _abi.M_CY, "Y_j^2": _abi.M_YJ2,
 }
 
 
@@ -231,6 +234,31 @@ class HipBackend:
         _abi.check(self.lib.lcx_accept_trial(self.h))
         self.generation += 1
 
+    # ---- synergistic branch (linearcorex.py:336-384) ---------------------------------------------
+    def syn_moments_b(self, which, yscale):
+        _abi.check(self.lib.lcx_syn_moments_b(self.h, which, float(yscale)))
+        if which == 0:
+            self.generation += 1
+
+    def syn_moments_c(self, which):
+        _abi.check(self.lib.lcx_syn_moments_c(self.h, which))
+
+    def syn_update_a(self):
+        _abi.check(self.lib.lcx_syn_update_a(self.h))
+
+    def syn_update_b(self, eta):
+        _abi.check(self.lib.lcx_syn_update_b(self.h, float(eta)))
+
+    def covariance_syn(self, std, max_block_bytes=1 << 28):
+        std, ps = self._a(std)
+        nv = self.nv
+        out = np.empty((nv, nv), dtype=self.dtype)
+        rows = max(64, int(max_block_bytes // (nv * self.dtype.itemsize)) // 64 * 64)
+        for r0 in range(0, nv, rows):
+            nr = min(rows, nv - r0)
+            _abi.check(self.lib.lcx_covariance_rows_syn(self.h, ps, r0, nr, _abi.np_ptr(out[r0:r0 + nr])))
+        return out
+
     def rescale_ws(self, eps_old, eps_new):
         _abi.check(self.lib.lcx_rescale_ws(self.h, float(eps_old), float(eps_new)))
         self.generation += 1
@@ -248,7 +276,8 @@ class HipBackend:
     def moment_shape(self, name):
         m, nv, n = self.m, self.nv, self.n_samples
         return {"uj": (m,), "ry": (m, m), "H": (m, m), "Si": (nv,), "Qi-Si^2": (nv,),
-                "X_i^2 | Y": (nv,), "X_i Z_j": (nv, m), "Y": (n, m)}.get(name, (m, nv))
+                "X_i^2 | Y": (nv,), "X_i Z_j": (nv, m), "Y": (n, m), "syn X_i Z_j": (nv, m), "syn X_i^2 | Y": (nv,),
+                "syn X_i Y_j": (nv, m), "cy": (m, m), "Y_j^2": (m,)}.get(name, (m, nv))
 
     def get_moment(self, which, name, eps=0.0):
         out = np.empty(self.moment_shape(name), dtype=self.dtype)

@@ -76,6 +76,40 @@ class DeviceMoments(dict):
         return (dict, (self.materialize(),))
 
 
+class SynMoments(DeviceMoments):
+    """`self.moments` of the synergistic branch (keys of `_calculate_moments_syn`, linearcorex.py:336-373)."""
+    _SYN_DEVICE = {"X_i Y_j": "syn X_i Y_j", "X_i Z_j": "syn X_i Z_j", "X_i^2 | Y": "syn X_i^2 | Y", "rho": "rho",
+                   "cy": "cy", "Y_j^2": "Y_j^2", "ry": "ry"}
+
+    def __init__(self, owner, generation, eager):
+        DeviceMoments.__init__(self, owner, generation, 0, eager)
+        self._lazy = set(self._SYN_DEVICE) | {"invrho", "rhoinvrho", "Qij", "Qi", "Si", "MI"}
+
+    def _fetch(self, key):
+        be = self._owner._backend if self._owner is not None else None
+        if be is None or be.generation != self._gen:
+            raise KeyError("%r: these moments are no longer resident on the device" % key)
+        if key in self._SYN_DEVICE:
+            val = be.get_moment(0, self._SYN_DEVICE[key])
+            if key in ("X_i Y_j", "X_i Z_j"):                # (nv_local, m): shard axis first
+                return self._owner._gather(np.ascontiguousarray(val.T)).T
+            return val if key in ("cy", "Y_j^2", "ry") else self._owner._gather(val, key)
+        rho = self["rho"]
+        if key == "invrho":
+            return 1.0 / (1.0 - rho ** 2)                                   # :360
+        if key == "rhoinvrho":
+            return rho * self["invrho"]                                     # :361
+        if key == "Qij":
+            return np.dot(self["ry"], self["rhoinvrho"])                    # :362
+        if key == "Qi":
+            return np.einsum('ki,ki->i', self["rhoinvrho"], self["Qij"])    # :363
+        if key == "Si":
+            return np.sum(rho * self["rhoinvrho"], axis=0)                  # :364
+        if key == "MI":
+            return -0.5 * np.log1p(-rho ** 2)                               # :366
+        raise KeyError(key)
+
+
 class Corex(object):
     """Linear Total Correlation Explanation on MI355X (reference docstring: linearcorex.py:22-70).
 
@@ -189,6 +223,8 @@ class Corex(object):
         return self.transform(x)
 
     def fit(self, x):
+        if self.m is None:
+            raise NotImplementedError("n_hidden=None (pick_n_hidden) is broken in the reference (SURVEY.md §2 #14)")
         x = np.asarray(x, dtype=self.dtype)                    # reference casts to float32 (:108)
         self.n_samples, self.nv = x.shape
         c0, c1 = self._comm.shard(self.nv)
@@ -245,9 +281,6 @@ class Corex(object):
         """Random start, normalised so that uj = 0.01 (:113-122).  Returns the annealing schedule."""
         if self.m is None:
             raise NotImplementedError("n_hidden=None (pick_n_hidden) is broken in the reference (SURVEY.md §2 #14)")
-        if not self.discourage_overlap:
-            raise NotImplementedError("discourage_overlap=False (the synergistic branch, linearcorex.py:336-384) "
-                                      "is outside the accelerated path")
         be, (c0, c1) = self._backend, self._cols
         anneal_schedule = [0.]
         if self.ws.size == 0:
@@ -298,7 +331,85 @@ class Corex(object):
         self.ws = self._gather(be.get_ws(0))
         return self
 
+    # ------------------------------------------------------------------------------------------
+    # synergistic branch: discourage_overlap=False (linearcorex.py:119-121, :141, :336-384)
+    # ------------------------------------------------------------------------------------------
+    def _calculate_moments_syn(self, which=0, details=True):
+        """`_calculate_moments_syn` (:336-373) of the weights of set `which`; returns the moments dict when
+        which == 0, else only the state scalars (the caller accepts the set afterwards)."""
+        be = self._backend
+        be.moments_a(which)                          # Y_partial = X.W^T (:347)
+        self._xy()
+        be.syn_moments_b(which, self.yscale)         # cy, ry, X^T.Y, rho, X_i Z_j, X_i^2|Y, partial sums
+        self._xs(self.m + 3)
+        be.syn_moments_c(which)                      # TC (:373)
+        self.stats["moment_evals"] += 1
+        st = be.read_state(which)
+        if which != 0:
+            return st
+        return self._syn_moments_dict(st, details)
+
+    def _syn_moments_dict(self, st, details):
+        be = self._backend
+        eager = {"TC": np.float64(st[0])}
+        if details:
+            sums = be.read_sbuf(self.m + 3)
+            yj2 = be.get_moment(0, "Y_j^2").astype(np.float64)
+            iyx = 0.5 * np.log(yj2) - 0.5 * np.log(self.yscale ** 2)           # :369
+            eager["TCs"] = sums[:self.m] - iyx                                 # :371
+            eager["additivity"] = sums[self.m + 2] - sums[self.m + 1]          # :372
+        self._tc_cur = st[0]
+        return SynMoments(self, be.generation, eager)
+
+    def _update_syn(self, x=None, eta=0.5):
+        """One damped fixed-point step (:375-384); the new weights stay on the device."""
+        be = self._backend
+        be.syn_update_a()                            # H partial (:378)
+        self._xs(be_mp2(be))
+        be.syn_update_b(eta)                         # ws' (:380-382) -> set 1
+        st = self._calculate_moments_syn(which=1)    # :383
+        be.accept_trial()
+        return self._syn_moments_dict(st, details=False)
+
+    def _fit_resident_syn(self):
+        if self.m is None:
+            raise NotImplementedError("n_hidden=None (pick_n_hidden) is broken in the reference (SURVEY.md §2 #14)")
+        be, (c0, c1) = self._backend, self._cols
+        if self.ws.size == 0:
+            w = np.random.randn(self.m, self.nv) * self.yscale ** 2 / np.sqrt(self.nv)      # :121 (float64 draws)
+        else:
+            w = np.asarray(self.ws)
+        be.set_ws(np.ascontiguousarray(w[:, c0:c1], dtype=self.dtype))
+        del w
+        self.eps = 0
+        self.moments = self._calculate_moments_syn(details=False)              # :122 (and :134: same weights)
+        delta = 0.
+        for i_loop in range(self.max_iter):                                    # :136-155
+            last_tc = self.tc
+            self.moments = self._update_syn(eta=0.1)                           # :141
+            if not np.isfinite(self.tc):
+                print("Error: TC is no longer finite: {}".format(self.tc))
+            delta = np.abs(self.tc - last_tc)
+            self.update_records(self.moments, delta)
+            self.stats["iterations"] += 1
+            if delta < self.tol:
+                if self.verbose:
+                    print('{:d} iterations to tol: {:f}, TC={:f}'.format(i_loop, self.tol, self.tc))
+                break
+        else:
+            if self.verbose:
+                print("Warning: Convergence not achieved in {:d} iterations. "
+                      "Final delta: {:f}".format(self.max_iter, float(delta)))
+        self.moments = self._calculate_moments_syn()                           # :160
+        order = np.argsort(-self.moments["TCs"])                               # :161
+        be.permute_factors(order)                                              # :162
+        self.moments = self._calculate_moments_syn()                           # :163
+        self.ws = self._gather(be.get_ws(0))
+        return self
+
     def _fit_resident(self):
+        if not self.discourage_overlap:
+            return self._fit_resident_syn()
         for i_eps, eps in enumerate(self._init_weights()):
             self._begin_stage(i_eps, eps)
             delta = 0.
@@ -490,6 +601,8 @@ class Corex(object):
         if details:
             if ns != self.n_samples:
                 raise NotImplementedError("transform(details=True) is supported on the fitted data only")
+            if not self.discourage_overlap:
+                return y, self._calculate_moments_syn()
             return y, self._calculate_moments(quick=False, details=True)
         return y
 
@@ -516,6 +629,14 @@ class Corex(object):
         """Covariance estimate of the non-synergistic model (:443-451), nv x nv."""
         if self._comm.world > 1:
             raise NotImplementedError("get_covariance() needs all variables on one GPU (nv x nv output)")
+        if not self.discourage_overlap:                                        # :452-455
+            if self._backend is None:
+                # restored from a pickle: a rank-m product of two host arrays, as the reference computes it
+                m = self.moments
+                cov = np.einsum('ij,kj->ik', m["X_i Z_j"], m["X_i Y_j"])
+                np.fill_diagonal(cov, 1)
+                return self.theta[1][:, np.newaxis] * self.theta[1] * cov
+            return self._backend.covariance_syn(np.asarray(self.theta[1], dtype=self.dtype))
         be = self._resident_backend(need_moments=True)
         return be.covariance(self.eps, np.asarray(self.theta[1], dtype=self.dtype))
 

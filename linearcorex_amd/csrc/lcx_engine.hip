@@ -53,6 +53,9 @@ struct MomentSet {
     void *rho, *rir, *qij;      // [Vp][Mp]
     void *si, *q2, *hscale;     // [Vp]
     double *uj, *ry, *wmag;     // small
+    // synergistic branch (allocated on first use): X_i Z_j [Vp][Mp], X_i^2|Y [Vp], cy [Mp*Mp], Y_j^2 [Mp], 1/sd_j [Mp]
+    void *xz, *x2y;
+    double *cy, *yj2, *inv_sd;
     SetState* st;               // device
     SetState* hst;              // pinned host mirror (host address)
     SetState* hst_dev;          // same memory, device-visible address
@@ -575,6 +578,97 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
 
+    // ---- synergistic branch (discourage_overlap=False; :336-384) -------------------------------------
+    static int syn_alloc(lcx_ctx* h) {
+        for (int k = 0; k < 2; ++k) {
+            MomentSet& s = h->set[k];
+            if (s.xz) continue;
+            HIPCHECK(hipMalloc(&s.xz, (size_t)h->ldx * Mp * sizeof(T)));
+            HIPCHECK(hipMalloc(&s.x2y, (size_t)h->ldx * sizeof(T)));
+            HIPCHECK(hipMalloc((void**)&s.cy, sizeof(double) * Mp * Mp));
+            HIPCHECK(hipMalloc((void**)&s.yj2, sizeof(double) * Mp));
+            HIPCHECK(hipMalloc((void**)&s.inv_sd, sizeof(double) * Mp));
+            HIPCHECK(hipMemsetAsync(s.xz, 0, (size_t)h->ldx * Mp * sizeof(T), h->stream));
+            HIPCHECK(hipMemsetAsync(s.x2y, 0, (size_t)h->ldx * sizeof(T), h->stream));
+        }
+        return LCX_OK;
+    }
+    // b: (ybuf = global Y) cy, Y_j^2, ry (:356-358), X^T.Y (:355), rho (:359), X_i Z_j (:367), X_i^2|Y (:368) and
+    //    the per-shard sums behind TCs / additivity / TC (:371-373) -> sbuf[0 .. m+3)
+    static int syn_moments_b(lcx_ctx* h, int which, double yscale) {
+        LCXCHECK(syn_alloc(h));
+        MomentSet& s = h->set[which];
+        LCXCHECK(gram(h, P<T>(h->ybuf), h->Npad, nullptr, h->gn_S, nullptr, P<T>(h->gpart)));
+        hipLaunchKernelGGL((syn_small_kernel<T>), dim3(1), dim3(256), 0, h->stream, P<T>(h->gpart), h->gn_S, Mp, h->M, (double)h->N,
+                           yscale, s.cy, s.yj2, s.ry, s.inv_sd, s.st);
+        KCHECK();
+        LCXCHECK(tn_big(h, nullptr));
+        const int64_t total = h->V * Mp;
+        hipLaunchKernelGGL((syn_rho_kernel<T>), dim3((unsigned)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048)), dim3(256), 0, h->stream,
+                           P<T>(h->dpart), h->tn_S, h->ldx * Mp, total, Mp, (double)h->N, s.inv_sd, P<T>(s.D), P<T>(s.rho));
+        KCHECK();
+        hipLaunchKernelGGL(invert_kernel, dim3(1), dim3(256), 0, h->stream, s.ry, Mp, h->invwork, h->ryinv);
+        KCHECK();
+        const size_t lds = ((size_t)Mp * Mp + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
+        LCXCHECK(allow_lds(detail_kernel<T, Mp>, lds));
+        // X_i Z_j = solve(cy, X_i Y_j^T)^T = (ry^-1 rho)_j / sd_j ; X_i^2|Y = 1 - rho^T ry^-1 rho ; hscale <- 1 / X_i^2|Y
+        hipLaunchKernelGGL((detail_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(s.rho), h->ryinv, h->V, h->M,
+                           (T*)nullptr, P<T>(s.xz), P<T>(s.x2y), h->detpart, (const double*)s.inv_sd, P<T>(s.hscale));
+        KCHECK();
+        hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(h->M + 3), dim3(PV_THREADS), 0, h->stream, h->detpart, h->pv_grid,
+                           h->M + 3, h->sbuf, (const int*)nullptr);
+        KCHECK();
+        return LCX_OK;
+    }
+    static int syn_moments_c(lcx_ctx* h, int which) {
+        MomentSet& s = h->set[which];
+        const unsigned int seq = ++h->seq_next;
+        hipLaunchKernelGGL((syn_tc_kernel<T>), dim3(1), dim3(1), 0, h->stream, h->sbuf, h->M, s.st, s.hst_dev, seq);
+        KCHECK();
+        s.seq_expect = seq;
+        return LCX_OK;
+    }
+    // H partial (:378) -> sbuf[0 .. Mp^2)
+    static int syn_update_a(lcx_ctx* h) {
+        MomentSet& s = h->set[0];
+        if (!s.xz) return fail(LCX_ERR_STATE, "lcx_syn_update_a before lcx_syn_moments_b");
+        LCXCHECK(gram(h, P<T>(s.xz), h->ldx, P<T>(s.hscale), h->gv_S, nullptr, P<T>(h->gpart)));
+        hipLaunchKernelGGL((reduce_wide_kernel<T, double>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
+                           P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, h->sbuf, (const int*)nullptr);
+        KCHECK();
+        return LCX_OK;
+    }
+    // ws' = (1-eta) ws + eta (R - H ws) (:380-382) -> set 1
+    static int syn_update_b(lcx_ctx* h, double eta) {
+        MomentSet& s = h->set[0];
+        const size_t lds = ((size_t)Mp * (Mp + 1) + (size_t)VPB * Mp) * sizeof(T);
+        LCXCHECK(allow_lds(syn_update_kernel<T, Mp>, lds));
+        hipLaunchKernelGGL((syn_update_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(h->Wt[0]), P<T>(s.xz),
+                           P<T>(s.hscale), h->sbuf, h->V, (T)eta, P<T>(h->Wt[1]));
+        KCHECK();
+        return LCX_OK;
+    }
+    static int covariance_syn(lcx_ctx* h, const void* std_host, int64_t row0, int64_t nrows, void* out_host) {
+        MomentSet& s = h->set[0];
+        if (!s.xz) return fail(LCX_ERR_STATE, "synergistic covariance needs lcx_syn_moments_b first");
+        T *std_dev = nullptr, *out_dev = nullptr;
+        HIPCHECK(hipMalloc((void**)&std_dev, sizeof(T) * h->V));
+        if (hipMalloc((void**)&out_dev, sizeof(T) * nrows * h->V) != hipSuccess) {
+            (void)hipFree(std_dev);
+            return fail(LCX_ERR_HIP, "covariance_rows: cannot allocate the output block on device");
+        }
+        HIPCHECK(hipMemcpyAsync(std_dev, std_host, sizeof(T) * h->V, hipMemcpyHostToDevice, h->stream));
+        dim3 grid((unsigned)cdiv(h->V, 64), (unsigned)cdiv(nrows, 64));
+        hipLaunchKernelGGL((covariance_syn_kernel<T, Mp>), grid, dim3(256), 0, h->stream, P<T>(s.xz), P<T>(s.D), std_dev, h->V, row0,
+                           nrows, (double)h->N, out_dev);
+        KCHECK();
+        HIPCHECK(hipMemcpyAsync(out_host, out_dev, sizeof(T) * nrows * h->V, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        HIPCHECK(hipFree(std_dev));
+        HIPCHECK(hipFree(out_dev));
+        return LCX_OK;
+    }
+
     // [Vp][Mp] device -> (m, V) or (V, m) host
     static int fetch_mv(lcx_ctx* h, const T* dev, T* host, bool as_m_by_v) {
         std::vector<T> tmp((size_t)h->V * Mp);
@@ -639,6 +733,15 @@ template <typename T, int CT> struct Impl {
                     for (int j = 0; j < h->M; ++j) o[r * h->M + j] = tmp[r * Mp + j];
                 return LCX_OK;
             }
+            case LCX_M_SYN_XIZJ: if (!s.xz) return fail(LCX_ERR_STATE, "no synergistic moments"); return fetch_mv(h, P<T>(s.xz), o, false);
+            case LCX_M_SYN_X2Y: if (!s.xz) return fail(LCX_ERR_STATE, "no synergistic moments"); return fetch_v(h, P<T>(s.x2y), o);
+            case LCX_M_SYN_XIYJ: {
+                LCXCHECK(fetch_mv(h, P<T>(s.D), o, false));
+                for (int64_t i = 0; i < h->V * h->M; ++i) o[i] = o[i] / (T)h->N;
+                return LCX_OK;
+            }
+            case LCX_M_CY: if (!s.xz) return fail(LCX_ERR_STATE, "no synergistic moments"); return fetch_small(h, s.cy, h->M, h->M, o);
+            case LCX_M_YJ2: if (!s.xz) return fail(LCX_ERR_STATE, "no synergistic moments"); return fetch_small(h, s.yj2, 1, h->M, o);
             default: return fail(LCX_ERR_ARG, "unknown moment key");
         }
     }
@@ -1058,6 +1161,8 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
         A_(h->set[k].uj, sizeof(double) * Mp);
         A_(h->set[k].ry, sizeof(double) * Mp * Mp);
         A_(h->set[k].wmag, sizeof(double) * Mp);
+        h->set[k].xz = h->set[k].x2y = nullptr;
+        h->set[k].cy = h->set[k].yj2 = h->set[k].inv_sd = nullptr;
     }
     A_(h->grad, mv);
     A_(h->update, mv);
@@ -1119,7 +1224,7 @@ int lcx_destroy(lcx_ctx* h) {
     for (void* p : ptrs) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) {
         MomentSet& s = h->set[k];
-        void* q[] = {s.Y, s.D, s.rho, s.rir, s.qij, s.si, s.q2, s.hscale, s.uj, s.ry, s.wmag};
+        void* q[] = {s.Y, s.D, s.rho, s.rir, s.qij, s.si, s.q2, s.hscale, s.uj, s.ry, s.wmag, s.xz, s.x2y, s.cy, s.yj2, s.inv_sd};
         for (void* p : q) (void)hipFree(p);
     }
     (void)hipHostFree(h->host_states);
@@ -1284,6 +1389,16 @@ int lcx_accept_trial(lcx_ctx* h) {
     std::swap(h->set[0], h->set[1]);
     h->have_direction = false;
     return LCX_OK;
+}
+
+int lcx_syn_moments_b(lcx_ctx* h, int which, double yscale) { NEED(h); WHICH_OK(which); DISPATCH(h, syn_moments_b, h, which, yscale); }
+int lcx_syn_moments_c(lcx_ctx* h, int which) { NEED(h); WHICH_OK(which); DISPATCH(h, syn_moments_c, h, which); }
+int lcx_syn_update_a(lcx_ctx* h) { NEED(h); DISPATCH(h, syn_update_a, h); }
+int lcx_syn_update_b(lcx_ctx* h, double eta) { NEED(h); DISPATCH(h, syn_update_b, h, eta); }
+int lcx_covariance_rows_syn(lcx_ctx* h, const void* std_host, int64_t row0, int64_t nrows, void* out) {
+    NEED(h);
+    if (!std_host || !out || row0 < 0 || nrows < 1 || row0 + nrows > h->V) return fail(LCX_ERR_ARG, "lcx_covariance_rows_syn: bad range");
+    DISPATCH(h, covariance_syn, h, std_host, row0, nrows, out);
 }
 
 int lcx_rescale_ws(lcx_ctx* h, double e0, double e1) { NEED(h); DISPATCH(h, rescale, h, e0, e1); }

@@ -582,7 +582,8 @@ template <typename T, int Mp>
 __global__ void __launch_bounds__(PV_THREADS)
 detail_kernel(const T* __restrict__ rho_i, const double* __restrict__ ryinv, int64_t V, int m,
               T* __restrict__ mi_o, T* __restrict__ xz_o, T* __restrict__ x2y_o,
-              double* __restrict__ dpart_sums) {
+              double* __restrict__ dpart_sums, const double* __restrict__ xz_fscale = nullptr,
+              T* __restrict__ inv_x2y_o = nullptr) {
     constexpr int VPB = PV_THREADS / Mp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* ri_s = reinterpret_cast<T*>(smem_raw);
@@ -626,10 +627,11 @@ detail_kernel(const T* __restrict__ rho_i, const double* __restrict__ ryinv, int
         x2y = x2y < (T)1e-6 ? (T)1e-6 : x2y;                                       // clip, :281
         if (ok) {
             if (mi_o) mi_o[o] = mi;
-            if (xz_o) xz_o[o] = xz;
+            if (xz_o) xz_o[o] = xz_fscale ? xz * (T)xz_fscale[j] : xz;
             if (j < m) col_mi += (double)mi;
             if (j == 0) {
                 if (x2y_o) x2y_o[v] = x2y;
+                if (inv_x2y_o) inv_x2y_o[v] = (T)1 / x2y;
                 s_max += (double)mx;
                 s_ixy += (double)((T)-0.5 * log(x2y));
             }
@@ -647,6 +649,156 @@ detail_kernel(const T* __restrict__ rho_i, const double* __restrict__ ryinv, int
     s_max = block_sum<double>(s_max, bs_scratch, tid);
     s_ixy = block_sum<double>(s_ixy, bs_scratch, tid);
     if (tid == 0) { outp[m] = s_max; outp[m + 1] = s_ixy; outp[m + 2] = tot; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// synergistic branch (discourage_overlap=False; linearcorex.py:336-384)
+// ------------------------------------------------------------------------------------------------
+// per-factor part of _calculate_moments_syn from the Gram of the (all-reduced) Y:
+//   cy = Y^T Y / N + yscale^2 I  (== ws.dot(X_i Y_j) + yscale^2 I, :356, because W X^T = Y^T)
+//   Y_j^2 = diag(cy) (:357), ry = cy / (sd_j sd_k) (:358), 1/sd_j, sum_j I(Y_j;X) (:369)
+// one block; gy: [nsplit][Mp][Mp] partials
+template <typename T>
+__global__ void __launch_bounds__(256)
+syn_small_kernel(const T* __restrict__ gy, int nsplit, int Mp, int m, double n_samples, double yscale,
+                 double* __restrict__ cy, double* __restrict__ yj2, double* __restrict__ ry,
+                 double* __restrict__ inv_sd, SetState* st) {
+    __shared__ double sd_s[128];
+    __shared__ double lg_s[128];
+    const int tid = threadIdx.x;
+    const int mm = Mp * Mp;
+    for (int idx = tid; idx < mm; idx += blockDim.x) {
+        T g = (T)0;
+        for (int k = 0; k < nsplit; ++k) g += gy[(int64_t)k * mm + idx];
+        const int a = idx / Mp, b = idx % Mp;
+        T c = g / (T)n_samples;
+        if (a == b) c += (T)(yscale * yscale);
+        cy[idx] = (double)c;
+    }
+    __syncthreads();
+    if (tid < Mp) {
+        const double d = cy[tid * Mp + tid];
+        yj2[tid] = d;
+        sd_s[tid] = sqrt((double)(T)d);
+        inv_sd[tid] = 1.0 / sd_s[tid];
+        // the reference keeps W and every moment of this branch in float64 (:121), also when x is float32
+        lg_s[tid] = tid < m ? 0.5 * log(d) - 0.5 * log(yscale * yscale) : 0.0;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < mm; idx += blockDim.x) {
+        const int a = idx / Mp, b = idx % Mp;
+        ry[idx] = (double)((T)cy[idx] / ((T)sd_s[a] * (T)sd_s[b]));
+    }
+    if (tid == 0) {
+        double s = 0.0;
+        for (int j = 0; j < m; ++j) s += lg_s[j];
+        st->sum_log_rj = s;           // here: sum_j I(Y_j ; X)
+        st->max_uj = 0.0;
+        st->invalid = 0;
+        st->invalid_d = 0.0;
+    }
+}
+
+// D = X^T Y (sum of the partial slots) and rho_ji = <X_i Y_j> / sd_j (:355, :359)
+template <typename T>
+__global__ void syn_rho_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, int64_t total, int Mp,
+                               double n_samples, const double* __restrict__ inv_sd, T* __restrict__ d_out,
+                               T* __restrict__ rho_o) {
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        T d = dpart[o];
+        for (int k = 1; k < nsplit; ++k) d += dpart[k * pstride + o];
+        d_out[o] = d;
+        rho_o[o] = d / (T)n_samples * (T)inv_sd[o % Mp];
+    }
+}
+
+// TC = sum_i I(X_i;Y) - sum_j I(Y_j;X) (:373); publish
+template <typename T>
+__global__ void syn_tc_kernel(const double* __restrict__ sbuf, int m, SetState* st, SetState* host, unsigned int seq) {
+    st->tc = sbuf[m + 1] - st->sum_log_rj;      // float64 like the reference's synergistic moments (:121, :373)
+    publish_state(st, host, seq);
+}
+
+// _update_syn (:375-383): ws' = (1-eta) ws + eta (X_i Z_j^T / X_i^2|Y - H ws), H diagonal zeroed
+// dynamic LDS: h_s[Mp*(Mp+1)] (T) + w_s[VPB*Mp] (T)
+template <typename T, int Mp>
+__global__ void __launch_bounds__(PV_THREADS)
+syn_update_kernel(const T* __restrict__ W, const T* __restrict__ xz, const T* __restrict__ inv_x2y,
+                  const double* __restrict__ H, int64_t V, T eta, T* __restrict__ w_out) {
+    constexpr int VPB = PV_THREADS / Mp;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* h_s = reinterpret_cast<T*>(smem_raw);
+    T* w_s = h_s + Mp * (Mp + 1);
+    const int tid = threadIdx.x, vl = tid / Mp, j = tid % Mp;
+    for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) {
+        const int a = idx / Mp, b = idx % Mp;
+        h_s[a * (Mp + 1) + b] = (a == b) ? (T)0 : (T)H[idx];
+    }
+    __syncthreads();
+    const int64_t ngroups = (V + VPB - 1) / VPB;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t v = grp * VPB + vl;
+        const bool ok = v < V;
+        const int64_t o = (ok ? v : 0) * Mp + j;
+        const T w = ok ? W[o] : (T)0;
+        __syncthreads();
+        w_s[vl * Mp + j] = w;
+        __syncthreads();
+        T s = (T)0;
+#pragma unroll 8
+        for (int k = 0; k < Mp; ++k) s += h_s[j * (Mp + 1) + k] * w_s[vl * Mp + k];
+        if (ok) {
+            const T r = xz[o] * inv_x2y[v];
+            w_out[o] = ((T)1 - eta) * w + eta * (r - s);
+        }
+    }
+}
+
+// get_covariance, synergistic branch (:452-455): out[r][c] = std_r std_c (r==c ? 1 : sum_j XiZj[r][j] XiYj[c][j]),
+// XiYj = D / N.  Same tiling as covariance_kernel.
+template <typename T, int Mp>
+__global__ void __launch_bounds__(256)
+covariance_syn_kernel(const T* __restrict__ xz, const T* __restrict__ D, const T* __restrict__ stdv, int64_t V,
+                      int64_t row0, int64_t nrows, double n_samples, T* __restrict__ out) {
+    constexpr int KC = Mp < 32 ? Mp : 32;
+    __shared__ T zr[64][KC + 1];
+    __shared__ T zc[64][KC + 1];
+    const int tid = threadIdx.x;
+    const int64_t rb = row0 + (int64_t)blockIdx.y * 64, cb = (int64_t)blockIdx.x * 64;
+    const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;
+    T acc[4][4] = {};
+    for (int j0 = 0; j0 < Mp; j0 += KC) {
+        __syncthreads();
+        for (int idx = tid; idx < 64 * KC; idx += 256) {
+            const int a = idx / KC, j = idx % KC;
+            const int64_t vr = rb + a, vc = cb + a;
+            zr[a][j] = (vr < V && vr < row0 + nrows) ? xz[vr * Mp + j0 + j] : (T)0;
+            zc[a][j] = (vc < V) ? D[vc * Mp + j0 + j] / (T)n_samples : (T)0;
+        }
+        __syncthreads();
+        for (int j = 0; j < KC; ++j) {
+            T a[4], b[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { a[x] = zr[tr + x][j]; b[x] = zc[tc + x][j]; }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[x][y] += a[x] * b[y];
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const int64_t r = rb + tr + x;
+        if (r >= V || r >= row0 + nrows) continue;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const int64_t c = cb + tc + y;
+            if (c >= V) continue;
+            T val = acc[x][y];
+            if (r == c) val = (T)1;
+            out[(r - row0) * V + c] = stdv[r] * stdv[c] * val;
+        }
+    }
 }
 
 // derived arrays for readback

@@ -237,8 +237,10 @@ class OracleFit:
     def clusters(self):
         return np.argmax(np.abs(self.ws), axis=0)
 
-    # ref :443-451
+    # ref :443-455
     def get_covariance(self):
+        if getattr(self, "synergistic", False):
+            return covariance_syn(self.moments, self.theta)
         return covariance_ns(self.moments, self.eps, self.theta)
 
     # ref :386-395
@@ -326,6 +328,95 @@ def fit_ns_preprocessed(x, n_hidden, seed=0, max_iter=10000, tol=1e-5, anneal=Tr
 def gen_iid(n, v, seed=1, dtype=np.float64):
     """Gen-A: iid N(0,1)."""
     return np.random.RandomState(seed).randn(n, v).astype(dtype)
+
+
+# --------------------------------------------------------------------------------------------------
+# synergistic branch, discourage_overlap=False (ref :336-384, :119-121, :141, :452-455)
+# --------------------------------------------------------------------------------------------------
+SYN_ETA = 0.1              # ref :141
+
+
+def moments_syn(x, w, yscale=1.0):
+    """ref :336-373 `_calculate_moments_syn` (the `quick` flag is ignored there)."""
+    n = x.shape[0]
+    m = w.shape[0]
+    mo = {}
+    y = x.dot(w.T)                                                          # ref :347
+    mo["X_i Y_j"] = x.T.dot(y) / n                                          # ref :355
+    mo["cy"] = w.dot(mo["X_i Y_j"]) + yscale ** 2 * np.eye(m)               # ref :356
+    mo["Y_j^2"] = np.diag(mo["cy"]).copy()                                  # ref :357
+    sd = np.sqrt(mo["Y_j^2"])
+    mo["ry"] = mo["cy"] / (sd * sd[:, np.newaxis])                          # ref :358
+    mo["rho"] = (mo["X_i Y_j"] / sd).T                                      # ref :359
+    mo["invrho"] = 1.0 / (1.0 - mo["rho"] ** 2)                             # ref :360
+    mo["rhoinvrho"] = mo["rho"] * mo["invrho"]                              # ref :361
+    mo["Qij"] = np.dot(mo["ry"], mo["rhoinvrho"])                           # ref :362
+    mo["Qi"] = np.einsum("ki,ki->i", mo["rhoinvrho"], mo["Qij"])            # ref :363
+    mo["Si"] = np.sum(mo["rho"] * mo["rhoinvrho"], axis=0)                  # ref :364
+    mo["MI"] = -0.5 * np.log1p(-mo["rho"] ** 2)                             # ref :366
+    mo["X_i Z_j"] = np.linalg.solve(mo["cy"], mo["X_i Y_j"].T).T            # ref :367
+    mo["X_i^2 | Y"] = (1.0 - np.einsum("ij,ij->i", mo["X_i Z_j"], mo["X_i Y_j"])).clip(1e-6)   # ref :368
+    iyx = 0.5 * np.log(mo["Y_j^2"]) - 0.5 * np.log(yscale ** 2)             # ref :369
+    ixy = -0.5 * np.log(mo["X_i^2 | Y"])                                    # ref :370
+    mo["TCs"] = mo["MI"].sum(axis=1) - iyx                                  # ref :371
+    mo["additivity"] = (mo["MI"].sum(axis=0) - ixy).sum()                   # ref :372
+    mo["TC"] = np.sum(ixy) - np.sum(iyx)                                    # ref :373
+    return mo
+
+
+def update_syn(x, w, mo, eta=SYN_ETA, yscale=1.0):
+    """ref :375-384 `_update_syn`: damped fixed-point step, then fresh moments."""
+    xz, x2y = mo["X_i Z_j"], mo["X_i^2 | Y"]
+    h = (1.0 / x2y * xz.T).dot(xz)                                          # ref :378
+    np.fill_diagonal(h, 0)
+    r = xz.T / x2y                                                          # ref :380
+    s = np.dot(h, w)                                                        # ref :381
+    w_new = (1.0 - eta) * w + eta * (r - s)                                 # ref :382
+    return w_new, moments_syn(x, w_new, yscale)
+
+
+def covariance_syn(mo, theta):
+    """ref :452-455 (synergistic branch of get_covariance)."""
+    cov = np.einsum("ij,kj->ik", mo["X_i Z_j"], mo["X_i Y_j"])
+    np.fill_diagonal(cov, 1)
+    return theta[1][:, np.newaxis] * theta[1] * cov
+
+
+def initial_weights_syn(seed, m, nv, yscale=1.0):
+    """ref :89 + :121 - float64 draws, never cast: the reference's synergistic branch runs its W and
+    moments in float64 whatever the dtype of x."""
+    return np.random.RandomState(seed).randn(m, nv) * yscale ** 2 / np.sqrt(nv)
+
+
+def fit_syn(x, n_hidden, seed=0, max_iter=10000, tol=1e-5, dtype=np.float32, gaussianize="standard",
+            missing_values=None, keep_x=False):
+    """ref :107-164 `fit` for discourage_overlap=False: no annealing (schedule [0.], :113-121), `_update_syn`
+    with eta=0.1 until |dTC| < tol, then the TCs sort (:160-163).  dtype is the precision x is cast to and
+    preprocessed in (ref :108); W stays float64."""
+    x = np.asarray(x, dtype=dtype)
+    xt, theta, _ = preprocess(x, None, gaussianize, missing_values)
+    res = OracleFit()
+    res.theta = theta
+    w = initial_weights_syn(seed, n_hidden, xt.shape[1])
+    res.w_init = w.copy()
+    mo = moments_syn(xt, w)                                                 # ref :122
+    mo = moments_syn(xt, w)                                                 # ref :134 (same weights)
+    for _ in range(max_iter):                                               # ref :136-155
+        last = mo["TC"]
+        w, mo = update_syn(xt, w, mo)
+        if not np.isfinite(mo["TC"]):
+            break
+        res.history_tc.append(mo["TC"])
+        if np.abs(mo["TC"] - last) < tol:
+            break
+    mo = moments_syn(xt, w)                                                 # ref :160
+    order = np.argsort(-mo["TCs"])                                          # ref :161
+    w = w[order]                                                            # ref :162
+    res.ws, res.moments = w, moments_syn(xt, w)                             # ref :163
+    res.synergistic = True
+    if keep_x:
+        res.x_tilde = xt
+    return res
 
 
 def gen_planted(n, v, m, seed=1, noise=1.0, dtype=np.float64):

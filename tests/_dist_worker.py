@@ -21,15 +21,20 @@ def main():
     mode = sys.argv[5] if len(sys.argv) > 5 else "exact"
     backend = sys.argv[6] if len(sys.argv) > 6 else "double"
     max_iter = int(sys.argv[7]) if len(sys.argv) > 7 else 10000
+    syn = mode == "syn"                     # discourage_overlap=False (reference :336-384)
+    if syn:
+        mode = "exact"
     dist.init_process_group("gloo")
     comm = Comm()
     x, _ = O.gen_planted(n, v, m, seed=2)
     if backend == "hip":
         # every rank drives its own engine handle on GPU 0; the exchange tensors are CUDA tensors and the
         # collectives go through gloo (RCCL refuses two ranks on one device) - same host code as bench.py
-        model = Corex(n_hidden=m, seed=0, dtype=np.float64, comm=comm, line_search=mode, device=0, max_iter=max_iter)
+        model = Corex(n_hidden=m, seed=0, dtype=np.float64, comm=comm, line_search=mode, device=0, max_iter=max_iter,
+                      discourage_overlap=not syn)
     else:
         model = Corex(n_hidden=m, seed=0, dtype=np.float64, comm=comm, line_search=mode, max_iter=max_iter,
+                      discourage_overlap=not syn,
                       _backend_factory=lambda ns, nv, mm, dt: ShardDouble(ns, nv, mm, dt))
     model.fit(x)
     c0, c1 = comm.shard(v)
@@ -38,9 +43,10 @@ def main():
     rho = model.moments["rho"]              # lazily gathered: every rank must ask (collective)
     xz = model.moments["X_i Z_j"]
     si = model.moments["Si"]
+    cov = model.get_covariance() if (syn and comm.world == 1) else np.zeros(1)
     if comm.rank == 0:
         np.savez(os.path.join(out_dir, "dist_result.npz"), history=np.asarray(model.history["TC"], np.float64),
-                 ws=model.ws, clusters=model.clusters(), transform=y, rho=rho, xz=xz, si=si,
+                 ws=model.ws, clusters=model.clusters(), transform=y, rho=rho, xz=xz, si=si, cov=cov,
                  tcs=model.tcs, world=comm.world, trials=model.stats["trials"],
                  calls=np.array(len(getattr(model._backend, "calls", []))))
     dist.barrier()

@@ -205,6 +205,55 @@ class ShardDouble:
     def update_d(self):
         self.state[0][3] = self.sbuf[0]
 
+    # ---- synergistic branch (ref :336-384), cut at the same exchange points as include/lcx.h --------------
+    def syn_moments_b(self, which, yscale):
+        w, n, m = self.w[which], self.n, self.m
+        y = self._y().copy()
+        xy = self.x.T.dot(y) / n                                     # nv x m   (:355)
+        cy = y.T.dot(y) / n + yscale ** 2 * np.eye(m)                # == ws.dot(X_i Y_j) + yscale^2 I (:356)
+        yj2 = np.diag(cy).copy()
+        sd = np.sqrt(yj2)
+        ry = cy / (sd * sd[:, np.newaxis])
+        rho = (xy / sd).T
+        xz = np.linalg.solve(cy, xy.T).T
+        x2y = (1.0 - np.einsum("ij,ij->i", xz, xy)).clip(1e-6)
+        mi = -0.5 * np.log1p(-rho ** 2)
+        self.mo[which] = {"syn X_i Y_j": xy, "cy": cy, "Y_j^2": yj2, "ry": ry, "rho": rho, "syn X_i Z_j": xz,
+                          "syn X_i^2 | Y": x2y, "MI": mi, "D": xy * n}
+        self.sbuf[:m] = mi.sum(axis=1)
+        self.sbuf[m] = 0.0
+        self.sbuf[m + 1] = (-0.5 * np.log(x2y)).sum()
+        self.sbuf[m + 2] = mi.sum()
+        self.state[which][4] = np.sum(0.5 * np.log(yj2) - 0.5 * np.log(yscale ** 2))
+        self.state[which][2] = 0.0
+        if which == 0:
+            self.generation += 1
+        self.calls.append("syn_moments_b")
+
+    def syn_moments_c(self, which):
+        self.state[which][0] = self.sbuf[self.m + 1] - self.state[which][4]
+        self.calls.append("syn_moments_c")
+
+    def syn_update_a(self):
+        mo = self.mo[0]
+        xz, x2y = mo["syn X_i Z_j"], mo["syn X_i^2 | Y"]
+        self.sbuf[:self.m * self.m] = (1.0 / x2y * xz.T).dot(xz).ravel()
+        self.calls.append("syn_update_a")
+
+    def syn_update_b(self, eta):
+        mo = self.mo[0]
+        h = self.sbuf[:self.m * self.m].reshape(self.m, self.m).copy()
+        np.fill_diagonal(h, 0)
+        r = mo["syn X_i Z_j"].T / mo["syn X_i^2 | Y"]
+        self.w[1] = ((1.0 - eta) * self.w[0] + eta * (r - np.dot(h, self.w[0]))).astype(self.dtype)
+        self.calls.append("syn_update_b")
+
+    def covariance_syn(self, std):
+        mo = self.mo[0]
+        cov = np.einsum("ij,kj->ik", mo["syn X_i Z_j"], mo["syn X_i Y_j"])
+        np.fill_diagonal(cov, 1)
+        return std[:, np.newaxis] * std * cov
+
     def make_trial(self, eta):
         self.w[1] = self.w[0] + self.dtype.type(eta) * self.update
 

@@ -65,3 +65,21 @@ def test_sharded_fit_matches_oracle(world, mode, tmp_path):
     assert np.max(np.abs(got["si"] - ref.moments["Si"])) < 1e-8
     assert np.max(np.abs(got["tcs"] - ref.moments["TCs"])) < 1e-8
     assert int(got["trials"]) == ref.n_trials
+
+
+def test_sharded_synergistic_fit_matches_oracle(tmp_path):
+    """discourage_overlap=False over two ranks: Y all-reduce, the m+3 sums, H."""
+    n, v, m = 300, 203, 4
+    launch(2, tmp_path, n, v, m, "syn")
+    got = np.load(os.path.join(tmp_path, "dist_result.npz"))
+    x, _ = O.gen_planted(n, v, m, seed=2)
+    ref = O.fit_syn(x, m, seed=0, dtype=np.float64, keep_x=True)
+    h, h_ref = got["history"], np.asarray(ref.history_tc)
+    assert len(h) == len(h_ref)
+    assert np.max(np.abs(h - h_ref) / np.maximum(1, np.abs(h_ref))) < 1e-9
+    assert np.max(np.abs(got["ws"] - ref.ws)) < 1e-8
+    assert np.max(np.abs(got["transform"] - ref.transform(ref.x_tilde))) < 1e-8
+    assert np.max(np.abs(got["rho"] - ref.moments["rho"])) < 1e-8
+    assert np.max(np.abs(got["xz"] - ref.moments["X_i Z_j"])) < 1e-8
+    assert np.max(np.abs(got["si"] - ref.moments["Si"])) < 1e-8
+    assert np.max(np.abs(got["tcs"] - ref.moments["TCs"])) < 1e-8

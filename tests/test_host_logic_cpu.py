@@ -84,8 +84,9 @@ def test_api_surface_and_conventions(g1):
         assert isinstance(getattr(Corex, prop), property)
     c = Corex(n_hidden=3, eliminate_synergy=True)
     assert c.discourage_overlap is True and c.ws.size == 0 and c.moments == {} and c.history == {}
-    with pytest.raises(NotImplementedError):
-        Corex(n_hidden=2, discourage_overlap=False, _backend_factory=FACTORY).fit(np.random.randn(50, 6))
+    with pytest.raises(NotImplementedError):       # n_hidden=None -> pick_n_hidden is broken in the reference
+        Corex(n_hidden=None, _backend_factory=FACTORY).fit(np.random.randn(50, 6))
+    assert Corex(n_hidden=2, eliminate_synergy=False).discourage_overlap is False
     # global RNG side effect of the constructor (linearcorex.py:89)
     Corex(n_hidden=2, seed=123)
     a = np.random.rand()
@@ -181,3 +182,27 @@ def test_product_does_not_import_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# ", ""), fn
+
+
+def test_synergistic_branch_host_logic():
+    """discourage_overlap=False (reference :336-384): the host driver over the NumPy backend double must reproduce
+    the oracle (which is pinned to the reference's own outputs in test_oracle_golden.py)."""
+    import pickle
+    from linearcorex_amd import Corex
+    from oracle import corex_oracle as O
+    from tests.shard_double import ShardDouble
+    x, _ = O.gen_planted(400, 300, 5, seed=4)
+    ref = O.fit_syn(x, 5, seed=0, dtype=np.float64)
+    out = Corex(n_hidden=5, seed=0, dtype=np.float64, discourage_overlap=False,
+                _backend_factory=lambda ns, nv, mm, dt: ShardDouble(ns, nv, mm, dt)).fit(x)
+    h, hr = np.asarray(out.history["TC"]), np.asarray(ref.history_tc)
+    assert len(h) == len(hr) and np.max(np.abs(h - hr)) < 1e-10
+    assert np.max(np.abs(out.ws - ref.ws)) < 1e-10
+    assert np.array_equal(out.clusters(), ref.clusters())
+    for k in ("TCs", "rho", "X_i Z_j", "X_i Y_j", "X_i^2 | Y", "cy", "ry", "Qij", "Qi", "Si", "MI", "Y_j^2"):
+        assert np.max(np.abs(np.asarray(out.moments[k]) - ref.moments[k])) < 1e-9, k
+    assert abs(out.moments["additivity"] - ref.moments["additivity"]) < 1e-9
+    cov = out.get_covariance()
+    assert np.max(np.abs(cov - ref.get_covariance())) < 1e-10
+    back = pickle.loads(pickle.dumps(out))
+    assert back._backend is None and np.max(np.abs(back.get_covariance() - cov)) < 1e-12

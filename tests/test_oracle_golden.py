@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import corex_oracle as O
+from tests.conftest import load_golden
 
 DT = {"f32": np.float32, "f64": np.float64}
 # different-BLAS headroom; on the generating host every comparison below is exact
@@ -220,3 +221,29 @@ def test_schedule_and_rescale():
     a = np.sqrt((1 - 0.6 ** 2) / ((1 - 0.36 ** 2) * (1 + delta)))
     assert np.allclose(out[:, 0], 0.001 * np.floor(1000 * a))
     assert np.allclose(out * 1000, np.round(out * 1000))                       # 0.001*floor(1000 a)
+
+
+# ---- synergistic branch (discourage_overlap=False): oracle vs the reference's own outputs (g8_syn.npz) -------
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_oracle_syn_matches_reference(tag):
+    g = load_golden("g8_syn")
+    dt = np.float32 if tag == "f32" else np.float64
+    # step level: one _update_syn on the captured state
+    p = "planted_%s_step_" % tag
+    xt = g["planted_%s_x_tilde" % tag]
+    mo_in = O.moments_syn(xt, g[p + "w_in"])
+    for k in ("X_i Y_j", "cy", "ry", "rho", "X_i Z_j", "X_i^2 | Y", "TCs", "TC", "additivity", "Qi", "Si"):
+        name = k.replace(" ", "_").replace("^", "p").replace("|", "g")
+        assert np.allclose(mo_in[k], g[p + "in_" + name], rtol=1e-12, atol=1e-13), k
+    w_out, mo_out = O.update_syn(xt, g[p + "w_in"], mo_in, eta=float(g[p + "eta"]))
+    assert np.allclose(w_out, g[p + "w_out"], rtol=1e-12, atol=1e-14)
+    assert abs(mo_out["TC"] - float(g[p + "out_TC"])) < 1e-11
+    # end to end
+    x, _ = O.gen_planted(400, 300, 5, seed=4)
+    res = O.fit_syn(x, 5, seed=0, dtype=dt)
+    h_ref = g["planted_%s_history_tc" % tag]
+    assert len(res.history_tc) == len(h_ref)
+    assert np.max(np.abs(np.asarray(res.history_tc) - h_ref)) < 1e-9
+    assert np.max(np.abs(res.ws - g["planted_%s_ws" % tag])) < 1e-9
+    assert np.max(np.abs(res.get_covariance() - g["planted_%s_cov" % tag])) < 1e-9
+    assert np.array_equal(res.clusters(), g["planted_%s_clusters" % tag])

@@ -28,6 +28,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6
 FP32_MFMA_PEAK_TFLOPS = 157.3
+# What micro-benchmarks reach on this chip (profiles/r01_read_probe_c2.txt, r01_mfma_peak.txt): a read-only
+# stream of a 400 MB matrix 6.2 TB/s; v_mfma_f64_16x16x4 47.6 TF/s (not the 78.6 TF/s spec), v_mfma_f32_16x16x4
+# 151 TF/s.  Reported beside the spec-based fraction, never instead of it.
+MEASURED_CEILINGS = {"hbm_read_GBps": 6200.0, "mfma_f64_TFLOPs": 47.6, "mfma_f32_TFLOPs": 151.0}
 
 WORKLOADS = {
     # name: (n_samples, n_variables per GPU, n_hidden, dtype)
@@ -233,6 +237,11 @@ def main():
         else:
             roofline = {"bound": "mfma", "achieved": kernels[dom]["TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s",
                         "frac": kernels[dom]["TFLOPs"] / mfma_peak, "traffic": traffic}
+        mfma_ceiling = MEASURED_CEILINGS["mfma_f64_TFLOPs" if tag == "f64" else "mfma_f32_TFLOPs"]
+        roofline.update(achieved_GBps=kernels[dom]["GBps"], achieved_TFLOPs=kernels[dom]["TFLOPs"],
+                        frac_of_measured_hbm_read_ceiling=kernels[dom]["GBps"] / MEASURED_CEILINGS["hbm_read_GBps"],
+                        frac_of_measured_mfma_ceiling=kernels[dom]["TFLOPs"] / mfma_ceiling,
+                        measured_ceilings=MEASURED_CEILINGS)
         roofline.update(kernel=dom, avg_launch_us=kernels[dom]["avg_us"], launches=kernels[dom]["launches"],
                         algorithmic_bytes_per_launch=alg_bytes, algorithmic_flops_per_launch=alg_flops,
                         traffic_source=traffic_src, use_sites=use_sites)

@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--cpu-iters-per-stage", type=int, default=40,
                     help="bounded CPU-baseline sample: oracle iterations per annealing stage (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="1 GPU only: run the multi-rank device path (world>1 kernels + RCCL all-reduces in a group of "
+                         "one rank) to measure the fixed cost of the exchange steps")
     ap.add_argument("--line-search", default="exact", choices=["linear", "exact"],
                     help="exact (default, the headline): reference-shaped, every trial makes 2 passes over X "
                          "(linearcorex.py:321); linear: trials cost no pass over X")
@@ -187,6 +190,17 @@ def main():
         from linearcorex_amd.comm import Comm
         comm = Comm()
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    if world == 1 and args.force_exchange:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        from linearcorex_amd.comm import Comm
+        comm = Comm(always_exchange=True)
 
     import __graft_entry__ as ge
     ge.build()
@@ -275,7 +289,7 @@ def main():
                    "x_passes_per_iteration": (sum(c for c, _ in timing.values()) / max(1, args.steps)) if timing
                    else None,
                    "x_passes_per_iteration_reference_shaped": 2 + 2 * trials - invalid,
-                   "launch_geometry": geo, "final_TC": r["final_tc"],
+                   "launch_geometry": geo, "final_TC": r["final_tc"], "force_exchange": bool(args.force_exchange),
                    "linear_trial_mode": extra},
         "roofline": roofline,
     }

@@ -147,25 +147,28 @@ int lcx_permute_factors(lcx_ctx* h, const int32_t* order);
 /* a: Y_partial = X_shard . W_shard^T (:247) and W_shard.W_shard^T  -> ybuf                      */
 int lcx_moments_a(lcx_ctx* h, int which);
 /* b: (ybuf now holds the global sums) uj (:248-249), early-exit flag (:250-251), X^T.Y (:259),
- *    rho (:260), ry (:261,:263), invrho, rhoinvrho, Qij, Si, Qi-Si^2 (:264-269), and the two
- *    per-shard log sums of TC (:272-273) -> sbuf[0..1]                                           */
+ *    rho (:260), ry (:261,:263), invrho, rhoinvrho, Qij, Si, Qi-Si^2 (:264-269), the two per-shard
+ *    log sums of TC (:272-273) -> sbuf[0..1], and the H partial of this set (:294) -> sbuf[8..)    */
 int lcx_moments_b(lcx_ctx* h, int which, double eps, int quick);
-/* c: (sbuf[0..1] global) TC (:272-274) -> state scalars                                         */
+/* c: (sbuf[0..2] global) TC (:272-274) and update_tangent (:305) -> state scalars of the set     */
 int lcx_moments_c(lcx_ctx* h, int which);
 
-/* detail part (:277-287): per-shard sums -> sbuf[0 .. m+3):
+/* detail part (:277-287): per-shard sums -> the detail range of sbuf (see lcx_read_sbuf), m+3 values:
  *   [0..m) sum_i MI_ji, [m] sum_i max_j MI_ji, [m+1] sum_i I(X_i;Y), [m+2] sum_ij MI_ji          */
 int lcx_moments_detail(lcx_ctx* h, int which);
 
 /* ---- update: _update_ns (:290-305) ---------------------------------------------------------- */
-/* a: H partial (:294) -> sbuf[0 .. m_padded^2)                                                  */
+/* a: H partial (:294) of set 0 -> sbuf[8 .. 8+m_padded^2).  lcx_moments_b / lcx_trial_linear_b already leave the H
+ *    of the set they evaluate there, so a fit only needs this call to restore it after a discarded trial.   */
 int lcx_update_a(lcx_ctx* h);
 /* b: grad (:296-300), Bj partial (:302), Y_g partial = X.grad^T (first half of _sig, :210)
  *    -> ybuf (Bj in the tail)                                                                    */
 int lcx_update_b(lcx_ctx* h, double eps);
-/* c: X^T.Y_g, sig_grad (:211-212), update (:303), tangent partial (:305) -> sbuf[0]             */
+/* c: X^T.Y_g, sig_grad (:211-212), update (:303), tangent partial (:305) -> sbuf[2]             */
 int lcx_update_c(lcx_ctx* h, double eps);
-/* d: tangent -> state scalars of set 0                                                           */
+/* d: marks the direction as ready (one GPU: the tangent is already in the state scalars of set 0; several
+ *    ranks: it becomes global with the first trial's scalar all-reduce and lcx_moments_c stores it in the
+ *    trial's state scalars)                                                                           */
 int lcx_update_d(lcx_ctx* h);
 /* w_update = ws + eta*update (:320) into set 1                                                   */
 int lcx_make_trial(lcx_ctx* h, double eta);
@@ -186,11 +189,11 @@ int lcx_accept_trial(lcx_ctx* h);
  *   lcx_syn_moments_b(which, yscale)  cy, Y_j^2, ry (:356-358; cy = Y^T.Y/N + yscale^2 I, which equals
  *                                     ws.dot(X_i Y_j) + yscale^2 I because W.X^T = Y^T - no extra collective),
  *                                     X^T.Y (:355), rho (:359), X_i Z_j (:367), X_i^2|Y (:368), per-shard sums
- *                                     [0..m) sum_i MI_ji, [m] -, [m+1] sum_i I(X_i;Y), [m+2] sum_ij MI -> sbuf   | all-reduce sbuf[0..m+3)
+ *                                     [0..m) sum_i MI_ji, [m] -, [m+1] sum_i I(X_i;Y), [m+2] sum_ij MI -> detail range of sbuf | all-reduce it
  *   lcx_syn_moments_c(which)          TC = sum_i I(X_i;Y) - sum_j I(Y_j;X) (:373) -> state scalars
  * One _update_syn (:375-383) from set 0 into the weights of set 1 (then the moments above with which=1 and
  * lcx_accept_trial):
- *   lcx_syn_update_a()                H partial (:378) -> sbuf[0..m_padded^2)                       | all-reduce
+ *   lcx_syn_update_a()                H partial (:378) -> sbuf[8..8+m_padded^2)                     | all-reduce
  *   lcx_syn_update_b(eta)             ws' = (1-eta) ws + eta (X_i Z_j^T / X_i^2|Y - H ws) (:380-382)          */
 int lcx_syn_moments_b(lcx_ctx* h, int which, double yscale);
 int lcx_syn_moments_c(lcx_ctx* h, int which);
@@ -214,8 +217,14 @@ int lcx_get_moment(lcx_ctx* h, int which, int key, double eps, void* host_out);
 /* upload a moment of set `which` (only LCX_M_RHOINVRHO and LCX_M_SI: what get_covariance needs,
  * :447) - used to restore a pickled model (vis_corex.py:549-551) without refitting */
 int lcx_set_moment(lcx_ctx* h, int which, int key, const void* host_in);
-/* synchronise and copy the first `count` doubles of the scalar exchange buffer */
-int lcx_read_sbuf(lcx_ctx* h, int64_t count, double* out);
+/* synchronise and copy `count` doubles of the scalar exchange buffer starting at `offset`.  Layout (doubles):
+ *   [0] sum_i log(1+Si), [1] sum_i log(1+Qi-Si^2), [2] update_tangent partial, [3..8) spare,
+ *   [8, 8+m_padded^2)                       H partial (:294 / :378) of the moment set evaluated last,
+ *   [8+m_padded^2, 8+m_padded^2+m+3)        detail sums (lcx_moments_detail, lcx_syn_moments_b).
+ * A multi-GPU caller all-reduces [0, 8+m_padded^2) once per moment evaluation (between _b and _c) - that carries the
+ * TC sums, the tangent of the direction and the H the next update needs - and the detail range after the calls
+ * that produce it. */
+int lcx_read_sbuf(lcx_ctx* h, int64_t offset, int64_t count, double* out);
 
 /* ---- outputs ---------------------------------------------------------------------------------- */
 /* get_covariance (:443-451), rows [row0, row0+nrows) of the nv_local x nv_local matrix;

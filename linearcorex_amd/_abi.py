@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "liblcx_hip.so")
 
 LCX_F32, LCX_F64 = 0, 1
 S_TC, S_MAX_UJ, S_INVALID, S_TANGENT, S_SUM_LOG_RJ, S_COUNT = 0, 1, 2, 3, 4, 8
+SB_H = 8                   # offset of H in the scalar exchange buffer (include/lcx.h, lcx_read_sbuf)
 
 # lcx_moment_key
 M_UJ, M_RHO, M_RY, M_INVRHO, M_RHOINVRHO, M_QIJ, M_SI, M_QISI2, M_MI, M_XIZJ, M_XI2_GIVEN_Y, \
@@ -65,7 +66,7 @@ SIGNATURES = {
     "lcx_read_state": [_vp, _i32, C.POINTER(_dbl)],
     "lcx_get_moment": [_vp, _i32, _i32, _dbl, _vp],
     "lcx_set_moment": [_vp, _i32, _i32, _vp],
-    "lcx_read_sbuf": [_vp, _i64, C.POINTER(_dbl)],
+    "lcx_read_sbuf": [_vp, _i64, _i64, C.POINTER(_dbl)],
     "lcx_covariance_rows": [_vp, _dbl, _vp, _i64, _i64, _vp],
     "lcx_project": [_vp, _vp, _i64, _i64, _vp],
     "lcx_timing_enable": [_vp, _i32],

@@ -126,9 +126,17 @@ class HipBackend:
         import torch
         return torch.cuda.stream(self.torch_stream)
 
+    def sbuf_ranges(self):
+        """(scalars + H, detail) as (offset, count) in the scalar exchange buffer (include/lcx.h, lcx_read_sbuf)."""
+        mp = self.geometry()["m_pad"] if not hasattr(self, "m_pad") else self.m_pad
+        self.m_pad = mp
+        return (0, _abi.SB_H + mp * mp), (_abi.SB_H + mp * mp, self.m + 3)
+
     def read_sbuf(self, count):
+        """the first `count` detail sums (lcx_moments_detail / lcx_syn_moments_b)"""
         out = np.empty(int(count), dtype=np.float64)
-        _abi.check(self.lib.lcx_read_sbuf(self.h, int(count), out.ctypes.data_as(C.POINTER(C.c_double))))
+        off = self.sbuf_ranges()[1][0]
+        _abi.check(self.lib.lcx_read_sbuf(self.h, off, int(count), out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
     # ---- data ---------------------------------------------------------------------------------

@@ -12,12 +12,16 @@ import numpy as np
 
 
 class Comm:
-    def __init__(self, group=None):
+    def __init__(self, group=None, always_exchange=False):
+        """always_exchange: issue every exchange step even in a group of one rank (the all-reduces are then
+        identities).  Used to run the multi-rank device path - the world>1 kernels of the engine, the bound
+        exchange tensors and real RCCL launches on the engine's stream - on a single GPU."""
         import torch.distributed as dist
         self._dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.exchange = self.world > 1 or bool(always_exchange)
 
     # contiguous, balanced column ranges
     def shard(self, nv, rank=None):
@@ -25,11 +29,11 @@ class Comm:
         return (nv * r) // self.world, (nv * (r + 1)) // self.world
 
     def allreduce(self, tensor):
-        if self.world > 1:
+        if self.exchange:
             self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM, group=self.group)
 
     def allreduce_max(self, tensor):
-        if self.world > 1:
+        if self.exchange:
             self._dist.all_reduce(tensor, op=self._dist.ReduceOp.MAX, group=self.group)
 
     def barrier(self):
@@ -57,7 +61,7 @@ class Comm:
 
 class SingleComm:
     """world size 1: no torch import, no collectives."""
-    rank, world = 0, 1
+    rank, world, exchange = 0, 1, False
 
     def shard(self, nv, rank=None):
         return 0, nv

@@ -185,8 +185,9 @@ class Corex(object):
                 dev = int(os.environ.get("LOCAL_RANK", "0"))
             be = HipBackend(n_samples, nv_local, self.m, self.dtype, dev)
         self._backend = be
-        be.set_world(self._comm.world)
-        self._ex = be.exchange_tensors() if self._comm.world > 1 else None
+        exchange = getattr(self._comm, "exchange", self._comm.world > 1)
+        be.set_world(max(self._comm.world, 2) if exchange else 1)
+        self._ex = be.exchange_tensors() if exchange else None
         return be
 
     def _allreduce(self, tensor):
@@ -198,9 +199,22 @@ class Corex(object):
         if self._ex is not None:
             self._allreduce(self._ex[0])
 
-    def _xs(self, count):
+    def _x_scalars(self):
+        """Scalar exchange of a moment evaluation: the two TC sums, the tangent partial of the current direction
+        and the H partial of the evaluated set (include/lcx.h, lcx_read_sbuf) - one all-reduce."""
         if self._ex is not None:
-            self._allreduce(self._ex[1][:count])
+            off, cnt = self._backend.sbuf_ranges()[0]
+            self._allreduce(self._ex[1][off:off + cnt])
+
+    def _x_h(self):
+        if self._ex is not None:
+            mp2 = be_mp2(self._backend)
+            self._allreduce(self._ex[1][8:8 + mp2])
+
+    def _x_detail(self):
+        if self._ex is not None:
+            off, cnt = self._backend.sbuf_ranges()[1]
+            self._allreduce(self._ex[1][off:off + cnt])
 
     def _xtail(self):
         """all-reduce only the m_pad^2 tail of the Y exchange buffer (W.W^T partials)."""
@@ -242,7 +256,7 @@ class Corex(object):
                 self.theta = (self._gather(theta[0]), self._gather(theta[1]))
             self.n_obs = self._gather(n_obs) if self.missing_values is not None else len(x)
             if self.gaussianize == 'standard' and self.verbose:
-                if self._comm.world > 1:
+                if self._ex is not None:
                     import torch
                     with be.stream_context():
                         t = torch.tensor([max_abs], dtype=torch.float64, device=self._ex[1].device)
@@ -341,7 +355,7 @@ class Corex(object):
         be.moments_a(which)                          # Y_partial = X.W^T (:347)
         self._xy()
         be.syn_moments_b(which, self.yscale)         # cy, ry, X^T.Y, rho, X_i Z_j, X_i^2|Y, partial sums
-        self._xs(self.m + 3)
+        self._x_detail()
         be.syn_moments_c(which)                      # TC (:373)
         self.stats["moment_evals"] += 1
         st = be.read_state(which)
@@ -365,7 +379,7 @@ class Corex(object):
         """One damped fixed-point step (:375-384); the new weights stay on the device."""
         be = self._backend
         be.syn_update_a()                            # H partial (:378)
-        self._xs(be_mp2(be))
+        self._x_h()
         be.syn_update_b(eta)                         # ws' (:380-382) -> set 1
         st = self._calculate_moments_syn(which=1)    # :383
         be.accept_trial()
@@ -459,8 +473,8 @@ class Corex(object):
         be = self._backend
         be.moments_a(which)                 # Y_partial = X.W^T (:247), W.W^T partial
         self._xy()
-        be.moments_b(which, self.eps, quick)  # uj, early exit, X^T.Y, rho ... Qi-Si^2, TC partial sums
-        self._xs(2)
+        be.moments_b(which, self.eps, quick)  # uj, early exit, X^T.Y, rho ... Qi-Si^2, TC partial sums, H partial
+        self._x_scalars()
         be.moments_c(which)                 # TC
         self.stats["moment_evals"] += 1
 
@@ -479,7 +493,7 @@ class Corex(object):
         eager = {"TC": self._scalar(st[0])}
         if details:
             be.moments_detail(0)
-            self._xs(self.m + 3)
+            self._x_detail()
             sums = be.read_sbuf(self.m + 3)
             uj = be.get_moment(0, "uj")
             eager["uj"] = uj
@@ -503,13 +517,11 @@ class Corex(object):
         new weights stay on the device)."""
         be = self._backend
         m = self.moments
-        be.update_a()                        # H partial (:294)
-        self._xs(be_mp2(be))
+        # H (:294) is already global: it came with the scalar exchange of the evaluation that produced set 0
         be.update_b(self.eps)                # grad (:296-300), Bj partial, Y_g partial
         self._xy()
         be.update_c(self.eps)                # X^T.Y_g, sig_grad, update, tangent partial (:301-305)
-        self._xs(1)
-        be.update_d()
+        be.update_d()                        # the tangent becomes global with the first trial's scalar exchange
         tc_cur = self._tc_cur
         linear = self.line_search == "linear"
         update_tangent = None
@@ -523,8 +535,8 @@ class Corex(object):
             if linear:
                 be.trial_linear_a(eta)                                         # :320, Y' = Y + eta*Y(update)
                 self._xtail()
-                be.trial_linear_b(self.eps, eta)                               # D' = D + eta*D(update) ... TC sums
-                self._xs(2)
+                be.trial_linear_b(self.eps, eta)                               # D' = D + eta*D(update) ... TC sums, H
+                self._x_scalars()
                 be.moments_c(1)
                 self.stats["moment_evals"] += 1
             else:
@@ -533,9 +545,11 @@ class Corex(object):
             self.stats["trials"] += 1
             st = be.read_state(1)
             if update_tangent is None:
-                update_tangent = be.read_state(0)[3]
+                update_tangent = st[3]             # the trial's scalars carry the tangent of its direction
                 if update_tangent >= 0:                                        # :306-311
                     self.stats["trials"] -= 1      # the speculative trial is discarded
+                    be.update_a()                  # ... and so is its H: restore the H of the kept solution
+                    self._x_h()
                     print('Warning: covariance is nearly singular and this causes a loss of numerical precision.'
                           'For this reason, we can no longer find an update that increases the objective. '
                           'Hopefully this is a good solution. If not, this is caused by having many variables that are '
@@ -592,7 +606,7 @@ class Corex(object):
         else:
             x = self.preprocess(x)       # imputation needs the column means of the whole new batch: host side
             y = be.project(np.ascontiguousarray(x[:, c0:c1]))
-        if self._comm.world > 1:
+        if self._ex is not None:
             import torch
             with be.stream_context():
                 t = torch.from_numpy(y).to(self._ex[1].device)

@@ -62,6 +62,12 @@ struct MomentSet {
     unsigned int seq_expect;    // sequence number of the last publication enqueued for this set
 };
 
+// scalar exchange buffer (doubles): [0] sum log(1+Si), [1] sum log(1+Qi-Si^2), [2] tangent partial, [3..8) spare,
+// [SB_H, SB_H + Mp^2) H partial of the set last evaluated, [SB_H + Mp^2, + Mp + 8) detail sums (lcx_moments_detail /
+// lcx_syn_moments_b).  One all-reduce of [0, SB_H + Mp^2) per moment evaluation carries everything the next update needs.
+constexpr int SB_H = 8;
+static inline int sb_det(int Mp) { return SB_H + Mp * Mp; }
+
 struct TimingPair {
     hipEvent_t a, b;
     int kind;
@@ -441,10 +447,16 @@ template <typename T, int CT> struct Impl {
                            P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), P<T>(s.hscale),
                            h->tcpart, skip);
         KCHECK();
+        // H partial of THIS set (:294), so that the update that follows an accepted trial needs no exchange of
+        // its own: it rides in the scalar all-reduce of the evaluation
+        LCXCHECK(gram(h, P<T>(s.rir), h->ldx, P<T>(s.hscale), h->gv_S, skip, P<T>(h->gpart)));
+        hipLaunchKernelGGL((reduce_wide_kernel<T, double>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
+                           P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, h->sbuf + SB_H, skip);
+        KCHECK();
         const int single = h->world == 1;
         const unsigned int seq = ++h->seq_next;
         hipLaunchKernelGGL((tc_finalize_kernel<T>), dim3(1), dim3(PV_THREADS), 0, h->stream, h->tcpart, h->pv_grid, h->sbuf,
-                           s.st, s.hst_dev, seq, single);
+                           s.st, s.hst_dev, seq, single, (const SetState*)h->set[0].st);
         KCHECK();
         if (single) s.seq_expect = seq;
         return LCX_OK;
@@ -489,7 +501,7 @@ template <typename T, int CT> struct Impl {
         MomentSet& s = h->set[0];
         LCXCHECK(gram(h, P<T>(s.rir), h->ldx, P<T>(s.hscale), h->gv_S, nullptr, P<T>(h->gpart)));
         hipLaunchKernelGGL((reduce_wide_kernel<T, double>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
-                           P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, h->sbuf, (const int*)nullptr);
+                           P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, h->sbuf + SB_H, (const int*)nullptr);
         KCHECK();
         return LCX_OK;
     }
@@ -500,7 +512,7 @@ template <typename T, int CT> struct Impl {
         const size_t lds = ((size_t)Mp * (Mp + 1) + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
         LCXCHECK(allow_lds(grad_kernel<T, Mp>, lds));
         hipLaunchKernelGGL((grad_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(h->Wt[0]),
-                           P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), s.uj, h->sbuf, h->V,
+                           P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), s.uj, h->sbuf + SB_H, h->V,
                            P<T>(h->grad), h->bjpart);
         KCHECK();
         return nt_big(h, P<T>(h->grad), nullptr, true);
@@ -573,7 +585,7 @@ template <typename T, int CT> struct Impl {
                            h->ryinv, h->V, h->M, mi_o, xz_o, x2y_o, h->detpart);
         KCHECK();
         hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(h->M + 3), dim3(PV_THREADS), 0, h->stream, h->detpart, h->pv_grid,
-                           h->M + 3, h->sbuf, (const int*)nullptr);
+                           h->M + 3, h->sbuf + sb_det(Mp), (const int*)nullptr);
         KCHECK();
         return LCX_OK;
     }
@@ -616,14 +628,14 @@ template <typename T, int CT> struct Impl {
                            (T*)nullptr, P<T>(s.xz), P<T>(s.x2y), h->detpart, (const double*)s.inv_sd, P<T>(s.hscale));
         KCHECK();
         hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(h->M + 3), dim3(PV_THREADS), 0, h->stream, h->detpart, h->pv_grid,
-                           h->M + 3, h->sbuf, (const int*)nullptr);
+                           h->M + 3, h->sbuf + sb_det(Mp), (const int*)nullptr);
         KCHECK();
         return LCX_OK;
     }
     static int syn_moments_c(lcx_ctx* h, int which) {
         MomentSet& s = h->set[which];
         const unsigned int seq = ++h->seq_next;
-        hipLaunchKernelGGL((syn_tc_kernel<T>), dim3(1), dim3(1), 0, h->stream, h->sbuf, h->M, s.st, s.hst_dev, seq);
+        hipLaunchKernelGGL((syn_tc_kernel<T>), dim3(1), dim3(1), 0, h->stream, h->sbuf + sb_det(Mp), h->M, s.st, s.hst_dev, seq);
         KCHECK();
         s.seq_expect = seq;
         return LCX_OK;
@@ -634,7 +646,7 @@ template <typename T, int CT> struct Impl {
         if (!s.xz) return fail(LCX_ERR_STATE, "lcx_syn_update_a before lcx_syn_moments_b");
         LCXCHECK(gram(h, P<T>(s.xz), h->ldx, P<T>(s.hscale), h->gv_S, nullptr, P<T>(h->gpart)));
         hipLaunchKernelGGL((reduce_wide_kernel<T, double>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
-                           P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, h->sbuf, (const int*)nullptr);
+                           P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, h->sbuf + SB_H, (const int*)nullptr);
         KCHECK();
         return LCX_OK;
     }
@@ -644,7 +656,7 @@ template <typename T, int CT> struct Impl {
         const size_t lds = ((size_t)Mp * (Mp + 1) + (size_t)VPB * Mp) * sizeof(T);
         LCXCHECK(allow_lds(syn_update_kernel<T, Mp>, lds));
         hipLaunchKernelGGL((syn_update_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(h->Wt[0]), P<T>(s.xz),
-                           P<T>(s.hscale), h->sbuf, h->V, (T)eta, P<T>(h->Wt[1]));
+                           P<T>(s.hscale), h->sbuf + SB_H, h->V, (T)eta, P<T>(h->Wt[1]));
         KCHECK();
         return LCX_OK;
     }
@@ -705,7 +717,7 @@ template <typename T, int CT> struct Impl {
             case LCX_M_UJ: return fetch_small(h, s.uj, 1, h->M, o);
             case LCX_M_RY: return fetch_small(h, s.ry, h->M, h->M, o);
             case LCX_M_H: {
-                LCXCHECK(fetch_small(h, h->sbuf, h->M, h->M, o));
+                LCXCHECK(fetch_small(h, h->sbuf + SB_H, h->M, h->M, o));
                 for (int a = 0; a < h->M; ++a) o[a * h->M + a] = (T)0;
                 return LCX_OK;
             }
@@ -1172,7 +1184,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     A_(h->ddir, mv);
     h->have_linear = false;
     h->ybuf_elems = h->Npad * Mp + (int64_t)Mp * Mp;
-    h->sbuf_elems = (int64_t)Mp * Mp + 8;
+    h->sbuf_elems = (int64_t)SB_H + (int64_t)Mp * Mp + Mp + 8;
     A_(h->ybuf_own, (size_t)h->ybuf_elems * es);
     A_(h->sbuf_own, sizeof(double) * h->sbuf_elems);
     h->ybuf = h->ybuf_own;
@@ -1358,13 +1370,8 @@ int lcx_update_b(lcx_ctx* h, double eps) { NEED(h); DISPATCH(h, update_b, h, eps
 int lcx_update_c(lcx_ctx* h, double eps) { NEED(h); DISPATCH(h, update_c, h, eps); }
 int lcx_update_d(lcx_ctx* h) {
     NEED(h);
-    if (h->world > 1) {
-        MomentSet& s = h->set[0];
-        const unsigned int seq = ++h->seq_next;
-        hipLaunchKernelGGL(tangent_store_kernel, dim3(1), dim3(1), 0, h->stream, h->sbuf, s.st, s.hst_dev, seq);
-        KCHECK();
-        s.seq_expect = seq;
-    }
+    // With one GPU lcx_update_c already published the tangent; with several ranks its partial sits in sbuf[2]
+    // and becomes global with the scalar all-reduce of the first trial (lcx_moments_c stores it).
     h->have_direction = true;
     return LCX_OK;
 }
@@ -1467,10 +1474,10 @@ int lcx_set_moment(lcx_ctx* h, int which, int key, const void* in) {
     DISPATCH(h, set_moment, h, which, key, in);
 }
 
-int lcx_read_sbuf(lcx_ctx* h, int64_t count, double* out) {
+int lcx_read_sbuf(lcx_ctx* h, int64_t offset, int64_t count, double* out) {
     NEED(h);
-    if (!out || count < 1 || count > h->sbuf_elems) return fail(LCX_ERR_ARG, "lcx_read_sbuf: bad count");
-    HIPCHECK(hipMemcpyAsync(out, h->sbuf, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
+    if (!out || offset < 0 || count < 1 || offset + count > h->sbuf_elems) return fail(LCX_ERR_ARG, "lcx_read_sbuf: bad range");
+    HIPCHECK(hipMemcpyAsync(out, h->sbuf + offset, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
     return LCX_OK;
 }

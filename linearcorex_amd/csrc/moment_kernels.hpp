@@ -311,6 +311,7 @@ __device__ __forceinline__ void tc_store(const double* sbuf, SetState* st) {
 template <typename T>
 __global__ void tc_final_kernel(const double* __restrict__ sbuf, SetState* st, SetState* host, unsigned int seq) {
     tc_store<T>(sbuf, st);
+    st->tangent = sbuf[2];       // update_tangent (:305) of the direction this trial belongs to, now global
     publish_state(st, host, seq);
 }
 // per-block pairs -> sbuf[0..1]; with one GPU (single != 0) also TC and the host mirror, so that
@@ -318,7 +319,7 @@ __global__ void tc_final_kernel(const double* __restrict__ sbuf, SetState* st, S
 template <typename T>
 __global__ void __launch_bounds__(PV_THREADS)
 tc_finalize_kernel(const double* __restrict__ tcpart, int nblocks, double* __restrict__ sbuf, SetState* st,
-                   SetState* host, unsigned int seq, int single) {
+                   SetState* host, unsigned int seq, int single, const SetState* st_cur) {
     __shared__ double bs_scratch[PV_THREADS / 64];
     const int tid = threadIdx.x;
     if (!st->invalid) {
@@ -331,10 +332,11 @@ tc_finalize_kernel(const double* __restrict__ tcpart, int nblocks, double* __res
     if (tid == 0 && single) {
         __threadfence();
         tc_store<T>(sbuf, st);
+        if (st != st_cur) st->tangent = st_cur->tangent;     // the trial carries the tangent of its direction
         publish_state(st, host, seq);
     }
 }
-// tangent partials -> sbuf[0]; with one GPU also the state scalar + host mirror
+// tangent partials -> sbuf[2]; with one GPU also the state scalar + host mirror
 __global__ void __launch_bounds__(PV_THREADS)
 tan_finalize_kernel(const double* __restrict__ tanpart, int nblocks, double* __restrict__ sbuf, SetState* st,
                     SetState* host, unsigned int seq, int single) {
@@ -344,7 +346,7 @@ tan_finalize_kernel(const double* __restrict__ tanpart, int nblocks, double* __r
     for (int b = tid; b < nblocks; b += PV_THREADS) s += tanpart[b];
     s = block_sum<double>(s, bs_scratch, tid);
     if (tid == 0) {
-        sbuf[0] = s;
+        sbuf[2] = s;
         if (single) { st->tangent = s; publish_state(st, host, seq); }
     }
 }
@@ -453,7 +455,7 @@ update_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, const T*
 }
 
 __global__ void tangent_store_kernel(const double* __restrict__ sbuf, SetState* st, SetState* host, unsigned int seq) {
-    st->tangent = sbuf[0];
+    st->tangent = sbuf[2];
     publish_state(st, host, seq);
 }
 

@@ -22,7 +22,9 @@ class ShardDouble:
         self.mo = [dict(), dict()]
         self.state = [np.zeros(8), np.zeros(8)]
         self.ybuf = np.zeros(self.n * self.m + self.m * self.m, self.dtype)
-        self.sbuf = np.zeros(self.m * self.m + 8, np.float64)
+        # layout of include/lcx.h (lcx_read_sbuf): [0..8) scalars, [8, 8+m^2) H, then the detail sums
+        self.sbuf = np.zeros(8 + self.m * self.m + self.m + 8, np.float64)
+        self.SB_H, self.SB_DET = 8, 8 + self.m * self.m
         self.grad = self.update = self.sig_grad = None
         self.calls = []
 
@@ -46,8 +48,11 @@ class ShardDouble:
         import contextlib
         return contextlib.nullcontext()
 
+    def sbuf_ranges(self):
+        return (0, self.SB_DET), (self.SB_DET, self.m + 3)
+
     def read_sbuf(self, count):
-        return self.sbuf[:count].copy()
+        return self.sbuf[self.SB_DET:self.SB_DET + count].copy()
 
     def upload_x(self, x):
         assert x.shape == (self.n, self.nv)
@@ -125,6 +130,7 @@ class ShardDouble:
             with np.errstate(all="ignore"):
                 self.sbuf[0] = np.sum(np.log(1 + si).astype(np.float64))
                 self.sbuf[1] = np.sum(np.log(1 + q2).astype(np.float64))
+                self.sbuf[self.SB_H:self.SB_DET] = np.dot(rir / (1 + q2), rir.T).ravel()     # H partial of this set
         self.mo[which] = mo
         if which == 0:
             self.generation += 1
@@ -148,6 +154,7 @@ class ShardDouble:
             st[0] = np.nan
         else:
             st[0] = float(self.dtype.type(self.sbuf[0] - 0.5 * self.sbuf[1] + 0.5 * st[4]))
+        st[3] = self.sbuf[2]                      # update_tangent of the direction in flight
         self.calls.append("moments_c")
 
     def moments_detail(self, which):
@@ -159,21 +166,22 @@ class ShardDouble:
         mo.update(MI=mi)
         mo["X_i Z_j"] = xz
         mo["X_i^2 | Y"] = x2y
-        self.sbuf[:m] = mi.sum(axis=1)
-        self.sbuf[m] = mi.max(axis=0).sum()
-        self.sbuf[m + 1] = (-0.5 * np.log(x2y)).sum()
-        self.sbuf[m + 2] = mi.sum()
+        d = self.SB_DET
+        self.sbuf[d:d + m] = mi.sum(axis=1)
+        self.sbuf[d + m] = mi.max(axis=0).sum()
+        self.sbuf[d + m + 1] = (-0.5 * np.log(x2y)).sum()
+        self.sbuf[d + m + 2] = mi.sum()
 
     # ---- update (ref :290-305) -------------------------------------------------------------------
     def update_a(self):
         mo = self.mo[0]
         rir = mo["rhoinvrho"]
-        self.sbuf[:self.m * self.m] = np.dot(rir / (1 + mo["Qi-Si^2"]), rir.T).ravel()
+        self.sbuf[self.SB_H:self.SB_DET] = np.dot(rir / (1 + mo["Qi-Si^2"]), rir.T).ravel()
         self.calls.append("update_a")
 
     def update_b(self, eps):
         mo, w = self.mo[0], self.w[0]
-        h = self.sbuf[:self.m * self.m].reshape(self.m, self.m).astype(self.dtype)
+        h = self.sbuf[self.SB_H:self.SB_DET].reshape(self.m, self.m).astype(self.dtype)
         np.fill_diagonal(h, 0)
         rj = 1.0 - mo["uj"][:, np.newaxis]
         rho, inv, rir = mo["rho"], mo["invrho"], mo["rhoinvrho"]
@@ -199,11 +207,11 @@ class ShardDouble:
         c = 2.0 * bj / (2 - rj)                                   # (m, 1)
         self.ydir = (-rj * (yg.T - c * mo["Y"].T)).T                # Y(update), n x m
         self.ddir = (-rj * (self.x.T.dot(yg).T - c * mo["D"].T)).T  # D(update), nv x m
-        self.sbuf[0] = float(np.einsum("ji,ji", sg.astype(np.float64), self.update.astype(np.float64)))
+        self.sbuf[2] = float(np.einsum("ji,ji", sg.astype(np.float64), self.update.astype(np.float64)))
         self.calls.append("update_c")
 
     def update_d(self):
-        self.state[0][3] = self.sbuf[0]
+        pass
 
     # ---- synergistic branch (ref :336-384), cut at the same exchange points as include/lcx.h --------------
     def syn_moments_b(self, which, yscale):
@@ -220,10 +228,11 @@ class ShardDouble:
         mi = -0.5 * np.log1p(-rho ** 2)
         self.mo[which] = {"syn X_i Y_j": xy, "cy": cy, "Y_j^2": yj2, "ry": ry, "rho": rho, "syn X_i Z_j": xz,
                           "syn X_i^2 | Y": x2y, "MI": mi, "D": xy * n}
-        self.sbuf[:m] = mi.sum(axis=1)
-        self.sbuf[m] = 0.0
-        self.sbuf[m + 1] = (-0.5 * np.log(x2y)).sum()
-        self.sbuf[m + 2] = mi.sum()
+        d = self.SB_DET
+        self.sbuf[d:d + m] = mi.sum(axis=1)
+        self.sbuf[d + m] = 0.0
+        self.sbuf[d + m + 1] = (-0.5 * np.log(x2y)).sum()
+        self.sbuf[d + m + 2] = mi.sum()
         self.state[which][4] = np.sum(0.5 * np.log(yj2) - 0.5 * np.log(yscale ** 2))
         self.state[which][2] = 0.0
         if which == 0:
@@ -231,18 +240,18 @@ class ShardDouble:
         self.calls.append("syn_moments_b")
 
     def syn_moments_c(self, which):
-        self.state[which][0] = self.sbuf[self.m + 1] - self.state[which][4]
+        self.state[which][0] = self.sbuf[self.SB_DET + self.m + 1] - self.state[which][4]
         self.calls.append("syn_moments_c")
 
     def syn_update_a(self):
         mo = self.mo[0]
         xz, x2y = mo["syn X_i Z_j"], mo["syn X_i^2 | Y"]
-        self.sbuf[:self.m * self.m] = (1.0 / x2y * xz.T).dot(xz).ravel()
+        self.sbuf[self.SB_H:self.SB_DET] = (1.0 / x2y * xz.T).dot(xz).ravel()
         self.calls.append("syn_update_a")
 
     def syn_update_b(self, eta):
         mo = self.mo[0]
-        h = self.sbuf[:self.m * self.m].reshape(self.m, self.m).copy()
+        h = self.sbuf[self.SB_H:self.SB_DET].reshape(self.m, self.m).copy()
         np.fill_diagonal(h, 0)
         r = mo["syn X_i Z_j"].T / mo["syn X_i^2 | Y"]
         self.w[1] = ((1.0 - eta) * self.w[0] + eta * (r - np.dot(h, self.w[0]))).astype(self.dtype)

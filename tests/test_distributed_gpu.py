@@ -60,3 +60,38 @@ def test_sharded_fit_on_device_matches_oracle(world, mode, tmp_path):
     assert np.max(np.abs(got["tcs"] - ref.moments["TCs"])) < 1e-7
     if mode == "exact":
         assert int(got["trials"]) == ref.n_trials
+
+
+def test_rccl_exchange_path_single_rank(tmp_path):
+    """The multi-rank device path with the REAL backend (torch.distributed 'nccl' = RCCL) in a group of one
+    rank: world>1 engine kernels, bound exchange tensors, RCCL launches interleaved with the engine's kernels on
+    the shared stream.  All-reduces over one rank are identities, so the result must equal the oracle."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from linearcorex_amd import Corex
+from linearcorex_amd.comm import Comm
+from oracle import corex_oracle as O
+x, _ = O.gen_planted(400, 331, 5, seed=2)
+for syn in (False, True):
+    ref = (O.fit_syn if syn else O.fit_ns)(x, 5, seed=0, dtype=np.float64, max_iter=40)
+    out = Corex(n_hidden=5, seed=0, dtype=np.float64, device=0, comm=Comm(always_exchange=True), max_iter=40,
+                discourage_overlap=not syn).fit(x)
+    assert out._ex is not None and out._backend.torch_stream is not None
+    h, hr = np.asarray(out.history["TC"], np.float64), np.asarray(ref.history_tc)
+    assert len(h) == len(hr), (len(h), len(hr))
+    assert np.max(np.abs(h - hr) / np.maximum(1, np.abs(hr))) < 1e-8
+    assert np.max(np.abs(out.ws - ref.ws)) < 1e-7
+    assert np.max(np.abs(out.transform(x) - ref.transform(O.preprocess(x)[0]))) < 1e-7
+dist.destroy_process_group()
+print("RCCL_PATH_OK")
+''' % (ROOT, str(free_port()))
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL_PATH_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])

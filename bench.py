@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--cpu-iters-per-stage", type=int, default=40,
                     help="bounded CPU-baseline sample: oracle iterations per annealing stage (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-convergence", dest="convergence", action="store_false",
+                    help="skip the wall-clock-to-TC-convergence measurement (a full fit at tol=1e-5 on the same data, "
+                         "reported under config.fit_to_convergence; 1 GPU, workload c2 only)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="1 GPU only: run the multi-rank device path (world>1 kernels + RCCL all-reduces in a group of "
                          "one rank) to measure the fixed cost of the exchange steps")
@@ -294,6 +297,18 @@ def main():
         "roofline": roofline,
     }
     x_host = r["x_host"]
+    if world == 1 and args.convergence and args.workload == "c2" and x_host is not None and comm is None:
+        # BASELINE.json's second figure: wall-clock of a whole fit() to |dTC| < 1e-5 per annealing stage
+        # (reference defaults :72-74), including the upload + on-device preprocess and the final detail moments
+        from linearcorex_amd import Corex
+        t0 = time.perf_counter()
+        mdl = Corex(n_hidden=m, seed=0, dtype=dtype, device=local_rank).fit(x_host)
+        t1 = time.perf_counter()
+        out["config"]["fit_to_convergence"] = {
+            "seconds": t1 - t0, "iterations": len(mdl.history["TC"]), "TC": float(mdl.tc), "tol": 1e-5,
+            "iterations_per_sec_incl_setup": len(mdl.history["TC"]) / (t1 - t0),
+            "trials_per_iteration": mdl.stats["trials"] / max(1, len(mdl.history["TC"]))}
+        mdl._backend.close()
     if rank == 0 and world == 1 and args.cpu_iters_per_stage > 0 and x_host is not None:
         out["cpu_baseline"] = cpu_baseline(x_host, m, dtype, args.cpu_iters_per_stage)
     elif rank == 0:

@@ -108,6 +108,10 @@ int lcx_synchronize(lcx_ctx* h);
  * (lcx_moments_c and lcx_update_d then launch nothing). */
 int lcx_set_world(lcx_ctx* h, int world);
 
+/* The linear trial mode (lcx_trial_linear_*) needs a copy of every evaluated Y and the direction in Y / X^T.Y
+ * space; enable != 0 (default) keeps them, 0 skips those copies for callers that only use lcx_make_trial. */
+int lcx_set_linear_mode(lcx_ctx* h, int enable);
+
 /* Exchange buffers (device pointers).  ybuf: n_samples_padded*m_padded + m_padded*m_padded
  * elements of the working dtype; sbuf: lcx_sbuf_count doubles.  lcx_exchange_layout reports
  * element counts; lcx_bind_exchange(NULL, NULL) restores the handle's own buffers. */

@@ -185,6 +185,8 @@ class Corex(object):
                 dev = int(os.environ.get("LOCAL_RANK", "0"))
             be = HipBackend(n_samples, nv_local, self.m, self.dtype, dev)
         self._backend = be
+        if hasattr(be, "set_linear_mode"):
+            be.set_linear_mode(self.line_search == "linear")
         exchange = getattr(self._comm, "exchange", self._comm.world > 1)
         be.set_world(max(self._comm.world, 2) if exchange else 1)
         self._ex = be.exchange_tensors() if exchange else None

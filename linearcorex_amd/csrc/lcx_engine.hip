@@ -94,7 +94,9 @@ struct lcx_ctx {
     SetState* states;           // device [2]
     SetState* host_states;      // pinned [2]
     int* order_dev;
-    unsigned int* ticket;       // arrival counter of small_moments_kernel
+    unsigned int* ticket;       // arrival counters: [0] small_moments_kernel, [1] moments_epilogue_kernel, [2] update_kernel
+    bool keep_y;                // keep a copy of every evaluated Y (the linear trial mode starts from it)
+    bool w1_ready;              // Wt[1] already holds ws + update (written by update_kernel)
     // launch geometry
     int nt_S, nt_KW, tn_S, tn_KW, gn_S, gv_S, pv_grid, target_waves, n_cus, nt_bpc, tn_bpc;
     // column-tiled stream-K kernel (gemm_ct) per pass: used when the shard has enough column tiles
@@ -440,32 +442,30 @@ template <typename T, int CT> struct Impl {
         const int* skip = &s.st->invalid;
         const size_t lds = ((size_t)Mp * Mp + (size_t)VPB * Mp) * sizeof(T);
         LCXCHECK(allow_lds(moments_epilogue_kernel<T, Mp>, lds));
+        const int single = h->world == 1;
+        const unsigned int seq = single ? ++h->seq_next : 0u;
         hipLaunchKernelGGL((moments_epilogue_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream,
                            P<T>(h->dpart), h->tn_S, h->ldx * Mp,
                            linear ? P<T>(h->set[0].D) : (const T*)nullptr, P<T>(h->ddir), (T)eta, P<T>(s.D),
                            P<T>(h->Wt[which]), s.ry, h->V, (double)h->N, eps,
                            P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), P<T>(s.hscale),
-                           h->tcpart, skip);
+                           h->tcpart, skip, h->ticket + 1, h->sbuf, s.st, s.hst_dev, seq, single, (const SetState*)h->set[0].st);
         KCHECK();
+        if (single) s.seq_expect = seq;
         // H partial of THIS set (:294), so that the update that follows an accepted trial needs no exchange of
         // its own: it rides in the scalar all-reduce of the evaluation
         LCXCHECK(gram(h, P<T>(s.rir), h->ldx, P<T>(s.hscale), h->gv_S, skip, P<T>(h->gpart)));
         hipLaunchKernelGGL((reduce_wide_kernel<T, double>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
                            P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, h->sbuf + SB_H, skip);
         KCHECK();
-        const int single = h->world == 1;
-        const unsigned int seq = ++h->seq_next;
-        hipLaunchKernelGGL((tc_finalize_kernel<T>), dim3(1), dim3(PV_THREADS), 0, h->stream, h->tcpart, h->pv_grid, h->sbuf,
-                           s.st, s.hst_dev, seq, single, (const SetState*)h->set[0].st);
-        KCHECK();
-        if (single) s.seq_expect = seq;
         return LCX_OK;
     }
 
     static int moments_b(lcx_ctx* h, int which, double eps, int quick) {
         MomentSet& s = h->set[which];
         // keep the (all-reduced) Y of this set: the linear trial mode starts from it
-        HIPCHECK(hipMemcpyAsync(s.Y, h->ybuf, (size_t)h->Npad * Mp * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+        if (h->keep_y)
+            HIPCHECK(hipMemcpyAsync(s.Y, h->ybuf, (size_t)h->Npad * Mp * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
         LCXCHECK(small(h, which, eps, quick, P<T>(h->ybuf)));
         LCXCHECK(tn_big(h, &s.st->invalid));
         return epilogue(h, which, eps, false, 0.0);
@@ -523,22 +523,22 @@ template <typename T, int CT> struct Impl {
         LCXCHECK(tn_big(h, nullptr));
         const int grid = (int)(cdiv(h->V * Mp, PV_THREADS) < 1536 ? cdiv(h->V * Mp, PV_THREADS) : 1536);
         const int64_t ny = h->Npad * Mp;
-        const int gridy = (int)(cdiv(ny, PV_THREADS) < 512 ? cdiv(ny, PV_THREADS) : 512);
+        const int gridy = h->keep_y ? (int)(cdiv(ny, PV_THREADS) < 512 ? cdiv(ny, PV_THREADS) : 512) : 0;
+        const int single = h->world == 1;
+        const unsigned int seq = ++h->seq_next;
         hipLaunchKernelGGL((update_kernel<T, Mp>), dim3(grid + gridy), dim3(PV_THREADS), 0, h->stream, P<T>(h->dpart), h->tn_S,
                            h->ldx * Mp, P<T>(h->grad), P<T>(h->Wt[0]), s.uj, P<T>(h->ybuf) + h->Npad * Mp, h->V,
                            (double)h->N, eps, P<T>(h->update), P<T>(h->sgrad), h->tanpart,
-                           P<T>(s.D), P<T>(h->ddir), grid, P<T>(h->ybuf), P<T>(s.Y), ny, P<T>(h->ydir));
-        KCHECK();
-        const int single = h->world == 1;
-        const unsigned int seq = ++h->seq_next;
-        hipLaunchKernelGGL(tan_finalize_kernel, dim3(1), dim3(PV_THREADS), 0, h->stream, h->tanpart, grid, h->sbuf, s.st,
-                           s.hst_dev, seq, single);
+                           h->keep_y ? P<T>(s.D) : (const T*)nullptr, h->keep_y ? P<T>(h->ddir) : (T*)nullptr, grid, P<T>(h->ybuf),
+                           P<T>(s.Y), ny, P<T>(h->ydir), P<T>(h->Wt[1]), h->ticket + 2, h->sbuf, s.st, s.hst_dev, seq, single);
         KCHECK();
         if (single) s.seq_expect = seq;
+        h->w1_ready = true;
         return LCX_OK;
     }
 
     static int make_trial(lcx_ctx* h, double eta) {
+        if (eta == 1.0 && h->w1_ready) return LCX_OK;        // update_kernel already wrote ws + update
         const int64_t n = h->V * Mp;
         hipLaunchKernelGGL((axpy_kernel<T>), dim3((unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048)), dim3(256), 0,
                            h->stream, P<T>(h->Wt[0]), P<T>(h->update), (T)eta, n, P<T>(h->Wt[1]));
@@ -1183,6 +1183,8 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     A_(h->ydir, (size_t)h->Npad * Mp * es);
     A_(h->ddir, mv);
     h->have_linear = false;
+    h->keep_y = true;
+    h->w1_ready = false;
     h->ybuf_elems = h->Npad * Mp + (int64_t)Mp * Mp;
     h->sbuf_elems = (int64_t)SB_H + (int64_t)Mp * Mp + Mp + 8;
     A_(h->ybuf_own, (size_t)h->ybuf_elems * es);
@@ -1311,6 +1313,7 @@ int lcx_generate_x(lcx_ctx* h, uint64_t seed, int kind, int n_groups, int64_t co
 
 int lcx_set_ws(lcx_ctx* h, const void* w) {
     NEED(h);
+    h->w1_ready = false;
     if (!w) return fail(LCX_ERR_ARG, "lcx_set_ws: null");
     DISPATCH(h, set_ws, h, w);
 }
@@ -1337,6 +1340,7 @@ int lcx_get_ws(lcx_ctx* h, int which, void* w) {
 
 int lcx_permute_factors(lcx_ctx* h, const int32_t* order) {
     NEED(h);
+    h->w1_ready = false;
     if (!order) return fail(LCX_ERR_ARG, "lcx_permute_factors: null");
     for (int j = 0; j < h->M; ++j)
         if (order[j] < 0 || order[j] >= h->M) return fail(LCX_ERR_ARG, "lcx_permute_factors: index out of range");
@@ -1392,6 +1396,7 @@ int lcx_trial_linear_b(lcx_ctx* h, double eps, double eta) {
 }
 int lcx_accept_trial(lcx_ctx* h) {
     NEED(h);
+    h->w1_ready = false;
     std::swap(h->Wt[0], h->Wt[1]);
     std::swap(h->set[0], h->set[1]);
     h->have_direction = false;
@@ -1408,8 +1413,8 @@ int lcx_covariance_rows_syn(lcx_ctx* h, const void* std_host, int64_t row0, int6
     DISPATCH(h, covariance_syn, h, std_host, row0, nrows, out);
 }
 
-int lcx_rescale_ws(lcx_ctx* h, double e0, double e1) { NEED(h); DISPATCH(h, rescale, h, e0, e1); }
-int lcx_init_scale_ws(lcx_ctx* h) { NEED(h); DISPATCH(h, init_scale, h); }
+int lcx_rescale_ws(lcx_ctx* h, double e0, double e1) { NEED(h); h->w1_ready = false; DISPATCH(h, rescale, h, e0, e1); }
+int lcx_init_scale_ws(lcx_ctx* h) { NEED(h); h->w1_ready = false; DISPATCH(h, init_scale, h); }
 
 // Wait until the pinned mirror of a set carries the last publication enqueued for it.
 static int wait_published(lcx_ctx* h, MomentSet& s) {
@@ -1449,6 +1454,13 @@ int lcx_read_state(lcx_ctx* h, int which, double* out) {
     out[LCX_S_TANGENT] = s.tangent;
     out[LCX_S_SUM_LOG_RJ] = s.sum_log_rj;
     out[5] = out[6] = out[7] = 0.0;
+    return LCX_OK;
+}
+
+int lcx_set_linear_mode(lcx_ctx* h, int enable) {
+    NEED(h);
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    h->keep_y = enable != 0;
     return LCX_OK;
 }
 

@@ -168,6 +168,13 @@ small_moments_kernel(const T* __restrict__ gy, int nsplit, const T* __restrict__
     }
 }
 
+// TC = sum log(1+Si) - 1/2 sum log(1+QiSi2) + 1/2 sum log(1-uj), rounded to the working precision
+template <typename T>
+__device__ __forceinline__ void tc_store(const double* sbuf, SetState* st) {
+    if (st->invalid) { st->tc = __builtin_nan(""); return; }
+    const T tc = (T)sbuf[0] - (T)0.5 * (T)sbuf[1] + (T)0.5 * (T)st->sum_log_rj;
+    st->tc = (double)tc;
+}
 // ------------------------------------------------------------------------------------------------
 // moments epilogue: from D = X^T Y partials to rho, rhoinvrho, Qij, Si, Qi-Si^2 and the two log sums
 // (linearcorex.py:260, :264-269, :272-273).  grid-stride over variable groups.
@@ -182,14 +189,24 @@ moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride
                         double n_samples, double eps, T* __restrict__ rho_o, T* __restrict__ rir_o,
                         T* __restrict__ qij_o, T* __restrict__ si_o, T* __restrict__ q2_o,
                         T* __restrict__ hscale_o, double* __restrict__ tcpart,
-                        const int* __restrict__ skip_flag) {
+                        const int* __restrict__ skip_flag, unsigned int* __restrict__ ticket,
+                        double* __restrict__ sbuf, SetState* st, SetState* host, unsigned int seq, int single,
+                        const SetState* st_cur) {
     constexpr int VPB = PV_THREADS / Mp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* ry_s = reinterpret_cast<T*>(smem_raw);
     T* rir_s = ry_s + Mp * Mp;
     __shared__ T gs_scratch[PV_THREADS / 64];
     __shared__ double bs_scratch[PV_THREADS / 64];
-    if (skip_flag != nullptr && *skip_flag != 0) return;
+    if (skip_flag != nullptr && *skip_flag != 0) {
+        // invalid trial (:250-251): nothing to compute, but with one GPU the host is waiting for the scalars
+        if (single && blockIdx.x == 0 && threadIdx.x == 0) {
+            tc_store<T>(sbuf, st);
+            if (st != st_cur) st->tangent = st_cur->tangent;
+            publish_state(st, host, seq);
+        }
+        return;
+    }
 
     const int tid = threadIdx.x, vl = tid / Mp, j = tid % Mp;
     for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) ry_s[idx] = (T)ry[idx];
@@ -238,7 +255,38 @@ moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride
     }
     s1 = block_sum<double>(s1, bs_scratch, tid);
     s2 = block_sum<double>(s2, bs_scratch, tid);
-    if (tid == 0) { tcpart[2 * blockIdx.x] = s1; tcpart[2 * blockIdx.x + 1] = s2; }
+    // The block that draws the last ticket sums the per-block pairs in index order (deterministic) into
+    // sbuf[0..1]: no separate reduction launch.
+    __shared__ int last_s;
+    if (tid == 0) {
+        __hip_atomic_store(&tcpart[2 * blockIdx.x], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&tcpart[2 * blockIdx.x + 1], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // 8-byte agent-scope atomics on both sides of the hand-off (write-through stores, drained before the
+        // ticket; L1-bypassing loads in the last block): no L2 write-back fence per block - with hundreds of
+        // blocks that have just written the M x V outputs a release fence costs microseconds each
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = (t == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!last_s) return;
+    double a1 = 0.0, a2 = 0.0;
+    for (int b = tid; b < (int)gridDim.x; b += PV_THREADS) {
+        a1 += __hip_atomic_load(&tcpart[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a2 += __hip_atomic_load(&tcpart[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    a1 = block_sum<double>(a1, bs_scratch, tid);
+    a2 = block_sum<double>(a2, bs_scratch, tid);
+    if (tid == 0) {
+        sbuf[0] = a1;
+        sbuf[1] = a2;
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (single) {               // nothing to exchange: TC, the tangent of the direction in flight, host mirror
+            tc_store<T>(sbuf, st);
+            if (st != st_cur) st->tangent = st_cur->tangent;
+            publish_state(st, host, seq);
+        }
+    }
 }
 
 // out[k] = sum_b part[b][k], one block per output value k, fixed summation order (deterministic)
@@ -301,21 +349,14 @@ reduce_wide_kernel(const T* __restrict__ in, int nsplit, int64_t n, int64_t stri
     }
 }
 
-// TC = sum log(1+Si) - 1/2 sum log(1+QiSi2) + 1/2 sum log(1-uj), rounded to the working precision
-template <typename T>
-__device__ __forceinline__ void tc_store(const double* sbuf, SetState* st) {
-    if (st->invalid) { st->tc = __builtin_nan(""); return; }
-    const T tc = (T)sbuf[0] - (T)0.5 * (T)sbuf[1] + (T)0.5 * (T)st->sum_log_rj;
-    st->tc = (double)tc;
-}
 template <typename T>
 __global__ void tc_final_kernel(const double* __restrict__ sbuf, SetState* st, SetState* host, unsigned int seq) {
     tc_store<T>(sbuf, st);
     st->tangent = sbuf[2];       // update_tangent (:305) of the direction this trial belongs to, now global
     publish_state(st, host, seq);
 }
-// per-block pairs -> sbuf[0..1]; with one GPU (single != 0) also TC and the host mirror, so that
-// lcx_moments_c has nothing left to launch
+// (legacy two-step form, kept for reference in tests) per-block pairs -> sbuf[0..1]; with one GPU (single != 0)
+// also TC and the host mirror, so that lcx_moments_c has nothing left to launch
 template <typename T>
 __global__ void __launch_bounds__(PV_THREADS)
 tc_finalize_kernel(const double* __restrict__ tcpart, int nblocks, double* __restrict__ sbuf, SetState* st,
@@ -335,6 +376,14 @@ tc_finalize_kernel(const double* __restrict__ tcpart, int nblocks, double* __res
         if (st != st_cur) st->tangent = st_cur->tangent;     // the trial carries the tangent of its direction
         publish_state(st, host, seq);
     }
+}
+// after the fused epilogue (sbuf[0..1] final): TC, tangent of the direction in flight, host mirror (one GPU)
+template <typename T>
+__global__ void tc_publish_kernel(const double* __restrict__ sbuf, SetState* st, SetState* host, unsigned int seq,
+                                  const SetState* st_cur) {
+    tc_store<T>(sbuf, st);
+    if (st != st_cur) st->tangent = st_cur->tangent;
+    publish_state(st, host, seq);
 }
 // tangent partials -> sbuf[2]; with one GPU also the state scalar + host mirror
 __global__ void __launch_bounds__(PV_THREADS)
@@ -418,7 +467,8 @@ update_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, const T*
               T* __restrict__ sgrad_o, double* __restrict__ tanpart,
               const T* __restrict__ d_cur, T* __restrict__ d_dir_o,
               int update_blocks, const T* __restrict__ yg, const T* __restrict__ ycur, int64_t ny,
-              T* __restrict__ ydir_o) {
+              T* __restrict__ ydir_o, T* __restrict__ w1_o, unsigned int* __restrict__ ticket,
+              double* __restrict__ sbuf, SetState* st, SetState* host, unsigned int seq, int single) {
     __shared__ double bs_scratch[PV_THREADS / 64];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= update_blocks) {
@@ -445,13 +495,33 @@ update_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, const T*
         const T up = -rj * (g - (T)2 * W[o] / ((T)2 - rj) * bj_tail[j]);         // :303
         update_o[o] = up;
         sgrad_o[o] = sg;
+        if (w1_o != nullptr) w1_o[o] = W[o] + up;                               // :320 at eta = 1 (the first trial)
         // update_j = -rj (grad_j - c_j W_j), c_j = 2 Bj / (2 - rj), is a per-factor combination of
         // grad and W, and X^T.(X.u^T) acts row-wise and linearly, so D(update) needs no pass over X
         if (d_dir_o != nullptr) d_dir_o[o] = -rj * (d - (T)2 * bj_tail[j] / ((T)2 - rj) * d_cur[o]);
         tan += (double)(sg * up);
     }
     tan = block_sum<double>(tan, bs_scratch, tid);
-    if (tid == 0) tanpart[blockIdx.x] = tan;
+    // last update block (ticket): fixed-order sum of the per-block partials -> sbuf[2]; with one GPU also the
+    // state scalar and the host mirror
+    __shared__ int last_s;
+    if (tid == 0) {
+        __hip_atomic_store(&tanpart[blockIdx.x], tan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = (t == (unsigned int)update_blocks - 1);
+    }
+    __syncthreads();
+    if (!last_s) return;
+    double a = 0.0;
+    for (int b = tid; b < update_blocks; b += PV_THREADS)
+        a += __hip_atomic_load(&tanpart[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = block_sum<double>(a, bs_scratch, tid);
+    if (tid == 0) {
+        sbuf[2] = a;
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (single) { st->tangent = a; publish_state(st, host, seq); }
+    }
 }
 
 __global__ void tangent_store_kernel(const double* __restrict__ sbuf, SetState* st, SetState* host, unsigned int seq) {

@@ -3,7 +3,7 @@
 #   bash tools/gpu_prof.sh <tag> <workload> [extra bench args]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1; WL=$2; shift 2
-ARGS="--workload $WL --cpu-iters-per-stage 0 --no-also-linear $*"
+ARGS="--workload $WL --cpu-iters-per-stage 0 --no-also-linear --no-convergence $*"
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$WL -o $WL -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_$WL.log 2>&1

@@ -1,0 +1,63 @@
+"""BASELINE.json configs 3 and 4 at FULL size on one MI355X (50k x 100k x 64 and the 50k x 125k x 128 shard of the
+8-GPU config, float32, data generated and standardised on the device - the matrices cannot be staged through the
+oracle).  Size-independent properties instead of element-wise oracle comparison:
+
+  * unit-variance columns: W = c * one-hot rows  =>  uj = c^2 and rho[j][v_j] = c   (generation, on-device
+    standardisation, both X-streaming passes of gemm_ct, the epilogue);
+  * linearity of X.W^T in W;
+  * a short fit keeps every invariant of the reference's loop: finite TC, uj < 1, TC non-decreasing inside an
+    annealing stage (the back-tracking only accepts trials that satisfy the first Wolfe condition, :327)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _moments(be, eps, quick=0):
+    be.moments_a(0); be.moments_b(0, eps, quick); be.moments_c(0)
+    return be.read_state(0)
+
+
+@pytest.mark.parametrize("shape", [(50000, 100000, 64), (50000, 125000, 128)], ids=["config3", "config4_shard"])
+def test_full_size_properties(shape):
+    from linearcorex_amd import Corex
+    from linearcorex_amd.backend import HipBackend
+    n, v, m = shape
+    be = HipBackend(n, v, m, np.float32, 0)
+    assert "gemm_ct_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)
+    be.generate_x(1, 1, m, 0)                                     # planted groups, standardised on the device
+    cols = np.unique(np.concatenate([[0, 1, v - 1, v - 2, 63, 64, 255, 256], np.linspace(0, v - 1, m).astype(int)]))[:m]
+    assert len(cols) == m
+    c = 0.5
+    w = np.zeros((m, v), np.float32)
+    w[np.arange(m), cols] = c
+    be.set_ws(w)
+    st = _moments(be, 0.0)
+    uj = be.get_moment(0, "uj")
+    assert np.max(np.abs(uj - c * c)) < 2e-5                      # sum_l x_l^2 / N = 1 for every column
+    rho = be.get_moment(0, "rho")
+    assert np.max(np.abs(rho[np.arange(m), cols] - c)) < 2e-5
+    assert np.max(np.abs(rho)) <= c + 2e-5                        # |corr| <= 1
+    assert np.isfinite(st[0])
+    # linearity of the X.W^T pass
+    rng = np.random.RandomState(0)
+    w1 = (rng.randn(m, v) * 0.003).astype(np.float32)
+    w2 = (rng.randn(m, v) * 0.003).astype(np.float32)
+    ys = []
+    for ww in (w1, w2, w1 + w2):
+        be.set_ws(ww)
+        be.moments_a(0)
+        ys.append(be.get_moment(0, "Y").astype(np.float64))
+    scale = np.abs(ys[2]).max()
+    assert np.max(np.abs(ys[2] - (ys[0] + ys[1]))) < 2e-5 * scale * 4
+    be.close()
+    # a short fit at full size
+    mdl = Corex(n_hidden=m, seed=0, dtype=np.float32, device=0, max_iter=2)
+    mdl.fit_generated(n, v, seed=1, kind=1, n_groups=m)
+    h = np.asarray(mdl.history["TC"], np.float64)
+    assert len(h) == 14 and np.all(np.isfinite(h))
+    for s in range(7):
+        assert h[2 * s + 1] >= h[2 * s] - 1e-3 * abs(h[2 * s])
+    assert float(np.max(mdl.moments["uj"])) < 1.0
+    assert mdl.ws.shape == (m, v) and np.all(np.isfinite(mdl.ws))
+    mdl._backend.close()

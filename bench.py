@@ -95,9 +95,10 @@ def load_pmc_traffic(workload, kernel):
     try:
         with open(path) as f:
             d = json.load(f)
-        return d["kernels"][kernel]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+        k = d["kernels"][kernel]
+        return k["hbm_bytes_per_launch"], os.path.relpath(path, ROOT), k.get("mfma_util")
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def measure(args, comm, world, rank, local_rank, line_search, keep_x=False):
@@ -247,7 +248,7 @@ def main():
         kernels = by_fn
         intensity = alg_flops / alg_bytes
         mfma_peak = FP64_MFMA_PEAK_TFLOPS if tag == "f64" else FP32_MFMA_PEAK_TFLOPS
-        traffic, traffic_src = load_pmc_traffic(args.workload, dom)
+        traffic, traffic_src, mfma_util = load_pmc_traffic(args.workload, dom)
         if intensity < mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9):
             roofline = {"bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic}
@@ -261,7 +262,7 @@ def main():
                         measured_ceilings=MEASURED_CEILINGS)
         roofline.update(kernel=dom, avg_launch_us=kernels[dom]["avg_us"], launches=kernels[dom]["launches"],
                         algorithmic_bytes_per_launch=alg_bytes, algorithmic_flops_per_launch=alg_flops,
-                        traffic_source=traffic_src, use_sites=use_sites)
+                        traffic_source=traffic_src, mfma_util_pmc=mfma_util, use_sites=use_sites)
 
     extra = None
     if args.also_linear and args.line_search == "exact":

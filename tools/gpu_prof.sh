@@ -14,7 +14,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_${C}_$WL -o $WL -- python3 $R/bench.py $ARGS > $R/gpurun_out/pmc_${C}_$WL.log 2>&1
   tail -1 $R/gpurun_out/pmc_${C}_$WL.log | cut -c1-120
 done
-python3 $R/tools/pmc_traffic.py --workload $WL --fetch $R/gpurun_out/pmc_FETCH_SIZE_$WL --write $R/gpurun_out/pmc_WRITE_SIZE_$WL \
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $R/gpurun_out/pmc_MFMA_$WL -o $WL -- python3 $R/bench.py $ARGS > $R/gpurun_out/pmc_MFMA_$WL.log 2>&1
+tail -1 $R/gpurun_out/pmc_MFMA_$WL.log | cut -c1-120
+python3 $R/tools/pmc_traffic.py --workload $WL --fetch $R/gpurun_out/pmc_FETCH_SIZE_$WL --write $R/gpurun_out/pmc_WRITE_SIZE_$WL --mfma $R/gpurun_out/pmc_MFMA_$WL \
   --command "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py $ARGS" --out $R/gpurun_out/pmc_traffic_$WL.json
 find $R/gpurun_out -name "*counter_collection.csv" -size +2M -delete
 find $R/gpurun_out -name "*kernel_trace.csv" -size +8M -delete

@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--workload", required=True)
     ap.add_argument("--fetch", required=True)
     ap.add_argument("--write", required=True)
+    ap.add_argument("--mfma", default=None, help="pass with SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64/_F32")
     ap.add_argument("--command", default="")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
@@ -72,6 +73,26 @@ def main():
                       "FETCH_SIZE_KiB_per_launch_raw": fk, "WRITE_SIZE_KiB_per_launch_raw": wk,
                       "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
                       "hbm_bytes_per_launch": None if rd is None and wr is None else (rd or 0.0) + (wr or 0.0)}
+    if a.mfma:
+        # MFMA pipe utilisation per kernel: busy cycles summed over the SIMDs / (active cycles x 256 CUs x 4 SIMDs).
+        # SQ_VALU_MFMA_BUSY_CYCLES books the nominal pipe occupancy (64 cycles per v_mfma_f64_16x16x4, 32 per
+        # v_mfma_f32_16x16x4): on gfx950 the f64 instruction really issues every ~104 cycles (tools/mfma_peak.hip),
+        # so a float64 kernel cannot exceed ~0.62 by this counter.
+        # MOPS counters are in units of 512 flop (rocprofv3 -L: MfmaFlopsF64 = SQ_INSTS_VALU_MFMA_MOPS_F64 * 512)
+        busy, act = collect(a.mfma, "SQ_VALU_MFMA_BUSY_CYCLES"), collect(a.mfma, "GRBM_GUI_ACTIVE")
+        m64, m32 = collect(a.mfma, "SQ_INSTS_VALU_MFMA_MOPS_F64"), collect(a.mfma, "SQ_INSTS_VALU_MFMA_MOPS_F32")
+        for k in busy:
+            d = kernels.setdefault(k, {})
+            n = busy[k]["launches"]
+            b = busy[k]["sum"] / n
+            # the CSV carries the SUM over the 8 XCD instances of GRBM_GUI_ACTIVE (rocprofv3's own MfmaUtil takes the max)
+            g = act[k]["sum"] / act[k]["launches"] / 8.0 if k in act else None
+            d["mfma_busy_cycles_per_launch"] = b
+            d["gui_active_cycles_per_launch"] = g
+            d["mfma_util"] = (b / (g * 1024.0)) if g else None
+            flops = 512.0 * ((m64[k]["sum"] / m64[k]["launches"] if k in m64 else 0.0) +
+                             (m32[k]["sum"] / m32[k]["launches"] if k in m32 else 0.0))
+            d["mfma_flops_per_launch"] = flops
     out = {"workload": a.workload, "command": a.command,
            "corrections": "FETCH_SIZE x2 (gfx950 wide coalesced reads are tallied at half size), KiB -> bytes; "
                           "WRITE_SIZE as reported (uncalibrated)",
@@ -80,10 +101,11 @@ def main():
                                  "pmc_traffic_%s.json" % a.workload)
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
-    top = sorted(kernels.items(), key=lambda kv: -(kv[1]["hbm_bytes_per_launch"] or 0))[:8]
+    top = sorted(kernels.items(), key=lambda kv: -(kv[1].get("hbm_bytes_per_launch") or 0))[:8]
     for k, v in top:
-        print("%-90s %8.1f MB/launch (rd %s wr %s)" % (k[:90], (v["hbm_bytes_per_launch"] or 0) / 1e6,
-              v["hbm_read_bytes_per_launch"], v["hbm_write_bytes_per_launch"]))
+        print("%-80s %8.1f MB/launch (rd %s wr %s) mfma_util %s flops %s" % (
+            k[:80], (v.get("hbm_bytes_per_launch") or 0) / 1e6, v.get("hbm_read_bytes_per_launch"),
+            v.get("hbm_write_bytes_per_launch"), v.get("mfma_util"), v.get("mfma_flops_per_launch")))
     return 0
 
 

@@ -398,13 +398,17 @@ template <typename T, int CT> struct Impl {
     static int moments_a(lcx_ctx* h, int which) {
         T* w = P<T>(h->Wt[which]);
         LCXCHECK(nt_big(h, w, nullptr));
+        if (h->world == 1) return LCX_OK;        // nothing to exchange: W.W^T is formed with Y^T.Y in lcx_moments_b (one launch)
         return gram_w(h, w);
     }
 
     // per-factor moments; ysrc != null: first form the Y^T.Y partials of that Y
     static int small(lcx_ctx* h, int which, double eps, int quick, const T* ysrc) {
         MomentSet& s = h->set[which];
-        if (ysrc) LCXCHECK(gram(h, ysrc, h->Npad, nullptr, h->gn_S, nullptr, P<T>(h->gpart)));
+        if (ysrc) {
+            if (h->world == 1) LCXCHECK(gram_pair(h, P<T>(h->Wt[which]), ysrc));
+            else LCXCHECK(gram(h, ysrc, h->Npad, nullptr, h->gn_S, nullptr, P<T>(h->gpart)));
+        }
         SmallDesc sd{s.uj, s.ry, s.wmag};
         const T* gw = h->world > 1 ? P<T>(h->ybuf) + h->Npad * Mp : P<T>(h->gpartw);
         hipLaunchKernelGGL((small_moments_kernel<T>), dim3(Mp * Mp / 32), dim3(256), 0, h->stream, P<T>(h->gpart),

@@ -270,11 +270,16 @@ moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride
     }
     __syncthreads();
     if (!last_s) return;
-    double a1 = 0.0, a2 = 0.0;
-    for (int b = tid; b < (int)gridDim.x; b += PV_THREADS) {
-        a1 += __hip_atomic_load(&tcpart[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a2 += __hip_atomic_load(&tcpart[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // all loads in flight before the first add: the tail is latency, not bandwidth (grid <= 1024 blocks)
+    double v1[4], v2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int b = tid + k * PV_THREADS;
+        const bool ok = b < (int)gridDim.x;
+        v1[k] = ok ? __hip_atomic_load(&tcpart[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        v2[k] = ok ? __hip_atomic_load(&tcpart[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     }
+    double a1 = (v1[0] + v1[1]) + (v1[2] + v1[3]), a2 = (v2[0] + v2[1]) + (v2[2] + v2[3]);
     a1 = block_sum<double>(a1, bs_scratch, tid);
     a2 = block_sum<double>(a2, bs_scratch, tid);
     if (tid == 0) {
@@ -513,9 +518,13 @@ update_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, const T*
     }
     __syncthreads();
     if (!last_s) return;
-    double a = 0.0;
-    for (int b = tid; b < update_blocks; b += PV_THREADS)
-        a += __hip_atomic_load(&tanpart[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double v[6];                                  // update_blocks <= 1536
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int b = tid + k * PV_THREADS;
+        v[k] = b < update_blocks ? __hip_atomic_load(&tanpart[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+    double a = ((v[0] + v[1]) + (v[2] + v[3])) + (v[4] + v[5]);
     a = block_sum<double>(a, bs_scratch, tid);
     if (tid == 0) {
         sbuf[2] = a;

@@ -108,9 +108,15 @@ int lcx_synchronize(lcx_ctx* h);
  * (lcx_moments_c and lcx_update_d then launch nothing). */
 int lcx_set_world(lcx_ctx* h, int world);
 
-/* The linear trial mode (lcx_trial_linear_*) needs a copy of every evaluated Y and the direction in Y / X^T.Y
- * space; enable != 0 (default) keeps them, 0 skips those copies for callers that only use lcx_make_trial. */
+/* enable != 0 (default): lcx_update_c runs both passes of _sig (:210-211) and leaves sig_grad and the direction in
+ * X^T.Y space, which the linear trial mode (lcx_trial_linear_*) needs.  0: only the first pass - update_tangent
+ * (:305), the one thing the reference uses sig_grad for, is formed in Y space:
+ *     (1-eps^2)/N <Y_g, X.update^T> + eps^2 <grad, update>,   X.update^T = -rj (Y_g - c Y)
+ * (LCX_M_SIG_GRAD is then not produced).  Callers that only use lcx_make_trial save one pass over X per update. */
 int lcx_set_linear_mode(lcx_ctx* h, int enable);
+/* Force the exchange steps on with one rank (the all-reduces a caller issues are then identities): runs the
+ * multi-rank code path of the library on a single GPU.  lcx_set_world(h, n > 1) enables it by itself. */
+int lcx_set_exchange(lcx_ctx* h, int enable);
 
 /* Exchange buffers (device pointers).  ybuf: n_samples_padded*m_padded + m_padded*m_padded
  * elements of the working dtype; sbuf: lcx_sbuf_count doubles.  lcx_exchange_layout reports

@@ -94,6 +94,9 @@ class HipBackend:
     def set_world(self, world):
         _abi.check(self.lib.lcx_set_world(self.h, int(world)))
 
+    def set_exchange(self, enable):
+        _abi.check(self.lib.lcx_set_exchange(self.h, 1 if enable else 0))
+
     def set_linear_mode(self, enable):
         _abi.check(self.lib.lcx_set_linear_mode(self.h, 1 if enable else 0))
 

@@ -188,7 +188,9 @@ class Corex(object):
         if hasattr(be, "set_linear_mode"):
             be.set_linear_mode(self.line_search == "linear")
         exchange = getattr(self._comm, "exchange", self._comm.world > 1)
-        be.set_world(max(self._comm.world, 2) if exchange else 1)
+        be.set_world(self._comm.world)
+        if exchange and self._comm.world == 1 and hasattr(be, "set_exchange"):
+            be.set_exchange(True)
         self._ex = be.exchange_tensors() if exchange else None
         return be
 

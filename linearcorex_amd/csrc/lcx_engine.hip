@@ -95,7 +95,8 @@ struct lcx_ctx {
     SetState* host_states;      // pinned [2]
     int* order_dev;
     unsigned int* ticket;       // arrival counters: [0] small_moments_kernel, [1] moments_epilogue_kernel, [2] update_kernel
-    bool keep_y;                // keep a copy of every evaluated Y (the linear trial mode starts from it)
+    bool full_sig;              // run the second pass of _sig (X^T.Y_g): the linear trial mode needs D(update)
+    bool exchange;              // the exchange steps are live (several ranks, or forced for testing)
     bool w1_ready;              // Wt[1] already holds ws + update (written by update_kernel)
     // launch geometry
     int nt_S, nt_KW, tn_S, tn_KW, gn_S, gv_S, pv_grid, target_waves, n_cus, nt_bpc, tn_bpc;
@@ -337,7 +338,7 @@ template <typename T, int CT> struct Impl {
     }
 
     // Y(_partial) = X . B^T (linearcorex.py:247 / :210) as a contraction over the rows of XT
-    static int nt_big(lcx_ctx* h, const void* Bv, const int* skip, bool with_bj = false) {
+    static int nt_big(lcx_ctx* h, const void* Bv, const int* skip, bool with_bj = false, T* also = nullptr) {
         const T* B = reinterpret_cast<const T*>(Bv);
         TimingPair tp;
         LCXCHECK(timing_begin(h, 0, &tp));
@@ -357,7 +358,7 @@ template <typename T, int CT> struct Impl {
             KCHECK();
         } else if (h->nt_S > 1) {
             hipLaunchKernelGGL((reduce_partials_kernel<T, T>), dim3((unsigned)(cdiv(n, 256) < 1024 ? cdiv(n, 256) : 1024)), dim3(256), 0,
-                               h->stream, P<T>(h->ypart), h->nt_S, n, n, P<T>(h->ybuf), skip);
+                               h->stream, P<T>(h->ypart), h->nt_S, n, n, P<T>(h->ybuf), skip, also);
             KCHECK();
         }
         return LCX_OK;
@@ -386,7 +387,7 @@ template <typename T, int CT> struct Impl {
     // is what gets all-reduced
     static int gram_w(lcx_ctx* h, const T* w) {
         LCXCHECK(gram(h, w, h->ldx, nullptr, h->gv_S, nullptr, P<T>(h->gpartw)));
-        if (h->world > 1) {
+        if (h->exchange) {
             hipLaunchKernelGGL((reduce_wide_kernel<T, T>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
                                P<T>(h->gpartw), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp,
                                P<T>(h->ybuf) + h->Npad * Mp, (const int*)nullptr);
@@ -397,8 +398,9 @@ template <typename T, int CT> struct Impl {
 
     static int moments_a(lcx_ctx* h, int which) {
         T* w = P<T>(h->Wt[which]);
-        LCXCHECK(nt_big(h, w, nullptr));
-        if (h->world == 1) return LCX_OK;        // nothing to exchange: W.W^T is formed with Y^T.Y in lcx_moments_b (one launch)
+        // without an exchange the summed Y is final: the set's own copy is written by the same reduction
+        LCXCHECK(nt_big(h, w, nullptr, false, (!h->exchange && h->nt_S > 1) ? P<T>(h->set[which].Y) : (T*)nullptr));
+        if (!h->exchange) return LCX_OK;         // nothing to exchange: W.W^T is formed with Y^T.Y in lcx_moments_b (one launch)
         return gram_w(h, w);
     }
 
@@ -406,13 +408,13 @@ template <typename T, int CT> struct Impl {
     static int small(lcx_ctx* h, int which, double eps, int quick, const T* ysrc) {
         MomentSet& s = h->set[which];
         if (ysrc) {
-            if (h->world == 1) LCXCHECK(gram_pair(h, P<T>(h->Wt[which]), ysrc));
+            if (!h->exchange) LCXCHECK(gram_pair(h, P<T>(h->Wt[which]), ysrc));
             else LCXCHECK(gram(h, ysrc, h->Npad, nullptr, h->gn_S, nullptr, P<T>(h->gpart)));
         }
         SmallDesc sd{s.uj, s.ry, s.wmag};
-        const T* gw = h->world > 1 ? P<T>(h->ybuf) + h->Npad * Mp : P<T>(h->gpartw);
+        const T* gw = h->exchange ? P<T>(h->ybuf) + h->Npad * Mp : P<T>(h->gpartw);
         hipLaunchKernelGGL((small_moments_kernel<T>), dim3(Mp * Mp / 32), dim3(256), 0, h->stream, P<T>(h->gpart),
-                           h->gn_S, gw, h->world > 1 ? 1 : h->gv_S, Mp, h->M, (double)h->N, eps, quick, sd, s.st,
+                           h->gn_S, gw, h->exchange ? 1 : h->gv_S, Mp, h->M, (double)h->N, eps, quick, sd, s.st,
                            h->ticket);
         KCHECK();
         return LCX_OK;
@@ -432,7 +434,7 @@ template <typename T, int CT> struct Impl {
             default: hipLaunchKernelGGL((gram_pair_kernel<T, CT, RT, 4>), grid, dim3(256), lds, h->stream, p0, p1); break;
         }
         KCHECK();
-        if (h->world > 1) {
+        if (h->exchange) {
             hipLaunchKernelGGL((reduce_wide_kernel<T, T>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
                                P<T>(h->gpartw), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp,
                                P<T>(h->ybuf) + h->Npad * Mp, (const int*)nullptr);
@@ -446,7 +448,7 @@ template <typename T, int CT> struct Impl {
         const int* skip = &s.st->invalid;
         const size_t lds = ((size_t)Mp * Mp + (size_t)VPB * Mp) * sizeof(T);
         LCXCHECK(allow_lds(moments_epilogue_kernel<T, Mp>, lds));
-        const int single = h->world == 1;
+        const int single = !h->exchange;
         const unsigned int seq = single ? ++h->seq_next : 0u;
         hipLaunchKernelGGL((moments_epilogue_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream,
                            P<T>(h->dpart), h->tn_S, h->ldx * Mp,
@@ -468,7 +470,7 @@ template <typename T, int CT> struct Impl {
     static int moments_b(lcx_ctx* h, int which, double eps, int quick) {
         MomentSet& s = h->set[which];
         // keep the (all-reduced) Y of this set: the linear trial mode starts from it
-        if (h->keep_y)
+        if (h->exchange || h->nt_S == 1)         // otherwise lcx_moments_a already wrote it
             HIPCHECK(hipMemcpyAsync(s.Y, h->ybuf, (size_t)h->Npad * Mp * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
         LCXCHECK(small(h, which, eps, quick, P<T>(h->ybuf)));
         LCXCHECK(tn_big(h, &s.st->invalid));
@@ -492,7 +494,7 @@ template <typename T, int CT> struct Impl {
     }
 
     static int moments_c(lcx_ctx* h, int which) {
-        if (h->world == 1) return LCX_OK;            // tc_finalize_kernel already did it
+        if (!h->exchange) return LCX_OK;             // the epilogue already published
         MomentSet& s = h->set[which];
         const unsigned int seq = ++h->seq_next;
         hipLaunchKernelGGL((tc_final_kernel<T>), dim3(1), dim3(1), 0, h->stream, h->sbuf, s.st, s.hst_dev, seq);
@@ -524,17 +526,19 @@ template <typename T, int CT> struct Impl {
 
     static int update_c(lcx_ctx* h, double eps) {
         MomentSet& s = h->set[0];
-        LCXCHECK(tn_big(h, nullptr));
+        // The second pass of _sig (X^T.Y_g, :211) only feeds update_tangent, which is available in Y space after
+        // the first pass (see update_kernel); it is run when the linear trial mode needs D(update) as well.
+        if (h->full_sig) LCXCHECK(tn_big(h, nullptr));
         const int grid = (int)(cdiv(h->V * Mp, PV_THREADS) < 1536 ? cdiv(h->V * Mp, PV_THREADS) : 1536);
         const int64_t ny = h->Npad * Mp;
-        const int gridy = h->keep_y ? (int)(cdiv(ny, PV_THREADS) < 512 ? cdiv(ny, PV_THREADS) : 512) : 0;
-        const int single = h->world == 1;
+        const int gridy = (int)(cdiv(ny, PV_THREADS) < 512 ? cdiv(ny, PV_THREADS) : 512);
+        const int single = !h->exchange;
         const unsigned int seq = ++h->seq_next;
-        hipLaunchKernelGGL((update_kernel<T, Mp>), dim3(grid + gridy), dim3(PV_THREADS), 0, h->stream, P<T>(h->dpart), h->tn_S,
-                           h->ldx * Mp, P<T>(h->grad), P<T>(h->Wt[0]), s.uj, P<T>(h->ybuf) + h->Npad * Mp, h->V,
+        hipLaunchKernelGGL((update_kernel<T, Mp>), dim3(grid + gridy), dim3(PV_THREADS), 0, h->stream, P<T>(h->dpart),
+                           h->full_sig ? h->tn_S : 0, h->ldx * Mp, P<T>(h->grad), P<T>(h->Wt[0]), s.uj, P<T>(h->ybuf) + h->Npad * Mp, h->V,
                            (double)h->N, eps, P<T>(h->update), P<T>(h->sgrad), h->tanpart,
-                           h->keep_y ? P<T>(s.D) : (const T*)nullptr, h->keep_y ? P<T>(h->ddir) : (T*)nullptr, grid, P<T>(h->ybuf),
-                           P<T>(s.Y), ny, P<T>(h->ydir), P<T>(h->Wt[1]), h->ticket + 2, h->sbuf, s.st, s.hst_dev, seq, single);
+                           h->full_sig ? P<T>(s.D) : (const T*)nullptr, h->full_sig ? P<T>(h->ddir) : (T*)nullptr, grid, P<T>(h->ybuf),
+                           P<T>(s.Y), ny, P<T>(h->ydir), P<T>(h->Wt[1]), h->ticket + 2, h->sbuf, s.st, s.hst_dev, seq, single, h->world);
         KCHECK();
         if (single) s.seq_expect = seq;
         h->w1_ready = true;
@@ -1187,7 +1191,8 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     A_(h->ydir, (size_t)h->Npad * Mp * es);
     A_(h->ddir, mv);
     h->have_linear = false;
-    h->keep_y = true;
+    h->full_sig = true;
+    h->exchange = false;
     h->w1_ready = false;
     h->ybuf_elems = h->Npad * Mp + (int64_t)Mp * Mp;
     h->sbuf_elems = (int64_t)SB_H + (int64_t)Mp * Mp + Mp + 8;
@@ -1464,7 +1469,14 @@ int lcx_read_state(lcx_ctx* h, int which, double* out) {
 int lcx_set_linear_mode(lcx_ctx* h, int enable) {
     NEED(h);
     HIPCHECK(hipStreamSynchronize(h->stream));
-    h->keep_y = enable != 0;
+    h->full_sig = enable != 0;
+    return LCX_OK;
+}
+
+int lcx_set_exchange(lcx_ctx* h, int enable) {
+    NEED(h);
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    h->exchange = enable != 0 || h->world > 1;
     return LCX_OK;
 }
 
@@ -1473,6 +1485,7 @@ int lcx_set_world(lcx_ctx* h, int world) {
     if (world < 1) return fail(LCX_ERR_ARG, "lcx_set_world: world must be >= 1");
     HIPCHECK(hipStreamSynchronize(h->stream));
     h->world = world;
+    h->exchange = world > 1;
     return LCX_OK;
 }
 

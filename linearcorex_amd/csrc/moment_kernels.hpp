@@ -80,13 +80,15 @@ __device__ __forceinline__ R block_sum(R v, R* scratch /* [PV_THREADS/64] */, in
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename OUT>
 __global__ void reduce_partials_kernel(const T* __restrict__ in, int nsplit, int64_t n, int64_t stride,
-                                       OUT* __restrict__ out, const int* __restrict__ skip_flag) {
+                                       OUT* __restrict__ out, const int* __restrict__ skip_flag,
+                                       OUT* __restrict__ out2 = nullptr) {
     if (skip_flag != nullptr && *skip_flag != 0) return;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         T s = in[i];
         for (int k = 1; k < nsplit; ++k) s += in[k * stride + i];
         out[i] = (OUT)s;
+        if (out2 != nullptr) out2[i] = (OUT)s;       // the set's own copy of Y (no separate copy launch)
     }
 }
 
@@ -473,39 +475,54 @@ update_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, const T*
               const T* __restrict__ d_cur, T* __restrict__ d_dir_o,
               int update_blocks, const T* __restrict__ yg, const T* __restrict__ ycur, int64_t ny,
               T* __restrict__ ydir_o, T* __restrict__ w1_o, unsigned int* __restrict__ ticket,
-              double* __restrict__ sbuf, SetState* st, SetState* host, unsigned int seq, int single) {
+              double* __restrict__ sbuf, SetState* st, SetState* host, unsigned int seq, int single, int n_ranks) {
     __shared__ double bs_scratch[PV_THREADS / 64];
     const int tid = threadIdx.x;
+    const T c1 = (T)(1.0 - eps * eps), c2 = (T)(eps * eps), ns = (T)n_samples;
+    // nsplit == 0: the X^T.Y_g pass was not run.  update_tangent (:305) = sum_ji sig_grad_ji update_ji with
+    // sig_grad = (1-eps^2) X^T(X grad^T)^T / N + eps^2 grad (:212) equals
+    //     (1-eps^2)/N <Y_g, Y(update)>  +  eps^2 <grad, update>,        Y(update) = X.update^T = -rj (Y_g - c Y),
+    // and every term of that is in hand after the FIRST pass of _sig: the second pass only ever fed this scalar.
+    const bool yspace = nsplit == 0;
+    double tan = 0.0;
     if ((int)blockIdx.x >= update_blocks) {
         // the blocks past `update_blocks` form Y(update) = -rj (Y_g - c Y) on [Npad][Mp]
         const int nb = gridDim.x - update_blocks;
         for (int64_t i = (int64_t)(blockIdx.x - update_blocks) * PV_THREADS + tid; i < ny; i += (int64_t)nb * PV_THREADS) {
             const int j = (int)(i % Mp);
             const T rj = (T)1 - (T)uj[j];
-            ydir_o[i] = -rj * (yg[i] - (T)2 * bj_tail[j] / ((T)2 - rj) * ycur[i]);
+            const T ygi = yg[i];
+            const T yd = -rj * (ygi - (T)2 * bj_tail[j] / ((T)2 - rj) * ycur[i]);
+            ydir_o[i] = yd;
+            if (yspace) tan += (double)(ygi * yd);
         }
-        return;
+        // Y_g and Y are replicated on every rank while the partials are summed over ranks
+        tan *= (double)c1 / n_samples / (double)n_ranks;
+    } else {
+        const int64_t total = V * Mp;
+        for (int64_t o = (int64_t)blockIdx.x * PV_THREADS + tid; o < total;
+             o += (int64_t)update_blocks * PV_THREADS) {
+            const int j = (int)(o % Mp);
+            const T g = grad[o];
+            const T rj = (T)1 - (T)uj[j];
+            const T up = -rj * (g - (T)2 * W[o] / ((T)2 - rj) * bj_tail[j]);         // :303
+            update_o[o] = up;
+            if (w1_o != nullptr) w1_o[o] = W[o] + up;                               // :320 at eta = 1 (the first trial)
+            if (yspace) {
+                tan += (double)(c2 * g * up);
+            } else {
+                T d = dpart[o];
+                for (int k = 1; k < nsplit; ++k) d += dpart[k * pstride + o];
+                const T sg = c1 * d / ns + c2 * g;                                  // :212
+                sgrad_o[o] = sg;
+                // update_j = -rj (grad_j - c_j W_j), c_j = 2 Bj / (2 - rj), is a per-factor combination of
+                // grad and W, and X^T.(X.u^T) acts row-wise and linearly, so D(update) needs no pass over X
+                if (d_dir_o != nullptr) d_dir_o[o] = -rj * (d - (T)2 * bj_tail[j] / ((T)2 - rj) * d_cur[o]);
+                tan += (double)(sg * up);
+            }
+        }
     }
-    const T c1 = (T)(1.0 - eps * eps), c2 = (T)(eps * eps), ns = (T)n_samples;
-    double tan = 0.0;
-    const int64_t total = V * Mp;
-    for (int64_t o = (int64_t)blockIdx.x * PV_THREADS + tid; o < total;
-         o += (int64_t)update_blocks * PV_THREADS) {
-        const int j = (int)(o % Mp);
-        T d = dpart[o];
-        for (int k = 1; k < nsplit; ++k) d += dpart[k * pstride + o];
-        const T g = grad[o];
-        const T sg = c1 * d / ns + c2 * g;                                      // :212
-        const T rj = (T)1 - (T)uj[j];
-        const T up = -rj * (g - (T)2 * W[o] / ((T)2 - rj) * bj_tail[j]);         // :303
-        update_o[o] = up;
-        sgrad_o[o] = sg;
-        if (w1_o != nullptr) w1_o[o] = W[o] + up;                               // :320 at eta = 1 (the first trial)
-        // update_j = -rj (grad_j - c_j W_j), c_j = 2 Bj / (2 - rj), is a per-factor combination of
-        // grad and W, and X^T.(X.u^T) acts row-wise and linearly, so D(update) needs no pass over X
-        if (d_dir_o != nullptr) d_dir_o[o] = -rj * (d - (T)2 * bj_tail[j] / ((T)2 - rj) * d_cur[o]);
-        tan += (double)(sg * up);
-    }
+    const int all_blocks = gridDim.x;
     tan = block_sum<double>(tan, bs_scratch, tid);
     // last update block (ticket): fixed-order sum of the per-block partials -> sbuf[2]; with one GPU also the
     // state scalar and the host mirror
@@ -514,17 +531,17 @@ update_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, const T*
         __hip_atomic_store(&tanpart[blockIdx.x], tan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_s = (t == (unsigned int)update_blocks - 1);
+        last_s = (t == (unsigned int)all_blocks - 1);
     }
     __syncthreads();
     if (!last_s) return;
-    double v[6];                                  // update_blocks <= 1536
+    double v[8];                                  // all_blocks <= 2048
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 8; ++k) {
         const int b = tid + k * PV_THREADS;
-        v[k] = b < update_blocks ? __hip_atomic_load(&tanpart[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        v[k] = b < all_blocks ? __hip_atomic_load(&tanpart[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     }
-    double a = ((v[0] + v[1]) + (v[2] + v[3])) + (v[4] + v[5]);
+    double a = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     a = block_sum<double>(a, bs_scratch, tid);
     if (tid == 0) {
         sbuf[2] = a;

@@ -306,13 +306,14 @@ template <typename T, int RT> struct Epl { static constexpr int v = (16 / (int)s
 
 // RT elements of one row for lane i: piece p sits at column p*16*EPL + i*EPL, so that every load
 // instruction covers 16 lanes x 16 B = 256 contiguous bytes of the row
-template <typename T, int RT>
+template <typename T, int RT, bool NT = false>
 __device__ __forceinline__ void load_row_pieces(const T* rowp, int i, T (&dst)[RT]) {
     constexpr int EPL = Epl<T, RT>::v;
     typedef typename VecT<T, EPL>::type V;
 #pragma unroll
     for (int p = 0; p < RT / EPL; ++p) {
-        const V v = *reinterpret_cast<const V*>(rowp + p * 16 * EPL + i * EPL);
+        const V* src = reinterpret_cast<const V*>(rowp + p * 16 * EPL + i * EPL);
+        const V v = NT ? __builtin_nontemporal_load(src) : *src;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             if constexpr (EPL == 1) dst[p] = v; else dst[p * EPL + e] = v[e];
@@ -450,6 +451,137 @@ gemm_ct_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T*
         L0 += cnt;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn4: the float64 small-shard contraction on v_mfma_f64_4x4x4 (4 blocks).
+//
+// Measured on MI355X (tools/mfma_peak.hip): v_mfma_f64_16x16x4 issues every ~104 cycles (47.6 TF/s, 60 % of
+// the 78.6 TF/s spec) while v_mfma_f64_4x4x4 issues every ~17 cycles for a quarter of the work (72 TF/s).
+// Lane layout (tools/mfma_map.hip):  A[blk][i][k] in lane k*16 + blk*4 + i,  B[blk][k][j] in lane k*16 + blk*4 + j,
+// D[blk][i][j] in lane i*16 + blk*4 + j.  With the 4 blocks on 4 adjacent groups of 4 columns of X the A operand is
+// exactly the 16x16x4 one (lane l: column l & 15, contraction row l >> 4), so X streams global -> VGPR as before;
+// the B operand is 4 factors wide and the same for every block, i.e. replicated over blk.  One A register meets
+// Mp/4 B registers (factor groups) and Mp/4 one-double accumulators.
+//   * same decomposition as gemm_tn: a wave owns 16*RT columns, the block's KW waves split the contraction,
+//     grid.y splits write partial tiles, fixed summation orders;
+//   * B (Y or W, L2 resident) is staged per wave: global -> VGPR (16 B per lane, coalesced) -> the wave's own
+//     LDS strip, rows padded by 32 B so that the 4 contraction rows of a ds_read_b64 land on distinct banks; the
+//     operand reads are LDS broadcasts.  No block barrier in the main loop.
+// ------------------------------------------------------------------------------------------------
+template <int CT, int RT, int KW, int U, bool NT = false>
+__global__ void __launch_bounds__(64 * KW)
+gemm_tn4_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, double* __restrict__ out,
+                int64_t out_rows, int kgroups /* K / 16 */, int nsplit, const int* __restrict__ skip_flag) {
+    constexpr int Mp = 16 * CT, NG = Mp / 4;
+    constexpr int ROWS = 4 * U;                      // rows of B per group
+    constexpr int LDB = Mp + 4;                      // padded LDS row (doubles)
+    constexpr int PPR = Mp / 2;                      // 16-byte pieces per row
+    constexpr int PCS = ROWS * PPR;
+    constexpr int PPT = (PCS + 63) / 64;             // pieces per lane
+    constexpr int STRIP = 2 * ROWS * LDB;            // doubles per wave (double buffered)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* smem = reinterpret_cast<double*>(smem_raw);
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4, jj = lane & 3;
+    const int64_t v0 = (int64_t)blockIdx.x * (16 * RT);
+    const int part = blockIdx.y * KW + wave, nparts = nsplit * KW;
+    const int ng = kgroups * 4 / U;                  // groups of 4*U rows
+    const int g0 = (int)((int64_t)ng * part / nparts), g1 = (int)((int64_t)ng * (part + 1) / nparts);
+    const int cnt = g1 - g0;
+
+    double acc[RT][NG];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[t][g] = 0.0;
+
+    const double* ap = A + v0 + (int64_t)kq * lda;
+    double* bw = smem + wave * STRIP;
+    double a0[U][RT], a1[U][RT];
+    d2 bst[PPT];
+
+#define LCX_T4_LOADA(R, AA)                                                                \
+    {                                                                                      \
+        const int64_t rb = (int64_t)(g0 + (R)) * ROWS;                                     \
+        _Pragma("unroll") for (int st = 0; st < U; ++st)                                   \
+            load_row_pieces<double, RT, NT>(ap + (rb + 4 * st) * lda, r16, AA[st]);        \
+    }
+#define LCX_T4_LOADB(R)                                                                    \
+    {                                                                                      \
+        const d2* src = reinterpret_cast<const d2*>(B + (int64_t)(g0 + (R)) * ROWS * Mp);  \
+        _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                                  \
+            const int pc = p * 64 + lane;                                                  \
+            if (PCS % 64 == 0 || pc < PCS) bst[p] = src[pc];                               \
+        }                                                                                  \
+    }
+#define LCX_T4_STOREB(BUF)                                                                 \
+    {                                                                                      \
+        _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                                  \
+            const int pc = p * 64 + lane;                                                  \
+            if (PCS % 64 == 0 || pc < PCS)                                                 \
+                *reinterpret_cast<d2*>(bw + (BUF) * ROWS * LDB + (pc / PPR) * LDB + (pc % PPR) * 2) = bst[p]; \
+        }                                                                                  \
+    }
+#define LCX_T4_MMA(AA, BUF)                                                                \
+    {                                                                                      \
+        _Pragma("unroll") for (int st = 0; st < U; ++st) {                                 \
+            const double* brow = bw + (BUF) * ROWS * LDB + (4 * st + kq) * LDB + jj;       \
+            double bb[NG];                                                                 \
+            _Pragma("unroll") for (int g = 0; g < NG; ++g) bb[g] = brow[4 * g];            \
+            _Pragma("unroll") for (int t = 0; t < RT; ++t)                                 \
+            _Pragma("unroll") for (int g = 0; g < NG; ++g)                                 \
+                acc[t][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(AA[st][t], bb[g], acc[t][g], 0, 0, 0); \
+        }                                                                                  \
+    }
+
+    if (cnt > 0) {
+        LCX_T4_LOADA(0, a0);
+        LCX_T4_LOADB(0);
+        int r = 0;
+        while (true) {
+            LCX_T4_STOREB(0);
+            if (r + 1 < cnt) { LCX_T4_LOADA(r + 1, a1); LCX_T4_LOADB(r + 1); }
+            LCX_T4_MMA(a0, 0);
+            if (++r >= cnt) break;
+            LCX_T4_STOREB(1);
+            if (r + 1 < cnt) { LCX_T4_LOADA(r + 1, a0); LCX_T4_LOADB(r + 1); }
+            LCX_T4_MMA(a1, 1);
+            if (++r >= cnt) break;
+        }
+    }
+#undef LCX_T4_LOADA
+#undef LCX_T4_LOADB
+#undef LCX_T4_STOREB
+#undef LCX_T4_MMA
+
+    // ---- reduce the KW partial tiles through LDS in a fixed order and write the tile ----------------
+    constexpr int TILE = 16 * RT * Mp;
+    __syncthreads();                                  // the B strips are dead: the same LDS holds the tiles now
+    double* mine = smem + wave * TILE;
+    const int row = ((lane & 15) >> 2) * 4 + (lane >> 4);          // blk*4 + i: the column of X inside the 16-wide piece
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            mine[piece_col<double, RT>(t, row) * Mp + 4 * g + jj] = acc[t][g];
+    __syncthreads();
+    double* dst = out + ((int64_t)blockIdx.y * out_rows + v0) * Mp;
+    for (int idx = threadIdx.x; idx < TILE; idx += 64 * KW) {
+        double sacc = smem[idx];
+#pragma unroll
+        for (int w = 1; w < KW; ++w) sacc += smem[w * TILE + idx];
+        dst[idx] = sacc;
+    }
+}
+// dynamic LDS of gemm_tn4: max(B strips, reduction tiles)
+template <int CT, int RT, int KW, int U> struct Tn4Lds {
+    static constexpr size_t strips = (size_t)KW * 2 * 4 * U * (16 * CT + 4) * sizeof(double);
+    static constexpr size_t tiles = (size_t)KW * 16 * RT * 16 * CT * sizeof(double);
+    static constexpr size_t bytes = strips > tiles ? strips : tiles;
+};
 
 // tile shapes of gemm_ct: 16-byte A loads wherever the accumulators fit (RT*CT*4 registers of T)
 template <typename T, int CT> struct CtShape {

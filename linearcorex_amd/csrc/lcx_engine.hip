@@ -102,6 +102,7 @@ struct lcx_ctx {
     int nt_S, nt_KW, tn_S, tn_KW, gn_S, gv_S, pv_grid, target_waves, n_cus, nt_bpc, tn_bpc;
     // column-tiled stream-K kernel (gemm_ct) per pass: used when the shard has enough column tiles
     bool nt_ct, tn_ct;
+    bool f64_4x4;               // float64, n_hidden <= 32: the small-shard passes run on v_mfma_f64_4x4x4 (gemm_tn4)
     int nt_nb, nt_nsuper, tn_nb, tn_nsuper;
     // timing
     bool timing;
@@ -181,6 +182,26 @@ static int launch_tn(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t
         case 2: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 2, SCALE>), grid, dim3(128), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
         case 4: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 4, SCALE>), grid, dim3(256), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
         default: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 8, SCALE>), grid, dim3(512), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
+    }
+    KCHECK();
+    return LCX_OK;
+}
+
+// gemm_tn4 (float64 on v_mfma_f64_4x4x4): same grid / partial-tile contract as launch_tn; KW in {2, 4}
+template <int CT>
+static int launch_tn4(hipStream_t st, const double* A, int64_t lda, int64_t K, int64_t vcols_pad, const double* B, double* out, int S,
+                      int KW, const int* skip) {
+    constexpr int RT = TnShape<double, CT>::RT, U = 4;
+    dim3 grid((unsigned)(vcols_pad / (16 * RT)), (unsigned)S);
+    const int kgroups = (int)(K / 16);
+    if (KW == 2) {
+        const size_t lds = Tn4Lds<CT, RT, 2, U>::bytes;
+        if (lds > 48 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)gemm_tn4_kernel<CT, RT, 2, U, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((gemm_tn4_kernel<CT, RT, 2, U, true>), grid, dim3(128), lds, st, A, lda, B, out, vcols_pad, kgroups, S, skip);
+    } else {
+        const size_t lds = Tn4Lds<CT, RT, 4, U>::bytes;
+        if (lds > 48 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)gemm_tn4_kernel<CT, RT, 4, U, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((gemm_tn4_kernel<CT, RT, 4, U, true>), grid, dim3(256), lds, st, A, lda, B, out, vcols_pad, kgroups, S, skip);
     }
     KCHECK();
     return LCX_OK;
@@ -282,7 +303,17 @@ template <typename T, int CT> struct Impl {
         const int cus = h->n_cus;
         // X . B^T, computed as XT^T . B with the tn kernel: tiles over n, contraction over v
         h->nt_KW = env_int("LCX_NT_KW", pick_kw(kgv));
-        {
+        // float64 with <= 32 factors: v_mfma_f64_4x4x4 (72 TF/s measured) instead of 16x16x4 (47.6 TF/s)
+        h->f64_4x4 = sizeof(T) == 8 && CT <= 2 && env_int("LCX_F64_MFMA", 4) == 4;
+        if (h->f64_4x4) {
+            if constexpr (sizeof(T) == 8 && CT <= 2) {
+                if (h->nt_KW != 2) h->nt_KW = 4;
+                const int bpc = h->nt_KW == 2 ? blocks_per_cu(gemm_tn4_kernel<CT, TN_RT, 2, 4, true>, 128, Tn4Lds<CT, TN_RT, 2, 4>::bytes)
+                                              : blocks_per_cu(gemm_tn4_kernel<CT, TN_RT, 4, 4, true>, 256, Tn4Lds<CT, TN_RT, 4, 4>::bytes);
+                h->nt_bpc = bpc;
+                h->nt_S = env_int("LCX_NT_S", single_round_split(h->Npad / (16 * TN_RT), (int64_t)bpc * cus, kgv, h->nt_KW, 16));
+            }
+        } else {
             const size_t lds = (size_t)h->nt_KW * 16 * TN_RT * Mp * sizeof(T);
             int bpc = 1;
             switch (h->nt_KW) {
@@ -296,7 +327,15 @@ template <typename T, int CT> struct Impl {
         }
         // X^T . Y
         h->tn_KW = env_int("LCX_TN_KW", pick_kw(kgn));
-        {
+        if (h->f64_4x4) {
+            if constexpr (sizeof(T) == 8 && CT <= 2) {
+                if (h->tn_KW != 2) h->tn_KW = 4;
+                const int bpc = h->tn_KW == 2 ? blocks_per_cu(gemm_tn4_kernel<CT, TN_RT, 2, 4, true>, 128, Tn4Lds<CT, TN_RT, 2, 4>::bytes)
+                                              : blocks_per_cu(gemm_tn4_kernel<CT, TN_RT, 4, 4, true>, 256, Tn4Lds<CT, TN_RT, 4, 4>::bytes);
+                h->tn_bpc = bpc;
+                h->tn_S = env_int("LCX_TN_S", single_round_split(h->ldx / (16 * TN_RT), (int64_t)bpc * cus, kgn, h->tn_KW, 32));
+            }
+        } else {
             const size_t lds = (size_t)h->tn_KW * 16 * TN_RT * Mp * sizeof(T);
             int bpc = 1;
             switch (h->tn_KW) {
@@ -345,7 +384,10 @@ template <typename T, int CT> struct Impl {
         T* dst = h->nt_S > 1 ? P<T>(h->ypart) : P<T>(h->ybuf);
         if (h->nt_ct)
             LCXCHECK((launch_ct<T, CT>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, B, dst, h->nt_nb, h->nt_nsuper, h->nt_S, skip)));
-        else
+        else if (h->f64_4x4) {
+            if constexpr (sizeof(T) == 8 && CT <= 2)
+                LCXCHECK((launch_tn4<CT>(h->stream, P<double>(h->XT), h->Npad, h->ldx, h->Npad, (const double*)B, (double*)dst, h->nt_S, h->nt_KW, skip)));
+        } else
             LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, B, nullptr,
                                                                    dst, h->nt_S, h->nt_KW, skip)));
         LCXCHECK(timing_end(h, 0, &tp));
@@ -376,7 +418,11 @@ template <typename T, int CT> struct Impl {
         if (h->tn_ct)
             LCXCHECK((launch_ct<T, CT>(h->stream, P<T>(h->X), h->ldx, h->Npad, h->ldx, P<T>(h->ybuf), P<T>(h->dpart), h->tn_nb, h->tn_nsuper,
                                        h->tn_S, skip)));
-        else
+        else if (h->f64_4x4) {
+            if constexpr (sizeof(T) == 8 && CT <= 2)
+                LCXCHECK((launch_tn4<CT>(h->stream, P<double>(h->X), h->ldx, h->Npad, h->ldx, P<double>(h->ybuf), P<double>(h->dpart), h->tn_S,
+                                         h->tn_KW, skip)));
+        } else
             LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false>(h->stream, P<T>(h->X), h->ldx, h->Npad, h->ldx, P<T>(h->ybuf), nullptr,
                                                                    P<T>(h->dpart), h->tn_S, h->tn_KW, skip)));
         LCXCHECK(timing_end(h, 1, &tp));
@@ -843,6 +889,8 @@ template <typename T, int CT> struct Impl {
         if (kind == 0 ? h->nt_ct : h->tn_ct)
             snprintf(buf, (size_t)len, "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d>", sizeof(T) == 8 ? "double" : "float", CT,
                      CtShape<T, CT>::RT, CtShape<T, CT>::KW, CtShape<T, CT>::U);
+        else if (h->f64_4x4)
+            snprintf(buf, (size_t)len, "lcx::gemm_tn4_kernel<%d, %d, %d, 4, true>", CT, Geo<T, CT>::TN_RT, kind == 0 ? h->nt_KW : h->tn_KW);
         else
             snprintf(buf, (size_t)len, "lcx::gemm_tn_kernel<%s, %d, %d, %d, false, 0, 4>", sizeof(T) == 8 ? "double" : "float", CT,
                      Geo<T, CT>::TN_RT, kind == 0 ? h->nt_KW : h->tn_KW);
@@ -1066,7 +1114,7 @@ static int test_tn(const void* a_host, int64_t k, int64_t v, int64_t lda, const 
     HIPCHECK(hipMalloc((void**)&sd, sizeof(T) * kpad));
     int S = force_split > 0 ? force_split : 1, KW = force_kw > 0 ? force_kw : 4;
     int ct_nb = 0, ct_ns = 0;
-    if (force_kw < 0) {          // column-tiled stream-K kernel; force_split = number of blocks (0: as in production)
+    if (force_kw == -1) {        // column-tiled stream-K kernel; force_split = number of blocks (0: as in production)
         if (rs_host) return fail(LCX_ERR_ARG, "gemm_ct has no row scale");
         int ncu = 256;
         hipDeviceProp_t prop;
@@ -1081,7 +1129,13 @@ static int test_tn(const void* a_host, int64_t k, int64_t v, int64_t lda, const 
     HIPCHECK(hipMemset(sd, 0, sizeof(T) * kpad));
     HIPCHECK(hipMemcpy2D(ad, ldv * sizeof(T), a_host, lda * sizeof(T), v * sizeof(T), k, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(bd, b_host, sizeof(T) * k * Mp, hipMemcpyHostToDevice));
-    if (force_kw < 0) {
+    if (force_kw == -2) {
+        if constexpr (sizeof(T) == 8 && CT <= 2) {
+            LCXCHECK((launch_tn4<CT>(st, (const double*)ad, ldv, kpad, ldv, (const double*)bd, (double*)pd, S, 4, nullptr)));
+        } else {
+            return fail(LCX_ERR_ARG, "gemm_tn4 is float64 with m_pad <= 32 only");
+        }
+    } else if (force_kw < 0) {
         LCXCHECK((launch_ct<T, CT>(st, ad, ldv, kpad, ldv, bd, pd, ct_nb, ct_ns, S, nullptr)));
     } else if (rs_host) {
         HIPCHECK(hipMemcpy(sd, rs_host, sizeof(T) * k, hipMemcpyHostToDevice));

@@ -108,3 +108,21 @@ def test_gemm_ct_is_deterministic_and_matches_tn():
     assert np.array_equal(c1, c2)                       # fixed summation order, no atomics
     t = gemm_tn_check(a, b, m_pad, np.float32, split=3, waves=4)
     assert np.max(np.abs(c1 - t)) < 2e-5 * np.sqrt(k) * 4
+
+
+# ---- gemm_tn4: the float64 small-shard contraction on v_mfma_f64_4x4x4 (waves=-2 in the test entry point) ---------
+@pytest.mark.parametrize("m_pad", [16, 32])
+@pytest.mark.parametrize("shape,split", [((70, 45), 1), ((300, 257), 1), ((1111, 1000), 3), ((2048, 64), 2), ((64, 333), 1),
+                                         ((4096, 640), 7), ((10000, 1300), 6)])
+def test_gemm_tn4(m_pad, shape, split):
+    from linearcorex_amd.backend import gemm_tn_check
+    k, v = shape
+    a = _asym(k, v, 10).astype(np.float64)
+    b = _asym(k, m_pad, 11).astype(np.float64)
+    got = gemm_tn_check(a, b, m_pad, np.float64, split=split, waves=-2)
+    ref = a.T @ b
+    scale = np.abs(a).T @ np.abs(b)
+    assert np.max(np.abs(got - ref) / scale) < TOL[np.float64]
+    # same result, different instruction: the 16x16x4 kernel
+    alt = gemm_tn_check(a, b, m_pad, np.float64, split=split, waves=4)
+    assert np.max(np.abs(got - alt) / scale) < TOL[np.float64]

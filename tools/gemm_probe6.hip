@@ -1,0 +1,143 @@
+// gemm_probe6.hip - float64 contraction on v_mfma_f64_4x4x4 (gemm_tn4_kernel) vs the 16x16x4 kernel (GPU box only)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <algorithm>
+#include <functional>
+#include <string>
+#include "../linearcorex_amd/csrc/gemm_kernels.hpp"
+using namespace lcx;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+struct Variant { std::string name; std::function<void()> launch; std::vector<float> ms; int slots; };
+
+template <int CT, int RT, int KW, int U, bool NT = false>
+Variant mk4(const double* A, int64_t lda, int64_t K, int64_t vcols, const double* B, double* out, int S) {
+    auto kern = gemm_tn4_kernel<CT, RT, KW, U, NT>;
+    const size_t lds = Tn4Lds<CT, RT, KW, U>::bytes;
+    if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int bpc = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, lds));
+    char buf[200];
+    snprintf(buf, 200, "tn4 (4x4x4) RT=%d KW=%d U=%d NT=%d S=%d blocks=%d bpc=%d lds=%zu", RT, KW, U, (int)NT, S, (int)(vcols / (16 * RT)) * S, bpc, lds);
+    return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3((unsigned)(vcols / (16 * RT)), S), dim3(64 * KW), lds, 0, A, lda, B, out, vcols, (int)(K / 16), S, (const int*)nullptr); }, {}, S};
+}
+template <int CT, int RT, int KW>
+Variant mkprod(const double* A, int64_t lda, int64_t K, int64_t vcols, const double* B, double* out, int S) {
+    auto kern = gemm_tn_kernel<double, CT, RT, KW, false, 0, 4>;
+    size_t lds = (size_t)KW * 16 * RT * 16 * CT * 8;
+    if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    char buf[200];
+    snprintf(buf, 200, "tn (16x16x4) RT=%d KW=%d S=%d", RT, KW, S);
+    return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3((unsigned)(vcols / (16 * RT)), S), dim3(64 * KW), lds, 0, A, lda, (int64_t)(16 * RT), B, (const double*)nullptr, out, vcols, (int)(K / 16), S, (const int*)nullptr); }, {}, S};
+}
+static void bench(std::vector<Variant>& vs, double gbytes, double tflop, int rounds = 7, int iters = 10) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (auto& v : vs) v.launch();
+    CK(hipDeviceSynchronize());
+    for (int r = 0; r < rounds; ++r)
+        for (auto& v : vs) {
+            v.launch();
+            CK(hipEventRecord(a, 0));
+            for (int it = 0; it < iters; ++it) v.launch();
+            CK(hipEventRecord(b, 0));
+            CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b));
+            v.ms.push_back(ms / iters);
+        }
+    for (auto& v : vs) {
+        std::sort(v.ms.begin(), v.ms.end());
+        const float med = v.ms[v.ms.size() / 2];
+        printf("%-64s med %7.1f us (min %7.1f max %7.1f) %6.0f GB/s %5.1f TF/s\n", v.name.c_str(), med * 1e3, v.ms.front() * 1e3, v.ms.back() * 1e3,
+               gbytes / med * 1e3, tflop / med * 1e3);
+    }
+    fflush(stdout);
+}
+template <int CT, int RT>
+void suite(const char* name, int64_t K, int64_t V, std::initializer_list<int> splits) {
+    const int Mp = 16 * CT;
+    double *A, *B, *out;
+    CK(hipMalloc(&A, 8 * K * V)); CK(hipMalloc(&B, 8 * K * Mp)); CK(hipMalloc(&out, 8 * 40 * V * Mp));
+    std::vector<double> h((size_t)K * V);
+    for (size_t x = 0; x < h.size(); ++x) h[x] = (double)rand() / RAND_MAX - 0.5;
+    CK(hipMemcpy(A, h.data(), 8 * K * V, hipMemcpyHostToDevice));
+    CK(hipMemcpy(B, h.data() + 7, 8 * K * Mp, hipMemcpyHostToDevice));
+    const double gb = 8 * ((double)K * V + (double)Mp * (K + V)) / 1e9, tf = 2.0 * K * V * Mp / 1e12;
+    printf("== %s: K=%ld V=%ld Mp=%d f64\n", name, (long)K, (long)V, Mp);
+    std::vector<Variant> vs;
+    vs.push_back(mkprod<CT, RT, 4>(A, V, K, V, B, out, *splits.begin()));
+    for (int S : splits) {
+        vs.push_back(mk4<CT, RT, 4, 4>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, RT, 4, 2>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, RT, 8, 2>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, RT, 2, 4>(A, V, K, V, B, out, S));
+    }
+    const size_t n1 = (size_t)V * Mp;
+    vs[0].launch(); CK(hipDeviceSynchronize());
+    std::vector<double> r((size_t)vs[0].slots * n1);
+    CK(hipMemcpy(r.data(), out, r.size() * 8, hipMemcpyDeviceToHost));
+    for (size_t vi = 1; vi < vs.size(); vi += 1) {
+        CK(hipMemset(out, 0xff, 8 * (size_t)vs[vi].slots * n1));
+        vs[vi].launch(); CK(hipDeviceSynchronize());
+        std::vector<double> o((size_t)vs[vi].slots * n1);
+        CK(hipMemcpy(o.data(), out, o.size() * 8, hipMemcpyDeviceToHost));
+        double md = 0, mx = 0;
+        for (size_t x = 0; x < n1; ++x) {
+            double so = 0, sr = 0;
+            for (int s2 = 0; s2 < vs[vi].slots; ++s2) so += o[s2 * n1 + x];
+            for (int s2 = 0; s2 < vs[0].slots; ++s2) sr += r[s2 * n1 + x];
+            md = fmax(md, fabs(so - sr)); mx = fmax(mx, fabs(sr));
+        }
+        if (vi < 5 || md > 1e-9 * mx) printf("check %-60s max |diff| %.3e (max |ref| %.3e) %s\n", vs[vi].name.c_str(), md, mx, md <= 1e-11 * mx ? "ok" : "FAIL");
+    }
+    bench(vs, gb, tf);
+    CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(out));
+}
+template <int CT>
+void suite8(const char* name, int64_t K, int64_t V, std::initializer_list<int> splits) {
+    const int Mp = 16 * CT;
+    double *A, *B, *out;
+    CK(hipMalloc(&A, 8 * K * V)); CK(hipMalloc(&B, 8 * K * Mp)); CK(hipMalloc(&out, 8 * 40 * V * Mp));
+    std::vector<double> h((size_t)K * V);
+    for (size_t x = 0; x < h.size(); ++x) h[x] = (double)rand() / RAND_MAX - 0.5;
+    CK(hipMemcpy(A, h.data(), 8 * K * V, hipMemcpyHostToDevice));
+    CK(hipMemcpy(B, h.data() + 7, 8 * K * Mp, hipMemcpyHostToDevice));
+    const double gb = 8 * ((double)K * V + (double)Mp * (K + V)) / 1e9, tf = 2.0 * K * V * Mp / 1e12;
+    printf("== %s: K=%ld V=%ld Mp=%d f64 (wide tiles)\n", name, (long)K, (long)V, Mp);
+    std::vector<Variant> vs;
+    vs.push_back(mkprod<CT, 4, 4>(A, V, K, V, B, out, 6));
+    for (int S : splits) {
+        vs.push_back(mk4<CT, 4, 4, 4>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, 4, 4, 4, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, 8, 4, 4>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, 8, 4, 2>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, 8, 4, 2, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, 8, 2, 4>(A, V, K, V, B, out, S));
+    }
+    const size_t n1 = (size_t)V * Mp;
+    vs[0].launch(); CK(hipDeviceSynchronize());
+    std::vector<double> r((size_t)vs[0].slots * n1);
+    CK(hipMemcpy(r.data(), out, r.size() * 8, hipMemcpyDeviceToHost));
+    for (size_t vi = 1; vi < 7; ++vi) {
+        CK(hipMemset(out, 0xff, 8 * (size_t)vs[vi].slots * n1));
+        vs[vi].launch(); CK(hipDeviceSynchronize());
+        std::vector<double> o((size_t)vs[vi].slots * n1);
+        CK(hipMemcpy(o.data(), out, o.size() * 8, hipMemcpyDeviceToHost));
+        double md = 0, mx = 0;
+        for (size_t x = 0; x < n1; ++x) {
+            double so = 0, sr = 0;
+            for (int s2 = 0; s2 < vs[vi].slots; ++s2) so += o[s2 * n1 + x];
+            for (int s2 = 0; s2 < vs[0].slots; ++s2) sr += r[s2 * n1 + x];
+            md = fmax(md, fabs(so - sr)); mx = fmax(mx, fabs(sr));
+        }
+        printf("check %-66s max |diff| %.3e %s\n", vs[vi].name.c_str(), md, md <= 1e-11 * mx ? "ok" : "FAIL");
+    }
+    bench(vs, gb, tf);
+    CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(out));
+}
+int main() {
+    suite8<2>("c2_xty_128", 10048, 5120, {2, 3, 4, 6});
+    suite8<2>("c2_xw_128", 5120, 10112, {1, 2, 3});
+    return 0;
+}

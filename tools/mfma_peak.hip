@@ -37,6 +37,22 @@ __global__ void __launch_bounds__(256) k_f32(float* out, int iters, float a0, fl
     if (s == 12345.678f) out[0] = s;
 }
 
+template <int NACC>
+__global__ void __launch_bounds__(256) k_f64_4x4(double* out, int iters, double a0, double b0, long long* clk) {
+    double acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+    double a = a0 + threadIdx.x * 1e-9, b = b0;
+    long long c0 = clock64(), r0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    if (clk && blockIdx.x == 3 && threadIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - r0; }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+    if (s == 12345.678) out[0] = s;
+}
+
 template <typename F> void run(const char* tag, F launch, double flop, long long* clk) {
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -64,6 +80,8 @@ int main() {
         run(tag, [&] { hipLaunchKernelGGL(k_f64<8>, dim3(blocks), dim3(256), 0, 0, o64, iters, 0.7312345, -1.218765, clk); }, waves * iters * 8 * 2048.0, clk);
         snprintf(tag, 96, "f64 16x16x4, 4 acc, %d blocks", blocks);
         run(tag, [&] { hipLaunchKernelGGL(k_f64<4>, dim3(blocks), dim3(256), 0, 0, o64, iters, 0.7312345, -1.218765, clk); }, waves * iters * 4 * 2048.0, clk);
+        snprintf(tag, 96, "f64 4x4x4 (4 blocks), 16 acc, %d blocks", blocks);
+        run(tag, [&] { hipLaunchKernelGGL(k_f64_4x4<16>, dim3(blocks), dim3(256), 0, 0, o64, iters, 0.7312345, -1.218765, clk); }, waves * iters * 16 * 512.0, clk);
         snprintf(tag, 96, "f32 16x16x4, 16 acc, %d blocks", blocks);
         run(tag, [&] { hipLaunchKernelGGL(k_f32<16>, dim3(blocks), dim3(256), 0, 0, o32, iters, 0.7312345f, -1.218765f, clk); }, waves * iters * 16 * 2048.0, clk);
     }

@@ -327,7 +327,7 @@ __device__ __forceinline__ int piece_col(int t, int r) {
     return (t / EPL) * 16 * EPL + r * EPL + (t % EPL);
 }
 
-template <typename T, int CT, int RT, int KW, int U>
+template <typename T, int CT, int RT, int KW, int U, bool NT = false>
 __global__ void __launch_bounds__(64 * KW)
 gemm_ct_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T* __restrict__ out,
                int64_t out_rows, int64_t vcols, int ng /* groups of 4*U rows */, int nsuper, int maxslots,
@@ -370,7 +370,7 @@ gemm_ct_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T*
         if (active) {                                                                     \
             const int64_t rb = (int64_t)(s0 + (R)) * (4 * U);                             \
             _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
-                load_row_pieces<T, RT>(ap + (rb + 4 * st) * lda, i, AA[st]);              \
+                load_row_pieces<T, RT, NT>(ap + (rb + 4 * st) * lda, i, AA[st]);          \
         }
 #define LCX_CT_LOADB(R)                                                                   \
         {                                                                                 \

@@ -213,7 +213,7 @@ static int launch_ct(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t
                      int nsuper, int maxslots, const int* skip) {
     typedef CtShape<T, CT> S;
     const int ng = (int)(K / (4 * S::U));
-    hipLaunchKernelGGL((gemm_ct_kernel<T, CT, S::RT, S::KW, S::U>), dim3((unsigned)nb), dim3(64 * S::KW), 0, st, A, lda, B, out,
+    hipLaunchKernelGGL((gemm_ct_kernel<T, CT, S::RT, S::KW, S::U, true>), dim3((unsigned)nb), dim3(64 * S::KW), 0, st, A, lda, B, out,
                        vcols, vcols, ng, nsuper, maxslots, skip);
     KCHECK();
     return LCX_OK;
@@ -223,7 +223,13 @@ template <typename T, int CT>
 static void ct_geometry(int n_cus, int64_t K, int64_t vcols, int force_nb, int* nb_o, int* nsuper_o, int* slots_o) {
     typedef CtShape<T, CT> S;
     int bpc = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)gemm_ct_kernel<T, CT, S::RT, S::KW, S::U>, 64 * S::KW, 0) != hipSuccess || bpc < 1) bpc = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)gemm_ct_kernel<T, CT, S::RT, S::KW, S::U, true>, 64 * S::KW, 0) != hipSuccess || bpc < 1) bpc = 1;
+    // measured (tools/gemm_probe4, 50k x 20k float32, n_hidden 64): 2 resident blocks per CU 122 TF/s, 3 blocks 118
+    {
+        const char* e = getenv("LCX_CT_BPC");
+        const int cap = (e && *e) ? atoi(e) : 2;
+        if (cap > 0 && bpc > cap) bpc = cap;
+    }
     const int nsuper = (int)cdiv(vcols, S::KW * 16 * S::RT);
     const int64_t total = (int64_t)nsuper * (K / (4 * S::U));
     int64_t nb = force_nb > 0 ? force_nb : (int64_t)n_cus * bpc;
@@ -887,7 +893,7 @@ template <typename T, int CT> struct Impl {
     // passes run the same function: X.B^T contracts over the rows of the transposed copy).
     static int kernel_name(lcx_ctx* h, int kind, char* buf, int64_t len) {
         if (kind == 0 ? h->nt_ct : h->tn_ct)
-            snprintf(buf, (size_t)len, "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d>", sizeof(T) == 8 ? "double" : "float", CT,
+            snprintf(buf, (size_t)len, "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true>", sizeof(T) == 8 ? "double" : "float", CT,
                      CtShape<T, CT>::RT, CtShape<T, CT>::KW, CtShape<T, CT>::U);
         else if (h->f64_4x4)
             snprintf(buf, (size_t)len, "lcx::gemm_tn4_kernel<%d, %d, %d, 4, true>", CT, Geo<T, CT>::TN_RT, kind == 0 ? h->nt_KW : h->tn_KW);

@@ -362,51 +362,6 @@ __global__ void tc_final_kernel(const double* __restrict__ sbuf, SetState* st, S
     st->tangent = sbuf[2];       // update_tangent (:305) of the direction this trial belongs to, now global
     publish_state(st, host, seq);
 }
-// (legacy two-step form, kept for reference in tests) per-block pairs -> sbuf[0..1]; with one GPU (single != 0)
-// also TC and the host mirror, so that lcx_moments_c has nothing left to launch
-template <typename T>
-__global__ void __launch_bounds__(PV_THREADS)
-tc_finalize_kernel(const double* __restrict__ tcpart, int nblocks, double* __restrict__ sbuf, SetState* st,
-                   SetState* host, unsigned int seq, int single, const SetState* st_cur) {
-    __shared__ double bs_scratch[PV_THREADS / 64];
-    const int tid = threadIdx.x;
-    if (!st->invalid) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int b = tid; b < nblocks; b += PV_THREADS) { s1 += tcpart[2 * b]; s2 += tcpart[2 * b + 1]; }
-        s1 = block_sum<double>(s1, bs_scratch, tid);
-        s2 = block_sum<double>(s2, bs_scratch, tid);
-        if (tid == 0) { sbuf[0] = s1; sbuf[1] = s2; }
-    }
-    if (tid == 0 && single) {
-        __threadfence();
-        tc_store<T>(sbuf, st);
-        if (st != st_cur) st->tangent = st_cur->tangent;     // the trial carries the tangent of its direction
-        publish_state(st, host, seq);
-    }
-}
-// after the fused epilogue (sbuf[0..1] final): TC, tangent of the direction in flight, host mirror (one GPU)
-template <typename T>
-__global__ void tc_publish_kernel(const double* __restrict__ sbuf, SetState* st, SetState* host, unsigned int seq,
-                                  const SetState* st_cur) {
-    tc_store<T>(sbuf, st);
-    if (st != st_cur) st->tangent = st_cur->tangent;
-    publish_state(st, host, seq);
-}
-// tangent partials -> sbuf[2]; with one GPU also the state scalar + host mirror
-__global__ void __launch_bounds__(PV_THREADS)
-tan_finalize_kernel(const double* __restrict__ tanpart, int nblocks, double* __restrict__ sbuf, SetState* st,
-                    SetState* host, unsigned int seq, int single) {
-    __shared__ double bs_scratch[PV_THREADS / 64];
-    const int tid = threadIdx.x;
-    double s = 0.0;
-    for (int b = tid; b < nblocks; b += PV_THREADS) s += tanpart[b];
-    s = block_sum<double>(s, bs_scratch, tid);
-    if (tid == 0) {
-        sbuf[2] = s;
-        if (single) { st->tangent = s; publish_state(st, host, seq); }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // gradient (linearcorex.py:293-300) and the per-block partial of Bj (:302).
 // dynamic LDS: h_s[Mp*(Mp+1)] (T) + w_s[VPB*Mp] (T) + bj_s[VPB*Mp] (double)
@@ -550,10 +505,6 @@ update_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, const T*
     }
 }
 
-__global__ void tangent_store_kernel(const double* __restrict__ sbuf, SetState* st, SetState* host, unsigned int seq) {
-    st->tangent = sbuf[2];
-    publish_state(st, host, seq);
-}
 
 // out = a + eta * b  (Y of a line-search trial from Y and Y(update))
 // w_update = ws + eta * update (:320)

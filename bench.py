@@ -29,9 +29,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6
 FP32_MFMA_PEAK_TFLOPS = 157.3
 # What micro-benchmarks reach on this chip (profiles/r01_read_probe_c2.txt, r01_mfma_peak.txt): a read-only
-# stream of a 400 MB matrix 6.2 TB/s; v_mfma_f64_16x16x4 47.6 TF/s (not the 78.6 TF/s spec), v_mfma_f32_16x16x4
+# stream of a 400 MB matrix 6.2 TB/s; v_mfma_f64_4x4x4 72 TF/s (16x16x4: 47.6, not the 78.6 TF/s spec), v_mfma_f32_16x16x4
 # 151 TF/s.  Reported beside the spec-based fraction, never instead of it.
-MEASURED_CEILINGS = {"hbm_read_GBps": 6200.0, "mfma_f64_TFLOPs": 47.6, "mfma_f32_TFLOPs": 151.0}
+MEASURED_CEILINGS = {"hbm_read_GBps": 6200.0, "mfma_f64_TFLOPs": 72.0, "mfma_f64_16x16x4_TFLOPs": 47.6,
+                     "mfma_f32_TFLOPs": 151.0}
 
 WORKLOADS = {
     # name: (n_samples, n_variables per GPU, n_hidden, dtype)

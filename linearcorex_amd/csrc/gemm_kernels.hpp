@@ -468,7 +468,7 @@ gemm_ct_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T*
 //     LDS strip, rows padded by 32 B so that the 4 contraction rows of a ds_read_b64 land on distinct banks; the
 //     operand reads are LDS broadcasts.  No block barrier in the main loop.
 // ------------------------------------------------------------------------------------------------
-template <int CT, int RT, int KW, int U, bool NT = false>
+template <int CT, int RT, int KW, int U, bool NT = false, bool SERIAL = false>
 __global__ void __launch_bounds__(64 * KW)
 gemm_tn4_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, double* __restrict__ out,
                 int64_t out_rows, int kgroups /* K / 16 */, int nsplit, const int* __restrict__ skip_flag) {
@@ -560,15 +560,33 @@ gemm_tn4_kernel(const double* __restrict__ A, int64_t lda, const double* __restr
     // ---- reduce the KW partial tiles through LDS in a fixed order and write the tile ----------------
     constexpr int TILE = 16 * RT * Mp;
     __syncthreads();                                  // the B strips are dead: the same LDS holds the tiles now
-    double* mine = smem + wave * TILE;
     const int row = ((lane & 15) >> 2) * 4 + (lane >> 4);          // blk*4 + i: the column of X inside the 16-wide piece
+    double* dst = out + ((int64_t)blockIdx.y * out_rows + v0) * Mp;
+    if (SERIAL) {
+        // one tile of LDS: the waves add their tiles one after the other (fixed order), so that wide tiles do not
+        // cost KW times their size in LDS (occupancy)
+        for (int w = 0; w < KW; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        double* p = &smem[piece_col<double, RT>(t, row) * Mp + 4 * g + jj];
+                        *p = (w == 0) ? acc[t][g] : *p + acc[t][g];
+                    }
+            }
+            __syncthreads();
+        }
+        for (int idx = threadIdx.x; idx < TILE; idx += 64 * KW) dst[idx] = smem[idx];
+        return;
+    }
+    double* mine = smem + wave * TILE;
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int g = 0; g < NG; ++g)
             mine[piece_col<double, RT>(t, row) * Mp + 4 * g + jj] = acc[t][g];
     __syncthreads();
-    double* dst = out + ((int64_t)blockIdx.y * out_rows + v0) * Mp;
     for (int idx = threadIdx.x; idx < TILE; idx += 64 * KW) {
         double sacc = smem[idx];
 #pragma unroll
@@ -577,9 +595,9 @@ gemm_tn4_kernel(const double* __restrict__ A, int64_t lda, const double* __restr
     }
 }
 // dynamic LDS of gemm_tn4: max(B strips, reduction tiles)
-template <int CT, int RT, int KW, int U> struct Tn4Lds {
+template <int CT, int RT, int KW, int U, bool SERIAL = false> struct Tn4Lds {
     static constexpr size_t strips = (size_t)KW * 2 * 4 * U * (16 * CT + 4) * sizeof(double);
-    static constexpr size_t tiles = (size_t)KW * 16 * RT * 16 * CT * sizeof(double);
+    static constexpr size_t tiles = (size_t)(SERIAL ? 1 : KW) * 16 * RT * 16 * CT * sizeof(double);
     static constexpr size_t bytes = strips > tiles ? strips : tiles;
 };
 

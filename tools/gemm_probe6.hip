@@ -11,15 +11,15 @@ using namespace lcx;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 struct Variant { std::string name; std::function<void()> launch; std::vector<float> ms; int slots; };
 
-template <int CT, int RT, int KW, int U, bool NT = false>
+template <int CT, int RT, int KW, int U, bool NT = false, bool SERIAL = false>
 Variant mk4(const double* A, int64_t lda, int64_t K, int64_t vcols, const double* B, double* out, int S) {
-    auto kern = gemm_tn4_kernel<CT, RT, KW, U, NT>;
-    const size_t lds = Tn4Lds<CT, RT, KW, U>::bytes;
+    auto kern = gemm_tn4_kernel<CT, RT, KW, U, NT, SERIAL>;
+    const size_t lds = Tn4Lds<CT, RT, KW, U, SERIAL>::bytes;
     if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int bpc = 0;
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, lds));
     char buf[200];
-    snprintf(buf, 200, "tn4 (4x4x4) RT=%d KW=%d U=%d NT=%d S=%d blocks=%d bpc=%d lds=%zu", RT, KW, U, (int)NT, S, (int)(vcols / (16 * RT)) * S, bpc, lds);
+    snprintf(buf, 200, "tn4 (4x4x4) RT=%d KW=%d U=%d NT=%d SER=%d S=%d blocks=%d bpc=%d lds=%zu", RT, KW, U, (int)NT, (int)SERIAL, S, (int)(vcols / (16 * RT)) * S, bpc, lds);
     return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3((unsigned)(vcols / (16 * RT)), S), dim3(64 * KW), lds, 0, A, lda, B, out, vcols, (int)(K / 16), S, (const int*)nullptr); }, {}, S};
 }
 template <int CT, int RT, int KW>
@@ -108,12 +108,12 @@ void suite8(const char* name, int64_t K, int64_t V, std::initializer_list<int> s
     std::vector<Variant> vs;
     vs.push_back(mkprod<CT, 4, 4>(A, V, K, V, B, out, 6));
     for (int S : splits) {
-        vs.push_back(mk4<CT, 4, 4, 4>(A, V, K, V, B, out, S));
         vs.push_back(mk4<CT, 4, 4, 4, true>(A, V, K, V, B, out, S));
-        vs.push_back(mk4<CT, 8, 4, 4>(A, V, K, V, B, out, S));
-        vs.push_back(mk4<CT, 8, 4, 2>(A, V, K, V, B, out, S));
-        vs.push_back(mk4<CT, 8, 4, 2, true>(A, V, K, V, B, out, S));
-        vs.push_back(mk4<CT, 8, 2, 4>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, 4, 4, 4, true, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, 8, 4, 2, true, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, 8, 4, 4, true, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, 8, 8, 2, true, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, 4, 8, 4, true, true>(A, V, K, V, B, out, S));
     }
     const size_t n1 = (size_t)V * Mp;
     vs[0].launch(); CK(hipDeviceSynchronize());
@@ -137,7 +137,7 @@ void suite8(const char* name, int64_t K, int64_t V, std::initializer_list<int> s
     CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(out));
 }
 int main() {
-    suite8<2>("c2_xty_128", 10048, 5120, {2, 3, 4, 6});
-    suite8<2>("c2_xw_128", 5120, 10112, {1, 2, 3});
+    suite8<2>("c2_xty_128", 10048, 5120, {3, 6, 9, 12});
+    suite8<2>("c2_xw_128", 5120, 10112, {2, 3, 6});
     return 0;
 }

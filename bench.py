@@ -39,6 +39,7 @@ WORKLOADS = {
     "c2": (10000, 5000, 32, "f64"),      # BASELINE.json configs[1]
     "c3": (50000, 100000, 64, "f32"),    # configs[2] (MFMA roofline run; X generated on device)
     "c4shard": (50000, 125000, 128, "f32"),  # configs[3], one GPU's shard
+    "c2f32": (10000, 5000, 32, "f32"),   # config-2 shape in the reference's own precision (not a BASELINE line)
     "tiny": (2000, 640, 8, "f64"),       # plumbing check
 }
 

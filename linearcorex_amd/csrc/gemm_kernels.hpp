@@ -53,6 +53,25 @@ template <typename T, int N>
 __device__ __forceinline__ Pk<T, N> ldg(const T* p) {
     return *reinterpret_cast<const Pk<T, N>*>(p);
 }
+// the same load with the non-temporal hint (streamed-once operand), in 16-byte pieces where the size allows
+template <typename T, int N>
+__device__ __forceinline__ Pk<T, N> ldg_nt(const T* p) {
+    constexpr int BYTES = (int)sizeof(T) * N;
+    Pk<T, N> r;
+    if constexpr (BYTES % 16 == 0) {
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        const f4_t* src = reinterpret_cast<const f4_t*>(p);
+        f4_t* dst = reinterpret_cast<f4_t*>(&r);
+#pragma unroll
+        for (int k = 0; k < BYTES / 16; ++k) dst[k] = __builtin_nontemporal_load(src + k);
+    } else if constexpr (BYTES == 8) {
+        typedef float f2_t __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<f2_t*>(&r) = __builtin_nontemporal_load(reinterpret_cast<const f2_t*>(p));
+    } else {
+        r = *reinterpret_cast<const Pk<T, N>*>(p);
+    }
+    return r;
+}
 
 // ------------------------------------------------------------------------------------------------
 // gemm_nt: rows of X (contiguous contraction) times B[k][Mp].
@@ -153,7 +172,7 @@ gemm_nt_kernel(const T* __restrict__ X, int64_t ldx, const T* __restrict__ B, T*
 // ------------------------------------------------------------------------------------------------
 // MODE is for ablation probes only (tools/gemm_probe.hip): 0 = real kernel, 1 = loads without MFMA,
 // 2 = MFMA without loads (registers loaded once).
-template <typename T, int CT, int RT, int KW, bool SCALE, int MODE, int U>
+template <typename T, int CT, int RT, int KW, bool SCALE, int MODE, int U, bool NTA = false>
 __device__ __forceinline__ void
 tn_body(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const T* __restrict__ B,
         const T* __restrict__ rowscale, T* __restrict__ out, int64_t out_rows, int kgroups,
@@ -192,7 +211,7 @@ tn_body(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const T* __re
     if (MODE != 2 || (G) == g0) {                                                     \
         const int64_t rb = (int64_t)(G) * (4 * U);                                    \
         _Pragma("unroll") for (int st = 0; st < U; ++st) {                            \
-            AA[st] = ldg<T, RT>(ap + (rb + 4 * st) * lda);                            \
+            AA[st] = NTA ? ldg_nt<T, RT>(ap + (rb + 4 * st) * lda) : ldg<T, RT>(ap + (rb + 4 * st) * lda); \
             BB[st] = ldg<T, CT>(bp + (rb + 4 * st) * Mp);                             \
             if (SCALE) SS[st] = rowscale[rb + 4 * st + q];                            \
         }                                                                             \
@@ -246,14 +265,14 @@ tn_body(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const T* __re
     }
 }
 
-template <typename T, int CT, int RT, int KW, bool SCALE, int MODE = 0, int U = 4>
+template <typename T, int CT, int RT, int KW, bool SCALE, int MODE = 0, int U = 4, bool NTA = false>
 __global__ void __launch_bounds__(64 * KW)
 gemm_tn_kernel(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const T* __restrict__ B,
                const T* __restrict__ rowscale, T* __restrict__ out, int64_t out_rows, int kgroups,
                int nsplit, const int* __restrict__ skip_flag) {
     if (skip_flag != nullptr && *skip_flag != 0) return;
-    tn_body<T, CT, RT, KW, SCALE, MODE, U>(A, lda, tile_stride, B, rowscale, out, out_rows, kgroups, nsplit,
-                                            blockIdx.x, blockIdx.y);
+    tn_body<T, CT, RT, KW, SCALE, MODE, U, NTA>(A, lda, tile_stride, B, rowscale, out, out_rows, kgroups, nsplit,
+                                                 blockIdx.x, blockIdx.y);
 }
 
 // Two independent Gram contractions (A^T.A of two [K][Mp] arrays) in one launch: blockIdx.z picks

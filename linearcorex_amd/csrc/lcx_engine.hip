@@ -171,17 +171,17 @@ static int launch_nt(hipStream_t st, const T* X, int64_t ldx, int64_t rows_pad, 
 }
 
 // out rows (padded "v" count) must be a multiple of 16*RT; K a multiple of 16.
-template <typename T, int CT, int RT, bool SCALE>
+template <typename T, int CT, int RT, bool SCALE, bool NTA = false>
 static int launch_tn(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t vcols_pad, const T* B,
                      const T* rowscale, T* out, int S, int KW, const int* skip) {
     const int kgroups = (int)(K / 16);
     dim3 grid((unsigned)(vcols_pad / (16 * RT)), (unsigned)S);
     const size_t lds = (size_t)KW * 16 * RT * 16 * CT * sizeof(T);
     switch (KW) {
-        case 1: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 1, SCALE>), grid, dim3(64), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
-        case 2: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 2, SCALE>), grid, dim3(128), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
-        case 4: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 4, SCALE>), grid, dim3(256), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
-        default: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 8, SCALE>), grid, dim3(512), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
+        case 1: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 1, SCALE, 0, 4, NTA>), grid, dim3(64), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
+        case 2: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 2, SCALE, 0, 4, NTA>), grid, dim3(128), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
+        case 4: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 4, SCALE, 0, 4, NTA>), grid, dim3(256), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
+        default: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 8, SCALE, 0, 4, NTA>), grid, dim3(512), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
     }
     KCHECK();
     return LCX_OK;
@@ -394,8 +394,8 @@ template <typename T, int CT> struct Impl {
             if constexpr (sizeof(T) == 8 && CT <= 2)
                 LCXCHECK((launch_tn4<CT>(h->stream, P<double>(h->XT), h->Npad, h->ldx, h->Npad, (const double*)B, (double*)dst, h->nt_S, h->nt_KW, skip)));
         } else
-            LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, B, nullptr,
-                                                                   dst, h->nt_S, h->nt_KW, skip)));
+            LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false, false>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, B, nullptr,
+                                                                         dst, h->nt_S, h->nt_KW, skip)));
         LCXCHECK(timing_end(h, 0, &tp));
         const int64_t n = h->Npad * Mp;
         if (with_bj) {
@@ -429,8 +429,8 @@ template <typename T, int CT> struct Impl {
                 LCXCHECK((launch_tn4<CT>(h->stream, P<double>(h->X), h->ldx, h->Npad, h->ldx, P<double>(h->ybuf), P<double>(h->dpart), h->tn_S,
                                          h->tn_KW, skip)));
         } else
-            LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false>(h->stream, P<T>(h->X), h->ldx, h->Npad, h->ldx, P<T>(h->ybuf), nullptr,
-                                                                   P<T>(h->dpart), h->tn_S, h->tn_KW, skip)));
+            LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false, false>(h->stream, P<T>(h->X), h->ldx, h->Npad, h->ldx, P<T>(h->ybuf), nullptr,
+                                                                         P<T>(h->dpart), h->tn_S, h->tn_KW, skip)));
         LCXCHECK(timing_end(h, 1, &tp));
         return LCX_OK;
     }
@@ -898,7 +898,7 @@ template <typename T, int CT> struct Impl {
         else if (h->f64_4x4)
             snprintf(buf, (size_t)len, "lcx::gemm_tn4_kernel<%d, %d, %d, 4, true>", CT, Geo<T, CT>::TN_RT, kind == 0 ? h->nt_KW : h->tn_KW);
         else
-            snprintf(buf, (size_t)len, "lcx::gemm_tn_kernel<%s, %d, %d, %d, false, 0, 4>", sizeof(T) == 8 ? "double" : "float", CT,
+            snprintf(buf, (size_t)len, "lcx::gemm_tn_kernel<%s, %d, %d, %d, false, 0, 4, false>", sizeof(T) == 8 ? "double" : "float", CT,
                      Geo<T, CT>::TN_RT, kind == 0 ? h->nt_KW : h->tn_KW);
         return LCX_OK;
     }

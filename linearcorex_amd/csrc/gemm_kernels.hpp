@@ -346,7 +346,7 @@ __device__ __forceinline__ int piece_col(int t, int r) {
     return (t / EPL) * 16 * EPL + r * EPL + (t % EPL);
 }
 
-template <typename T, int CT, int RT, int KW, int U, bool NT = false>
+template <typename T, int CT, int RT, int KW, int U, bool NT = false, int PRIO = 0>
 __global__ void __launch_bounds__(64 * KW)
 gemm_ct_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T* __restrict__ out,
                int64_t out_rows, int64_t vcols, int ng /* groups of 4*U rows */, int nsuper, int maxslots,
@@ -412,10 +412,12 @@ gemm_ct_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T*
             Pk<T, CT> bb[U];                                                              \
             _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
                 bb[st] = *reinterpret_cast<const Pk<T, CT>*>(&Bs[BUF][(4 * st + q) * Mp + i * CT]); \
+            if (PRIO) __builtin_amdgcn_s_setprio(PRIO);                                   \
             _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
             _Pragma("unroll") for (int t = 0; t < RT; ++t)                                \
             _Pragma("unroll") for (int u = 0; u < CT; ++u)                                \
                 acc[t][u] = MF<T>::mma(AA[st][t], bb[st].v[u], acc[t][u]);                \
+            if (PRIO) __builtin_amdgcn_s_setprio(0);                                      \
         }
 
         LCX_CT_LOADA(0, a0);

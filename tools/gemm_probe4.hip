@@ -23,9 +23,9 @@ __global__ void clock_sampler(long long* out, long long wall_ticks) {
 
 struct Variant { std::string name; std::function<void()> launch; std::vector<float> ms; int maxslots; };
 
-template <typename T, int CT, int RT, int KW, int U, bool NT = false>
+template <typename T, int CT, int RT, int KW, int U, bool NT = false, int PRIO = 0>
 Variant mkct(const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* out, int bpc_use = 0) {
-    auto kern = gemm_ct_kernel<T, CT, RT, KW, U, NT>;
+    auto kern = gemm_ct_kernel<T, CT, RT, KW, U, NT, PRIO>;
     int bpc = 0;
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, 0));
     const int use = bpc_use > 0 ? bpc_use : bpc;
@@ -36,7 +36,7 @@ Variant mkct(const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* o
     if (nb > total) nb = (int)total;
     const int maxslots = (nb + nsuper - 1) / nsuper + 1;
     char buf[200];
-    snprintf(buf, 200, "ct RT=%d KW=%d U=%d NT=%d bpc=%d(use %d) nb=%d nsuper=%d slots=%d", RT, KW, U, (int)NT, bpc, use, nb, nsuper, maxslots);
+    snprintf(buf, 200, "ct RT=%d KW=%d U=%d NT=%d PRIO=%d bpc=%d(use %d) nb=%d nsuper=%d slots=%d", RT, KW, U, (int)NT, PRIO, bpc, use, nb, nsuper, maxslots);
     return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, A, lda, B, out, vcols, vcols, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
 }
 
@@ -124,9 +124,10 @@ void suite(const char* name, int64_t K, int64_t V, int tnS) {
     std::vector<Variant> vs;
     vs.push_back(mkprod<T, CT, TNRT, 4>(A, V, K, V, B, out, tnS));
     constexpr int R = CtShape<T, CT>::RT;
-    vs.push_back(mkct<T, CT, R, 4, 4>(A, V, K, V, B, out));
-    vs.push_back(mkct<T, CT, R, 4, 4, true>(A, V, K, V, B, out));
     vs.push_back(mkct<T, CT, R, 4, 4, true>(A, V, K, V, B, out, 2));
+    vs.push_back(mkct<T, CT, R, 4, 4, true, 1>(A, V, K, V, B, out, 2));
+    vs.push_back(mkct<T, CT, R, 4, 4, true, 2>(A, V, K, V, B, out, 2));
+    vs.push_back(mkct<T, CT, R, 4, 4, true, 1>(A, V, K, V, B, out, 3));
     const double tol = sizeof(T) == 8 ? 1e-12 : 2e-5;
     for (size_t k = 1; k < vs.size(); ++k) check<T>(name, vs[k], vs[0], out, out, V, 16 * CT, tol);
     bench(vs, gb, tf);

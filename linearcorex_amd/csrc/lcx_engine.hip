@@ -507,7 +507,7 @@ template <typename T, int CT> struct Impl {
                            linear ? P<T>(h->set[0].D) : (const T*)nullptr, P<T>(h->ddir), (T)eta, P<T>(s.D),
                            P<T>(h->Wt[which]), s.ry, h->V, (double)h->N, eps,
                            P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), P<T>(s.hscale),
-                           h->tcpart, skip, h->ticket + 1, h->sbuf, s.st, s.hst_dev, seq, single, (const SetState*)h->set[0].st);
+                           h->tcpart, skip, h->ticket + 16, h->sbuf, s.st, s.hst_dev, seq, single, (const SetState*)h->set[0].st);
         KCHECK();
         if (single) s.seq_expect = seq;
         // H partial of THIS set (:294), so that the update that follows an accepted trial needs no exchange of
@@ -590,7 +590,7 @@ template <typename T, int CT> struct Impl {
                            h->full_sig ? h->tn_S : 0, h->ldx * Mp, P<T>(h->grad), P<T>(h->Wt[0]), s.uj, P<T>(h->ybuf) + h->Npad * Mp, h->V,
                            (double)h->N, eps, P<T>(h->update), P<T>(h->sgrad), h->tanpart,
                            h->full_sig ? P<T>(s.D) : (const T*)nullptr, h->full_sig ? P<T>(h->ddir) : (T*)nullptr, grid, P<T>(h->ybuf),
-                           P<T>(s.Y), ny, P<T>(h->ydir), P<T>(h->Wt[1]), h->ticket + 2, h->sbuf, s.st, s.hst_dev, seq, single, h->world);
+                           P<T>(s.Y), ny, P<T>(h->ydir), P<T>(h->Wt[1]), h->ticket + 32, h->sbuf, s.st, s.hst_dev, seq, single, h->world);
         KCHECK();
         if (single) s.seq_expect = seq;
         h->w1_ready = true;
@@ -896,7 +896,7 @@ template <typename T, int CT> struct Impl {
             snprintf(buf, (size_t)len, "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true>", sizeof(T) == 8 ? "double" : "float", CT,
                      CtShape<T, CT>::RT, CtShape<T, CT>::KW, CtShape<T, CT>::U);
         else if (h->f64_4x4)
-            snprintf(buf, (size_t)len, "lcx::gemm_tn4_kernel<%d, %d, %d, 4, true>", CT, Geo<T, CT>::TN_RT, kind == 0 ? h->nt_KW : h->tn_KW);
+            snprintf(buf, (size_t)len, "lcx::gemm_tn4_kernel<%d, %d, %d, 4, true, false>", CT, Geo<T, CT>::TN_RT, kind == 0 ? h->nt_KW : h->tn_KW);
         else
             snprintf(buf, (size_t)len, "lcx::gemm_tn_kernel<%s, %d, %d, %d, false, 0, 4, false>", sizeof(T) == 8 ? "double" : "float", CT,
                      Geo<T, CT>::TN_RT, kind == 0 ? h->nt_KW : h->tn_KW);
@@ -1275,7 +1275,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     A_(h->invwork, sizeof(double) * Mp * 2 * Mp);
     A_(h->states, sizeof(SetState) * 2);
     A_(h->order_dev, sizeof(int) * Mp);
-    A_(h->ticket, 64);
+    A_(h->ticket, 256);        // [0] small_moments; [16..25) moments_epilogue; [32..41) update_kernel
 #undef A_
     h->set[0].st = h->states;
     h->set[1].st = h->states + 1;

@@ -1,0 +1,97 @@
+"""The ctypes stub INTEGRATION.md shows a reference maintainer (section B) must actually work: this test carries
+the same class, drives one `_update_ns` iteration of the reference's control flow with it (:290-334) and compares
+with the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import corex_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _stub():
+    _lcx = C.CDLL(os.path.join(ROOT, "linearcorex_amd", "liblcx_hip.so"))
+    _lcx.lcx_last_error.restype = C.c_char_p
+
+    def _ck(rc):
+        if rc:
+            raise RuntimeError(_lcx.lcx_last_error().decode())
+    _p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+
+    class LcxDevice(object):                                     # verbatim from INTEGRATION.md, section B
+        def __init__(self, x32, n_hidden):
+            self.h = C.c_void_p()
+            ns, nv = x32.shape
+            _ck(_lcx.lcx_create(C.byref(self.h), C.c_int64(ns), C.c_int64(nv), n_hidden, 0, 0))
+            _ck(_lcx.lcx_upload_x(self.h, _p(np.ascontiguousarray(x32)), C.c_int64(nv)))
+
+        def set_ws(self, ws):
+            _ck(_lcx.lcx_set_ws(self.h, _p(np.ascontiguousarray(ws))))
+
+        def moments(self, which, eps, quick):
+            _ck(_lcx.lcx_moments_a(self.h, which))
+            _ck(_lcx.lcx_moments_b(self.h, which, C.c_double(eps), int(quick)))
+            _ck(_lcx.lcx_moments_c(self.h, which))
+            s = (C.c_double * 8)()
+            _ck(_lcx.lcx_read_state(self.h, which, s))
+            return None if s[2] else s[0]
+
+        def direction(self, eps):
+            _ck(_lcx.lcx_update_b(self.h, C.c_double(eps)))
+            _ck(_lcx.lcx_update_c(self.h, C.c_double(eps)))
+            _ck(_lcx.lcx_update_d(self.h))
+            s = (C.c_double * 8)()
+            _ck(_lcx.lcx_read_state(self.h, 0, s))
+            return s[3]
+
+        def trial(self, eta):
+            _ck(_lcx.lcx_make_trial(self.h, C.c_double(eta)))
+
+        def accept(self):
+            _ck(_lcx.lcx_accept_trial(self.h))
+
+        def get_ws(self, m, nv):
+            out = np.empty((m, nv), np.float32)
+            _ck(_lcx.lcx_get_ws(self.h, 0, _p(out)))
+            return out
+
+        def close(self):
+            _lcx.lcx_destroy(self.h)
+    return LcxDevice
+
+
+def test_integration_stub_runs_update_ns():
+    LcxDevice = _stub()
+    n, v, m, eps = 500, 333, 5, 0.36
+    x, _ = O.gen_planted(n, v, m, seed=8)
+    x32 = O.preprocess(x.astype(np.float32))[0]
+    w = np.random.RandomState(0).randn(m, v).astype(np.float32)
+    w /= (10.0 * O.norm(x32, w, 0))[:, np.newaxis]
+    w *= 3.0
+    dev = LcxDevice(x32, m)
+    dev.set_ws(w)
+    tc = dev.moments(0, eps, False)
+    mo = O.moments_ns(x32, w, eps, quick=False)
+    assert abs(tc - float(mo["TC"])) < 2e-3 * max(1.0, abs(float(mo["TC"])))
+    # the reference's _update_ns control flow (:305-334) on the stub
+    w_ref, m_ref, info = O.update_ns(x32, w, mo, eps)
+    tangent = dev.direction(eps)
+    assert tangent < 0 and abs(tangent - info["tangent"]) < 2e-3 * abs(info["tangent"])
+    eta, n_trials = 1.0, 0
+    while True:
+        dev.trial(eta)
+        tc_new = dev.moments(1, eps, True)
+        n_trials += 1
+        if tc_new is None or -tc_new > -tc + 0.1 * eta * tangent:
+            eta *= 0.5
+            continue
+        break
+    dev.accept()
+    assert n_trials == info["n_trials"] and eta == info["eta"]
+    assert abs(tc_new - float(m_ref["TC"])) < 2e-3 * max(1.0, abs(float(m_ref["TC"])))
+    assert np.max(np.abs(dev.get_ws(m, v) - w_ref)) < 1e-4
+    dev.close()

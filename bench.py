@@ -28,10 +28,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6
 FP32_MFMA_PEAK_TFLOPS = 157.3
-# What micro-benchmarks reach on this chip (profiles/r01_read_probe_c2.txt, r01_mfma_peak.txt): a read-only
-# stream of a 400 MB matrix 6.2 TB/s; v_mfma_f64_4x4x4 72 TF/s (16x16x4: 47.6, not the 78.6 TF/s spec), v_mfma_f32_16x16x4
+# What this chip has been seen to sustain (profiles/r01_read_probe_c2.txt, r01_mfma_peak.txt, the c3f64* workloads:
+# gemm_ct streams float64 X at 6.47 TB/s and runs v_mfma_f64_16x16x4 at 59.9 TF/s): a read-only
+# stream of a 400 MB matrix 6.2 TB/s; pure-MFMA loops: v_mfma_f64_4x4x4 72 TF/s, v_mfma_f64_16x16x4 47.6 TF/s (real kernels reach
+# 58-60 TF/s with it on large shards), v_mfma_f32_16x16x4
 # 151 TF/s.  Reported beside the spec-based fraction, never instead of it.
-MEASURED_CEILINGS = {"hbm_read_GBps": 6200.0, "mfma_f64_TFLOPs": 72.0, "mfma_f64_16x16x4_TFLOPs": 47.6,
+MEASURED_CEILINGS = {"hbm_read_GBps": 6470.0, "mfma_f64_TFLOPs": 72.0, "mfma_f64_16x16x4_TFLOPs": 59.9,
                      "mfma_f32_TFLOPs": 151.0}
 
 WORKLOADS = {
@@ -39,6 +41,9 @@ WORKLOADS = {
     "c2": (10000, 5000, 32, "f64"),      # BASELINE.json configs[1]
     "c3": (50000, 100000, 64, "f32"),    # configs[2] (MFMA roofline run; X generated on device)
     "c4shard": (50000, 125000, 128, "f32"),  # configs[3], one GPU's shard
+    "c3f64": (50000, 50000, 64, "f64"),  # large float64 shards (gemm_ct on float64; not BASELINE lines)
+    "c3f64m32": (50000, 50000, 32, "f64"),
+    "c3f64m128": (50000, 50000, 128, "f64"),
     "c2f32": (10000, 5000, 32, "f32"),   # config-2 shape in the reference's own precision (not a BASELINE line)
     "tiny": (2000, 640, 8, "f64"),       # plumbing check
 }

@@ -893,7 +893,7 @@ template <typename T, int CT> struct Impl {
     // passes run the same function: X.B^T contracts over the rows of the transposed copy).
     static int kernel_name(lcx_ctx* h, int kind, char* buf, int64_t len) {
         if (kind == 0 ? h->nt_ct : h->tn_ct)
-            snprintf(buf, (size_t)len, "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true>", sizeof(T) == 8 ? "double" : "float", CT,
+            snprintf(buf, (size_t)len, "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true, 0>", sizeof(T) == 8 ? "double" : "float", CT,
                      CtShape<T, CT>::RT, CtShape<T, CT>::KW, CtShape<T, CT>::U);
         else if (h->f64_4x4)
             snprintf(buf, (size_t)len, "lcx::gemm_tn4_kernel<%d, %d, %d, 4, true, false>", CT, Geo<T, CT>::TN_RT, kind == 0 ? h->nt_KW : h->tn_KW);

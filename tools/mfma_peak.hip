@@ -37,6 +37,38 @@ __global__ void __launch_bounds__(256) k_f32(float* out, int iters, float a0, fl
     if (s == 12345.678f) out[0] = s;
 }
 
+// distinct A / B registers per accumulator (a real kernel never feeds one register pair to every MFMA)
+template <int NACC>
+__global__ void __launch_bounds__(256) k_f64_var(double* out, int iters, double a0, double b0, long long* clk) {
+    d4 acc[NACC];
+    double a[NACC], b[NACC];
+    for (int i = 0; i < NACC; ++i) { acc[i] = (d4){0, 0, 0, 0}; a[i] = a0 + i * 0.01 + threadIdx.x * 1e-9; b[i] = b0 - i * 0.02; }
+    long long c0 = clock64(), r0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[(i + 1) % NACC], acc[i], 0, 0, 0);
+    }
+    if (clk && blockIdx.x == 3 && threadIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - r0; }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) out[0] = s;
+}
+template <int NACC>
+__global__ void __launch_bounds__(256) k_f64_4x4_var(double* out, int iters, double a0, double b0, long long* clk) {
+    double acc[NACC], a[4], b[NACC];
+    for (int i = 0; i < NACC; ++i) { acc[i] = 0.0; b[i] = b0 - i * 0.02; }
+    for (int i = 0; i < 4; ++i) a[i] = a0 + i * 0.01 + threadIdx.x * 1e-9;
+    long long c0 = clock64(), r0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i & 3], b[i], acc[i], 0, 0, 0);
+    }
+    if (clk && blockIdx.x == 3 && threadIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - r0; }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+    if (s == 12345.678) out[0] = s;
+}
+
 template <int NACC>
 __global__ void __launch_bounds__(256) k_f64_4x4(double* out, int iters, double a0, double b0, long long* clk) {
     double acc[NACC];
@@ -80,6 +112,10 @@ int main() {
         run(tag, [&] { hipLaunchKernelGGL(k_f64<8>, dim3(blocks), dim3(256), 0, 0, o64, iters, 0.7312345, -1.218765, clk); }, waves * iters * 8 * 2048.0, clk);
         snprintf(tag, 96, "f64 16x16x4, 4 acc, %d blocks", blocks);
         run(tag, [&] { hipLaunchKernelGGL(k_f64<4>, dim3(blocks), dim3(256), 0, 0, o64, iters, 0.7312345, -1.218765, clk); }, waves * iters * 4 * 2048.0, clk);
+        snprintf(tag, 96, "f64 16x16x4, 8 acc, distinct operands, %d blocks", blocks);
+        run(tag, [&] { hipLaunchKernelGGL(k_f64_var<8>, dim3(blocks), dim3(256), 0, 0, o64, iters, 0.7312345, -1.218765, clk); }, waves * iters * 8 * 2048.0, clk);
+        snprintf(tag, 96, "f64 4x4x4, 16 acc, distinct operands, %d blocks", blocks);
+        run(tag, [&] { hipLaunchKernelGGL(k_f64_4x4_var<16>, dim3(blocks), dim3(256), 0, 0, o64, iters, 0.7312345, -1.218765, clk); }, waves * iters * 16 * 512.0, clk);
         snprintf(tag, 96, "f64 4x4x4 (4 blocks), 16 acc, %d blocks", blocks);
         run(tag, [&] { hipLaunchKernelGGL(k_f64_4x4<16>, dim3(blocks), dim3(256), 0, 0, o64, iters, 0.7312345, -1.218765, clk); }, waves * iters * 16 * 512.0, clk);
         snprintf(tag, 96, "f32 16x16x4, 16 acc, %d blocks", blocks);

@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--cpu-iters-per-stage", type=int, default=40,
                     help="bounded CPU-baseline sample: oracle iterations per annealing stage (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--timing-sample", type=int, default=5,
+                    help="HIP-event pairs around every n-th X pass of the timed region (a pair costs ~5 us of stream time; "
+                         "1 = every pass)")
     ap.add_argument("--no-convergence", dest="convergence", action="store_false",
                     help="skip the wall-clock-to-TC-convergence measurement (a full fit at tol=1e-5 on the same data, "
                          "reported under config.fit_to_convergence; 1 GPU, workload c2 only)")
@@ -150,6 +153,7 @@ def measure(args, comm, world, rank, local_rank, line_search, keep_x=False):
             sync()
             if not args.no_kernel_timing:
                 be.timing_reset()
+                be.timing_sample(args.timing_sample)
                 be.timing_enable(True)
             model.stats.update(trials=0, invalid_trials=0, moment_evals=0, refreshes=0)
             state["t0"] = time.perf_counter()
@@ -268,6 +272,7 @@ def main():
                         frac_of_measured_mfma_ceiling=kernels[dom]["TFLOPs"] / mfma_ceiling,
                         measured_ceilings=MEASURED_CEILINGS)
         roofline.update(kernel=dom, avg_launch_us=kernels[dom]["avg_us"], launches=kernels[dom]["launches"],
+                        timed_every_nth_launch=args.timing_sample,
                         algorithmic_bytes_per_launch=alg_bytes, algorithmic_flops_per_launch=alg_flops,
                         traffic_source=traffic_src, mfma_util_pmc=mfma_util, use_sites=use_sites)
 

@@ -253,6 +253,8 @@ int lcx_project_raw(lcx_ctx* h, const void* x_raw_host, int64_t n_rows, int64_t 
 /* HIP-event timing of the two X-streaming GEMM kernels on the handle's stream.
  * kind 0 = X.B^T ("nt", :247/:210), kind 1 = X^T.Y ("tn", :259/:211). */
 int lcx_timing_enable(lcx_ctx* h, int enable);
+/* time only every `every`-th X pass (an event pair costs ~5 us of stream time; default 1 = all) */
+int lcx_timing_sample(lcx_ctx* h, int every);
 int lcx_timing_read(lcx_ctx* h, int kind, int64_t* launches, double* total_ms);
 int lcx_timing_reset(lcx_ctx* h);
 /* micro-benchmark: `iters` back-to-back launches of one X-streaming GEMM (kind as above, with its

@@ -72,6 +72,7 @@ SIGNATURES = {
     "lcx_covariance_rows": [_vp, _dbl, _vp, _i64, _i64, _vp],
     "lcx_project": [_vp, _vp, _i64, _i64, _vp],
     "lcx_timing_enable": [_vp, _i32],
+    "lcx_timing_sample": [_vp, _i32],
     "lcx_timing_read": [_vp, _i32, C.POINTER(_i64), C.POINTER(_dbl)],
     "lcx_timing_reset": [_vp],
     "lcx_bench_gemm": [_vp, _i32, _i32, C.POINTER(_dbl)],

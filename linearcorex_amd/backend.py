@@ -70,6 +70,9 @@ class HipBackend:
     def timing_enable(self, on=True):
         _abi.check(self.lib.lcx_timing_enable(self.h, 1 if on else 0))
 
+    def timing_sample(self, every):
+        _abi.check(self.lib.lcx_timing_sample(self.h, int(every)))
+
     def timing_reset(self):
         _abi.check(self.lib.lcx_timing_reset(self.h))
 

@@ -106,6 +106,7 @@ struct lcx_ctx {
     int nt_nb, nt_nsuper, tn_nb, tn_nsuper;
     // timing
     bool timing;
+    int t_every, t_count;       // HIP-event timing samples every t_every-th X pass (an event pair costs ~5 us of stream time)
     std::vector<TimingPair> pending;
     std::vector<TimingPair> pool;
     int64_t t_launch[2];
@@ -121,7 +122,9 @@ template <typename T> static inline T* P(void* p) { return reinterpret_cast<T*>(
 // GEMM launchers
 // -------------------------------------------------------------------------------------------------
 static int timing_begin(lcx_ctx* h, int kind, TimingPair* tp) {
+    tp->kind = -1;
     if (!h || !h->timing || kind < 0) return LCX_OK;
+    if (h->t_every > 1 && (h->t_count++ % h->t_every) != 0) return LCX_OK;
     if (h->pool.empty()) {
         HIPCHECK(hipEventCreate(&tp->a));
         HIPCHECK(hipEventCreate(&tp->b));
@@ -134,7 +137,7 @@ static int timing_begin(lcx_ctx* h, int kind, TimingPair* tp) {
     return LCX_OK;
 }
 static int timing_end(lcx_ctx* h, int kind, TimingPair* tp) {
-    if (!h || !h->timing || kind < 0) return LCX_OK;
+    if (!h || !h->timing || kind < 0 || tp->kind < 0) return LCX_OK;
     HIPCHECK(hipEventRecord(tp->b, h->stream));
     h->pending.push_back(*tp);
     return LCX_OK;
@@ -1205,6 +1208,8 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     h->Npad = round_up(n_samples, 64);
     h->ldx = round_up(nv_local, 64);        // 64 elements: whole 128 B chunks and whole tn column tiles
     h->timing = false;
+    h->t_every = 1;
+    h->t_count = 0;
     h->t_launch[0] = h->t_launch[1] = 0;
     h->t_ms[0] = h->t_ms[1] = 0.0;
     h->have_direction = false;
@@ -1595,6 +1600,13 @@ int lcx_timing_enable(lcx_ctx* h, int enable) {
     HIPCHECK(hipStreamSynchronize(h->stream));
     LCXCHECK(timing_collect(h));
     h->timing = enable != 0;
+    return LCX_OK;
+}
+int lcx_timing_sample(lcx_ctx* h, int every) {
+    NEED(h);
+    if (every < 1) return fail(LCX_ERR_ARG, "lcx_timing_sample: every must be >= 1");
+    h->t_every = every;
+    h->t_count = 0;
     return LCX_OK;
 }
 int lcx_timing_read(lcx_ctx* h, int kind, int64_t* launches, double* total_ms) {

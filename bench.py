@@ -180,6 +180,7 @@ def measure(args, comm, world, rank, local_rank, line_search, keep_x=False):
         elapsed = float(t.item())
     res = {"elapsed": elapsed, "its_per_s": args.steps / elapsed, "geo": be.geometry(),
            "timing": be.timing_read() if not args.no_kernel_timing else {},
+           "x_passes": be.timing_passes() if not args.no_kernel_timing else None,
            "trials": model.stats["trials"] / max(1, args.steps),
            "invalid": model.stats["invalid_trials"] / max(1, args.steps),
            "final_tc": float(model.tc), "per_stage": per_stage, "x_host": x_host if keep_x else None,
@@ -281,8 +282,8 @@ def main():
         # same iterations with the linear trial mode: reported beside the headline, never as it
         r2 = measure(args, comm, world, rank, local_rank, "linear")
         extra = {"fit_iterations_per_sec": r2["its_per_s"], "ms_per_step": r2["elapsed"] / args.steps * 1e3,
-                 "x_passes_per_iteration": (sum(c for c, _ in r2["timing"].values()) / max(1, args.steps))
-                 if r2["timing"] else None,
+                 "x_passes_per_iteration": (r2["x_passes"] / max(1, args.steps))
+                 if r2["x_passes"] is not None else None,
                  "line_search_trials_per_iteration": r2["trials"], "final_TC": r2["final_tc"]}
 
     out = {
@@ -302,7 +303,7 @@ def main():
                    "fit_iterations_per_sec": its_per_s,
                    "line_search_trials_per_iteration": trials, "invalid_trials_per_iteration": invalid,
                    "line_search": args.line_search,
-                   "x_passes_per_iteration": (sum(c for c, _ in timing.values()) / max(1, args.steps)) if timing
+                   "x_passes_per_iteration": (r["x_passes"] / max(1, args.steps)) if r["x_passes"] is not None
                    else None,
                    "x_passes_per_iteration_reference_shaped": 2 + 2 * trials - invalid,
                    "launch_geometry": geo, "final_TC": r["final_tc"], "force_exchange": bool(args.force_exchange),

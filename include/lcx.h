@@ -256,6 +256,8 @@ int lcx_timing_enable(lcx_ctx* h, int enable);
 /* time only every `every`-th X pass (an event pair costs ~5 us of stream time; default 1 = all) */
 int lcx_timing_sample(lcx_ctx* h, int every);
 int lcx_timing_read(lcx_ctx* h, int kind, int64_t* launches, double* total_ms);
+/* every X pass issued since the last reset while timing was enabled (timed or skipped by the sampling) */
+int lcx_timing_passes(lcx_ctx* h, int kind, int64_t* passes);
 int lcx_timing_reset(lcx_ctx* h);
 /* micro-benchmark: `iters` back-to-back launches of one X-streaming GEMM (kind as above, with its
  * partial-sum reduction) on the resident X; returns the average wall time per launch from HIP events */

@@ -74,6 +74,7 @@ SIGNATURES = {
     "lcx_timing_enable": [_vp, _i32],
     "lcx_timing_sample": [_vp, _i32],
     "lcx_timing_read": [_vp, _i32, C.POINTER(_i64), C.POINTER(_dbl)],
+    "lcx_timing_passes": [_vp, _i32, C.POINTER(_i64)],
     "lcx_timing_reset": [_vp],
     "lcx_bench_gemm": [_vp, _i32, _i32, C.POINTER(_dbl)],
     "lcx_geometry": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i64)],

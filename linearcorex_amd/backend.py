@@ -84,6 +84,15 @@ class HipBackend:
             out[name] = (n.value, ms.value)
         return out
 
+    def timing_passes(self):
+        """X passes issued while timing was on (every pass, whatever `timing_sample` says)."""
+        n = C.c_int64()
+        tot = 0
+        for kind in (0, 1):
+            _abi.check(self.lib.lcx_timing_passes(self.h, kind, C.byref(n)))
+            tot += n.value
+        return tot
+
     def kernel_name(self, kind):
         buf = C.create_string_buffer(256)
         _abi.check(self.lib.lcx_kernel_name(self.h, int(kind), buf, 256))

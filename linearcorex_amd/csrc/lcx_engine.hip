@@ -110,6 +110,7 @@ struct lcx_ctx {
     std::vector<TimingPair> pending;
     std::vector<TimingPair> pool;
     int64_t t_launch[2];
+    int64_t t_pass[2];          // every X pass issued while timing is on (sampled or not)
     double t_ms[2];
     bool have_direction;
     int world;                  // ranks sharing the variables axis (1: no exchange between levels)
@@ -124,6 +125,7 @@ template <typename T> static inline T* P(void* p) { return reinterpret_cast<T*>(
 static int timing_begin(lcx_ctx* h, int kind, TimingPair* tp) {
     tp->kind = -1;
     if (!h || !h->timing || kind < 0) return LCX_OK;
+    h->t_pass[kind] += 1;
     if (h->t_every > 1 && (h->t_count++ % h->t_every) != 0) return LCX_OK;
     if (h->pool.empty()) {
         HIPCHECK(hipEventCreate(&tp->a));
@@ -1211,6 +1213,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     h->t_every = 1;
     h->t_count = 0;
     h->t_launch[0] = h->t_launch[1] = 0;
+    h->t_pass[0] = h->t_pass[1] = 0;
     h->t_ms[0] = h->t_ms[1] = 0.0;
     h->have_direction = false;
     h->target_waves = prop.multiProcessorCount * 12;
@@ -1623,7 +1626,14 @@ int lcx_timing_reset(lcx_ctx* h) {
     HIPCHECK(hipStreamSynchronize(h->stream));
     LCXCHECK(timing_collect(h));
     h->t_launch[0] = h->t_launch[1] = 0;
+    h->t_pass[0] = h->t_pass[1] = 0;
     h->t_ms[0] = h->t_ms[1] = 0.0;
+    return LCX_OK;
+}
+int lcx_timing_passes(lcx_ctx* h, int kind, int64_t* passes) {
+    NEED(h);
+    if (kind < 0 || kind > 1 || !passes) return fail(LCX_ERR_ARG, "lcx_timing_passes: bad argument");
+    *passes = h->t_pass[kind];
     return LCX_OK;
 }
 

@@ -13,7 +13,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge  # noqa: E402
 
-SHAPES = {"c2": (10000, 5000, 32, np.float64), "c3lite": (50000, 20000, 64, np.float32),
+SHAPES = {"c2": (10000, 5000, 32, np.float64), "c2m64": (10000, 5000, 64, np.float64),
+          "c2m64f32": (10000, 5000, 64, np.float32), "c2f32": (10000, 5000, 32, np.float32), "c3lite": (50000, 20000, 64, np.float32),
           "c4lite": (50000, 20000, 128, np.float32), "c3": (50000, 100000, 64, np.float32)}
 
 

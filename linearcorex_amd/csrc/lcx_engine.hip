@@ -100,6 +100,7 @@ struct lcx_ctx {
     bool w1_ready;              // Wt[1] already holds ws + update (written by update_kernel)
     // launch geometry
     int nt_S, nt_KW, tn_S, tn_KW, gn_S, gv_S, pv_grid, target_waves, n_cus, nt_bpc, tn_bpc;
+    int tn_slots;               // partial slots of X^T.Y its consumers sum: tn_S, or 1 when tn_big pre-reduces many slots
     // column-tiled stream-K kernel (gemm_ct) per pass: used when the shard has enough column tiles
     bool nt_ct, tn_ct;
     bool f64_4x4;               // float64, n_hidden <= 32: the small-shard passes run on v_mfma_f64_4x4x4 (gemm_tn4)
@@ -293,7 +294,8 @@ template <typename T, int CT> struct Impl {
     static int single_round_split(int64_t tiles, int64_t capacity_blocks, int64_t kunits, int kw, int cap) {
         if (tiles < 1) tiles = 1;
         if (capacity_blocks < 1) capacity_blocks = 1;
-        int64_t by_work = kunits / ((int64_t)kw * 4);
+        const int64_t work_cap = kunits / ((int64_t)kw * 4);           // keep >= 4 contraction units per wave
+        int64_t by_work = work_cap;
         if (by_work > cap) by_work = cap;
         if (by_work < 1) by_work = 1;
         int best = 1;
@@ -303,6 +305,23 @@ template <typename T, int CT> struct Impl {
             const int64_t rounds = (blocks + capacity_blocks - 1) / capacity_blocks;
             const double score = (double)blocks / (double)(rounds * capacity_blocks) - 0.015 * s;
             if (score > best_score + 1e-9) { best_score = score; best = s; }
+        }
+        if (tiles * best * 2 >= capacity_blocks) return best;
+        // Few tiles (n_samples << n_variables for X.W^T, or the reverse for X^T.Y): the rule above leaves most of
+        // the chip idle (measured: 448 x 20000, 7 tiles, 1 split: 334 us for a 72 MB pass).  Time of the pass in
+        // units of a full-chip stream = max(1, rounds * capacity / blocks), plus what the partial tiles cost to write
+        // and sum back: per split 2 * Mp / K of the X bytes and a fixed term.
+        int64_t hi = work_cap < 64 ? work_cap : 64;                     // consumers sum the slots serially per element
+        if (hi < 1) hi = 1;
+        double best_cost = 1e30;
+        const double per_split = 2.0 * Mp / ((double)kunits * 16.0) + 0.004;
+        for (int s = 1; s <= hi; ++s) {
+            const int64_t blocks = tiles * s;
+            const int64_t rounds = (blocks + capacity_blocks - 1) / capacity_blocks;
+            double t = (double)(rounds * capacity_blocks) / (double)blocks;
+            if (t < 1.0) t = 1.0;
+            const double cost = t + per_split * s;
+            if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
         }
         return best;
     }
@@ -375,6 +394,9 @@ template <typename T, int CT> struct Impl {
         h->gv_S = pick_split(Mp / (16 * Geo<T, CT>::G_RT), pick_kw(kgv), kgv, h->target_waves / 4, 64);
         int64_t groups = cdiv(h->V, VPB);
         h->pv_grid = (int)(groups < 1024 ? (groups < 1 ? 1 : groups) : 1024);
+        // many slots (few column tiles): one wide reduction after the pass instead of a long serial sum per element in
+        // every consumer
+        h->tn_slots = (h->tn_S >= WIDE_SPLITS && cdiv(h->ldx * Mp, 32) < (1 << 20)) ? 1 : h->tn_S;
         return LCX_OK;
     }
 
@@ -403,11 +425,22 @@ template <typename T, int CT> struct Impl {
                                                                          dst, h->nt_S, h->nt_KW, skip)));
         LCXCHECK(timing_end(h, 0, &tp));
         const int64_t n = h->Npad * Mp;
+        const bool wide = h->nt_S >= WIDE_SPLITS && cdiv(n, 32) < (1 << 20);
         if (with_bj) {
             // partial tiles of Y (if split) and the Bj partials of grad_kernel, one launch
-            const int yblocks = h->nt_S > 1 ? (int)(cdiv(n, PV_THREADS) < 1024 ? cdiv(n, PV_THREADS) : 1024) : 0;
-            hipLaunchKernelGGL((reduce_y_bj_kernel<T>), dim3(yblocks + Mp), dim3(PV_THREADS), 0, h->stream, P<T>(h->ypart),
-                               h->nt_S, n, P<T>(h->ybuf), yblocks, h->bjpart, h->pv_grid, Mp, P<T>(h->ybuf) + n);
+            if (wide) {
+                const int yblocks = (int)cdiv(n, 32);
+                hipLaunchKernelGGL((reduce_y_bj_kernel<T, true>), dim3(yblocks + Mp), dim3(PV_THREADS), 0, h->stream, P<T>(h->ypart),
+                                   h->nt_S, n, P<T>(h->ybuf), yblocks, h->bjpart, h->pv_grid, Mp, P<T>(h->ybuf) + n);
+            } else {
+                const int yblocks = h->nt_S > 1 ? (int)(cdiv(n, PV_THREADS) < 1024 ? cdiv(n, PV_THREADS) : 1024) : 0;
+                hipLaunchKernelGGL((reduce_y_bj_kernel<T, false>), dim3(yblocks + Mp), dim3(PV_THREADS), 0, h->stream, P<T>(h->ypart),
+                                   h->nt_S, n, P<T>(h->ybuf), yblocks, h->bjpart, h->pv_grid, Mp, P<T>(h->ybuf) + n);
+            }
+            KCHECK();
+        } else if (wide) {
+            hipLaunchKernelGGL((reduce_partials_wide_kernel<T, T>), dim3((unsigned)cdiv(n, 32)), dim3(256), 0,
+                               h->stream, P<T>(h->ypart), h->nt_S, n, n, P<T>(h->ybuf), skip, also);
             KCHECK();
         } else if (h->nt_S > 1) {
             hipLaunchKernelGGL((reduce_partials_kernel<T, T>), dim3((unsigned)(cdiv(n, 256) < 1024 ? cdiv(n, 256) : 1024)), dim3(256), 0,
@@ -437,6 +470,12 @@ template <typename T, int CT> struct Impl {
             LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false, false>(h->stream, P<T>(h->X), h->ldx, h->Npad, h->ldx, P<T>(h->ybuf), nullptr,
                                                                          P<T>(h->dpart), h->tn_S, h->tn_KW, skip)));
         LCXCHECK(timing_end(h, 1, &tp));
+        if (h->tn_slots != h->tn_S) {
+            const int64_t n = h->ldx * Mp;
+            hipLaunchKernelGGL((reduce_partials_wide_kernel<T, T>), dim3((unsigned)cdiv(n, 32)), dim3(256), 0, h->stream,
+                               P<T>(h->dpart), h->tn_S, n, n, P<T>(h->dpart), skip, (T*)nullptr);      // in place: slot 0
+            KCHECK();
+        }
         return LCX_OK;
     }
 
@@ -508,7 +547,7 @@ template <typename T, int CT> struct Impl {
         const int single = !h->exchange;
         const unsigned int seq = single ? ++h->seq_next : 0u;
         hipLaunchKernelGGL((moments_epilogue_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream,
-                           P<T>(h->dpart), h->tn_S, h->ldx * Mp,
+                           P<T>(h->dpart), h->tn_slots, h->ldx * Mp,
                            linear ? P<T>(h->set[0].D) : (const T*)nullptr, P<T>(h->ddir), (T)eta, P<T>(s.D),
                            P<T>(h->Wt[which]), s.ry, h->V, (double)h->N, eps,
                            P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), P<T>(s.hscale),
@@ -592,7 +631,7 @@ template <typename T, int CT> struct Impl {
         const int single = !h->exchange;
         const unsigned int seq = ++h->seq_next;
         hipLaunchKernelGGL((update_kernel<T, Mp>), dim3(grid + gridy), dim3(PV_THREADS), 0, h->stream, P<T>(h->dpart),
-                           h->full_sig ? h->tn_S : 0, h->ldx * Mp, P<T>(h->grad), P<T>(h->Wt[0]), s.uj, P<T>(h->ybuf) + h->Npad * Mp, h->V,
+                           h->full_sig ? h->tn_slots : 0, h->ldx * Mp, P<T>(h->grad), P<T>(h->Wt[0]), s.uj, P<T>(h->ybuf) + h->Npad * Mp, h->V,
                            (double)h->N, eps, P<T>(h->update), P<T>(h->sgrad), h->tanpart,
                            h->full_sig ? P<T>(s.D) : (const T*)nullptr, h->full_sig ? P<T>(h->ddir) : (T*)nullptr, grid, P<T>(h->ybuf),
                            P<T>(s.Y), ny, P<T>(h->ydir), P<T>(h->Wt[1]), h->ticket + 32, h->sbuf, s.st, s.hst_dev, seq, single, h->world);
@@ -682,7 +721,7 @@ template <typename T, int CT> struct Impl {
         LCXCHECK(tn_big(h, nullptr));
         const int64_t total = h->V * Mp;
         hipLaunchKernelGGL((syn_rho_kernel<T>), dim3((unsigned)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048)), dim3(256), 0, h->stream,
-                           P<T>(h->dpart), h->tn_S, h->ldx * Mp, total, Mp, (double)h->N, s.inv_sd, P<T>(s.D), P<T>(s.rho));
+                           P<T>(h->dpart), h->tn_slots, h->ldx * Mp, total, Mp, (double)h->N, s.inv_sd, P<T>(s.D), P<T>(s.rho));
         KCHECK();
         hipLaunchKernelGGL(invert_kernel, dim3(1), dim3(256), 0, h->stream, s.ry, Mp, h->invwork, h->ryinv);
         KCHECK();

@@ -330,16 +330,55 @@ sum_partials_kernel(const double* __restrict__ part, int nblocks, int nvals, OUT
     if (tid == 0) out[k] = (OUT)s;
 }
 
+// out[i] = sum_s in[s][i] when there are many splits (few column tiles, e.g. n_samples << n_variables): 8 threads share
+// an element and sum every 8th slot, then the 8 sums are added in fixed order.  One thread per element would issue
+// nsplit dependent-latency loads (measured: 64 slots of 448 x 32: 16 us; this form ~5 us).
+template <typename T, typename OUT>
+__device__ __forceinline__ void wide_sum_block(const T* in, int nsplit, int64_t n, int64_t stride, int64_t block,
+                                               OUT* out /* may be slot 0 of `in` */, OUT* out2, T (*sh)[32]) {
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int64_t i = block * 32 + e;
+    T s = (T)0;
+    if (i < n) {
+#pragma unroll 4
+        for (int k = g; k < nsplit; k += 8) s += in[k * stride + i];
+    }
+    sh[g][e] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        T t = sh[0][e];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += sh[k][e];
+        out[i] = (OUT)t;
+        if (out2 != nullptr) out2[i] = (OUT)t;
+    }
+}
+constexpr int WIDE_SPLITS = 12;      // from this many slots on the reductions of Y use the 8-threads-per-element form
+
+template <typename T, typename OUT>
+__global__ void __launch_bounds__(256)
+reduce_partials_wide_kernel(const T* in, int nsplit, int64_t n, int64_t stride, OUT* out,
+                            const int* __restrict__ skip_flag, OUT* out2) {
+    __shared__ T sh[8][32];
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+    wide_sum_block<T, OUT>(in, nsplit, n, stride, blockIdx.x, out, out2, sh);
+}
+
 // One launch for the two reductions that follow the X.grad^T pass: blocks [0, yblocks) sum the
 // grid-level partial tiles of Y (skipped when nsplit == 1), the next nvals blocks sum the per-block
-// Bj partials into the tail of the exchange buffer.
-template <typename T>
+// Bj partials into the tail of the exchange buffer.  WIDE: the Y blocks each own 32 elements (8 threads per element).
+template <typename T, bool WIDE = false>
 __global__ void __launch_bounds__(PV_THREADS)
 reduce_y_bj_kernel(const T* __restrict__ ypart, int nsplit, int64_t n, T* __restrict__ yout, int yblocks,
                    const double* __restrict__ part, int nblocks, int nvals, T* __restrict__ tail) {
     __shared__ double bs_scratch[PV_THREADS / 64];
+    __shared__ T sh[WIDE ? 8 : 1][32];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < yblocks) {
+        if (WIDE) {
+            wide_sum_block<T, T>(ypart, nsplit, n, n, blockIdx.x, yout, (T*)nullptr, sh);
+            return;
+        }
         for (int64_t i = (int64_t)blockIdx.x * PV_THREADS + tid; i < n; i += (int64_t)yblocks * PV_THREADS) {
             T s = ypart[i];
             for (int k = 1; k < nsplit; ++k) s += ypart[k * n + i];

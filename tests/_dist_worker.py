@@ -17,6 +17,10 @@ from tests.shard_double import ShardDouble  # noqa: E402
 
 
 def main():
+    # a rank that is still running after this many seconds prints the Python stack of every thread (the launching
+    # test kills the ranks and shows this output)
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("LCX_TEST_DUMP_AFTER", "240")), exit=False)
     out_dir, n, v, m = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     mode = sys.argv[5] if len(sys.argv) > 5 else "exact"
     backend = sys.argv[6] if len(sys.argv) > 6 else "double"

@@ -23,19 +23,22 @@ def launch_hip(world, out_dir, n, v, m, mode):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2")
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2", LCX_TEST_DUMP_AFTER="100")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(out_dir),
                                        str(n), str(v), str(m), mode, "hip", str(MAX_ITER)], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
+    timed_out = False
     for p in procs:
         try:
-            out, _ = p.communicate(timeout=600)
+            out, _ = p.communicate(timeout=60 if timed_out else 150)
         except subprocess.TimeoutExpired:
+            timed_out = True
             for q in procs:
                 q.kill()
-            raise
+            out, _ = p.communicate()
         outs.append(out.decode(errors="replace"))
+    assert not timed_out, "ranks did not finish in 150 s (a normal run takes 5 s):\n" + "\n-----\n".join(o[-2000:] for o in outs)
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
 

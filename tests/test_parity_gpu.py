@@ -56,6 +56,11 @@ CASES = [
     (1000, 65, 17, 0.36, 17),
     (333, 129, 128, 0.0, 18),
     (65, 1025, 3, 0.216, 19),
+    # few column tiles against a long contraction: the split of the pass goes up to 64 slots and the slots are summed
+    # by the 8-threads-per-element reductions (n_samples << n_variables for X.W^T, the reverse for X^T.Y)
+    (200, 8000, 6, 0.36, 20),
+    (20000, 100, 5, 0.216, 21),
+    (448, 6000, 30, 0.0, 22),
 ]
 
 
@@ -383,9 +388,10 @@ def test_singular_warning_path(g4, capsys):
     # rank-deficient covariance: the problem is ill-conditioned, so the trajectory is only
     # reproducible to ~1e-5 for the first iterations and then amplifies last-bit differences of the
     # standardised data (device column sums vs NumPy's pairwise sums): the run towards the singular
-    # solution may stop some iterations earlier or later
+    # solution may stop some iterations earlier or later (any change of summation order moves it: 88 iterations in
+    # the reference, 70-95 here depending on how the contraction of the passes is split)
     h, h_ref = np.asarray(out.history["TC"], np.float64), g4["f64_dup_history_tc"]
-    assert abs(len(h) - len(h_ref)) <= 0.2 * len(h_ref)
+    assert abs(len(h) - len(h_ref)) <= 0.3 * len(h_ref)
     assert relerr(h[:20], h_ref[:20]) < 1e-6, (relerr(h[:20], h_ref[:20]), relerr(h[:40], h_ref[:40]), len(h), h[-1], h_ref[-1])
     assert abs(h[-1] - h_ref[-1]) < 3e-2 * abs(h_ref[-1])   # TC diverges towards the singular solution
     out32 = _fit(g4["dup_x"], 3, "f32", max_iter=300)
@@ -425,3 +431,22 @@ def test_generated_data_is_standardised():
     assert np.allclose(be2.download_x(), x[:, 100:], atol=1e-6)
     be.close()
     be2.close()
+
+
+@pytest.mark.parametrize("shape", [(300, 6000, 8), (12000, 90, 4)])
+def test_many_slots_end_to_end(shape):
+    """Few samples against many variables (the regime of BASELINE.json configs[4]) and the reverse: one of the two X
+    passes has only a handful of column tiles, its contraction is split into up to 64 slots.  A short float64 fit must
+    follow the oracle step for step."""
+    from linearcorex_amd import Corex
+    n, v, m = shape
+    x, _ = O.gen_planted(n, v, m, seed=31)
+    ref = O.fit_ns(x, m, seed=0, dtype=np.float64, max_iter=12)
+    out = Corex(n_hidden=m, seed=0, max_iter=12, dtype=np.float64, device=0).fit(x)
+    geo = out._backend.geometry()
+    assert max(geo["nt_split"], geo["tn_split"]) >= 12, geo
+    h_ref, h_out = np.array(ref.history_tc), np.array(out.history["TC"], dtype=np.float64)
+    assert len(h_ref) == len(h_out)
+    assert np.max(np.abs(h_ref - h_out) / np.maximum(1.0, np.abs(h_ref))) < 1e-8
+    assert np.array_equal(out.clusters(), ref.clusters())
+    assert relerr(out.ws, ref.ws) < 1e-6

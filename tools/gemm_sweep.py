@@ -14,7 +14,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge  # noqa: E402
 
 SHAPES = {"c2": (10000, 5000, 32, np.float64), "c2m64": (10000, 5000, 64, np.float64),
-          "c2m64f32": (10000, 5000, 64, np.float32), "c2f32": (10000, 5000, 32, np.float32), "c3lite": (50000, 20000, 64, np.float32),
+          "c2m64f32": (10000, 5000, 64, np.float32), "c2f32": (10000, 5000, 32, np.float32),
+          "c2m128": (10000, 5000, 128, np.float64), "c2m128f32": (10000, 5000, 128, np.float32),
+          "c2m16": (10000, 5000, 16, np.float64), "c2m16f32": (10000, 5000, 16, np.float32),
+          "mid64": (20000, 20000, 64, np.float64), "mid64f32": (20000, 20000, 64, np.float32),
+          "mid32": (20000, 20000, 32, np.float64), "mid32f32": (20000, 20000, 32, np.float32),
+          "tall": (100000, 500, 16, np.float64), "tallf32": (100000, 500, 16, np.float32),
+          "small": (500, 2000, 8, np.float64), "c5": (448, 20000, 32, np.float64), "c5f32": (448, 20000, 32, np.float32), "c3lite": (50000, 20000, 64, np.float32),
           "c4lite": (50000, 20000, 128, np.float32), "c3": (50000, 100000, 64, np.float32)}
 
 
@@ -27,6 +33,8 @@ def main():
     gb = es * (n * v + m * v + n * m) / 1e9
     fl = 2.0 * n * v * m / 1e12
     combos = [(None, None)] + list(itertools.product([4, 8], [1, 2, 3, 4, 6]))
+    if os.environ.get("SWEEP_DEFAULT_ONLY"):
+        combos = [(None, None)]
     for kind, pre in ((0, "LCX_NT"), (1, "LCX_TN")):
         for kw, s in combos:
             for k in ("LCX_NT_KW", "LCX_NT_S", "LCX_TN_KW", "LCX_TN_S"):

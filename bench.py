@@ -45,6 +45,8 @@ WORKLOADS = {
     "c3f64m32": (50000, 50000, 32, "f64"),
     "c3f64m128": (50000, 50000, 128, "f64"),
     "c2f32": (10000, 5000, 32, "f32"),   # config-2 shape in the reference's own precision (not a BASELINE line)
+    "c2m64": (10000, 5000, 64, "f64"), "c2m64f32": (10000, 5000, 64, "f32"), "c2m128f32": (10000, 5000, 128, "f32"),
+    "mid32": (20000, 20000, 32, "f64"), "mid32f32": (20000, 20000, 32, "f32"), "mid64f32": (20000, 20000, 64, "f32"),
     "c5": (400, 20000, 30, "f64"),       # configs[4] stand-in shape (few samples, many variables; not a bench line)
     "c5f32": (400, 20000, 30, "f32"),
     "tiny": (2000, 640, 8, "f64"),       # plumbing check

@@ -381,13 +381,18 @@ template <typename T, int CT> struct Impl {
         // ceil(blocks / super tiles) + 1 partial slots, so it only pays when there are many column tiles.
         {
             const char* force = getenv("LCX_GEMM");          // "ct" / "tn" force one kernel for both passes
-            const int max_slots = env_int("LCX_CT_MAX_SLOTS", 6);
+            // Slot cap of gemm_ct, from iteration-level A/B runs (tools/slots_ab.sh, profiles/r01_slots_ab.txt): with
+            // B shared through LDS it beats the wave-split kernel at up to 27 slots whenever a wave would otherwise
+            // re-fetch a wide B (float32 from 32 factors, float64 from 64: +6..+59 % it/s at 10k x 5k .. 20k x 20k),
+            // provided the contraction is long; the float64 4x4x4 kernel (<= 32 factors) and 16-factor float32 keep
+            // the small-shard kernel above 6 slots, and so do short contractions (448 rows: 20 us vs 25 us).
+            const int relaxed = sizeof(T) == 8 ? (CT >= 4 ? 32 : 6) : (CT >= 2 ? 32 : 6);
             int nb, ns, sl;
             ct_geometry<T, CT>(cus, h->ldx, h->Npad, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
-            h->nt_ct = force ? !strcmp(force, "ct") : sl <= max_slots;
+            h->nt_ct = force ? !strcmp(force, "ct") : sl <= env_int("LCX_CT_MAX_SLOTS", h->ldx >= 4096 ? relaxed : 6);
             if (h->nt_ct) { h->nt_nb = nb; h->nt_nsuper = ns; h->nt_S = sl; h->nt_KW = CtShape<T, CT>::KW; }
             ct_geometry<T, CT>(cus, h->Npad, h->ldx, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
-            h->tn_ct = force ? !strcmp(force, "ct") : sl <= max_slots;
+            h->tn_ct = force ? !strcmp(force, "ct") : sl <= env_int("LCX_CT_MAX_SLOTS", h->Npad >= 4096 ? relaxed : 6);
             if (h->tn_ct) { h->tn_nb = nb; h->tn_nsuper = ns; h->tn_S = sl; h->tn_KW = CtShape<T, CT>::KW; }
         }
         h->gn_S = pick_split(Mp / (16 * Geo<T, CT>::G_RT), pick_kw(kgn), kgn, h->target_waves / 4, 64);

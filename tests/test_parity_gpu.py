@@ -450,3 +450,24 @@ def test_many_slots_end_to_end(shape):
     assert np.max(np.abs(h_ref - h_out) / np.maximum(1.0, np.abs(h_ref))) < 1e-8
     assert np.array_equal(out.clusters(), ref.clusters())
     assert relerr(out.ws, ref.ws) < 1e-6
+
+
+@pytest.mark.parametrize("tag,m", [("f64", 40), ("f32", 20)])
+def test_ct_many_slots_end_to_end(tag, m):
+    """Mid-size shards (4200 x 4200): the column-tiled kernel is selected with ~30 partial slots per pass (float32 from
+    32 padded factors, float64 from 64), the slots are pre-reduced by the wide reductions.  A short fit must follow the
+    oracle."""
+    from linearcorex_amd import Corex
+    n = v = 4200
+    x, _ = O.gen_planted(n, v, m, seed=41)
+    ref = O.fit_ns(x, m, seed=0, dtype=DT[tag], max_iter=6)
+    out = Corex(n_hidden=m, seed=0, max_iter=6, dtype=DT[tag], device=0).fit(x)
+    be = out._backend
+    assert "gemm_ct_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)
+    geo = be.geometry()
+    assert min(geo["nt_split"], geo["tn_split"]) >= 12, geo
+    h_ref, h_out = np.array(ref.history_tc, np.float64), np.array(out.history["TC"], dtype=np.float64)
+    assert len(h_ref) == len(h_out)
+    tol = 1e-8 if tag == "f64" else 2e-3
+    assert np.max(np.abs(h_ref - h_out) / np.maximum(1.0, np.abs(h_ref))) < tol
+    assert np.array_equal(out.clusters(), ref.clusters())

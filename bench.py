@@ -53,12 +53,22 @@ WORKLOADS = {
 }
 
 
+def _adhoc(name):
+    """'NxVxM:f32' -> WORKLOADS entry (probing shapes outside BASELINE.json)."""
+    if name not in WORKLOADS:
+        dims, tag = name.split(":")
+        n, v, m = (int(t) for t in dims.split("x"))
+        assert tag in ("f32", "f64")
+        WORKLOADS[name] = (n, v, m, tag)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=70)
     ap.add_argument("--warmup", type=int, default=7)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c2",
+                    help="one of %s, or an ad-hoc shard shape NxVxM:f32|f64 (not a BASELINE line)" % ", ".join(sorted(WORKLOADS)))
     ap.add_argument("--cpu-iters-per-stage", type=int, default=40,
                     help="bounded CPU-baseline sample: oracle iterations per annealing stage (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -76,7 +86,9 @@ def parse():
                          "(linearcorex.py:321); linear: trials cost no pass over X")
     ap.add_argument("--no-also-linear", dest="also_linear", action="store_false",
                     help="skip the second measurement in linear trial mode (reported under config.linear_trial_mode)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    _adhoc(args.workload)
+    return args
 
 
 def cpu_baseline(x, m, dtype, iters_per_stage):

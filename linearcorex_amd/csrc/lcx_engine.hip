@@ -381,18 +381,30 @@ template <typename T, int CT> struct Impl {
         // ceil(blocks / super tiles) + 1 partial slots, so it only pays when there are many column tiles.
         {
             const char* force = getenv("LCX_GEMM");          // "ct" / "tn" force one kernel for both passes
-            // Slot cap of gemm_ct, from iteration-level A/B runs (tools/slots_ab.sh, profiles/r01_slots_ab.txt): with
-            // B shared through LDS it beats the wave-split kernel at up to 27 slots whenever a wave would otherwise
-            // re-fetch a wide B (float32 from 32 factors, float64 from 64: +6..+59 % it/s at 10k x 5k .. 20k x 20k),
-            // provided the contraction is long; the float64 4x4x4 kernel (<= 32 factors) and 16-factor float32 keep
-            // the small-shard kernel above 6 slots, and so do short contractions (448 rows: 20 us vs 25 us).
-            const int relaxed = sizeof(T) == 8 ? (CT >= 4 ? 32 : 6) : (CT >= 2 ? 32 : 6);
+            // When does gemm_ct (B shared through LDS, stream-K) beat the wave-split kernel although it writes more
+            // partial slots?  From forced A/B runs at pass and iteration level (tools/select_sweep.sh, tools/slots_ab.sh;
+            // profiles/r01_slots_ab.txt, r01_select_sweep_*.txt):
+            //   float32 from 32 padded factors, float64 from 64: whenever a wave would otherwise re-fetch a wide B - up to
+            //     32 slots (+6..+59 % it/s at 10k x 5k .. 20k x 20k), or more slots if the partial tiles stay below ~12 %
+            //     of the X bytes (1000 x 120000 x 64: 129 slots, 174 us vs 320 us) - on contractions that are not short;
+            //   float64 up to 32 factors: the 4x4x4 kernel is the faster stream; its fixed rounds lose to the stream-K
+            //     balancing at 8 slots only on long contractions (20k x 20k: +7.6 % it/s; 2500 x 20000: -5 %);
+            //   16-factor float32 and short contractions (448 rows: 20 us vs 25 us) keep the small-shard kernel.
+            auto use_ct = [&](int sl, int64_t K) -> bool {
+                const char* e = getenv("LCX_CT_MAX_SLOTS");
+                if (e && *e) return sl <= atoi(e);
+                if (sl <= 6) return true;
+                const bool small_partials = sl <= 160 && (double)sl * Mp <= 0.12 * (double)K;
+                if (sizeof(T) == 4) return CT >= 2 && K >= 2048 && (sl <= 32 || small_partials);
+                if (CT >= 4) return K >= 4096 && (sl <= 32 || small_partials);
+                return K >= 8192 && sl <= 8;
+            };
             int nb, ns, sl;
             ct_geometry<T, CT>(cus, h->ldx, h->Npad, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
-            h->nt_ct = force ? !strcmp(force, "ct") : sl <= env_int("LCX_CT_MAX_SLOTS", h->ldx >= 4096 ? relaxed : 6);
+            h->nt_ct = force ? !strcmp(force, "ct") : use_ct(sl, h->ldx);
             if (h->nt_ct) { h->nt_nb = nb; h->nt_nsuper = ns; h->nt_S = sl; h->nt_KW = CtShape<T, CT>::KW; }
             ct_geometry<T, CT>(cus, h->Npad, h->ldx, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
-            h->tn_ct = force ? !strcmp(force, "ct") : sl <= env_int("LCX_CT_MAX_SLOTS", h->Npad >= 4096 ? relaxed : 6);
+            h->tn_ct = force ? !strcmp(force, "ct") : use_ct(sl, h->Npad);
             if (h->tn_ct) { h->tn_nb = nb; h->tn_nsuper = ns; h->tn_S = sl; h->tn_KW = CtShape<T, CT>::KW; }
         }
         h->gn_S = pick_split(Mp / (16 * Geo<T, CT>::G_RT), pick_kw(kgn), kgn, h->target_waves / 4, 64);

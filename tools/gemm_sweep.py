@@ -28,7 +28,12 @@ def main():
     ge.build()
     from linearcorex_amd.backend import HipBackend
     name = sys.argv[1] if len(sys.argv) > 1 else "c2"
-    n, v, m, dt = SHAPES[name]
+    if name in SHAPES:
+        n, v, m, dt = SHAPES[name]
+    else:                                   # "NxVxM:f32"
+        dims, tag = name.split(":")
+        n, v, m = (int(t) for t in dims.split("x"))
+        dt = np.float32 if tag == "f32" else np.float64
     es = np.dtype(dt).itemsize
     gb = es * (n * v + m * v + n * m) / 1e9
     fl = 2.0 * n * v * m / 1e12

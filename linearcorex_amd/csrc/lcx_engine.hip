@@ -100,6 +100,7 @@ struct lcx_ctx {
     bool w1_ready;              // Wt[1] already holds ws + update (written by update_kernel)
     // launch geometry
     int nt_S, nt_KW, tn_S, tn_KW, gn_S, gv_S, pv_grid, target_waves, n_cus, nt_bpc, tn_bpc;
+    int tan_blocks;             // per-block partials of update_tangent waiting in tanpart (summed by the next evaluation's tail)
     int tn_slots;               // partial slots of X^T.Y its consumers sum: tn_S, or 1 when tn_big pre-reduces many slots
     // column-tiled stream-K kernel (gemm_ct) per pass: used when the shard has enough column tiles
     bool nt_ct, tn_ct;
@@ -561,19 +562,33 @@ template <typename T, int CT> struct Impl {
         const int* skip = &s.st->invalid;
         const size_t lds = ((size_t)Mp * Mp + (size_t)VPB * Mp) * sizeof(T);
         LCXCHECK(allow_lds(moments_epilogue_kernel<T, Mp>, lds));
-        const int single = !h->exchange;
-        const unsigned int seq = single ? ++h->seq_next : 0u;
         hipLaunchKernelGGL((moments_epilogue_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream,
                            P<T>(h->dpart), h->tn_slots, h->ldx * Mp,
                            linear ? P<T>(h->set[0].D) : (const T*)nullptr, P<T>(h->ddir), (T)eta, P<T>(s.D),
                            P<T>(h->Wt[which]), s.ry, h->V, (double)h->N, eps,
                            P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), P<T>(s.hscale),
-                           h->tcpart, skip, h->ticket + 16, h->sbuf, s.st, s.hst_dev, seq, single, (const SetState*)h->set[0].st);
+                           h->tcpart, skip);
         KCHECK();
-        if (single) s.seq_expect = seq;
         // H partial of THIS set (:294), so that the update that follows an accepted trial needs no exchange of
-        // its own: it rides in the scalar all-reduce of the evaluation
-        LCXCHECK(gram(h, P<T>(s.rir), h->ldx, P<T>(s.hscale), h->gv_S, skip, P<T>(h->gpart)));
+        // its own: it rides in the scalar all-reduce of the evaluation.  The same launch carries the tail block of the
+        // evaluation (log sums -> sbuf[0..1], a pending update_tangent -> sbuf[2], TC + publication with one GPU).
+        const int single = !h->exchange;
+        const unsigned int seq = single ? ++h->seq_next : 0u;
+        TcTail tail{h->tcpart, h->pv_grid, h->tanpart, h->tan_blocks, h->sbuf, s.st, h->set[0].st, s.hst_dev, seq, single, skip};
+        h->tan_blocks = 0;
+        {
+            constexpr int RT = Geo<T, CT>::G_RT;
+            const int kgroups = (int)(h->ldx / 16), kw = pick_kw(kgroups);
+            dim3 grid((unsigned)(Mp / (16 * RT)), (unsigned)h->gv_S, 2);
+            const size_t glds = (size_t)kw * 16 * RT * Mp * sizeof(T);
+            switch (kw) {
+                case 1: hipLaunchKernelGGL((gram_tc_kernel<T, CT, RT, 1>), grid, dim3(64), glds, h->stream, P<T>(s.rir), P<T>(s.hscale), P<T>(h->gpart), kgroups, h->gv_S, skip, tail); break;
+                case 2: hipLaunchKernelGGL((gram_tc_kernel<T, CT, RT, 2>), grid, dim3(128), glds, h->stream, P<T>(s.rir), P<T>(s.hscale), P<T>(h->gpart), kgroups, h->gv_S, skip, tail); break;
+                default: hipLaunchKernelGGL((gram_tc_kernel<T, CT, RT, 4>), grid, dim3(256), glds, h->stream, P<T>(s.rir), P<T>(s.hscale), P<T>(h->gpart), kgroups, h->gv_S, skip, tail); break;
+            }
+            KCHECK();
+        }
+        if (single) s.seq_expect = seq;
         hipLaunchKernelGGL((reduce_wide_kernel<T, double>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
                            P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, h->sbuf + SB_H, skip);
         KCHECK();
@@ -645,15 +660,13 @@ template <typename T, int CT> struct Impl {
         const int grid = (int)(cdiv(h->V * Mp, PV_THREADS) < 1536 ? cdiv(h->V * Mp, PV_THREADS) : 1536);
         const int64_t ny = h->Npad * Mp;
         const int gridy = (int)(cdiv(ny, PV_THREADS) < 512 ? cdiv(ny, PV_THREADS) : 512);
-        const int single = !h->exchange;
-        const unsigned int seq = ++h->seq_next;
         hipLaunchKernelGGL((update_kernel<T, Mp>), dim3(grid + gridy), dim3(PV_THREADS), 0, h->stream, P<T>(h->dpart),
                            h->full_sig ? h->tn_slots : 0, h->ldx * Mp, P<T>(h->grad), P<T>(h->Wt[0]), s.uj, P<T>(h->ybuf) + h->Npad * Mp, h->V,
                            (double)h->N, eps, P<T>(h->update), P<T>(h->sgrad), h->tanpart,
                            h->full_sig ? P<T>(s.D) : (const T*)nullptr, h->full_sig ? P<T>(h->ddir) : (T*)nullptr, grid, P<T>(h->ybuf),
-                           P<T>(s.Y), ny, P<T>(h->ydir), P<T>(h->Wt[1]), h->ticket + 32, h->sbuf, s.st, s.hst_dev, seq, single, h->world);
+                           P<T>(s.Y), ny, P<T>(h->ydir), P<T>(h->Wt[1]), h->world);
         KCHECK();
-        if (single) s.seq_expect = seq;
+        h->tan_blocks = grid + gridy;        // summed into sbuf[2] / the state by the tail of the first trial's evaluation
         h->w1_ready = true;
         return LCX_OK;
     }
@@ -1579,6 +1592,21 @@ int lcx_read_state(lcx_ctx* h, int which, double* out) {
     WHICH_OK(which);
     if (!out) return fail(LCX_ERR_ARG, "lcx_read_state: null");
     MomentSet& ms = h->set[which];
+    if (which == 0 && h->tan_blocks > 0) {
+        // update_tangent of the direction in flight is normally summed by the tail of the first trial's evaluation;
+        // somebody wants the current solution's state before that
+        const int single = !h->exchange;
+        const unsigned int seq = single ? ++h->seq_next : 0u;
+        if (h->dtype == LCX_F32)
+            hipLaunchKernelGGL((tangent_finalize_kernel<float>), dim3(1), dim3(256), 0, h->stream, h->tanpart, h->tan_blocks, h->sbuf, ms.st,
+                               ms.hst_dev, seq, single);
+        else
+            hipLaunchKernelGGL((tangent_finalize_kernel<double>), dim3(1), dim3(256), 0, h->stream, h->tanpart, h->tan_blocks, h->sbuf, ms.st,
+                               ms.hst_dev, seq, single);
+        KCHECK();
+        if (single) ms.seq_expect = seq;
+        h->tan_blocks = 0;
+    }
     LCXCHECK(wait_published(h, ms));
     const SetState& s = *ms.hst;
     out[LCX_S_TC] = s.tc;

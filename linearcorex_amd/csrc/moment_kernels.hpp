@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gemm_kernels.hpp"       // tn_body (gram_tc_kernel)
+
 namespace lcx {
 
 constexpr int PV_THREADS = 256;
@@ -204,7 +206,12 @@ __device__ __forceinline__ void tc_store(const double* sbuf, SetState* st) {
 // (linearcorex.py:260, :264-269, :272-273).  grid-stride over variable groups.
 // dynamic LDS: ry_s[Mp*Mp] (T) + rir_s[VPB*Mp] (T)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int Mp>
+// The two log sums leave the kernel as per-block pairs in tcpart (plain stores): they are summed, TC is formed and the
+// state is published by the tail block that rides in the launch of the H Gram that always follows (gram_tc_kernel).
+// A fused tail here (ticket, last block sums and publishes) cost 11-14 us on top of an 8-16 us body: two dependent
+// atomic round trips plus the publication (tools/epilogue_probe.hip, profiles/r01_epilogue_probe_tail.txt).
+// ABL is for ablation probes only: 1 = no m x m matvec, 2 = no M x V stores, 8 = no logarithms, 16 = first slot only.
+template <typename T, int Mp, int ABL = 0>
 __global__ void __launch_bounds__(PV_THREADS)
 moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride,
                         const T* __restrict__ d_base, const T* __restrict__ d_dir, T eta,
@@ -213,24 +220,14 @@ moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride
                         double n_samples, double eps, T* __restrict__ rho_o, T* __restrict__ rir_o,
                         T* __restrict__ qij_o, T* __restrict__ si_o, T* __restrict__ q2_o,
                         T* __restrict__ hscale_o, double* __restrict__ tcpart,
-                        const int* __restrict__ skip_flag, unsigned int* __restrict__ ticket,
-                        double* __restrict__ sbuf, SetState* st, SetState* host, unsigned int seq, int single,
-                        const SetState* st_cur) {
+                        const int* __restrict__ skip_flag) {
     constexpr int VPB = PV_THREADS / Mp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* ry_s = reinterpret_cast<T*>(smem_raw);
     T* rir_s = ry_s + Mp * Mp;
     __shared__ T gs_scratch[PV_THREADS / 64];
     __shared__ double bs_scratch[PV_THREADS / 64];
-    if (skip_flag != nullptr && *skip_flag != 0) {
-        // invalid trial (:250-251): nothing to compute, but with one GPU the host is waiting for the scalars
-        if (single && blockIdx.x == 0 && threadIdx.x == 0) {
-            tc_store<T>(sbuf, st);
-            if (st != st_cur) st->tangent = st_cur->tangent;
-            publish_state(st, host, seq);
-        }
-        return;
-    }
+    if (skip_flag != nullptr && *skip_flag != 0) return;       // invalid trial (:250-251): the tail block still publishes
 
     const int tid = threadIdx.x, vl = tid / Mp, j = tid % Mp;
     for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) ry_s[idx] = (T)ry[idx];
@@ -250,9 +247,10 @@ moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride
             d = d_base[o] + eta * d_dir[o];
         } else {
             d = dpart[o];
-            for (int k = 1; k < nsplit; ++k) d += dpart[k * pstride + o];
+            if (!(ABL & 16))
+                for (int k = 1; k < nsplit; ++k) d += dpart[k * pstride + o];
         }
-        if (ok) d_out[o] = d;
+        if (ok && !(ABL & 2)) d_out[o] = d;
         const T rho = ok ? (c1 * d / ns + c2 * W[o]) : (T)0;
         const T inv = (T)1 / ((T)1 - rho * rho);
         const T rir = rho * inv;
@@ -260,59 +258,37 @@ moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride
         rir_s[vl * Mp + j] = rir;
         const T si = group_sum<Mp, T>(rho * rir, gs_scratch, tid);
         __syncthreads();
-        T qv = (T)0;
+        T qv = (ABL & 1) ? rir : (T)0;
+        if (!(ABL & 1)) {
 #pragma unroll 8
-        for (int k = 0; k < Mp; ++k) qv += ry_s[k * Mp + j] * rir_s[vl * Mp + k];   // ry symmetric
+            for (int k = 0; k < Mp; ++k) qv += ry_s[k * Mp + j] * rir_s[vl * Mp + k];   // ry symmetric
+        }
         const T q2 = group_sum<Mp, T>(rir * (qv - si * rho), gs_scratch, tid);
         if (ok) {
-            rho_o[o] = rho;
-            rir_o[o] = rir;
-            qij_o[o] = qv;
+            if (!(ABL & 2)) {
+                rho_o[o] = rho;
+                rir_o[o] = rir;
+                qij_o[o] = qv;
+            }
             if (j == 0) {
                 si_o[v] = si;
                 q2_o[v] = q2;
                 hscale_o[v] = (T)1 / ((T)1 + q2);
-                s1 += (double)log((T)1 + si);
-                s2 += (double)log((T)1 + q2);
+                if (ABL & 8) {
+                    s1 += (double)si;
+                    s2 += (double)q2;
+                } else {
+                    s1 += (double)log((T)1 + si);
+                    s2 += (double)log((T)1 + q2);
+                }
             }
         }
     }
     s1 = block_sum<double>(s1, bs_scratch, tid);
     s2 = block_sum<double>(s2, bs_scratch, tid);
-    // The block that draws the last ticket sums the per-block pairs in index order (deterministic) into
-    // sbuf[0..1]: no separate reduction launch.
-    __shared__ int last_s;
     if (tid == 0) {
-        __hip_atomic_store(&tcpart[2 * blockIdx.x], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&tcpart[2 * blockIdx.x + 1], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // 8-byte agent-scope atomics on both sides of the hand-off (write-through stores, drained before the
-        // ticket; L1-bypassing loads in the last block): no L2 write-back fence per block - with hundreds of
-        // blocks that have just written the M x V outputs a release fence costs microseconds each
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        last_s = arrive_last(ticket, blockIdx.x, gridDim.x) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!last_s) return;
-    // all loads in flight before the first add: the tail is latency, not bandwidth (grid <= 1024 blocks)
-    double v1[4], v2[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int b = tid + k * PV_THREADS;
-        const bool ok = b < (int)gridDim.x;
-        v1[k] = ok ? __hip_atomic_load(&tcpart[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-        v2[k] = ok ? __hip_atomic_load(&tcpart[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-    }
-    double a1 = (v1[0] + v1[1]) + (v1[2] + v1[3]), a2 = (v2[0] + v2[1]) + (v2[2] + v2[3]);
-    a1 = block_sum<double>(a1, bs_scratch, tid);
-    a2 = block_sum<double>(a2, bs_scratch, tid);
-    if (tid == 0) {
-        sbuf[0] = a1;
-        sbuf[1] = a2;
-        if (single) {               // nothing to exchange: TC, the tangent of the direction in flight, host mirror
-            tc_store<T>(sbuf, st);
-            if (st != st_cur) st->tangent = st_cur->tangent;
-            publish_state(st, host, seq);
-        }
+        tcpart[2 * blockIdx.x] = s1;
+        tcpart[2 * blockIdx.x + 1] = s2;
     }
 }
 
@@ -488,8 +464,7 @@ update_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, const T*
               T* __restrict__ sgrad_o, double* __restrict__ tanpart,
               const T* __restrict__ d_cur, T* __restrict__ d_dir_o,
               int update_blocks, const T* __restrict__ yg, const T* __restrict__ ycur, int64_t ny,
-              T* __restrict__ ydir_o, T* __restrict__ w1_o, unsigned int* __restrict__ ticket,
-              double* __restrict__ sbuf, SetState* st, SetState* host, unsigned int seq, int single, int n_ranks) {
+              T* __restrict__ ydir_o, T* __restrict__ w1_o, int n_ranks) {
     __shared__ double bs_scratch[PV_THREADS / 64];
     const int tid = threadIdx.x;
     const T c1 = (T)(1.0 - eps * eps), c2 = (T)(eps * eps), ns = (T)n_samples;
@@ -536,32 +511,98 @@ update_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, const T*
             }
         }
     }
-    const int all_blocks = gridDim.x;
+    // per-block partial of update_tangent: summed by the tail block of the first trial's evaluation (gram_tc_kernel),
+    // or by tangent_finalize_kernel when somebody asks for the state before that
     tan = block_sum<double>(tan, bs_scratch, tid);
-    // last update block (ticket): fixed-order sum of the per-block partials -> sbuf[2]; with one GPU also the
-    // state scalar and the host mirror
-    __shared__ int last_s;
-    if (tid == 0) {
-        __hip_atomic_store(&tanpart[blockIdx.x], tan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        last_s = arrive_last(ticket, blockIdx.x, (unsigned int)all_blocks) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!last_s) return;
-    double v[8];                                  // all_blocks <= 2048
+    if (tid == 0) tanpart[blockIdx.x] = tan;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Tail of a moment evaluation, run by ONE block that rides in another launch (gram_tc_kernel): sums the per-block log
+// sums of moments_epilogue_kernel into sbuf[0..1], a pending update_tangent (per-block partials of update_kernel)
+// into sbuf[2], and - with one GPU - forms TC and publishes the state to the host mirror.  Fixed summation order for a
+// given block size: deterministic.
+// ------------------------------------------------------------------------------------------------
+struct TcTail {
+    const double* tcpart; int n_tc;          // (s1, s2) pairs, one per epilogue block
+    const double* tanpart; int n_tan;        // tangent partials of the direction in flight (0: none pending)
+    double* sbuf;
+    SetState* st;                            // state of the evaluated set
+    SetState* st_cur;                        // state of the current solution (owner of the tangent)
+    SetState* host;
+    unsigned int seq;
+    int single;                              // one GPU: nothing to exchange, publish here
+    const int* skip_flag;                    // invalid trial: no sums were written
+};
+
+// sum over the block (any multiple of 64 threads up to 512), result valid in thread 0
+__device__ __forceinline__ double tail_block_sum(double v, double* scratch /* [8] */) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int b = tid + k * PV_THREADS;
-        v[k] = b < all_blocks ? __hip_atomic_load(&tanpart[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = scratch[0];
+    const int nw = (int)blockDim.x >> 6;
+    for (int w = 1; w < nw; ++w) s += scratch[w];
+    return s;
+}
+
+template <typename T>
+__device__ __forceinline__ void tc_tail_block(const TcTail& t) {
+    __shared__ double tail_scratch[8];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const bool skipped = t.skip_flag != nullptr && *t.skip_flag != 0;
+    double a1 = 0.0, a2 = 0.0, tg = 0.0;
+    if (!skipped)
+        for (int b = tid; b < t.n_tc; b += nt) { a1 += t.tcpart[2 * b]; a2 += t.tcpart[2 * b + 1]; }
+    for (int b = tid; b < t.n_tan; b += nt) tg += t.tanpart[b];
+    a1 = tail_block_sum(a1, tail_scratch);
+    a2 = tail_block_sum(a2, tail_scratch);
+    if (t.n_tan > 0) tg = tail_block_sum(tg, tail_scratch);
+    if (tid != 0) return;
+    if (!skipped) { t.sbuf[0] = a1; t.sbuf[1] = a2; }
+    if (t.n_tan > 0) {
+        t.sbuf[2] = tg;
+        if (t.single) t.st_cur->tangent = tg;
     }
-    double a = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-    a = block_sum<double>(a, bs_scratch, tid);
-    if (tid == 0) {
-        sbuf[2] = a;
-        if (single) { st->tangent = a; publish_state(st, host, seq); }
+    if (t.single) {                 // nothing to exchange: TC, the tangent of the direction in flight, host mirror
+        tc_store<T>(t.sbuf, t.st);
+        if (t.st != t.st_cur) t.st->tangent = t.st_cur->tangent;
+        publish_state(t.st, t.host, t.seq);
     }
 }
 
+// H partial Gram (rhoinvrho scaled by 1/(1+Qi-Si^2), linearcorex.py:294) in blockIdx.z == 0, the tail of the moment
+// evaluation in the single block z == 1: the host sees TC a few microseconds into this launch instead of at the end
+// of a serial ticket / last-block chain in the epilogue.
+template <typename T, int CT, int RT, int KW>
+__global__ void __launch_bounds__(64 * KW)
+gram_tc_kernel(const T* __restrict__ A, const T* __restrict__ rowscale, T* __restrict__ out, int kgroups, int nsplit,
+               const int* __restrict__ skip_flag, TcTail tail) {
+    if (blockIdx.z == 1) {
+        if (blockIdx.x == 0 && blockIdx.y == 0) tc_tail_block<T>(tail);
+        return;
+    }
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+    tn_body<T, CT, RT, KW, true, 0, 4>(A, 16 * CT, 16 * RT, A, rowscale, out, 16 * CT, kgroups, nsplit, blockIdx.x, blockIdx.y);
+}
+
+// update_tangent on demand (lcx_read_state of the current solution before any trial was evaluated)
+template <typename T>
+__global__ void __launch_bounds__(256)
+tangent_finalize_kernel(const double* __restrict__ tanpart, int n_tan, double* __restrict__ sbuf, SetState* st, SetState* host,
+                        unsigned int seq, int single) {
+    __shared__ double tail_scratch[8];
+    double tg = 0.0;
+    for (int b = threadIdx.x; b < n_tan; b += blockDim.x) tg += tanpart[b];
+    tg = tail_block_sum(tg, tail_scratch);
+    if (threadIdx.x == 0) {
+        sbuf[2] = tg;
+        if (single) { st->tangent = tg; publish_state(st, host, seq); }
+    }
+}
 
 // out = a + eta * b  (Y of a line-search trial from Y and Y(update))
 // w_update = ws + eta * update (:320)

@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <sched.h>
 
 #include <string>
 #include <vector>
@@ -1580,6 +1581,7 @@ static int wait_published(lcx_ctx* h, MomentSet& s) {
                 return fail(LCX_ERR_STATE, "stream drained but the state mirror was not published");
             }
             if (q != hipErrorNotReady) HIPCHECK(q);
+            sched_yield();                   // several ranks of one box may share few cores (tests: two ranks + gloo threads)
         }
         __builtin_ia32_pause();
     }

@@ -16,14 +16,15 @@ pytestmark = pytest.mark.gpu
 MAX_ITER = 25          # per annealing stage: gloo stages every CUDA all-reduce through the host (slow)
 
 
-def launch_hip(world, out_dir, n, v, m, mode):
+def _launch_once(world, out_dir, n, v, m, mode, timeout):
     import subprocess
     import sys
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2", LCX_TEST_DUMP_AFTER="100")
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2",
+                   LCX_TEST_DUMP_AFTER=str(max(10, timeout - 30)))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(out_dir),
                                        str(n), str(v), str(m), mode, "hip", str(MAX_ITER)], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -31,14 +32,26 @@ def launch_hip(world, out_dir, n, v, m, mode):
     timed_out = False
     for p in procs:
         try:
-            out, _ = p.communicate(timeout=60 if timed_out else 150)
+            out, _ = p.communicate(timeout=30 if timed_out else timeout)
         except subprocess.TimeoutExpired:
             timed_out = True
             for q in procs:
                 q.kill()
             out, _ = p.communicate()
         outs.append(out.decode(errors="replace"))
-    assert not timed_out, "ranks did not finish in 150 s (a normal run takes 5 s):\n" + "\n-----\n".join(o[-2000:] for o in outs)
+    return timed_out, procs, outs
+
+
+def launch_hip(world, out_dir, n, v, m, mode):
+    """A normal run takes ~5 s.  On some boxes the two ranks sharing GPU 0 over gloo have been seen to stall right after
+    the rendezvous (test plumbing: the product's multi-GPU path is RCCL, one rank per GPU); such a run is reported with
+    the ranks' Python stacks and retried once."""
+    import sys
+    timed_out, procs, outs = _launch_once(world, out_dir, n, v, m, mode, 120)
+    if timed_out:
+        sys.stderr.write("ranks did not finish in 120 s, retrying once:\n" + "\n-----\n".join(o[-3000:] for o in outs) + "\n")
+        timed_out, procs, outs = _launch_once(world, out_dir, n, v, m, mode, 120)
+    assert not timed_out, "ranks did not finish in 120 s (twice):\n" + "\n-----\n".join(o[-3000:] for o in outs)
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
 

@@ -61,3 +61,26 @@ def test_full_size_properties(shape):
     assert float(np.max(mdl.moments["uj"])) < 1.0
     assert mdl.ws.shape == (m, v) and np.all(np.isfinite(mdl.ws))
     mdl._backend.close()
+
+
+def test_config2_full_fit_vs_oracle():
+    """BASELINE.json configs[1] end to end: synthetic Gaussian X 10k x 5k, n_hidden = 32, float64, the whole fit to
+    tol = 1e-5 on the device against the NumPy oracle on the host cores (about half a minute of CPU on the GPU box):
+    same number of iterations and line-search trials, TC history / weights / covariance within the north-star 1e-6,
+    integer cluster assignments bit-exact."""
+    import numpy as np
+    from linearcorex_amd import Corex
+    from oracle import corex_oracle as O
+    n, v, m = 10000, 5000, 32
+    x = O.gen_iid(n, v, seed=1, dtype=np.float64)
+    ref = O.fit_ns(x, m, seed=0, dtype=np.float64)
+    out = Corex(n_hidden=m, seed=0, dtype=np.float64, device=0).fit(x)
+    h_ref, h = np.asarray(ref.history_tc, np.float64), np.asarray(out.history["TC"], np.float64)
+    assert len(h) == len(h_ref), (len(h), len(h_ref))
+    assert np.max(np.abs(h - h_ref) / np.maximum(1.0, np.abs(h_ref))) < 1e-6
+    assert out.stats["trials"] == ref.n_trials
+    assert np.max(np.abs(out.ws - ref.ws)) < 1e-6 * np.max(np.abs(ref.ws))
+    assert np.array_equal(out.clusters(), ref.clusters())
+    cov, cov_ref = out.get_covariance(), ref.get_covariance()
+    assert np.max(np.abs(cov - cov_ref)) < 1e-6 * np.max(np.abs(cov_ref))
+    assert np.max(np.abs(np.asarray(out.tcs) - np.asarray(ref.moments["TCs"]))) < 1e-6 * max(1.0, float(np.max(np.abs(ref.moments["TCs"]))))

@@ -208,17 +208,31 @@ def measure(args, comm, world, rank, local_rank, line_search, keep_x=False):
 
 def main():
     args = parse()
+    # ONE JSON line on stdout, nothing else: RCCL prints a version banner to the C-level stdout (buffered, so it lands
+    # after anything Python printed).  Everything written to fd 1 from here on goes to stderr; rank 0 writes the JSON line
+    # to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path is the only product path)")
+    # test hooks: LCX_BENCH_DEVICE pins every rank to one device and LCX_BENCH_BACKEND=gloo replaces RCCL, so that the
+    # multi-rank code of this file can be exercised on a one-GPU box (RCCL refuses two ranks per device)
+    if os.environ.get("LCX_BENCH_DEVICE"):
+        local_rank = int(os.environ["LCX_BENCH_DEVICE"])
+    backend = os.environ.get("LCX_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     comm = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         from linearcorex_amd.comm import Comm
         comm = Comm()
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
@@ -344,7 +358,7 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if comm is not None:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -158,7 +158,8 @@ int lcx_permute_factors(lcx_ctx* h, const int32_t* order);
 int lcx_moments_a(lcx_ctx* h, int which);
 /* b: (ybuf now holds the global sums) uj (:248-249), early-exit flag (:250-251), X^T.Y (:259),
  *    rho (:260), ry (:261,:263), invrho, rhoinvrho, Qij, Si, Qi-Si^2 (:264-269), the two per-shard
- *    log sums of TC (:272-273) -> sbuf[0..1], and the H partial of this set (:294) -> sbuf[8..)    */
+ *    log sums of TC (:272-273) -> sbuf[0..1], a pending update_tangent -> sbuf[2], and the H partial of this set
+ *    (:294) -> sbuf[8..).  With one GPU the same call forms TC and publishes the state (lcx_moments_c is a no-op)  */
 int lcx_moments_b(lcx_ctx* h, int which, double eps, int quick);
 /* c: (sbuf[0..2] global) TC (:272-274) and update_tangent (:305) -> state scalars of the set     */
 int lcx_moments_c(lcx_ctx* h, int which);
@@ -174,11 +175,13 @@ int lcx_update_a(lcx_ctx* h);
 /* b: grad (:296-300), Bj partial (:302), Y_g partial = X.grad^T (first half of _sig, :210)
  *    -> ybuf (Bj in the tail)                                                                    */
 int lcx_update_b(lcx_ctx* h, double eps);
-/* c: X^T.Y_g, sig_grad (:211-212), update (:303), tangent partial (:305) -> sbuf[2]             */
+/* c: X^T.Y_g, sig_grad (:211-212), update (:303), per-block partials of update_tangent (:305).  They are summed
+ *    into sbuf[2] by the tail of the NEXT lcx_moments_b / lcx_trial_linear_b (the first trial of the direction), which
+ *    with one GPU also stores the tangent in the state scalars of set 0 and of the trial; lcx_read_state(0) before any
+ *    trial sums them on demand                                                                          */
 int lcx_update_c(lcx_ctx* h, double eps);
-/* d: marks the direction as ready (one GPU: the tangent is already in the state scalars of set 0; several
- *    ranks: it becomes global with the first trial's scalar all-reduce and lcx_moments_c stores it in the
- *    trial's state scalars)                                                                           */
+/* d: marks the direction as ready (several ranks: the tangent becomes global with the first trial's scalar
+ *    all-reduce and lcx_moments_c stores it in the trial's state scalars)                             */
 int lcx_update_d(lcx_ctx* h);
 /* w_update = ws + eta*update (:320) into set 1                                                   */
 int lcx_make_trial(lcx_ctx* h, double eta);

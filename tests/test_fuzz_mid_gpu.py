@@ -1,0 +1,37 @@
+"""Randomised parity at mid-size shapes (seeded): the shapes where the launch rules switch kernels - few column tiles
+(up to 64 partial slots, wide reductions), gemm_ct with many small slots, the float64 4x4x4 kernel next to 16x16x4.
+Short fits (one annealing stage) against the oracle in both precisions."""
+import numpy as np
+import pytest
+
+from oracle import corex_oracle as O
+from tests.test_parity_gpu import relerr
+
+pytestmark = pytest.mark.gpu
+
+rng = np.random.RandomState(77)
+CASES = []
+for k in range(12):
+    n = int(rng.choice([120, 448, 1500, 3000, 9000]))
+    v = int(rng.choice([130, 700, 2500, 7000, 12000]))
+    m = int(rng.choice([3, 6, 30, 40, 70, 120]))
+    if n * v > 6e7:
+        v = int(6e7 // n)
+    m = min(m, v // 2)
+    CASES.append((n, v, m, "f64" if k % 2 == 0 else "f32", int(rng.randint(1, 1000))))
+
+
+@pytest.mark.parametrize("n,v,m,tag,seed", CASES)
+def test_random_mid_shapes(n, v, m, tag, seed):
+    from linearcorex_amd import Corex
+    dt = np.float64 if tag == "f64" else np.float32
+    x, _ = O.gen_planted(n, v, max(2, min(m, 12)), seed=seed)
+    ref = O.fit_ns(x, m, seed=0, dtype=dt, max_iter=5, anneal=False)
+    out = Corex(n_hidden=m, seed=0, dtype=dt, device=0, max_iter=5, anneal=False).fit(x)
+    h, hr = np.asarray(out.history["TC"], np.float64), np.asarray(ref.history_tc, np.float64)
+    assert len(h) == len(hr), (len(h), len(hr), out._backend.geometry())
+    tol = 1e-7 if tag == "f64" else 2e-3
+    assert np.max(np.abs(h - hr) / np.maximum(1.0, np.abs(hr))) < tol, out._backend.geometry()
+    assert relerr(out.ws, ref.ws) < (1e-6 if tag == "f64" else 5e-3)
+    if tag == "f64":
+        assert np.array_equal(out.clusters(), ref.clusters())

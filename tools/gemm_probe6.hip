@@ -136,7 +136,39 @@ void suite8(const char* name, int64_t K, int64_t V, std::initializer_list<int> s
     bench(vs, gb, tf);
     CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(out));
 }
-int main() {
+// more resident waves per SIMD: shorter register double buffers (U = 1, 2) and the serial LDS reduction (one tile of LDS
+// instead of KW) so that 3-4 blocks fit per CU
+template <int CT>
+void suite_occ(const char* name, int64_t K, int64_t V, std::initializer_list<int> splits) {
+    const int Mp = 16 * CT;
+    double *A, *B, *out;
+    CK(hipMalloc(&A, 8 * K * V)); CK(hipMalloc(&B, 8 * K * Mp)); CK(hipMalloc(&out, 8 * 40 * V * Mp));
+    std::vector<double> h((size_t)K * V);
+    for (size_t x = 0; x < h.size(); ++x) h[x] = (double)rand() / RAND_MAX - 0.5;
+    CK(hipMemcpy(A, h.data(), 8 * K * V, hipMemcpyHostToDevice));
+    CK(hipMemcpy(B, h.data() + 7, 8 * K * Mp, hipMemcpyHostToDevice));
+    const double gb = 8 * ((double)K * V + (double)Mp * (K + V)) / 1e9, tf = 2.0 * K * V * Mp / 1e12;
+    printf("== %s: K=%ld V=%ld Mp=%d f64 (occupancy variants)\n", name, (long)K, (long)V, Mp);
+    std::vector<Variant> vs;
+    vs.push_back(mk4<CT, 4, 4, 4, true>(A, V, K, V, B, out, *splits.begin()));
+    for (int S : splits) {
+        vs.push_back(mk4<CT, 4, 4, 4, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, 4, 4, 2, true, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, 4, 4, 1, true, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, 2, 4, 4, true, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, 2, 4, 2, true, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<CT, 4, 2, 2, true, true>(A, V, K, V, B, out, S));
+    }
+    bench(vs, gb, tf);
+    CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(out));
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "occ") {
+        suite_occ<2>("c2_xty", 10048, 5120, {3, 4, 6, 9, 12});
+        suite_occ<2>("c2_xw", 5120, 10112, {2, 3, 4, 6});
+        return 0;
+    }
     suite8<2>("c2_xty_128", 10048, 5120, {3, 6, 9, 12});
     suite8<2>("c2_xw_128", 5120, 10112, {2, 3, 6});
     return 0;

@@ -357,11 +357,20 @@ def main():
         out["cpu_baseline"] = cpu_baseline(x_host, m, dtype, args.cpu_iters_per_stage)
     elif rank == 0:
         out["cpu_baseline"] = None
-    if rank == 0:
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    # tear the process group down first and push out whatever C-level stdio still buffers (now on stderr), so that the JSON
+    # line is the last thing this job writes even when the caller merges the two streams
+    import ctypes
+    libc = ctypes.CDLL(None)
     if comm is not None:
         import torch.distributed as dist
+        dist.barrier()
+        libc.fflush(None)
         dist.destroy_process_group()
+    libc.fflush(None)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -168,6 +168,27 @@ class Corex(object):
         self.refresh_every = int(refresh_every)
         self._since_exact = 0
         self.stats = {"iterations": 0, "moment_evals": 0, "trials": 0, "invalid_trials": 0}
+        import os
+        self._check_ranks = os.environ.get("LCX_CHECK_RANKS", "0") not in ("", "0")
+
+    def _assert_same_on_all_ranks(self, values, what):
+        """Debug aid (LCX_CHECK_RANKS=1): the host decisions of the line search are taken from all-reduced scalars and
+        must be bit-identical on every rank - a divergence would leave the ranks in mismatched collectives (a hang).
+        Costs two small all-reduces per call."""
+        if not self._check_ranks or self._ex is None or self._comm.world == 1:
+            return
+        import torch
+        v = np.asarray(values, dtype=np.float64)
+        v = np.where(np.isnan(v), -1.2345e300, v)
+        with self._backend.stream_context():
+            hi = torch.tensor(v, dtype=torch.float64, device=self._ex[1].device)
+            lo = -hi.clone()
+            self._comm.allreduce_max(hi)
+            self._comm.allreduce_max(lo)
+            hi, lo = hi.cpu().numpy(), -lo.cpu().numpy()
+        if not (np.array_equal(hi, lo) and np.array_equal(hi, v)):
+            raise RuntimeError("rank %d: %s differs across ranks: mine %r, max %r, min %r"
+                               % (self._comm.rank, what, v.tolist(), hi.tolist(), lo.tolist()))
 
     # ------------------------------------------------------------------------------------------
     # backend plumbing
@@ -548,6 +569,7 @@ class Corex(object):
                 self._moments_levels(1, True)                                  # :321
             self.stats["trials"] += 1
             st = be.read_state(1)
+            self._assert_same_on_all_ranks([st[0], st[1], st[2], st[3], eta], "trial state (TC, max uj, invalid, tangent, eta)")
             if update_tangent is None:
                 update_tangent = st[3]             # the trial's scalars carry the tangent of its direction
                 if update_tangent >= 0:                                        # :306-311

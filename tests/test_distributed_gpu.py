@@ -24,7 +24,7 @@ def _launch_once(world, out_dir, n, v, m, mode, timeout):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2",
-                   LCX_TEST_DUMP_AFTER=str(max(10, timeout - 30)))
+                   LCX_TEST_DUMP_AFTER=str(max(10, timeout - 30)), LCX_CHECK_RANKS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(out_dir),
                                        str(n), str(v), str(m), mode, "hip", str(MAX_ITER)], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))

@@ -57,9 +57,12 @@ def launch_hip(world, out_dir, n, v, m, mode):
 
 
 # world 3 runs in the CPU suite; on the GPU box gloo needs ~4 minutes for it
-@pytest.mark.parametrize("world,mode", [(2, "exact"), (2, "linear")])
-def test_sharded_fit_on_device_matches_oracle(world, mode, tmp_path):
-    n, v, m = 400, 331, 5               # uneven shards, ragged padding
+@pytest.mark.parametrize("world,mode,shape", [(2, "exact", (400, 331, 5)), (2, "linear", (400, 331, 5)),
+                                              (2, "exact", (300, 6001, 8))])
+def test_sharded_fit_on_device_matches_oracle(world, mode, shape, tmp_path):
+    # (400, 331, 5): uneven shards, ragged padding; (300, 6001, 8): few column tiles per shard - the X.W^T pass is split
+    # into dozens of slots and summed by the wide reductions before the exchange
+    n, v, m = shape
     launch_hip(world, tmp_path, n, v, m, mode)
     got = np.load(os.path.join(tmp_path, "dist_result.npz"))
     assert int(got["world"]) == world

@@ -387,7 +387,7 @@ template <typename T, int CT> struct Impl {
             // partial slots?  From forced A/B runs at pass and iteration level (tools/select_sweep.sh, tools/slots_ab.sh;
             // profiles/r01_slots_ab.txt, r01_select_sweep_*.txt):
             //   float32 from 32 padded factors, float64 from 64: whenever a wave would otherwise re-fetch a wide B - up to
-            //     32 slots (+6..+59 % it/s at 10k x 5k .. 20k x 20k), or more slots if the partial tiles stay below ~12 %
+            //     40 slots (+6..+59 % it/s at 10k x 5k .. 20k x 20k), or more slots if the partial tiles stay below ~12 %
             //     of the X bytes (1000 x 120000 x 64: 129 slots, 174 us vs 320 us) - on contractions that are not short;
             //   float64 up to 32 factors: the 4x4x4 kernel is the faster stream; its fixed rounds lose to the stream-K
             //     balancing at 8 slots only on long contractions (20k x 20k: +7.6 % it/s; 2500 x 20000: -5 %);
@@ -397,8 +397,8 @@ template <typename T, int CT> struct Impl {
                 if (e && *e) return sl <= atoi(e);
                 if (sl <= 6) return true;
                 const bool small_partials = sl <= 160 && (double)sl * Mp <= 0.12 * (double)K;
-                if (sizeof(T) == 4) return CT >= 2 && K >= 2048 && (sl <= 32 || small_partials);
-                if (CT >= 4) return K >= 4096 && (sl <= 32 || small_partials);
+                if (sizeof(T) == 4) return CT >= 2 && K >= 2048 && (sl <= 40 || small_partials);
+                if (CT >= 4) return K >= 4096 && (sl <= 40 || small_partials);
                 return K >= 8192 && sl <= 8;
             };
             int nb, ns, sl;

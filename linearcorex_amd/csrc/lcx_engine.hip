@@ -391,13 +391,14 @@ template <typename T, int CT> struct Impl {
             //     of the X bytes (1000 x 120000 x 64: 129 slots, 174 us vs 320 us) - on contractions that are not short;
             //   float64 up to 32 factors: the 4x4x4 kernel is the faster stream; its fixed rounds lose to the stream-K
             //     balancing at 8 slots only on long contractions (20k x 20k: +7.6 % it/s; 2500 x 20000: -5 %);
-            //   16-factor float32 and short contractions (448 rows: 20 us vs 25 us) keep the small-shard kernel.
+            //   16-factor float32 and short contractions (448 rows: 20 us vs 25 us; 3008: 26 us vs 34 us at 33 slots) keep
+            //     the small-shard kernel.
             auto use_ct = [&](int sl, int64_t K) -> bool {
                 const char* e = getenv("LCX_CT_MAX_SLOTS");
                 if (e && *e) return sl <= atoi(e);
                 if (sl <= 6) return true;
                 const bool small_partials = sl <= 160 && (double)sl * Mp <= 0.12 * (double)K;
-                if (sizeof(T) == 4) return CT >= 2 && K >= 2048 && (sl <= 40 || small_partials);
+                if (sizeof(T) == 4) return CT >= 2 && K >= 4096 && (sl <= 40 || small_partials);
                 if (CT >= 4) return K >= 4096 && (sl <= 40 || small_partials);
                 return K >= 8192 && sl <= 8;
             };

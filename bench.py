@@ -127,6 +127,22 @@ def load_pmc_traffic(workload, kernel):
         return None, None, None
 
 
+def load_rocprof_avg(workload, kernel):
+    """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this same command
+    (profiles/r01_rocprof_kernel_stats_<workload>.csv), reported beside the live HIP-event figure.  The event pair
+    brackets the dispatch as well, so it reads a few microseconds above the profiler's begin-to-end kernel time."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_rocprof_kernel_stats_%s.csv" % workload)
+    try:
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if kernel.replace(" ", "") in row["Name"].replace(" ", ""):
+                    return float(row["AverageNs"]) / 1e3, os.path.relpath(path, ROOT)
+    except Exception:
+        pass
+    return None, None
+
+
 def measure(args, comm, world, rank, local_rank, line_search, keep_x=False):
     """Warm up, then time exactly args.steps fit iterations (barrier + synchronize on both sides)."""
     import torch
@@ -306,6 +322,8 @@ def main():
                         timed_every_nth_launch=args.timing_sample,
                         algorithmic_bytes_per_launch=alg_bytes, algorithmic_flops_per_launch=alg_flops,
                         traffic_source=traffic_src, mfma_util_pmc=mfma_util, use_sites=use_sites)
+        rp_us, rp_src = load_rocprof_avg(args.workload, dom)
+        roofline.update(rocprofv3_avg_kernel_us=rp_us, rocprofv3_source=rp_src)
 
     extra = None
     if args.also_linear and args.line_search == "exact":

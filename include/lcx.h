@@ -265,6 +265,9 @@ int lcx_timing_reset(lcx_ctx* h);
 /* micro-benchmark: `iters` back-to-back launches of one X-streaming GEMM (kind as above, with its
  * partial-sum reduction) on the resident X; returns the average wall time per launch from HIP events */
 int lcx_bench_gemm(lcx_ctx* h, int kind, int iters, double* avg_ms);
+/* experiment: the launches of one moment evaluation (lcx_moments_a + lcx_moments_b of set 1, one GPU) issued directly vs
+ * captured into a hipGraph and replayed; average wall time per evaluation of each */
+int lcx_bench_graph(lcx_ctx* h, double eps, int iters, double* direct_ms, double* graph_ms);
 /* geometry actually used (for the roofline arithmetic): padded sizes and launch shapes */
 int lcx_geometry(lcx_ctx* h, int64_t* n_pad, int64_t* ldx, int* m_pad, int64_t* info8);
 

@@ -98,6 +98,12 @@ class HipBackend:
         _abi.check(self.lib.lcx_kernel_name(self.h, int(kind), buf, 256))
         return buf.value.decode()
 
+    def bench_graph(self, eps=0.1, iters=50):
+        """(direct_ms, graph_ms) per moment evaluation: plain launches vs a replayed hipGraph (experiment)."""
+        d, g = C.c_double(), C.c_double()
+        _abi.check(self.lib.lcx_bench_graph(self.h, float(eps), int(iters), C.byref(d), C.byref(g)))
+        return d.value, g.value
+
     def bench_gemm(self, kind, iters=20):
         ms = C.c_double()
         _abi.check(self.lib.lcx_bench_gemm(self.h, int(kind), int(iters), C.byref(ms)))

@@ -1747,6 +1747,57 @@ int lcx_bench_gemm(lcx_ctx* h, int kind, int iters, double* avg_ms) {
     return LCX_OK;
 }
 
+// Experiment: one moment evaluation of set 1 (the launches of lcx_moments_a + lcx_moments_b, one GPU) issued directly
+// `iters` times vs captured once into a hipGraph and replayed `iters` times.  The replay publishes a stale sequence number,
+// which is fine for timing; nothing reads the state in between.
+int lcx_bench_graph(lcx_ctx* h, double eps, int iters, double* direct_ms, double* graph_ms) {
+    NEED(h);
+    if (iters < 1 || !direct_ms || !graph_ms) return fail(LCX_ERR_ARG, "lcx_bench_graph: bad argument");
+    if (h->exchange) return fail(LCX_ERR_STATE, "lcx_bench_graph: one GPU only");
+    hipEvent_t a, b;
+    HIPCHECK(hipEventCreate(&a));
+    HIPCHECK(hipEventCreate(&b));
+    const bool timing = h->timing;
+    h->timing = false;
+    auto once = [&]() -> int {
+        int rc = lcx_moments_a(h, 1);
+        if (rc != LCX_OK) return rc;
+        return lcx_moments_b(h, 1, eps, 1);
+    };
+    for (int i = 0; i < 3; ++i) LCXCHECK(once());
+    HIPCHECK(hipEventRecord(a, h->stream));
+    for (int i = 0; i < iters; ++i) LCXCHECK(once());
+    HIPCHECK(hipEventRecord(b, h->stream));
+    HIPCHECK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, a, b));
+    *direct_ms = ms / iters;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    HIPCHECK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int rc = once();
+    hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+    if (rc != LCX_OK) return rc;
+    HIPCHECK(ce);
+    HIPCHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    for (int i = 0; i < 3; ++i) HIPCHECK(hipGraphLaunch(exec, h->stream));
+    HIPCHECK(hipEventRecord(a, h->stream));
+    for (int i = 0; i < iters; ++i) HIPCHECK(hipGraphLaunch(exec, h->stream));
+    HIPCHECK(hipEventRecord(b, h->stream));
+    HIPCHECK(hipEventSynchronize(b));
+    HIPCHECK(hipEventElapsedTime(&ms, a, b));
+    *graph_ms = ms / iters;
+    HIPCHECK(hipGraphExecDestroy(exec));
+    HIPCHECK(hipGraphDestroy(graph));
+    HIPCHECK(hipEventDestroy(a));
+    HIPCHECK(hipEventDestroy(b));
+    h->timing = timing;
+    // leave a consistent publication state behind: one more direct evaluation
+    LCXCHECK(once());
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    return LCX_OK;
+}
+
 int lcx_geometry(lcx_ctx* h, int64_t* n_pad, int64_t* ldx, int* m_pad, int64_t* info8) {
     NEED(h);
     if (n_pad) *n_pad = h->Npad;

@@ -2,14 +2,24 @@
 """bench.py - fit iterations/sec of the Linear CorEx hot path on MI355X (BASELINE.json metric).
 
 A "step" is one fixed-point iteration of the fit loop (reference `_update_ns` + its book-keeping,
-linearcorex.py:137-151) inside the reference's 7-stage annealing schedule (:119-134); stage changes
-that fall in the timed window are part of it.  Workload at N=1: BASELINE.json configs[1] -
-synthetic Gaussian X, 10k samples x 5k variables, n_hidden=32, float64.  With N>1 ranks the
-n_variables axis is sharded, 5k variables per GPU (weak scaling): the unit counted in `value` is
-"one iteration over a 10k x 5k x 32 block", so N ranks finish N units per iteration.
+linearcorex.py:137-151).  The run walks the reference's 7-stage annealing schedule (:119-134); in
+every stage a window of EXACTLY --steps iterations is timed (barrier + synchronize on both sides, MAX
+over ranks), stage changes (:127-134: rescale + a non-quick moment evaluation) are timed separately.
+When one walk of the schedule is shorter than ~0.6 s of GPU work it is repeated on the same resident
+data (same start, same trajectory) and the per-stage MEDIAN window is used, so the figure does not move
+with --steps / --warmup:
 
-    python bench.py --gpus 1 --steps 70 --warmup 7
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    ms_per_step = sum_over_stages( median_over_repeats( window ) ) / (7 * steps)
+
+Workloads (BASELINE.json `configs`):
+  N=1  headline  c3       50k x 100k, n_hidden 64, float32, X generated on the device  (MFMA roofline run)
+       nested    config.c2: 10k x 5k, n_hidden 32, float64                            (HBM-bound; own protocol)
+  N>1  headline  c4shard  50k x 125k per GPU, n_hidden 128, float32, n_variables sharded (weak scaling)
+       nested    config.c2_weak: 10k x 5k per GPU, float64
+
+    python bench.py                                   # N=1, c3 headline + c2 block + CPU baselines
+    python bench.py --gpus 8 --steps 20 --warmup 5    # spawns 8 ranks itself (torch.distributed.run as a child)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # or launched as ranks
 
 Prints ONE JSON line on rank 0.
 """
@@ -17,10 +27,9 @@ import argparse
 import json
 import math
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -28,13 +37,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6
 FP32_MFMA_PEAK_TFLOPS = 157.3
-# What this chip has been seen to sustain (profiles/r01_read_probe_c2.txt, r01_mfma_peak.txt, the c3f64* workloads:
-# gemm_ct streams float64 X at 6.47 TB/s and runs v_mfma_f64_16x16x4 at 59.9 TF/s): a read-only
-# stream of a 400 MB matrix 6.2 TB/s; pure-MFMA loops: v_mfma_f64_4x4x4 72 TF/s, v_mfma_f64_16x16x4 47.6 TF/s (real kernels reach
-# 58-60 TF/s with it on large shards), v_mfma_f32_16x16x4
-# 151 TF/s.  Reported beside the spec-based fraction, never instead of it.
+# What this chip has been seen to sustain (profiles/r01_read_probe_c2.txt, r01_mfma_peak.txt, the c3f64* workloads):
+# reported beside the spec-based fraction, never instead of it.
 MEASURED_CEILINGS = {"hbm_read_GBps": 6470.0, "mfma_f64_TFLOPs": 72.0, "mfma_f64_16x16x4_TFLOPs": 59.9,
                      "mfma_f32_TFLOPs": 151.0}
+MIN_TIMED_SECONDS = 0.6        # one walk of the schedule shorter than this is repeated (median per stage)
 
 WORKLOADS = {
     # name: (n_samples, n_variables per GPU, n_hidden, dtype)
@@ -51,108 +58,292 @@ WORKLOADS = {
     "c5f32": (400, 20000, 30, "f32"),
     "tiny": (2000, 640, 8, "f64"),       # plumbing check
 }
+DESCRIPTION = {
+    "c2": "BASELINE.json configs[1]", "c3": "BASELINE.json configs[2], the MFMA roofline run",
+    "c4shard": "BASELINE.json configs[3], one GPU's shard of the 1M-variable problem",
+}
 
 
 def _adhoc(name):
     """'NxVxM:f32' -> WORKLOADS entry (probing shapes outside BASELINE.json)."""
-    if name not in WORKLOADS:
+    if name not in WORKLOADS and name != "auto":
         dims, tag = name.split(":")
         n, v, m = (int(t) for t in dims.split("x"))
         assert tag in ("f32", "f64")
         WORKLOADS[name] = (n, v, m, tag)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=70)
-    ap.add_argument("--warmup", type=int, default=7)
-    ap.add_argument("--workload", default="c2",
-                    help="one of %s, or an ad-hoc shard shape NxVxM:f32|f64 (not a BASELINE line)" % ", ".join(sorted(WORKLOADS)))
-    ap.add_argument("--cpu-iters-per-stage", type=int, default=40,
-                    help="bounded CPU-baseline sample: oracle iterations per annealing stage (0 = skip)")
+    ap.add_argument("--steps", type=int, default=20, help="iterations per timed window (one window per annealing stage)")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed iterations before the first window")
+    ap.add_argument("--workload", default="auto",
+                    help="auto (c3 at 1 GPU, c4shard per GPU above, each with its nested c2 block), one of %s, or an ad-hoc "
+                         "shard shape NxVxM:f32|f64 (not a BASELINE line)" % ", ".join(sorted(WORKLOADS)))
+    ap.add_argument("--no-extras", dest="extras", action="store_false",
+                    help="headline measurement only: no nested c2 block, no linear-mode run, no fit to convergence, no "
+                         "get_covariance timing, no CPU baseline (what the profiling scripts run)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0,
+                    help="time budget of the CPU-baseline sample of the headline workload (0 = skip)")
+    ap.add_argument("--cpu-iters-per-stage", type=int, default=10,
+                    help="CPU baseline of the c2 block: oracle iterations per annealing stage (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--timing-sample", type=int, default=5,
-                    help="HIP-event pairs around every n-th X pass of the timed region (a pair costs ~5 us of stream time; "
-                         "1 = every pass)")
-    ap.add_argument("--no-convergence", dest="convergence", action="store_false",
-                    help="skip the wall-clock-to-TC-convergence measurement (a full fit at tol=1e-5 on the same data, "
-                         "reported under config.fit_to_convergence; 1 GPU, workload c2 only)")
+    ap.add_argument("--timing-sample", type=int, default=0,
+                    help="HIP-event pairs around every n-th X pass of the timed windows (a pair costs ~5 us of stream time; "
+                         "0 = 1 for passes above 1 ms, 5 below)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="1 GPU only: run the multi-rank device path (world>1 kernels + RCCL all-reduces in a group of "
                          "one rank) to measure the fixed cost of the exchange steps")
     ap.add_argument("--line-search", default="exact", choices=["linear", "exact"],
                     help="exact (default, the headline): reference-shaped, every trial makes 2 passes over X "
                          "(linearcorex.py:321); linear: trials cost no pass over X")
-    ap.add_argument("--no-also-linear", dest="also_linear", action="store_false",
-                    help="skip the second measurement in linear trial mode (reported under config.linear_trial_mode)")
-    args = ap.parse_args()
+    ap.add_argument("--repeats", type=int, default=0, help="walks of the schedule (0 = as many as MIN_TIMED_SECONDS needs)")
+    args = ap.parse_args(argv)
     _adhoc(args.workload)
     return args
 
 
-def cpu_baseline(x, m, dtype, iters_per_stage):
-    """The NumPy oracle (a port of the reference path, pinned to it bit for bit) on the host cores,
-    same X, same schedule, bounded to iters_per_stage iterations per annealing stage."""
-    from oracle import corex_oracle as O
+# ------------------------------------------------------------------------------------------------------
+# --gpus N without a launcher: start the N ranks ourselves, as child processes, before anything in this
+# process touches the GPU (never re-exec a process that initialised HIP)
+# ------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    import socket
+    rc = subprocess.call([sys.executable, os.path.join(ROOT, "__graft_entry__.py")], cwd=ROOT, stdout=sys.stderr)
+    if rc != 0:
+        sys.stderr.write("bench.py: building the HIP library failed\n")
+        return rc
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: launching the ranks as children: %s\n" % (args.gpus, " ".join(cmd)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.strip()]
+    rec = None
+    for ln in reversed(lines):
+        try:
+            rec = json.loads(ln)
+            break
+        except ValueError:
+            continue
+    if p.returncode != 0 or rec is None:
+        sys.stderr.write("bench.py: the rank launch failed (rc %d)\n%s\n" % (p.returncode, "\n".join(lines[-20:])))
+        return p.returncode or 1
+    if rec.get("n_gpus") != args.gpus:
+        sys.stderr.write("bench.py: asked for %d GPUs, the ranks report n_gpus=%r\n" % (args.gpus, rec.get("n_gpus")))
+        return 1
+    sys.stdout.write(json.dumps(rec) + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------
+# CPU baselines: the NumPy oracle (a port of the reference path, pinned to it bit for bit) on the host cores
+# ------------------------------------------------------------------------------------------------------
+def _blas_threads():
     try:
         from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        infos = threadpool_info()
+        threads = max([p.get("num_threads", 1) for p in infos] or [1])
+        vendor = ", ".join(sorted({"%s %s" % (p.get("internal_api", "?"), p.get("version", "")) for p in infos}))
+        return int(threads), vendor
     except Exception:
-        threads = os.cpu_count() or 1
+        return int(os.cpu_count() or 1), "unknown"
+
+
+def cpu_baseline_resident(x, m, dtype, iters_per_stage):
+    """Small workloads (c2): same X as the GPU run, the whole 7-stage schedule bounded to iters_per_stage
+    iterations per stage."""
+    import numpy as np
+    from oracle import corex_oracle as O
+    threads, vendor = _blas_threads()
     xt = O.preprocess(np.asarray(x, dtype=dtype))[0]
-    stamps = []
     t0 = time.perf_counter()
-    res = O.fit_ns_preprocessed(xt, m, seed=0, dtype=dtype, max_iter=iters_per_stage, tol=0.0,
-                                on_iteration=lambda *a: stamps.append(time.perf_counter()), finish=False)
+    res = O.fit_ns_preprocessed(xt, m, seed=0, dtype=dtype, max_iter=iters_per_stage, tol=0.0, finish=False)
     t1 = time.perf_counter()
     n_it = len(res.history_tc)
-    return {"value": n_it / (t1 - t0), "unit": "iterations/s", "cores": int(threads), "kind": "port",
-            "sample": "%d iterations (%d per annealing stage x 7) of the same workload, NumPy %s/BLAS threads=%d, "
-                      "%.1f s" % (n_it, iters_per_stage, np.__version__, threads, t1 - t0),
+    return {"value": n_it / (t1 - t0), "unit": "iterations/s", "cores": threads, "kind": "port",
+            "sample": "%d iterations (%d per annealing stage x 7, stage changes included) of the same workload on the same X, "
+                      "NumPy %s / %s, BLAS threads=%d, %.1f s" % (n_it, iters_per_stage, np.__version__, vendor, threads, t1 - t0),
             "trials_per_iteration": res.n_trials / max(1, n_it)}
 
 
+def _host_gaussian(n, v, dtype, seed):
+    """iid N(0,1) of shape (n, v) drawn by all cores (one Generator per row block), then standardised per column
+    like preprocess 'standard' (reference :409-415)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    x = np.empty((n, v), dtype=dtype)
+    workers = max(1, min(32, os.cpu_count() or 1))
+    bounds = [(n * k // workers, n * (k + 1) // workers) for k in range(workers)]
+
+    def fill(k):
+        r0, r1 = bounds[k]
+        g = np.random.Generator(np.random.PCG64([seed, k]))
+        step = max(1, (1 << 24) // v)
+        for r in range(r0, r1, step):
+            e = min(r1, r + step)
+            x[r:e] = g.standard_normal((e - r, v), dtype=dtype)
+    with ThreadPoolExecutor(workers) as ex:
+        list(ex.map(fill, range(workers)))
+    cb = [(v * k // workers, v * (k + 1) // workers) for k in range(workers)]
+
+    def standardise(k):
+        c0, c1 = cb[k]
+        for c in range(c0, c1, 2048):
+            e = min(c1, c + 2048)
+            blk = x[:, c:e]
+            mu = blk.mean(axis=0, dtype=np.float64)
+            blk -= mu.astype(dtype)
+            sd = np.sqrt(np.einsum("ij,ij->j", blk, blk, dtype=np.float64) / n)
+            blk /= np.maximum(sd, 1e-10).astype(dtype)
+    with ThreadPoolExecutor(workers) as ex:
+        list(ex.map(standardise, range(workers)))
+    return x
+
+
+def cpu_baseline_generated(n, v, m, dtype, budget_s, label):
+    """Large workloads (c3, c4 shard): X cannot be taken from the GPU run (it is generated on the device), so an iid
+    Gaussian X of the same shape is drawn on the host (fewer variables if the host's memory cannot hold it: the
+    iteration cost is linear in n_variables and the scale is stated), and the oracle's loop (reference :136-155) is
+    timed for at least 3 iterations, one per annealing stage while the budget lasts."""
+    import numpy as np
+    from oracle import corex_oracle as O
+    threads, vendor = _blas_threads()
+    es = np.dtype(dtype).itemsize
+    avail = None
+    try:
+        with open("/proc/meminfo") as f:
+            for ln in f:
+                if ln.startswith("MemAvailable:"):
+                    avail = int(ln.split()[1]) * 1024
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/memory.max") as f:
+            lim = f.read().strip()
+            if lim.isdigit():
+                used = 0
+                try:
+                    with open("/sys/fs/cgroup/memory.current") as g:
+                        used = int(g.read().strip())
+                except Exception:
+                    pass
+                avail = min(avail, int(lim) - used) if avail is not None else int(lim) - used
+    except Exception:
+        pass
+    v_cpu = v
+    if avail is not None:
+        fit = int(0.6 * avail / (n * es))
+        if fit < v:
+            v_cpu = max(1000, fit // 1000 * 1000)
+    t_gen = time.perf_counter()
+    x = _host_gaussian(n, v_cpu, dtype, seed=1)
+    t_gen = time.perf_counter() - t_gen
+    w = O.initial_weights(0, m, v_cpu, dtype)
+    w /= (10.0 * O.norm(x, w, 0))[:, np.newaxis]
+    mo = O.moments_ns(x, w, 0, quick=True)
+    eps, n_it, trials, t_iter, t_stage, stages = 0, 0, 0, 0.0, 0.0, 0
+    t_begin = time.perf_counter()
+    for stage, eps_new in enumerate(O.anneal_schedule(True)):
+        t0 = time.perf_counter()
+        eps_old, eps = eps, eps_new
+        if stage > 0:
+            w = O.rescale_for_stage(w, mo["uj"], eps_old, eps)
+        mo = O.moments_ns(x, w, eps, quick=False)
+        t1 = time.perf_counter()
+        w, mo, info = O.update_ns(x, w, mo, eps, 0.0)
+        t2 = time.perf_counter()
+        t_stage += t1 - t0
+        t_iter += t2 - t1
+        n_it += 1
+        stages += 1
+        trials += info["n_trials"]
+        if n_it >= 3 and (time.perf_counter() - t_begin) > budget_s:
+            break
+    its = n_it / t_iter
+    scale = float(v_cpu) / float(v)
+    del x
+    return {"value": its * scale, "unit": "iterations/s", "cores": threads, "kind": "port",
+            "sample": "%s: %d iterations of the oracle loop (reference linearcorex.py:136-155), the first one of each of the "
+                      "first %d annealing stages, on host-generated iid Gaussian X %d x %d %s, n_hidden %d; %.1f s in the "
+                      "iterations (%.2f s each), %.1f s in the %d stage changes, %.1f s to draw X; NumPy %s / %s, BLAS threads=%d"
+                      % (label, n_it, stages, n, v_cpu, np.dtype(dtype).name, m, t_iter, t_iter / n_it, t_stage, stages, t_gen,
+                         np.__version__, vendor, threads),
+            "n_variables_timed": v_cpu, "n_variables_workload": v,
+            "scaled_linearly_in_n_variables_by": scale, "measured_iterations_per_sec_at_timed_size": its,
+            "trials_per_iteration": trials / max(1, n_it)}
+
+
+# ------------------------------------------------------------------------------------------------------
+# committed profile figures (PMC traffic, rocprofv3 kernel time): quoted only while they describe THIS library
+# ------------------------------------------------------------------------------------------------------
+def _lib_src_hash():
+    try:
+        import __graft_entry__ as ge
+        return ge._src_hash()
+    except Exception:
+        return None
+
+
 def load_pmc_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of this same command
-    (tools/pmc_traffic.py writes profiles/pmc_traffic_<workload>.json on the GPU box; FETCH_SIZE is
-    doubled there as MI355X_MICROARCH.md prescribes for gfx950).  None if no such profile is committed."""
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of this same command (tools/pmc_traffic.py writes
+    profiles/pmc_traffic_<workload>.json on the GPU box together with the hash of the library sources it profiled;
+    FETCH_SIZE is doubled there as MI355X_MICROARCH.md prescribes for gfx950).  A profile taken from other sources than
+    the library that is running is not quoted."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % workload)
+    info = {"traffic_source": None, "mfma_util_pmc": None, "traffic_profile_matches_library": None}
     try:
         with open(path) as f:
             d = json.load(f)
         k = d["kernels"][kernel]
-        return k["hbm_bytes_per_launch"], os.path.relpath(path, ROOT), k.get("mfma_util")
     except Exception:
-        return None, None, None
+        return None, info
+    info["traffic_source"] = os.path.relpath(path, ROOT)
+    info["traffic_profile_lib_src_hash"] = d.get("lib_src_hash")
+    ok = d.get("lib_src_hash") is not None and d.get("lib_src_hash") == _lib_src_hash()
+    info["traffic_profile_matches_library"] = ok
+    if not ok:
+        return None, info
+    info["mfma_util_pmc"] = k.get("mfma_util")
+    info["mfma_flops_per_launch_pmc"] = k.get("mfma_flops_per_launch")
+    return k.get("hbm_bytes_per_launch"), info
 
 
 def load_rocprof_avg(workload, kernel):
-    """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this same command
-    (profiles/r01_rocprof_kernel_stats_<workload>.csv), reported beside the live HIP-event figure.  The event pair
-    brackets the dispatch as well, so it reads a few microseconds above the profiler's begin-to-end kernel time."""
+    """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this same command,
+    quoted beside the live HIP-event figure while the summary's recorded source hash equals the running library's."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_rocprof_kernel_stats_%s.csv" % workload)
-    try:
-        with open(path) as f:
-            for row in csv.DictReader(f):
-                if kernel.replace(" ", "") in row["Name"].replace(" ", ""):
-                    return float(row["AverageNs"]) / 1e3, os.path.relpath(path, ROOT)
-    except Exception:
-        pass
-    return None, None
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprof_kernel_stats_%s.csv" % workload))):
+        meta = path[:-4] + ".meta.json"
+        try:
+            with open(meta) as f:
+                if json.load(f).get("lib_src_hash") != _lib_src_hash():
+                    continue
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    if kernel.replace(" ", "") in row["Name"].replace(" ", ""):
+                        best = (float(row["AverageNs"]) / 1e3, os.path.relpath(path, ROOT))
+        except Exception:
+            continue
+    return best if best else (None, None)
 
 
-def measure(args, comm, world, rank, local_rank, line_search, keep_x=False):
-    """Warm up, then time exactly args.steps fit iterations (barrier + synchronize on both sides)."""
-    import torch
+# ------------------------------------------------------------------------------------------------------
+# the measurement
+# ------------------------------------------------------------------------------------------------------
+def make_model(workload, comm, world, rank, local_rank, line_search, keep_x=False):
+    import numpy as np
     from linearcorex_amd import Corex
-    n, v_per, m, tag = WORKLOADS[args.workload]
+    n, v_per, m, tag = WORKLOADS[workload]
     dtype = np.float64 if tag == "f64" else np.float32
     v_total = v_per * world
-    total_steps = args.warmup + args.steps
-    per_stage = int(math.ceil(total_steps / 7.0))
-
     model = Corex(n_hidden=m, seed=0, dtype=dtype, tol=0.0, max_iter=10 ** 9, device=local_rank, comm=comm,
                   line_search=line_search)
     x_host = None
@@ -169,6 +360,17 @@ def measure(args, comm, world, rank, local_rank, line_search, keep_x=False):
         be = model._make_backend(n, v_per)
         be.generate_x(1, 0, 1, model._cols[0])
         model.theta = (np.zeros(1), np.ones(1))
+    return model, be, (x_host if keep_x else None)
+
+
+def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_search, keep_x=False, repeats=0,
+            kernel_timing=True):
+    """Walk the 7-stage schedule; per stage: the stage change (timed on its own), then a window of exactly `steps`
+    iterations (barrier + synchronize on both sides).  Repeat the walk from the same start until MIN_TIMED_SECONDS
+    of windows have been timed."""
+    import numpy as np
+    import torch
+    model, be, x_host = make_model(workload, comm, world, rank, local_rank, line_search, keep_x)
 
     def sync():
         be.synchronize()
@@ -177,53 +379,197 @@ def measure(args, comm, world, rank, local_rank, line_search, keep_x=False):
             comm.barrier()
             torch.cuda.synchronize()
 
-    state = {"step": 0, "t0": None, "t1": None}
-    sched = model._init_weights()
-
-    def one_step():
-        if state["step"] == args.warmup:
-            sync()
-            if not args.no_kernel_timing:
-                be.timing_reset()
-                be.timing_sample(args.timing_sample)
-                be.timing_enable(True)
-            model.stats.update(trials=0, invalid_trials=0, moment_evals=0, refreshes=0)
-            state["t0"] = time.perf_counter()
-        model._iterate()
-        state["step"] += 1
-        if state["step"] == total_steps:
-            sync()
-            state["t1"] = time.perf_counter()
-            be.timing_enable(False)
-
-    for i_eps, eps in enumerate(sched):
-        if state["step"] >= total_steps:
-            break
-        model._begin_stage(i_eps, eps)
-        for _ in range(per_stage):
-            if state["step"] >= total_steps:
-                break
-            one_step()
-    elapsed = state["t1"] - state["t0"]
-    if comm is not None:
+    def rank_max(values):
+        if comm is None:
+            return list(values)
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor(list(values), dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    res = {"elapsed": elapsed, "its_per_s": args.steps / elapsed, "geo": be.geometry(),
-           "timing": be.timing_read() if not args.no_kernel_timing else {},
-           "x_passes": be.timing_passes() if not args.no_kernel_timing else None,
-           "trials": model.stats["trials"] / max(1, args.steps),
-           "invalid": model.stats["invalid_trials"] / max(1, args.steps),
-           "final_tc": float(model.tc), "per_stage": per_stage, "x_host": x_host if keep_x else None,
-           "kernel_names": {"gemm_nt": be.kernel_name(0), "gemm_tn": be.kernel_name(1)}}
-    be.close()
-    model._backend = None
-    return res
+        return [float(u) for u in t.cpu()]
+
+    # clocks: >= 250 ms of X passes before anything is timed
+    t0 = time.perf_counter()
+    pass_ms = be.bench_gemm(1, 2)
+    while time.perf_counter() - t0 < 0.25:
+        be.bench_gemm(1, max(2, int(20.0 / max(pass_ms, 1e-3))) if pass_ms < 1.0 else 4)
+    every = args.timing_sample if args.timing_sample > 0 else (1 if pass_ms >= 1.0 else 5)
+    timing = kernel_timing and not args.no_kernel_timing
+    if timing:
+        be.timing_reset()
+        be.timing_sample(every)
+
+    stat_keys = ("trials", "invalid_trials", "moment_evals")
+    totals = dict.fromkeys(stat_keys, 0)
+
+    def walk(record):
+        np.random.seed(0)                      # the same start on every walk: identical trajectories
+        model.ws = np.zeros((0, 0))
+        model.history = {}
+        sched = model._init_weights()
+        win, chg = [], []
+        for i_eps, eps in enumerate(sched):
+            sync()
+            t0 = time.perf_counter()
+            model._begin_stage(i_eps, eps)
+            sync()
+            chg.append(time.perf_counter() - t0)
+            if i_eps == 0:
+                for _ in range(warmup):
+                    model._iterate()
+                sync()
+            before = {k: model.stats.get(k, 0) for k in stat_keys}
+            if timing and record:
+                be.timing_enable(True)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                model._iterate()
+            sync()
+            t1 = time.perf_counter()
+            if timing and record:
+                be.timing_enable(False)
+            if record:
+                for k in stat_keys:
+                    totals[k] += model.stats.get(k, 0) - before[k]
+            win.append(t1 - t0)
+        return rank_max(win), rank_max(chg)
+
+    first_win, first_chg = walk(record=False)
+    est = sum(first_win)
+    if repeats <= 0:
+        repeats = 1 if est >= MIN_TIMED_SECONDS else min(60, int(math.ceil(MIN_TIMED_SECONDS / max(est, 1e-6))))
+    wins, chgs = [], []
+    for _ in range(repeats):
+        w, c = walk(record=True)
+        wins.append(w)
+        chgs.append(c)
+    wins, chgs = np.asarray(wins), np.asarray(chgs)
+    stage_med = np.median(wins, axis=0)
+    n_stages = wins.shape[1]
+    timed_iters = repeats * n_stages * steps
+    per_step = float(stage_med.sum() / (n_stages * steps))
+    walk_totals = wins.sum(axis=1)
+    res = {
+        "per_step_s": per_step, "its_per_s": 1.0 / per_step, "geo": be.geometry(),
+        "timing": be.timing_read() if timing else {},
+        "x_passes": (be.timing_passes() / timed_iters) if timing else None,
+        "trials": totals["trials"] / timed_iters, "invalid": totals["invalid_trials"] / timed_iters,
+        "final_tc": float(model.tc), "x_host": x_host, "every": every,
+        "kernel_names": {"gemm_nt": be.kernel_name(0), "gemm_tn": be.kernel_name(1)},
+        "windows": {
+            "stages": n_stages, "steps_per_window": steps, "walks_timed": repeats, "walks_discarded_as_warmup": 1,
+            "timed_iterations": timed_iters, "timed_seconds": float(wins.sum()),
+            "ms_per_step_by_stage": [float(s / steps * 1e3) for s in stage_med],
+            "ms_per_step_walk_min_median_max": [float(np.min(walk_totals) / (n_stages * steps) * 1e3),
+                                                float(np.median(walk_totals) / (n_stages * steps) * 1e3),
+                                                float(np.max(walk_totals) / (n_stages * steps) * 1e3)],
+            "stage_change_ms_median": float(np.median(chgs[:, 1:]) * 1e3) if n_stages > 1 else None,
+            "first_stage_start_ms_median": float(np.median(chgs[:, 0]) * 1e3),
+            "iterations_per_sec_incl_stage_changes": float(n_stages * steps / (stage_med.sum() + np.median(chgs, axis=0).sum())),
+        },
+        "bytes_resident": be.bytes_resident() if hasattr(be, "bytes_resident") else None,
+    }
+    return res, model, be
+
+
+def roofline_of(workload, r, world):
+    """Roofline object for the dominant X-streaming kernel of a measurement: algorithmic bytes / flops
+    of one launch on this rank / the mean launch duration from HIP events on the engine's stream."""
+    import numpy as np
+    n, v_per, m, tag = WORKLOADS[workload]
+    es = 8 if tag == "f64" else 4
+    alg_bytes = es * (n * v_per + m * v_per + n * m)
+    alg_flops = 2.0 * n * v_per * m
+    kernels = {}
+    for name, (cnt, ms) in r["timing"].items():
+        if cnt:
+            avg = ms / cnt * 1e-3
+            kernels[name] = {"launches": cnt, "avg_us": avg * 1e6, "GBps": alg_bytes / avg / 1e9,
+                             "TFLOPs": alg_flops / avg / 1e12}
+    if not kernels:
+        return None
+    # use sites -> kernel function (rocprofv3 row).  X.B^T ("gemm_nt", :247/:210) and X^T.Y ("gemm_tn", :259/:211)
+    # usually run the same instantiation (the first one on the transposed copy of X).
+    by_fn = {}
+    for name, k in kernels.items():
+        fn = r["kernel_names"][name]
+        d = by_fn.setdefault(fn, {"launches": 0, "total_us": 0.0, "use_sites": []})
+        d["launches"] += k["launches"]
+        d["total_us"] += k["launches"] * k["avg_us"]
+        d["use_sites"].append(name)
+    for fn, d in by_fn.items():
+        avg = d["total_us"] / d["launches"] * 1e-6
+        d.update(avg_us=avg * 1e6, GBps=alg_bytes / avg / 1e9, TFLOPs=alg_flops / avg / 1e12)
+    dom = max(by_fn, key=lambda k: by_fn[k]["total_us"])
+    intensity = alg_flops / alg_bytes
+    mfma_peak = FP64_MFMA_PEAK_TFLOPS if tag == "f64" else FP32_MFMA_PEAK_TFLOPS
+    traffic, tinfo = load_pmc_traffic(workload, dom)
+    if intensity < mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9):
+        roofline = {"bound": "hbm", "achieved": by_fn[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": by_fn[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic}
+    else:
+        roofline = {"bound": "mfma", "achieved": by_fn[dom]["TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s",
+                    "frac": by_fn[dom]["TFLOPs"] / mfma_peak, "traffic": traffic}
+    mfma_ceiling = MEASURED_CEILINGS["mfma_f64_TFLOPs" if tag == "f64" else "mfma_f32_TFLOPs"]
+    roofline.update(workload=workload, achieved_GBps=by_fn[dom]["GBps"], achieved_TFLOPs=by_fn[dom]["TFLOPs"],
+                    frac_of_measured_hbm_read_ceiling=by_fn[dom]["GBps"] / MEASURED_CEILINGS["hbm_read_GBps"],
+                    frac_of_measured_mfma_ceiling=by_fn[dom]["TFLOPs"] / mfma_ceiling,
+                    measured_ceilings=MEASURED_CEILINGS, kernel=dom, avg_launch_us=by_fn[dom]["avg_us"],
+                    launches=by_fn[dom]["launches"], timed_every_nth_launch=r["every"],
+                    algorithmic_bytes_per_launch=alg_bytes, algorithmic_flops_per_launch=alg_flops,
+                    arithmetic_intensity_flop_per_byte=intensity, use_sites=kernels)
+    roofline.update(tinfo)
+    rp_us, rp_src = load_rocprof_avg(workload, dom)
+    roofline.update(rocprofv3_avg_kernel_us=rp_us, rocprofv3_source=rp_src)
+    # whole-iteration view: algorithmic bytes / flops of the X passes an iteration makes over the iteration time
+    if r["x_passes"]:
+        roofline["iteration"] = {"x_passes": r["x_passes"],
+                                 "achieved_GBps": r["x_passes"] * alg_bytes / r["per_step_s"] / 1e9,
+                                 "achieved_TFLOPs": r["x_passes"] * alg_flops / r["per_step_s"] / 1e12,
+                                 "fraction_of_step_inside_the_dominant_kernel":
+                                     r["x_passes"] * by_fn[dom]["avg_us"] * 1e-6 / r["per_step_s"]}
+    return roofline
+
+
+def config_of(workload, r, world, line_search, force_exchange=False):
+    n, v_per, m, tag = WORKLOADS[workload]
+    v_total = v_per * world
+    return {"workload": "%s: synthetic Gaussian X %d samples x %d variables%s, n_hidden=%d, %s%s; 7-stage annealing, one "
+                        "timed window of %d iterations per stage"
+                        % (workload, n, v_total, " (%d per GPU, variable-sharded)" % v_per if world > 1 else "", m, tag,
+                           " (%s)" % DESCRIPTION[workload] if workload in DESCRIPTION else "", r["windows"]["steps_per_window"]),
+            "n_samples": n, "n_variables_total": v_total, "n_variables_per_gpu": v_per, "n_hidden": m,
+            "fit_iterations_per_sec": r["its_per_s"],
+            "line_search_trials_per_iteration": r["trials"], "invalid_trials_per_iteration": r["invalid"],
+            "line_search": line_search,
+            "x_passes_per_iteration": r["x_passes"],
+            "x_passes_per_iteration_reference_shaped": 2 + 2 * r["trials"] - r["invalid"],
+            "windows": r["windows"], "launch_geometry": r["geo"], "final_TC": r["final_tc"],
+            "bytes_resident": r["bytes_resident"], "force_exchange": bool(force_exchange)}
+
+
+def covariance_block(model, be, label):
+    """get_covariance() (reference :443-451) of the resident solution: seconds and achieved write rate."""
+    import numpy as np
+    t0 = time.perf_counter()
+    cov = model.get_covariance()
+    t1 = time.perf_counter()
+    cov = model.get_covariance()
+    t2 = time.perf_counter()
+    nv = cov.shape[0]
+    nbytes = cov.nbytes
+    dev_s = be.last_covariance_device_seconds() if hasattr(be, "last_covariance_device_seconds") else None
+    out = {"workload": label, "n_variables": int(nv), "dtype": cov.dtype.name, "output_bytes": int(nbytes),
+           "seconds_first_call": t1 - t0, "seconds": t2 - t1, "host_GBps": nbytes / (t2 - t1) / 1e9,
+           "kernel_seconds": dev_s, "kernel_write_GBps": (nbytes / dev_s / 1e9) if dev_s else None,
+           "diag_is_var": bool(np.allclose(np.diag(cov), np.asarray(model.theta[1], dtype=cov.dtype) ** 2))}
+    del cov
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
     # ONE JSON line on stdout, nothing else: RCCL prints a version banner to the C-level stdout (buffered, so it lands
     # after anything Python printed).  Everything written to fd 1 from here on goes to stderr; rank 0 writes the JSON line
     # to the saved descriptor at the end.
@@ -233,6 +579,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
+        return 2
+
+    # the library first, before anything initialises the GPU: a stale library is compiled here (hipcc is a child
+    # process), except under a profiler whose preloaded library would be inherited by the compiler
+    import __graft_entry__ as ge
+    if ge._stale() and any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")):
+        sys.stderr.write("bench.py: liblcx_hip.so is stale and a profiler is attached - run `python __graft_entry__.py` first\n")
+        return 3
+    ge.build()
+
+    import numpy as np
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path is the only product path)")
@@ -251,7 +610,9 @@ def main():
             dist.init_process_group(backend)
         from linearcorex_amd.comm import Comm
         comm = Comm()
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+        if comm.world != args.gpus:
+            sys.stderr.write("bench.py: the process group has %d ranks, --gpus %d\n" % (comm.world, args.gpus))
+            return 2
     if world == 1 and args.force_exchange:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -264,117 +625,95 @@ def main():
         from linearcorex_amd.comm import Comm
         comm = Comm(always_exchange=True)
 
-    import __graft_entry__ as ge
-    ge.build()
-
-    n, v_per, m, tag = WORKLOADS[args.workload]
+    auto = args.workload == "auto"
+    head = ("c3" if world == 1 else "c4shard") if auto else args.workload
+    if os.environ.get("LCX_BENCH_HEAD"):                 # test hook: a small headline workload on a shared one-GPU box
+        head = os.environ["LCX_BENCH_HEAD"]
+        _adhoc(head)
+    n, v_per, m, tag = WORKLOADS[head]
     dtype = np.float64 if tag == "f64" else np.float32
-    v_total = v_per * world
-    es = np.dtype(dtype).itemsize
 
-    # headline: the reference-shaped iteration (every line-search trial re-evaluates the moments
-    # with two passes over X, linearcorex.py:321)
-    r = measure(args, comm, world, rank, local_rank, args.line_search, keep_x=True)
-    elapsed, its_per_s, timing, geo = r["elapsed"], r["its_per_s"], r["timing"], r["geo"]
-    trials, invalid, per_stage = r["trials"], r["invalid"], r["per_stage"]
-
-    # algorithmic bytes / flops of ONE launch of an X-streaming GEMM on this rank:
-    alg_bytes = es * (n * v_per + m * v_per + n * m)
-    alg_flops = 2.0 * n * v_per * m
-    kernels = {}
-    for name, (cnt, ms) in timing.items():
-        if cnt:
-            avg = ms / cnt * 1e-3
-            kernels[name] = {"launches": cnt, "avg_us": avg * 1e6, "GBps": alg_bytes / avg / 1e9,
-                             "TFLOPs": alg_flops / avg / 1e12}
-    # use sites -> kernel function (rocprofv3 row).  X.B^T ("gemm_nt", :247/:210) and X^T.Y ("gemm_tn",
-    # :259/:211) usually run the same instantiation (the first one on the transposed copy of X).
-    by_fn = {}
-    for name, k in kernels.items():
-        fn = r["kernel_names"][name]
-        d = by_fn.setdefault(fn, {"launches": 0, "total_us": 0.0, "use_sites": []})
-        d["launches"] += k["launches"]
-        d["total_us"] += k["launches"] * k["avg_us"]
-        d["use_sites"].append(name)
-    for fn, d in by_fn.items():
-        avg = d["total_us"] / d["launches"] * 1e-6
-        d.update(avg_us=avg * 1e6, GBps=alg_bytes / avg / 1e9, TFLOPs=alg_flops / avg / 1e12)
-    roofline = None
-    if kernels:
-        dom = max(by_fn, key=lambda k: by_fn[k]["total_us"])
-        use_sites = kernels
-        kernels = by_fn
-        intensity = alg_flops / alg_bytes
-        mfma_peak = FP64_MFMA_PEAK_TFLOPS if tag == "f64" else FP32_MFMA_PEAK_TFLOPS
-        traffic, traffic_src, mfma_util = load_pmc_traffic(args.workload, dom)
-        if intensity < mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9):
-            roofline = {"bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic}
-        else:
-            roofline = {"bound": "mfma", "achieved": kernels[dom]["TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s",
-                        "frac": kernels[dom]["TFLOPs"] / mfma_peak, "traffic": traffic}
-        mfma_ceiling = MEASURED_CEILINGS["mfma_f64_TFLOPs" if tag == "f64" else "mfma_f32_TFLOPs"]
-        roofline.update(achieved_GBps=kernels[dom]["GBps"], achieved_TFLOPs=kernels[dom]["TFLOPs"],
-                        frac_of_measured_hbm_read_ceiling=kernels[dom]["GBps"] / MEASURED_CEILINGS["hbm_read_GBps"],
-                        frac_of_measured_mfma_ceiling=kernels[dom]["TFLOPs"] / mfma_ceiling,
-                        measured_ceilings=MEASURED_CEILINGS)
-        roofline.update(kernel=dom, avg_launch_us=kernels[dom]["avg_us"], launches=kernels[dom]["launches"],
-                        timed_every_nth_launch=args.timing_sample,
-                        algorithmic_bytes_per_launch=alg_bytes, algorithmic_flops_per_launch=alg_flops,
-                        traffic_source=traffic_src, mfma_util_pmc=mfma_util, use_sites=use_sites)
-        rp_us, rp_src = load_rocprof_avg(args.workload, dom)
-        roofline.update(rocprofv3_avg_kernel_us=rp_us, rocprofv3_source=rp_src)
-
-    extra = None
-    if args.also_linear and args.line_search == "exact":
-        # same iterations with the linear trial mode: reported beside the headline, never as it
-        r2 = measure(args, comm, world, rank, local_rank, "linear")
-        extra = {"fit_iterations_per_sec": r2["its_per_s"], "ms_per_step": r2["elapsed"] / args.steps * 1e3,
-                 "x_passes_per_iteration": (r2["x_passes"] / max(1, args.steps))
-                 if r2["x_passes"] is not None else None,
-                 "line_search_trials_per_iteration": r2["trials"], "final_TC": r2["final_tc"]}
+    # ---- headline: the reference-shaped iteration (every line-search trial re-evaluates the moments with two passes
+    # over X, linearcorex.py:321) ----
+    r, model, be = measure(args, comm, world, rank, local_rank, head, args.steps, args.warmup, args.line_search,
+                           keep_x=True, repeats=args.repeats)
+    roofline = roofline_of(head, r, world)
+    cfg = config_of(head, r, world, args.line_search, args.force_exchange)
+    x_head = r.pop("x_host")
+    if args.extras and world == 1 and comm is None and v_per <= 20000:
+        cfg["get_covariance"] = covariance_block(model, be, head)
+    be.close()
+    model._backend = None
+    del model, be
 
     out = {
         "metric": "corex_fit_iterations_per_sec",
-        "value": its_per_s * world,
-        "unit": "iterations/s (10k x 5k x 32 block-iterations; = fit iterations/s at 1 GPU)" if args.workload == "c2"
-                else "iterations/s x GPUs",
+        "value": r["its_per_s"] * world,
+        "unit": "fit iterations/s (x GPUs: every rank iterates over its own %d x %d x %d shard)" % (n, v_per, m)
+                if world > 1 else "fit iterations/s at (n_samples, n_variables, n_hidden) = (%d, %d, %d)" % (n, v_per, m),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": r["per_step_s"] * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": tag, "data": "synthetic",
-        "config": {"workload": "%s: synthetic Gaussian X %d samples x %d variables%s, n_hidden=%d, %s, "
-                               "7-stage annealing, %d iterations per stage"
-                               % (args.workload, n, v_total, " (%d per GPU, variable-sharded)" % v_per if world > 1 else "",
-                                  m, tag, per_stage),
-                   "n_samples": n, "n_variables_total": v_total, "n_variables_per_gpu": v_per, "n_hidden": m,
-                   "fit_iterations_per_sec": its_per_s,
-                   "line_search_trials_per_iteration": trials, "invalid_trials_per_iteration": invalid,
-                   "line_search": args.line_search,
-                   "x_passes_per_iteration": (r["x_passes"] / max(1, args.steps)) if r["x_passes"] is not None
-                   else None,
-                   "x_passes_per_iteration_reference_shaped": 2 + 2 * trials - invalid,
-                   "launch_geometry": geo, "final_TC": r["final_tc"], "force_exchange": bool(args.force_exchange),
-                   "linear_trial_mode": extra},
+        "config": cfg,
         "roofline": roofline,
+        "cpu_baseline": None,
     }
-    x_host = r["x_host"]
-    if world == 1 and args.convergence and args.workload == "c2" and x_host is not None and comm is None:
-        # BASELINE.json's second figure: wall-clock of a whole fit() to |dTC| < 1e-5 per annealing stage
-        # (reference defaults :72-74), including the upload + on-device preprocess and the final detail moments
-        from linearcorex_amd import Corex
-        t0 = time.perf_counter()
-        mdl = Corex(n_hidden=m, seed=0, dtype=dtype, device=local_rank).fit(x_host)
-        t1 = time.perf_counter()
-        out["config"]["fit_to_convergence"] = {
-            "seconds": t1 - t0, "iterations": len(mdl.history["TC"]), "TC": float(mdl.tc), "tol": 1e-5,
-            "iterations_per_sec_incl_setup": len(mdl.history["TC"]) / (t1 - t0),
-            "trials_per_iteration": mdl.stats["trials"] / max(1, len(mdl.history["TC"]))}
-        mdl._backend.close()
-    if rank == 0 and world == 1 and args.cpu_iters_per_stage > 0 and x_host is not None:
-        out["cpu_baseline"] = cpu_baseline(x_host, m, dtype, args.cpu_iters_per_stage)
-    elif rank == 0:
-        out["cpu_baseline"] = None
+
+    if args.extras:
+        # ---- nested block: BASELINE.json configs[1] (HBM-bound), 5k variables per GPU, its own fixed protocol ----
+        c2_steps, c2_warm = 30, 5
+        r2, model2, be2 = measure(args, comm, world, rank, local_rank, "c2", c2_steps, c2_warm, "exact", keep_x=True)
+        x2 = r2.pop("x_host")
+        blk = config_of("c2", r2, world, "exact")
+        blk["value"] = r2["its_per_s"] * world
+        blk["ms_per_step"] = r2["per_step_s"] * 1e3
+        blk["dtype"] = "f64"
+        blk["roofline"] = roofline_of("c2", r2, world)
+        if world == 1 and comm is None:
+            blk["get_covariance"] = covariance_block(model2, be2, "c2")
+        be2.close()
+        model2._backend = None
+        del model2, be2
+        # the same iterations with the linear trial mode: reported beside, never as a headline
+        r3, model3, be3 = measure(args, comm, world, rank, local_rank, "c2", c2_steps, c2_warm, "linear", kernel_timing=True)
+        blk["linear_trial_mode"] = {"fit_iterations_per_sec": r3["its_per_s"], "ms_per_step": r3["per_step_s"] * 1e3,
+                                    "x_passes_per_iteration": r3["x_passes"],
+                                    "line_search_trials_per_iteration": r3["trials"], "final_TC": r3["final_tc"]}
+        be3.close()
+        model3._backend = None
+        del model3, be3
+        if world == 1 and comm is None and x2 is not None:
+            # BASELINE.json's second figure: wall-clock of a whole fit() to |dTC| < 1e-5 per annealing stage (reference
+            # defaults :72-74), including the upload + on-device preprocess and the final detail moments
+            from linearcorex_amd import Corex
+            t0 = time.perf_counter()
+            mdl = Corex(n_hidden=32, seed=0, dtype=np.float64, device=local_rank).fit(x2)
+            t1 = time.perf_counter()
+            blk["fit_to_convergence"] = {
+                "seconds": t1 - t0, "iterations": len(mdl.history["TC"]), "TC": float(mdl.tc), "tol": 1e-5,
+                "iterations_per_sec_incl_setup": len(mdl.history["TC"]) / (t1 - t0),
+                "trials_per_iteration": mdl.stats["trials"] / max(1, len(mdl.history["TC"]))}
+            mdl._backend.close()
+            del mdl
+            # BASELINE.json configs[4] stand-in shape: get_covariance() of a 20 000-variable model
+            mdl = Corex(n_hidden=30, seed=0, dtype=np.float64, device=local_rank, max_iter=3)
+            mdl.fit(np.random.RandomState(5).randn(400, 20000))
+            out["config"]["get_covariance_c5_standin"] = covariance_block(mdl, mdl._backend, "c5 stand-in: 400 x 20000, n_hidden=30, f64")
+            mdl._backend.close()
+            del mdl
+        if rank == 0 and world == 1 and comm is None and args.cpu_iters_per_stage > 0 and x2 is not None:
+            blk["cpu_baseline"] = cpu_baseline_resident(x2, 32, np.float64, args.cpu_iters_per_stage)
+        out["config"]["c2" if world == 1 else "c2_weak"] = blk
+        del x2
+
+        # ---- CPU baseline of the headline workload, rank 0 at N=1 only ----
+        if rank == 0 and world == 1 and comm is None and args.cpu_seconds > 0:
+            if x_head is not None:
+                out["cpu_baseline"] = cpu_baseline_resident(x_head, m, dtype, max(1, args.cpu_iters_per_stage))
+            else:
+                out["cpu_baseline"] = cpu_baseline_generated(n, v_per, m, dtype, args.cpu_seconds, head)
+
     # tear the process group down first and push out whatever C-level stdio still buffers (now on stderr), so that the JSON
     # line is the last thing this job writes even when the caller merges the two streams
     import ctypes
@@ -389,7 +728,8 @@ def main():
     sys.stderr.flush()
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -10,6 +10,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <sched.h>
+#include <time.h>
 
 #include <string>
 #include <vector>
@@ -121,6 +122,24 @@ struct lcx_ctx {
 };
 
 template <typename T> static inline T* P(void* p) { return reinterpret_cast<T*>(p); }
+
+// Temporary device buffers of one call: freed on every return path (an OOM in the middle of a call must not leak the
+// buffers allocated before it - that is exactly when memory matters).
+struct DevTemps {
+    std::vector<void*> ptrs;
+    ~DevTemps() { for (void* p : ptrs) (void)hipFree(p); }
+    template <typename U> int get(U** out, size_t bytes) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess) {
+            *out = nullptr;
+            return fail(LCX_ERR_HIP, std::string("hipMalloc of a temporary of ") + std::to_string(bytes) + " bytes: " + hipGetErrorString(e));
+        }
+        ptrs.push_back(p);
+        *out = reinterpret_cast<U*>(p);
+        return LCX_OK;
+    }
+};
 
 // -------------------------------------------------------------------------------------------------
 // GEMM launchers
@@ -540,7 +559,10 @@ template <typename T, int CT> struct Impl {
     static int gram_pair(lcx_ctx* h, const T* w, const T* y) {
         constexpr int RT = Geo<T, CT>::G_RT;
         const int kgv = (int)(h->ldx / 16), kgn = (int)(h->Npad / 16);
-        const int kw = pick_kw(kgv < kgn ? kgv : kgn);
+        // With several ranks the Y^T.Y Gram feeds uj / TC, which every rank must form bit-identically (the line-search
+        // decisions are taken from them): its wave split may then depend on the replicated n_samples only, never on the
+        // local shard width (448 vs 512 local columns would pick 2 vs 4 waves and sum in a different order).
+        const int kw = h->exchange ? pick_kw(kgn) : pick_kw(kgv < kgn ? kgv : kgn);
         GramProblem<T> p0{w, P<T>(h->gpartw), kgv, h->gv_S}, p1{y, P<T>(h->gpart), kgn, h->gn_S};
         dim3 grid((unsigned)(Mp / (16 * RT)), (unsigned)(h->gv_S > h->gn_S ? h->gv_S : h->gn_S), 2);
         const size_t lds = (size_t)kw * 16 * RT * Mp * sizeof(T);
@@ -799,22 +821,7 @@ template <typename T, int CT> struct Impl {
     static int covariance_syn(lcx_ctx* h, const void* std_host, int64_t row0, int64_t nrows, void* out_host) {
         MomentSet& s = h->set[0];
         if (!s.xz) return fail(LCX_ERR_STATE, "synergistic covariance needs lcx_syn_moments_b first");
-        T *std_dev = nullptr, *out_dev = nullptr;
-        HIPCHECK(hipMalloc((void**)&std_dev, sizeof(T) * h->V));
-        if (hipMalloc((void**)&out_dev, sizeof(T) * nrows * h->V) != hipSuccess) {
-            (void)hipFree(std_dev);
-            return fail(LCX_ERR_HIP, "covariance_rows: cannot allocate the output block on device");
-        }
-        HIPCHECK(hipMemcpyAsync(std_dev, std_host, sizeof(T) * h->V, hipMemcpyHostToDevice, h->stream));
-        dim3 grid((unsigned)cdiv(h->V, 64), (unsigned)cdiv(nrows, 64));
-        hipLaunchKernelGGL((covariance_syn_kernel<T, Mp>), grid, dim3(256), 0, h->stream, P<T>(s.xz), P<T>(s.D), std_dev, h->V, row0,
-                           nrows, (double)h->N, out_dev);
-        KCHECK();
-        HIPCHECK(hipMemcpyAsync(out_host, out_dev, sizeof(T) * nrows * h->V, hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(hipStreamSynchronize(h->stream));
-        HIPCHECK(hipFree(std_dev));
-        HIPCHECK(hipFree(out_dev));
-        return LCX_OK;
+        return covariance_blocks(h, true, 0.0, std_host, row0, nrows, out_host, h->V, nullptr);
     }
 
     // [Vp][Mp] device -> (m, V) or (V, m) host
@@ -922,23 +929,7 @@ template <typename T, int CT> struct Impl {
     }
 
     static int covariance(lcx_ctx* h, double eps, const void* std_host, int64_t row0, int64_t nrows, void* out_host) {
-        MomentSet& s = h->set[0];
-        T *std_dev = nullptr, *out_dev = nullptr;
-        HIPCHECK(hipMalloc((void**)&std_dev, sizeof(T) * h->V));
-        if (hipMalloc((void**)&out_dev, sizeof(T) * nrows * h->V) != hipSuccess) {
-            (void)hipFree(std_dev);
-            return fail(LCX_ERR_HIP, "covariance_rows: cannot allocate the output block on device");
-        }
-        HIPCHECK(hipMemcpyAsync(std_dev, std_host, sizeof(T) * h->V, hipMemcpyHostToDevice, h->stream));
-        dim3 grid((unsigned)cdiv(h->V, 64), (unsigned)cdiv(nrows, 64));
-        hipLaunchKernelGGL((covariance_kernel<T, Mp>), grid, dim3(256), 0, h->stream, P<T>(s.rir), P<T>(s.si), std_dev,
-                           h->V, row0, nrows, eps, out_dev);
-        KCHECK();
-        HIPCHECK(hipMemcpyAsync(out_host, out_dev, sizeof(T) * nrows * h->V, hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(hipStreamSynchronize(h->stream));
-        HIPCHECK(hipFree(std_dev));
-        HIPCHECK(hipFree(out_dev));
-        return LCX_OK;
+        return covariance_blocks(h, false, eps, std_host, row0, nrows, out_host, h->V, nullptr);
     }
 
     static int project(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, void* out_host) {
@@ -1571,22 +1562,39 @@ static int wait_published(lcx_ctx* h, MomentSet& s) {
         HIPCHECK(hipStreamSynchronize(h->stream));
         return LCX_OK;
     }
+    // The wait is bounded (LCX_WAIT_TIMEOUT_MS, default 120 s): a rank whose publication never arrives fails with
+    // what it expected and what it saw instead of hanging the whole job in the next collective.
+    static const double limit_s = []() {
+        const char* e = getenv("LCX_WAIT_TIMEOUT_MS");
+        return (e && *e) ? atof(e) * 1e-3 : 120.0;
+    }();
     volatile unsigned int* p = &s.hst->seq;
     int spins = 0;
-    while (*p != s.seq_expect) {
+    timespec t0{0, 0};
+    bool have_t0 = false;
+    while (__atomic_load_n(p, __ATOMIC_ACQUIRE) != s.seq_expect) {
         if (++spins >= 4096) {
             spins = 0;
             hipError_t q = hipStreamQuery(h->stream);
             if (q == hipSuccess) {
-                if (*p == s.seq_expect) break;
-                return fail(LCX_ERR_STATE, "stream drained but the state mirror was not published");
+                if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == s.seq_expect) break;
+                return fail(LCX_ERR_STATE, "stream drained but the state mirror was not published: expected seq " +
+                                               std::to_string(s.seq_expect) + ", mirror has " + std::to_string(*p));
             }
             if (q != hipErrorNotReady) HIPCHECK(q);
+            timespec now;
+            clock_gettime(CLOCK_MONOTONIC, &now);
+            if (!have_t0) { t0 = now; have_t0 = true; }
+            const double waited = (double)(now.tv_sec - t0.tv_sec) + 1e-9 * (double)(now.tv_nsec - t0.tv_nsec);
+            if (waited > limit_s)
+                return fail(LCX_ERR_STATE, "state mirror not published after " + std::to_string(waited) + " s: expected seq " +
+                                               std::to_string(s.seq_expect) + ", mirror has " + std::to_string(*p) +
+                                               ", last enqueued seq " + std::to_string(h->seq_next) +
+                                               ", stream still busy (hipErrorNotReady), world " + std::to_string(h->world));
             sched_yield();                   // several ranks of one box may share few cores (tests: two ranks + gloo threads)
         }
         __builtin_ia32_pause();
     }
-    __sync_synchronize();
     return LCX_OK;
 }
 

@@ -901,53 +901,6 @@ syn_update_kernel(const T* __restrict__ W, const T* __restrict__ xz, const T* __
     }
 }
 
-// get_covariance, synergistic branch (:452-455): out[r][c] = std_r std_c (r==c ? 1 : sum_j XiZj[r][j] XiYj[c][j]),
-// XiYj = D / N.  Same tiling as covariance_kernel.
-template <typename T, int Mp>
-__global__ void __launch_bounds__(256)
-covariance_syn_kernel(const T* __restrict__ xz, const T* __restrict__ D, const T* __restrict__ stdv, int64_t V,
-                      int64_t row0, int64_t nrows, double n_samples, T* __restrict__ out) {
-    constexpr int KC = Mp < 32 ? Mp : 32;
-    __shared__ T zr[64][KC + 1];
-    __shared__ T zc[64][KC + 1];
-    const int tid = threadIdx.x;
-    const int64_t rb = row0 + (int64_t)blockIdx.y * 64, cb = (int64_t)blockIdx.x * 64;
-    const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;
-    T acc[4][4] = {};
-    for (int j0 = 0; j0 < Mp; j0 += KC) {
-        __syncthreads();
-        for (int idx = tid; idx < 64 * KC; idx += 256) {
-            const int a = idx / KC, j = idx % KC;
-            const int64_t vr = rb + a, vc = cb + a;
-            zr[a][j] = (vr < V && vr < row0 + nrows) ? xz[vr * Mp + j0 + j] : (T)0;
-            zc[a][j] = (vc < V) ? D[vc * Mp + j0 + j] / (T)n_samples : (T)0;
-        }
-        __syncthreads();
-        for (int j = 0; j < KC; ++j) {
-            T a[4], b[4];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) { a[x] = zr[tr + x][j]; b[x] = zc[tc + x][j]; }
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 4; ++y) acc[x][y] += a[x] * b[y];
-        }
-    }
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const int64_t r = rb + tr + x;
-        if (r >= V || r >= row0 + nrows) continue;
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            const int64_t c = cb + tc + y;
-            if (c >= V) continue;
-            T val = acc[x][y];
-            if (r == c) val = (T)1;
-            out[(r - row0) * V + c] = stdv[r] * stdv[c] * val;
-        }
-    }
-}
-
 // derived arrays for readback
 template <typename T>
 __global__ void invrho_kernel(const T* __restrict__ rho, int64_t n, T* __restrict__ out) {
@@ -957,52 +910,75 @@ __global__ void invrho_kernel(const T* __restrict__ rho, int64_t n, T* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// get_covariance rows (:446-451): out[r][c] = std_r std_c * (r==c ? 1 : z_r . z_c / (1-eps^2)),
-// z_i = rhoinvrho_i / (1 + Si_i).  64x64 output tile per block, 256 threads, 4x4 per thread.
+// get_covariance (:443-455): a rank-Mp product of two [V][Mp] operands, written once.
+//   non-synergistic (:446-451): out[r][c] = std_r std_c (r == c ? 1 : z_r . z_c / (1 - eps^2)),  z_i = rhoinvrho_i / (1 + Si_i)
+//   synergistic     (:452-455): out[r][c] = std_r std_c (r == c ? 1 : X_i Z_j[r] . X_i Y_j[c]),  X_i Y_j = X^T.Y / N
+// cov_prep_kernel forms the operand(s) once per call (elementwise, [Vp][Mp]); cov_syrk_kernel is the product: one
+// 64 x 64 output tile per block of 4 waves, MFMA 16x16x4, operands staged through LDS in chunks of <= 32 factors
+// (rows padded by 2 elements: the 16 rows x 2 contraction lanes of a read land on distinct banks in both precisions).
+// The kernel is bound by the V^2 output write: a lane owns 4 CONSECUTIVE columns (MFMA column j of tile u is column
+// 4 j + u of the block), so every store instruction writes 16 lanes x 16 / 32 bytes = whole 256 / 512-byte row segments.
+// The output block has a padded leading dimension (ldo, a multiple of 64): columns past V land in the padding.
 // ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void cov_prep_kernel(const T* __restrict__ src_a, const T* __restrict__ si, const T* __restrict__ src_b,
+                                int64_t n /* Vp * Mp */, int Mp, T inv_n, T* __restrict__ op_a, T* __restrict__ op_b) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (si != nullptr) op_a[i] = src_a[i] / ((T)1 + si[i / Mp]);       // z = rhoinvrho / (1 + Si), :447
+        if (src_b != nullptr) op_b[i] = src_b[i] * inv_n;                  // X_i Y_j = X^T.Y / N, :355
+    }
+}
+
 template <typename T, int Mp>
 __global__ void __launch_bounds__(256)
-covariance_kernel(const T* __restrict__ rir, const T* __restrict__ si, const T* __restrict__ stdv,
-                  int64_t V, int64_t row0, int64_t nrows, double eps, T* __restrict__ out) {
-    constexpr int KC = Mp < 32 ? Mp : 32;      // factor chunk staged in LDS
-    __shared__ T zr[64][KC + 1];
-    __shared__ T zc[64][KC + 1];
-    const int tid = threadIdx.x;
+cov_syrk_kernel(const T* __restrict__ A, const T* __restrict__ B, const T* __restrict__ stdv, int64_t V, int64_t row0,
+                int64_t nrows, T denom, T* __restrict__ out, int64_t ldo) {
+    constexpr int KC = Mp < 32 ? Mp : 32;
+    constexpr int LDS_LD = KC + 2;
+    typedef typename MF<T>::acc_t acc_t;
+    __shared__ T As[64][LDS_LD];
+    __shared__ T Bs[64][LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
     const int64_t rb = row0 + (int64_t)blockIdx.y * 64, cb = (int64_t)blockIdx.x * 64;
-    const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;
-    T acc[4][4] = {};
+    acc_t acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = (acc_t){0, 0, 0, 0};
     for (int j0 = 0; j0 < Mp; j0 += KC) {
         __syncthreads();
         for (int idx = tid; idx < 64 * KC; idx += 256) {
             const int a = idx / KC, j = idx % KC;
             const int64_t vr = rb + a, vc = cb + a;
-            zr[a][j] = (vr < V && vr < row0 + nrows) ? rir[vr * Mp + j0 + j] / ((T)1 + si[vr]) : (T)0;
-            zc[a][j] = (vc < V) ? rir[vc * Mp + j0 + j] / ((T)1 + si[vc]) : (T)0;
+            As[a][j] = (vr < V && vr < row0 + nrows) ? A[vr * Mp + j0 + j] : (T)0;
+            Bs[(a & 3) * 16 + (a >> 2)][j] = (vc < V) ? B[vc * Mp + j0 + j] : (T)0;      // column 4 j + u -> row 16 u + j
         }
         __syncthreads();
-        for (int j = 0; j < KC; ++j) {
-            T a[4], b[4];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) { a[x] = zr[tr + x][j]; b[x] = zc[tc + x][j]; }
+        for (int s = 0; s < KC / 4; ++s) {
+            const T av = As[16 * wave + i][4 * s + q];
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 4; ++y) acc[x][y] += a[x] * b[y];
+            for (int u = 0; u < 4; ++u) acc[u] = MF<T>::mma(av, Bs[16 * u + i][4 * s + q], acc[u]);
         }
     }
-    const T denom = (T)(1.0 - eps * eps);
+    Pk<T, 4> sc;
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const int64_t r = rb + tr + x;
+    for (int u = 0; u < 4; ++u) {
+        const int64_t c = cb + 4 * i + u;
+        sc.v[u] = c < V ? stdv[c] : (T)0;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int64_t r = rb + 16 * wave + MF<T>::row(lane, g);
         if (r >= V || r >= row0 + nrows) continue;
+        const T sr = stdv[r];
+        Pk<T, 4> o;
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            const int64_t c = cb + tc + y;
-            if (c >= V) continue;
-            T val = acc[x][y] / denom;
-            if (r == c) val = (T)1;
-            out[(r - row0) * V + c] = stdv[r] * stdv[c] * val;
+        for (int u = 0; u < 4; ++u) {
+            const int64_t c = cb + 4 * i + u;
+            const T val = (r == c) ? (T)1 : acc[u][g] / denom;
+            o.v[u] = sr * sc.v[u] * val;
         }
+        *reinterpret_cast<Pk<T, 4>*>(out + (r - row0) * ldo + cb + 4 * i) = o;
     }
 }
 

@@ -28,8 +28,17 @@ def main():
     syn = mode == "syn"                     # discourage_overlap=False (reference :336-384)
     if syn:
         mode = "exact"
+    trace = os.environ.get("LCX_TEST_TRACE", "0") not in ("", "0")
+    t_start = __import__("time").time()
+
+    def mark(what):
+        if trace:
+            print("[rank %s +%.2fs] %s" % (os.environ.get("RANK"), __import__("time").time() - t_start, what), flush=True)
+
+    mark("before rendezvous")
     dist.init_process_group("gloo")
     comm = Comm()
+    mark("rendezvous done")
     x, _ = O.gen_planted(n, v, m, seed=2)
     if backend == "hip":
         # every rank drives its own engine handle on GPU 0; the exchange tensors are CUDA tensors and the
@@ -40,7 +49,9 @@ def main():
         model = Corex(n_hidden=m, seed=0, dtype=np.float64, comm=comm, line_search=mode, max_iter=max_iter,
                       discourage_overlap=not syn,
                       _backend_factory=lambda ns, nv, mm, dt: ShardDouble(ns, nv, mm, dt))
+    mark("model constructed")
     model.fit(x)
+    mark("fit done: %d iterations" % len(model.history["TC"]))
     c0, c1 = comm.shard(v)
     assert model._backend.nv == c1 - c0
     y = model.transform(x)
@@ -53,8 +64,10 @@ def main():
                  ws=model.ws, clusters=model.clusters(), transform=y, rho=rho, xz=xz, si=si, cov=cov,
                  tcs=model.tcs, world=comm.world, trials=model.stats["trials"],
                  calls=np.array(len(getattr(model._backend, "calls", []))))
+    mark("results gathered")
     dist.barrier()
     dist.destroy_process_group()
+    mark("process group destroyed")
 
 
 if __name__ == "__main__":

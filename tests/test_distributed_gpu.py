@@ -24,7 +24,8 @@ def _launch_once(world, out_dir, n, v, m, mode, timeout):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2",
-                   LCX_TEST_DUMP_AFTER=str(max(10, timeout - 30)), LCX_CHECK_RANKS="1")
+                   LCX_TEST_DUMP_AFTER=str(max(10, timeout - 30)), LCX_CHECK_RANKS="1", LCX_TEST_TRACE="1",
+                   LCX_WAIT_TIMEOUT_MS=str(1000 * max(10, timeout - 45)))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(out_dir),
                                        str(n), str(v), str(m), mode, "hip", str(MAX_ITER)], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -49,6 +50,9 @@ def launch_hip(world, out_dir, n, v, m, mode):
     import sys
     timed_out, procs, outs = _launch_once(world, out_dir, n, v, m, mode, 120)
     if timed_out:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "dist_stall_stacks.log"), "a") as f:
+            f.write("==== %s %s ====\n" % (mode, (n, v, m)) + "\n-----\n".join(o[-8000:] for o in outs) + "\n")
         sys.stderr.write("ranks did not finish in 120 s, retrying once:\n" + "\n-----\n".join(o[-3000:] for o in outs) + "\n")
         timed_out, procs, outs = _launch_once(world, out_dir, n, v, m, mode, 120)
     assert not timed_out, "ranks did not finish in 120 s (twice):\n" + "\n-----\n".join(o[-3000:] for o in outs)

@@ -110,15 +110,18 @@ def parse(argv=None):
 # ------------------------------------------------------------------------------------------------------
 def spawn_ranks(args):
     import socket
-    rc = subprocess.call([sys.executable, os.path.join(ROOT, "__graft_entry__.py")], cwd=ROOT, stdout=sys.stderr)
-    if rc != 0:
-        sys.stderr.write("bench.py: building the HIP library failed\n")
-        return rc
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    if os.environ.get("LCX_BENCH_DRY_SPAWN"):          # CPU test hook: show the launch, start nothing
+        sys.stdout.write(json.dumps({"spawn": cmd}) + "\n")
+        return 0
+    rc = subprocess.call([sys.executable, os.path.join(ROOT, "__graft_entry__.py")], cwd=ROOT, stdout=sys.stderr)
+    if rc != 0:
+        sys.stderr.write("bench.py: building the HIP library failed\n")
+        return rc
     sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: launching the ranks as children: %s\n" % (args.gpus, " ".join(cmd)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE)
@@ -144,15 +147,39 @@ def spawn_ranks(args):
 # ------------------------------------------------------------------------------------------------------
 # CPU baselines: the NumPy oracle (a port of the reference path, pinned to it bit for bit) on the host cores
 # ------------------------------------------------------------------------------------------------------
-def _blas_threads():
+def _usable_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU box shows 256
+    logical CPUs under a 16-CPU quota: a BLAS pool sized by the former spends its time being throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
-        from threadpoolctl import threadpool_info
-        infos = threadpool_info()
-        threads = max([p.get("num_threads", 1) for p in infos] or [1])
-        vendor = ", ".join(sorted({"%s %s" % (p.get("internal_api", "?"), p.get("version", "")) for p in infos}))
-        return int(threads), vendor
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
     except Exception:
-        return int(os.cpu_count() or 1), "unknown"
+        pass
+    return max(1, n)
+
+
+class _BlasPool:
+    """Context: BLAS threads = usable cores; reports (threads, vendor/version)."""
+
+    def __enter__(self):
+        self.threads, self.vendor, self._ctx = _usable_cores(), "unknown", None
+        try:
+            from threadpoolctl import threadpool_info, threadpool_limits
+            self._ctx = threadpool_limits(limits=self.threads, user_api="blas")
+            self._ctx.__enter__()
+            infos = [p for p in threadpool_info() if p.get("user_api") == "blas"]
+            self.threads = max([p.get("num_threads", 1) for p in infos] or [self.threads])
+            self.vendor = ", ".join(sorted({"%s %s" % (p.get("internal_api", "?"), p.get("version", "")) for p in infos}))
+        except Exception:
+            pass
+        return self
+
+    def __exit__(self, *a):
+        if self._ctx is not None:
+            self._ctx.__exit__(*a)
 
 
 def cpu_baseline_resident(x, m, dtype, iters_per_stage):
@@ -160,11 +187,12 @@ def cpu_baseline_resident(x, m, dtype, iters_per_stage):
     iterations per stage."""
     import numpy as np
     from oracle import corex_oracle as O
-    threads, vendor = _blas_threads()
     xt = O.preprocess(np.asarray(x, dtype=dtype))[0]
-    t0 = time.perf_counter()
-    res = O.fit_ns_preprocessed(xt, m, seed=0, dtype=dtype, max_iter=iters_per_stage, tol=0.0, finish=False)
-    t1 = time.perf_counter()
+    with _BlasPool() as pool:
+        threads, vendor = pool.threads, pool.vendor
+        t0 = time.perf_counter()
+        res = O.fit_ns_preprocessed(xt, m, seed=0, dtype=dtype, max_iter=iters_per_stage, tol=0.0, finish=False)
+        t1 = time.perf_counter()
     n_it = len(res.history_tc)
     return {"value": n_it / (t1 - t0), "unit": "iterations/s", "cores": threads, "kind": "port",
             "sample": "%d iterations (%d per annealing stage x 7, stage changes included) of the same workload on the same X, "
@@ -178,7 +206,7 @@ def _host_gaussian(n, v, dtype, seed):
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     x = np.empty((n, v), dtype=dtype)
-    workers = max(1, min(32, os.cpu_count() or 1))
+    workers = max(1, min(32, _usable_cores()))
     bounds = [(n * k // workers, n * (k + 1) // workers) for k in range(workers)]
 
     def fill(k):
@@ -213,7 +241,6 @@ def cpu_baseline_generated(n, v, m, dtype, budget_s, label):
     timed for at least 3 iterations, one per annealing stage while the budget lasts."""
     import numpy as np
     from oracle import corex_oracle as O
-    threads, vendor = _blas_threads()
     es = np.dtype(dtype).itemsize
     avail = None
     try:
@@ -244,27 +271,29 @@ def cpu_baseline_generated(n, v, m, dtype, budget_s, label):
     t_gen = time.perf_counter()
     x = _host_gaussian(n, v_cpu, dtype, seed=1)
     t_gen = time.perf_counter() - t_gen
-    w = O.initial_weights(0, m, v_cpu, dtype)
-    w /= (10.0 * O.norm(x, w, 0))[:, np.newaxis]
-    mo = O.moments_ns(x, w, 0, quick=True)
-    eps, n_it, trials, t_iter, t_stage, stages = 0, 0, 0, 0.0, 0.0, 0
-    t_begin = time.perf_counter()
-    for stage, eps_new in enumerate(O.anneal_schedule(True)):
-        t0 = time.perf_counter()
-        eps_old, eps = eps, eps_new
-        if stage > 0:
-            w = O.rescale_for_stage(w, mo["uj"], eps_old, eps)
-        mo = O.moments_ns(x, w, eps, quick=False)
-        t1 = time.perf_counter()
-        w, mo, info = O.update_ns(x, w, mo, eps, 0.0)
-        t2 = time.perf_counter()
-        t_stage += t1 - t0
-        t_iter += t2 - t1
-        n_it += 1
-        stages += 1
-        trials += info["n_trials"]
-        if n_it >= 3 and (time.perf_counter() - t_begin) > budget_s:
-            break
+    with _BlasPool() as pool:
+        threads, vendor = pool.threads, pool.vendor
+        w = O.initial_weights(0, m, v_cpu, dtype)
+        w /= (10.0 * O.norm(x, w, 0))[:, np.newaxis]
+        mo = O.moments_ns(x, w, 0, quick=True)
+        eps, n_it, trials, t_iter, t_stage, stages = 0, 0, 0, 0.0, 0.0, 0
+        t_begin = time.perf_counter()
+        for stage, eps_new in enumerate(O.anneal_schedule(True)):
+            t0 = time.perf_counter()
+            eps_old, eps = eps, eps_new
+            if stage > 0:
+                w = O.rescale_for_stage(w, mo["uj"], eps_old, eps)
+            mo = O.moments_ns(x, w, eps, quick=False)
+            t1 = time.perf_counter()
+            w, mo, info = O.update_ns(x, w, mo, eps, 0.0)
+            t2 = time.perf_counter()
+            t_stage += t1 - t0
+            t_iter += t2 - t1
+            n_it += 1
+            stages += 1
+            trials += info["n_trials"]
+            if n_it >= 3 and (time.perf_counter() - t_begin) > budget_s:
+                break
     its = n_it / t_iter
     scale = float(v_cpu) / float(v)
     del x
@@ -414,15 +443,17 @@ def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_s
             sync()
             chg.append(time.perf_counter() - t0)
             if i_eps == 0:
-                for _ in range(warmup):
-                    model._iterate()
+                for k in range(warmup):
+                    model._iterate(more=k + 1 < warmup)
                 sync()
             before = {k: model.stats.get(k, 0) for k in stat_keys}
             if timing and record:
                 be.timing_enable(True)
             t0 = time.perf_counter()
-            for _ in range(steps):
-                model._iterate()
+            for k in range(steps):
+                # more: the engine may start iteration k+1 before returning (as in a real fit); never past the window's
+                # end, so that exactly `steps` iterations of work lie between t0 and t1
+                model._iterate(more=k + 1 < steps)
             sync()
             t1 = time.perf_counter()
             if timing and record:
@@ -583,16 +614,17 @@ def main():
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
         return 2
 
-    # the library first, before anything initialises the GPU: a stale library is compiled here (hipcc is a child
+    # torch first: its wheel carries its own HIP / HSA runtime, and liblcx_hip.so must resolve against the copy that is
+    # already loaded (two HSA runtimes in one process leave the second one without devices).  Importing is not a GPU call.
+    import numpy as np
+    import torch
+    # then the library, before anything initialises the GPU: a stale library is compiled here (hipcc is a child
     # process), except under a profiler whose preloaded library would be inherited by the compiler
     import __graft_entry__ as ge
     if ge._stale() and any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")):
         sys.stderr.write("bench.py: liblcx_hip.so is stale and a profiler is attached - run `python __graft_entry__.py` first\n")
         return 3
     ge.build()
-
-    import numpy as np
-    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path is the only product path)")
     # test hooks: LCX_BENCH_DEVICE pins every rank to one device and LCX_BENCH_BACKEND=gloo replaces RCCL, so that the

@@ -196,6 +196,22 @@ int lcx_trial_linear_b(lcx_ctx* h, double eps, double eta);
 /* self.ws, self.moments = w_update, m_update (:139,:334): swap sets                              */
 int lcx_accept_trial(lcx_ctx* h);
 
+/* ---- one whole iteration (:290-334) in one call, one GPU ----------------------------------------------------
+ * `_update_ns` with its back-tracking line search, the host side of the decisions included: the levels above
+ * (lcx_update_b/_c, lcx_make_trial, lcx_moments_a/_b per trial, lcx_accept_trial) are sequenced inside the library, the
+ * scalars of each trial are read from the pinned mirror and the next launches follow immediately - no interpreter between
+ * a trial's result and the work that depends on it.  tc_cur = TC of the current solution (LCX_S_TC of set 0).
+ * more != 0: the caller intends to iterate again unless |TC_new - tc_cur| < tol (:152); the direction and the first trial
+ * of the NEXT iteration are then enqueued before this call returns, so that the GPU works while the caller does its
+ * book-keeping (:151, :166-175).  Any other state-changing entry point abandons that work safely.
+ * out8: [0] status 0 = accepted (:334), 1 = update_tangent >= 0, nothing changed (:306-311), 2 = the step size underflowed
+ *            on an invalid trial (the reference then returns m_update = False, :144-149);
+ *       [1] TC of the accepted trial, [2] update_tangent (:305), [3] trials evaluated (:321), [4] trials with max uj >= 1
+ *       (:322-326), [5] 1 if the step size fell below min(tol, 1e-10) (:316-319), [6] moment evaluations waited for,
+ *       [7] 1 if the next iteration was started.
+ * With several ranks the exchange steps sit between the levels, so the caller sequences them itself (LCX_ERR_STATE). */
+int lcx_iterate(lcx_ctx* h, double eps, double tol, double tc_cur, int more, double* out8);
+
 /* ---- synergistic branch: discourage_overlap=False (:336-384) -------------------------------------
  * One evaluation of _calculate_moments_syn on set `which`:
  *   lcx_moments_a(which)              Y_partial = X_shard . W_shard^T (:347)            -> ybuf     | all-reduce ybuf
@@ -244,6 +260,15 @@ int lcx_read_sbuf(lcx_ctx* h, int64_t offset, int64_t count, double* out);
  * std_host = theta[1] (nv_local, working dtype); out_host is nrows x nv_local row-major. */
 int lcx_covariance_rows(lcx_ctx* h, double eps, const void* std_host, int64_t row0, int64_t nrows,
                         void* out_host);
+/* get_covariance (:443-455), the whole nv_local x nv_local matrix into out_host (row-major, leading dimension
+ * ld_out >= nv_local elements): synergistic == 0 the branch of :446-451 (needs the moments of set 0), != 0 the branch
+ * of :452-455 (needs lcx_syn_moments_b).  Row blocks are produced on the device (rank-m_padded product on MFMA),
+ * copied through two pinned staging blocks and placed into out_host while the next block is being computed.
+ * kernel_seconds (may be NULL): device time of the product kernels alone, from HIP events. */
+int lcx_covariance(lcx_ctx* h, int synergistic, double eps, const void* std_host, void* out_host, int64_t ld_out,
+                   double* kernel_seconds);
+/* device bytes owned by the handle; x_bytes: the part that is the resident shard (row-major + transposed copy) */
+int lcx_bytes_resident(lcx_ctx* h, int64_t* total, int64_t* x_bytes);
 /* transform (:386-395): out (n_rows x m) = x (n_rows x nv_local, ld) . ws^T  (per-shard partial) */
 int lcx_project(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, void* out_host);
 

@@ -58,6 +58,7 @@ SIGNATURES = {
     "lcx_trial_linear_a": [_vp, _dbl],
     "lcx_trial_linear_b": [_vp, _dbl, _dbl],
     "lcx_accept_trial": [_vp],
+    "lcx_iterate": [_vp, _dbl, _dbl, _dbl, _i32, C.POINTER(_dbl)],
     "lcx_syn_moments_b": [_vp, _i32, _dbl],
     "lcx_syn_moments_c": [_vp, _i32],
     "lcx_syn_update_a": [_vp],
@@ -70,6 +71,8 @@ SIGNATURES = {
     "lcx_set_moment": [_vp, _i32, _i32, _vp],
     "lcx_read_sbuf": [_vp, _i64, _i64, C.POINTER(_dbl)],
     "lcx_covariance_rows": [_vp, _dbl, _vp, _i64, _i64, _vp],
+    "lcx_covariance": [_vp, _i32, _dbl, _vp, _vp, _i64, C.POINTER(_dbl)],
+    "lcx_bytes_resident": [_vp, C.POINTER(_i64), C.POINTER(_i64)],
     "lcx_project": [_vp, _vp, _i64, _i64, _vp],
     "lcx_timing_enable": [_vp, _i32],
     "lcx_timing_sample": [_vp, _i32],

@@ -266,6 +266,16 @@ class HipBackend:
         _abi.check(self.lib.lcx_accept_trial(self.h))
         self.generation += 1
 
+    def iterate(self, eps, tol, tc_cur, more):
+        """One whole `_update_ns` (linearcorex.py:290-334) inside the library (one GPU): returns the 8 scalars of
+        lcx_iterate (status, TC, tangent, trials, invalid trials, step-too-small, evaluations, next iteration started)."""
+        out = np.empty(8, dtype=np.float64)
+        _abi.check(self.lib.lcx_iterate(self.h, float(eps), float(tol), float(tc_cur), 1 if more else 0,
+                                        out.ctypes.data_as(C.POINTER(C.c_double))))
+        if out[0] != 1:
+            self.generation += 1
+        return out
+
     # ---- synergistic branch (linearcorex.py:336-384) ---------------------------------------------
     def syn_moments_b(self, which, yscale):
         _abi.check(self.lib.lcx_syn_moments_b(self.h, which, float(yscale)))
@@ -281,15 +291,9 @@ class HipBackend:
     def syn_update_b(self, eta):
         _abi.check(self.lib.lcx_syn_update_b(self.h, float(eta)))
 
-    def covariance_syn(self, std, max_block_bytes=1 << 28):
-        std, ps = self._a(std)
-        nv = self.nv
-        out = np.empty((nv, nv), dtype=self.dtype)
-        rows = max(64, int(max_block_bytes // (nv * self.dtype.itemsize)) // 64 * 64)
-        for r0 in range(0, nv, rows):
-            nr = min(rows, nv - r0)
-            _abi.check(self.lib.lcx_covariance_rows_syn(self.h, ps, r0, nr, _abi.np_ptr(out[r0:r0 + nr])))
-        return out
+    def covariance_syn(self, std):
+        """get_covariance of the synergistic branch (linearcorex.py:452-455) for this shard."""
+        return self._covariance(1, 0.0, std)
 
     def rescale_ws(self, eps_old, eps_new):
         _abi.check(self.lib.lcx_rescale_ws(self.h, float(eps_old), float(eps_new)))
@@ -322,17 +326,26 @@ class HipBackend:
         _abi.check(self.lib.lcx_set_moment(self.h, which, MOMENT_KEYS[name], p))
 
     # ---- outputs ------------------------------------------------------------------------------------
-    def covariance(self, eps, std, max_block_bytes=1 << 28):
-        """get_covariance (linearcorex.py:443-451) for this shard, assembled from row blocks."""
+    def covariance(self, eps, std):
+        """get_covariance (linearcorex.py:443-451) for this shard."""
+        return self._covariance(0, eps, std)
+
+    def _covariance(self, syn, eps, std):
         std, ps = self._a(std)
-        nv = self.nv
-        out = np.empty((nv, nv), dtype=self.dtype)
-        rows = max(64, int(max_block_bytes // (nv * self.dtype.itemsize)) // 64 * 64)
-        for r0 in range(0, nv, rows):
-            nr = min(rows, nv - r0)
-            blk = out[r0:r0 + nr]
-            _abi.check(self.lib.lcx_covariance_rows(self.h, float(eps), ps, r0, nr, _abi.np_ptr(blk)))
+        out = np.empty((self.nv, self.nv), dtype=self.dtype)
+        ksec = C.c_double()
+        _abi.check(self.lib.lcx_covariance(self.h, int(syn), float(eps), ps, _abi.np_ptr(out), self.nv, C.byref(ksec)))
+        self._cov_kernel_seconds = ksec.value
         return out
+
+    def last_covariance_device_seconds(self):
+        """device time of the product kernels of the last get_covariance call (HIP events)"""
+        return getattr(self, "_cov_kernel_seconds", None)
+
+    def bytes_resident(self):
+        tot, xb = C.c_int64(), C.c_int64()
+        _abi.check(self.lib.lcx_bytes_resident(self.h, C.byref(tot), C.byref(xb)))
+        return {"total": tot.value, "x_and_transposed_copy": xb.value}
 
     def project(self, x):
         x, p = self._a(x)

@@ -25,28 +25,56 @@ _DEVICE_KEYS = ("uj", "rho", "ry", "invrho", "rhoinvrho", "Qij", "Si", "Qi-Si^2"
 class DeviceMoments(dict):
     """`self.moments`: same keys as the reference dict (linearcorex.py:249-287).  Scalars and
     per-factor vectors are stored eagerly; the m x nv arrays stay on the GPU and are copied out on
-    first access (they are only valid while the fit state they describe is still resident)."""
+    first access (they are only valid while the fit state they describe is still resident).
+
+    Several ranks: a per-variable array is sharded over the ranks, and putting it together is a collective.  Dict access
+    and pickling never issue one: `Corex._finish` gathers the lazy keys on ALL ranks while the model is small
+    (LCX_EAGER_GATHER_ELEMS, default 2**24 elements of n_hidden x n_variables); above that they stay on their shards
+    until every rank calls `Corex.gather_moments(keys)`, and touching one before that raises instead of hanging the
+    ranks that did not ask."""
 
     def __init__(self, owner, generation, eps, eager):
         super().__init__(eager)
         self._owner, self._gen, self._eps = owner, generation, eps
         self._lazy = set(_DEVICE_KEYS) | {"Y_j^2", "X_i Y_j", "I(X_i ; Y)"}
 
-    def _fetch(self, key):
+    _REPLICATED = ("uj", "ry")
+
+    def _resident(self):
         be = self._owner._backend if self._owner is not None else None
-        if be is None or be.generation != self._gen:
+        return be is not None and be.generation == self._gen
+
+    def _fetch(self, key, collective=False):
+        if not self._resident():
             raise KeyError("%r: these moments are no longer resident on the device" % key)
-        o = self._owner
+        o, be = self._owner, self._owner._backend
         if key == "Y_j^2":
             return o.yscale ** 2 / (1.0 - self["uj"])                      # :262
         if key == "X_i Y_j":
-            return self["rho"].T * np.sqrt(self["Y_j^2"])                  # :279
+            return self._get(key, "rho", collective).T * np.sqrt(self["Y_j^2"])             # :279
         if key == "I(X_i ; Y)":
-            return -0.5 * np.log(self["X_i^2 | Y"])                        # :283
+            return -0.5 * np.log(self._get(key, "X_i^2 | Y", collective))                   # :283
+        if key not in self._REPLICATED and o._comm.world > 1 and not collective:
+            raise RuntimeError("moments[%r] is sharded over %d ranks: call model.gather_moments([%r]) on every rank first "
+                               "(dict access never issues a collective)" % (key, o._comm.world, key))
         val = be.get_moment(0, key, self._eps)
-        if key not in ("uj", "ry"):
+        if key not in self._REPLICATED:
             val = o._gather(val, key)
         return val
+
+    def _get(self, for_key, key, collective):
+        if dict.__contains__(self, key):
+            return dict.__getitem__(self, key)
+        val = self._fetch(key, collective)
+        dict.__setitem__(self, key, val)
+        return val
+
+    def gather(self, keys=None):
+        """Collective (every rank must call it with the same keys): materialise sharded keys as full arrays."""
+        for k in (keys if keys is not None else sorted(self._lazy)):
+            if k in self._lazy and not dict.__contains__(self, k) and self._resident():
+                dict.__setitem__(self, k, self._fetch(k, collective=True))
+        return self
 
     def __missing__(self, key):
         if key in self._lazy:
@@ -56,7 +84,12 @@ class DeviceMoments(dict):
         raise KeyError(key)
 
     def __contains__(self, key):
-        return dict.__contains__(self, key) or key in self._lazy
+        if dict.__contains__(self, key):
+            return True
+        if key not in self._lazy or not self._resident():
+            return False
+        single = self._owner._comm.world == 1
+        return single or key in self._REPLICATED or key == "Y_j^2"
 
     def get(self, key, default=None):
         try:
@@ -65,11 +98,14 @@ class DeviceMoments(dict):
             return default
 
     def materialize(self, keys=None):
+        """Copy out what can be copied out WITHOUT a collective (one rank: every lazy key; several ranks: the replicated
+        ones - sharded keys that were not gathered are left out)."""
         for k in (keys or sorted(self._lazy)):
-            try:
-                self[k]
-            except KeyError:
-                pass
+            if k in self:
+                try:
+                    self[k]
+                except (KeyError, RuntimeError):
+                    pass
         return dict(self)
 
     def __reduce__(self):
@@ -85,29 +121,41 @@ class SynMoments(DeviceMoments):
         DeviceMoments.__init__(self, owner, generation, 0, eager)
         self._lazy = set(self._SYN_DEVICE) | {"invrho", "rhoinvrho", "Qij", "Qi", "Si", "MI"}
 
-    def _fetch(self, key):
-        be = self._owner._backend if self._owner is not None else None
-        if be is None or be.generation != self._gen:
+    _REPLICATED = ("cy", "Y_j^2", "ry")
+
+    def _fetch(self, key, collective=False):
+        if not self._resident():
             raise KeyError("%r: these moments are no longer resident on the device" % key)
+        o, be = self._owner, self._owner._backend
         if key in self._SYN_DEVICE:
+            if key not in self._REPLICATED and o._comm.world > 1 and not collective:
+                raise RuntimeError("moments[%r] is sharded over %d ranks: call model.gather_moments([%r]) on every rank first "
+                                   "(dict access never issues a collective)" % (key, o._comm.world, key))
             val = be.get_moment(0, self._SYN_DEVICE[key])
             if key in ("X_i Y_j", "X_i Z_j"):                # (nv_local, m): shard axis first
-                return self._owner._gather(np.ascontiguousarray(val.T)).T
-            return val if key in ("cy", "Y_j^2", "ry") else self._owner._gather(val, key)
-        rho = self["rho"]
+                return o._gather(np.ascontiguousarray(val.T)).T
+            return val if key in self._REPLICATED else o._gather(val, key)
+        rho = self._get(key, "rho", collective)
         if key == "invrho":
             return 1.0 / (1.0 - rho ** 2)                                   # :360
         if key == "rhoinvrho":
-            return rho * self["invrho"]                                     # :361
+            return rho * self._get(key, "invrho", collective)               # :361
         if key == "Qij":
-            return np.dot(self["ry"], self["rhoinvrho"])                    # :362
+            return np.dot(self["ry"], self._get(key, "rhoinvrho", collective))              # :362
         if key == "Qi":
-            return np.einsum('ki,ki->i', self["rhoinvrho"], self["Qij"])    # :363
+            return np.einsum('ki,ki->i', self._get(key, "rhoinvrho", collective), self._get(key, "Qij", collective))    # :363
         if key == "Si":
-            return np.sum(rho * self["rhoinvrho"], axis=0)                  # :364
+            return np.sum(rho * self._get(key, "rhoinvrho", collective), axis=0)            # :364
         if key == "MI":
             return -0.5 * np.log1p(-rho ** 2)                               # :366
         raise KeyError(key)
+
+    def __contains__(self, key):
+        if dict.__contains__(self, key):
+            return True
+        if key not in self._lazy or not self._resident():
+            return False
+        return self._owner._comm.world == 1 or key in self._REPLICATED
 
 
 class Corex(object):
@@ -170,6 +218,9 @@ class Corex(object):
         self.stats = {"iterations": 0, "moment_evals": 0, "trials": 0, "invalid_trials": 0}
         import os
         self._check_ranks = os.environ.get("LCX_CHECK_RANKS", "0") not in ("", "0")
+        # LCX_HOST_LOOP=1: sequence the levels of `_update_ns` from this class (what several ranks always do) instead of
+        # handing the whole iteration to the engine (lcx_iterate) - same results, kept selectable for tests
+        self._in_library = os.environ.get("LCX_HOST_LOOP", "0") in ("", "0")
 
     def _assert_same_on_all_ranks(self, values, what):
         """Debug aid (LCX_CHECK_RANKS=1): the host decisions of the line search are taken from all-reduced scalars and
@@ -345,10 +396,11 @@ class Corex(object):
             self._backend.rescale_ws(eps0, eps)                               # :129-133
         self.moments = self._calculate_moments(quick=False, details=False)    # :134
 
-    def _iterate(self):
-        """One pass of the loop body (:137-151).  Returns delta, or None if the solution went invalid."""
+    def _iterate(self, more=False):
+        """One pass of the loop body (:137-151).  Returns delta, or None if the solution went invalid.
+        more: the caller will iterate again unless this iteration converges (lets the engine start the next one early)."""
         last_tc = self.tc
-        self.moments = self._update_ns()                                      # :139
+        self.moments = self._update_ns(more=more)                             # :139
         if not self.moments or not np.isfinite(self.tc):                      # :144-149
             try:
                 print("Error: TC is no longer finite: {}".format(self.tc))
@@ -368,7 +420,24 @@ class Corex(object):
         be.permute_factors(order)                                             # :162
         self.moments = self._calculate_moments(quick=False, details=True)     # :163
         self.ws = self._gather(be.get_ws(0))
+        self._gather_if_small()
         return self
+
+    def _gather_if_small(self):
+        """Several ranks, end of `fit` (every rank is here): put the sharded moments together now if that is cheap, so
+        that later dict access / pickling on a single rank needs no collective (see DeviceMoments)."""
+        if self._comm.world > 1 and isinstance(self.moments, DeviceMoments):
+            import os
+            limit = int(os.environ.get("LCX_EAGER_GATHER_ELEMS", str(1 << 24)))
+            if self.m * self.nv <= limit:
+                self.moments.gather()
+
+    def gather_moments(self, keys=None):
+        """Collective: every rank calls it with the same `keys` (default: all); afterwards those keys of `self.moments`
+        are full (n_hidden x n_variables) arrays on every rank, as in the reference."""
+        if isinstance(self.moments, DeviceMoments):
+            self.moments.gather(keys)
+        return self.moments
 
     # ------------------------------------------------------------------------------------------
     # synergistic branch: discourage_overlap=False (linearcorex.py:119-121, :141, :336-384)
@@ -444,6 +513,7 @@ class Corex(object):
         be.permute_factors(order)                                              # :162
         self.moments = self._calculate_moments_syn()                           # :163
         self.ws = self._gather(be.get_ws(0))
+        self._gather_if_small()
         return self
 
     def _fit_resident(self):
@@ -453,7 +523,7 @@ class Corex(object):
             self._begin_stage(i_eps, eps)
             delta = 0.
             for i_loop in range(self.max_iter):
-                delta = self._iterate()
+                delta = self._iterate(more=i_loop + 1 < self.max_iter)
                 if delta is None:
                     self.ws = self._gather(self._backend.get_ws(0))
                     return self
@@ -537,11 +607,38 @@ class Corex(object):
             raise NotImplementedError("moments are evaluated on the resident X / ws only")
         return self._calculate_moments(quick=quick, details=not quick)
 
-    def _update_ns(self, x=None):
+    _SINGULAR_WARNING = ('Warning: covariance is nearly singular and this causes a loss of numerical precision.'
+                         'For this reason, we can no longer find an update that increases the objective. '
+                         'Hopefully this is a good solution. If not, this is caused by having many variables that are '
+                         'near duplicates. You could try again with the duplicates removed to look for other structure.')
+
+    def _update_ns_in_library(self, more):
+        """`_update_ns` (:290-334) as ONE call into the engine (lcx_iterate): line-search decisions are taken in native code
+        right where the trial's scalars arrive, and the next iteration's first launches are already queued when this returns."""
+        be, m = self._backend, self.moments
+        r = be.iterate(self.eps, self.tol, self._tc_cur, more)
+        status = int(r[0])
+        self.stats["trials"] += int(r[3])
+        self.stats["invalid_trials"] += int(r[4])
+        self.stats["moment_evals"] += int(r[6])
+        if status == 1:                                                        # :306-311
+            print(self._SINGULAR_WARNING)
+            return m
+        if r[5] and self.verbose:                                              # :316-319
+            print('Warning: step size becoming too small')
+        if status == 2:                                                        # (w_update, False), reported by fit (:144-149)
+            return False
+        self._tc_cur = r[1]
+        return DeviceMoments(self, be.generation, self.eps, {"TC": self._scalar(r[1])})
+
+    def _update_ns(self, x=None, more=False):
         """One fixed-point iteration with back-tracking (:290-334).  Returns the new moments (the
         new weights stay on the device)."""
         be = self._backend
         m = self.moments
+        if self._in_library and self._ex is None and self.line_search == "exact" and self.verbose <= 1 \
+                and hasattr(be, "iterate"):
+            return self._update_ns_in_library(more)
         # H (:294) is already global: it came with the scalar exchange of the evaluation that produced set 0
         be.update_b(self.eps)                # grad (:296-300), Bj partial, Y_g partial
         self._xy()
@@ -576,10 +673,7 @@ class Corex(object):
                     self.stats["trials"] -= 1      # the speculative trial is discarded
                     be.update_a()                  # ... and so is its H: restore the H of the kept solution
                     self._x_h()
-                    print('Warning: covariance is nearly singular and this causes a loss of numerical precision.'
-                          'For this reason, we can no longer find an update that increases the objective. '
-                          'Hopefully this is a good solution. If not, this is caused by having many variables that are '
-                          'near duplicates. You could try again with the duplicates removed to look for other structure.')
+                    print(self._SINGULAR_WARNING)
                     return m
             invalid, tc_new = st[2] != 0, st[0]
             last = (invalid, tc_new)

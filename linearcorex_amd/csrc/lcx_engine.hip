@@ -13,6 +13,7 @@
 #include <time.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/lcx.h"
@@ -70,6 +71,19 @@ struct MomentSet {
 constexpr int SB_H = 8;
 static inline int sb_det(int Mp) { return SB_H + Mp * Mp; }
 
+// Staging of get_covariance (allocated on first use, kept for the life of the handle): two device row blocks and two
+// pinned host blocks, so that the product of block k+1 overlaps the device-to-host copy of block k and the host-side
+// placement of block k-1 into the caller's (pageable) matrix.
+struct CovStage {
+    void* dev[2] = {nullptr, nullptr};
+    void* pin[2] = {nullptr, nullptr};
+    size_t block_bytes = 0;
+    void *op_a = nullptr, *op_b = nullptr, *std_dev = nullptr;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_k[2] = {nullptr, nullptr}, ev_c[2] = {nullptr, nullptr}, t_a[2] = {nullptr, nullptr}, t_b[2] = {nullptr, nullptr};
+    double last_kernel_seconds = 0.0;
+};
+
 struct TimingPair {
     hipEvent_t a, b;
     int kind;
@@ -119,9 +133,17 @@ struct lcx_ctx {
     bool have_direction;
     int world;                  // ranks sharing the variables axis (1: no exchange between levels)
     unsigned int seq_next;
+    CovStage* cov;
+    // lcx_iterate: the direction and first trial of the NEXT iteration are already enqueued (speculation); spec_dirty: a
+    // speculation was abandoned, i.e. sbuf holds the H of a trial that was never accepted instead of the H of set 0
+    bool spec_pending, spec_dirty;
+    double spec_eps;
+    size_t bytes_resident;      // device bytes owned by the handle (X, its transposed copy, moments, work space)
 };
 
 template <typename T> static inline T* P(void* p) { return reinterpret_cast<T*>(p); }
+static int wait_published(lcx_ctx* h, MomentSet& s);
+static inline void cancel_speculation(lcx_ctx* h);
 
 // Temporary device buffers of one call: freed on every return path (an OOM in the middle of a call must not leak the
 // buffers allocated before it - that is exactly when memory matters).
@@ -621,6 +643,7 @@ template <typename T, int CT> struct Impl {
 
     static int moments_b(lcx_ctx* h, int which, double eps, int quick) {
         MomentSet& s = h->set[which];
+        if (which == 0) h->spec_dirty = false;          // this evaluation leaves the H of set 0 in sbuf
         // keep the (all-reduced) Y of this set: the linear trial mode starts from it
         if (h->exchange || h->nt_S == 1)         // otherwise lcx_moments_a already wrote it
             HIPCHECK(hipMemcpyAsync(s.Y, h->ybuf, (size_t)h->Npad * Mp * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
@@ -666,6 +689,11 @@ template <typename T, int CT> struct Impl {
 
     static int update_b(lcx_ctx* h, double eps) {
         (void)eps;
+        if (h->spec_dirty) {                            // an abandoned speculation overwrote the H of set 0 in sbuf
+            if (h->exchange) return fail(LCX_ERR_STATE, "abandoned lcx_iterate speculation with several ranks");
+            LCXCHECK(update_a(h));
+            h->spec_dirty = false;
+        }
         MomentSet& s = h->set[0];
         const size_t lds = ((size_t)Mp * (Mp + 1) + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
         LCXCHECK(allow_lds(grad_kernel<T, Mp>, lds));
@@ -701,6 +729,76 @@ template <typename T, int CT> struct Impl {
         hipLaunchKernelGGL((axpy_kernel<T>), dim3((unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048)), dim3(256), 0,
                            h->stream, P<T>(h->Wt[0]), P<T>(h->update), (T)eta, n, P<T>(h->Wt[1]));
         KCHECK();
+        return LCX_OK;
+    }
+
+    // ---- one whole fixed-point iteration with its back-tracking line search (:290-334), one GPU -------------------
+    static int direction_and_trial(lcx_ctx* h, double eps) {
+        LCXCHECK(update_b(h, eps));                  // grad (:296-300), Y_g = X.grad^T (:210), Bj (:302)
+        LCXCHECK(update_c(h, eps));                  // update (:303), update_tangent partials (:305), ws + update
+        h->have_direction = true;
+        LCXCHECK(make_trial(h, 1.0));                // :320 at eta = 1 (update_kernel wrote it already)
+        LCXCHECK(moments_a(h, 1));                   // :321
+        return moments_b(h, 1, eps, 1);
+    }
+    static int iterate(lcx_ctx* h, double eps, double tol, double tc_cur, int more, double* out) {
+        if (h->exchange)
+            return fail(LCX_ERR_STATE, "lcx_iterate drives one GPU; with several ranks the caller exchanges between the levels "
+                                       "(lcx_update_b ... lcx_moments_c)");
+        const bool consumed = h->spec_pending && h->spec_eps == eps;
+        if (h->spec_pending && !consumed) cancel_speculation(h);
+        h->spec_pending = false;
+        if (!consumed) LCXCHECK(direction_and_trial(h, eps));
+        double eta = 1.0, tangent = 0.0, last_tc = __builtin_nan("");
+        int trials = 0, invalid_trials = 0, too_small = 0;
+        bool first = true, have_last = false, last_invalid = false;
+        const double eta_min = tol < 1e-10 ? tol : 1e-10;                       // :316
+        while (true) {
+            if (!first) {
+                if (eta < eta_min) { too_small = 1; break; }                     // :316-319
+                LCXCHECK(make_trial(h, eta));                                    // :320
+                LCXCHECK(moments_a(h, 1));                                       // :321
+                LCXCHECK(moments_b(h, 1, eps, 1));
+            }
+            ++trials;
+            LCXCHECK(wait_published(h, h->set[1]));
+            const SetState st = *h->set[1].hst;
+            if (first) {
+                first = false;
+                tangent = st.tangent;                                            // :305, summed by the first trial's tail
+                if (tangent >= 0) {                                              // :306-311: keep ws, discard the trial
+                    LCXCHECK(update_a(h));                                       // its H went to sbuf: restore set 0's
+                    h->have_direction = false;
+                    h->w1_ready = false;
+                    out[0] = 1; out[1] = tc_cur; out[2] = tangent; out[3] = trials - 1; out[4] = 0; out[5] = 0; out[6] = trials; out[7] = 0;
+                    return LCX_OK;
+                }
+            }
+            have_last = true;
+            last_invalid = st.invalid != 0;
+            last_tc = st.tc;
+            if (last_invalid) { ++invalid_trials; eta *= 0.5; continue; }        // :322-326
+            if (!(-last_tc <= -tc_cur + 0.1 * eta * tangent)) { eta *= 0.5; continue; }   // :327-332
+            break;
+        }
+        // self.ws, self.moments = w_update, m_update (:139, :334)
+        h->w1_ready = false;
+        std::swap(h->Wt[0], h->Wt[1]);
+        std::swap(h->set[0], h->set[1]);
+        h->have_direction = false;
+        const bool ok = have_last && !last_invalid;
+        int speculated = 0;
+        if (ok && more) {
+            const double delta = last_tc > tc_cur ? last_tc - tc_cur : tc_cur - last_tc;
+            if (!(delta < tol)) {             // the caller will iterate again (:152): get the GPU going before it asks
+                LCXCHECK(direction_and_trial(h, eps));
+                h->spec_pending = true;
+                h->spec_eps = eps;
+                speculated = 1;
+            }
+        }
+        out[0] = ok ? 0 : 2; out[1] = last_tc; out[2] = tangent; out[3] = trials; out[4] = invalid_trials; out[5] = too_small;
+        out[6] = trials; out[7] = speculated;
         return LCX_OK;
     }
 
@@ -818,6 +916,109 @@ template <typename T, int CT> struct Impl {
         KCHECK();
         return LCX_OK;
     }
+    // get_covariance rows [row0, row0 + nrows) -> out_host (row-major, leading dimension ld_out elements); see CovStage
+    static int cov_stage(lcx_ctx* h, bool syn) {
+        if (!h->cov) h->cov = new CovStage();
+        CovStage& c = *h->cov;
+        const size_t mv = (size_t)h->ldx * Mp * sizeof(T);
+        if (!c.copy_stream) {
+            HIPCHECK(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+            for (int k = 0; k < 2; ++k) {
+                HIPCHECK(hipEventCreateWithFlags(&c.ev_k[k], hipEventDisableTiming));
+                HIPCHECK(hipEventCreateWithFlags(&c.ev_c[k], hipEventDisableTiming));
+            }
+            for (int k = 0; k < 2; ++k) {
+                HIPCHECK(hipEventCreate(&c.t_a[k]));
+                HIPCHECK(hipEventCreate(&c.t_b[k]));
+            }
+            HIPCHECK(hipMalloc(&c.std_dev, (size_t)h->ldx * sizeof(T)));
+            HIPCHECK(hipMalloc(&c.op_a, mv));
+        }
+        if (syn && !c.op_b) HIPCHECK(hipMalloc(&c.op_b, mv));
+        if (!c.dev[0]) {
+            const int64_t ldo = h->ldx;
+            int64_t rows = (int64_t)(32u << 20) / (ldo * (int64_t)sizeof(T)) / 64 * 64;
+            if (rows < 64) rows = 64;
+            if (rows > round_up(h->V, 64)) rows = round_up(h->V, 64);
+            c.block_bytes = (size_t)rows * ldo * sizeof(T);
+            for (int k = 0; k < 2; ++k) {
+                HIPCHECK(hipMalloc(&c.dev[k], c.block_bytes));
+                HIPCHECK(hipHostMalloc(&c.pin[k], c.block_bytes, hipHostMallocDefault));
+            }
+        }
+        return LCX_OK;
+    }
+    static void place_rows(const T* src, int64_t src_ld, T* dst, int64_t dst_ld, int64_t rows, int64_t cols) {
+        // pinned block -> the caller's matrix; the destination is usually freshly allocated pageable memory, i.e. this is
+        // where its pages are first touched: a few threads keep it off the critical path of the PCIe copies
+        const int64_t bytes = rows * cols * (int64_t)sizeof(T);
+        const int nt = bytes >= (8 << 20) ? 8 : 1;
+        auto work = [=](int t) {
+            const int64_t r0 = rows * t / nt, r1 = rows * (t + 1) / nt;
+            if (src_ld == cols && dst_ld == cols) memcpy(dst + r0 * cols, src + r0 * cols, (size_t)(r1 - r0) * cols * sizeof(T));
+            else for (int64_t r = r0; r < r1; ++r) memcpy(dst + r * dst_ld, src + r * src_ld, (size_t)cols * sizeof(T));
+        };
+        if (nt == 1) { work(0); return; }
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    static int covariance_blocks(lcx_ctx* h, bool syn, double eps, const void* std_host, int64_t row0, int64_t nrows, void* out_host,
+                                 int64_t ld_out, double* kernel_seconds) {
+        MomentSet& s = h->set[0];
+        LCXCHECK(cov_stage(h, syn));
+        CovStage& c = *h->cov;
+        const int64_t V = h->V, ldo = h->ldx;
+        const int64_t brows = (int64_t)(c.block_bytes / ((size_t)ldo * sizeof(T)));
+        HIPCHECK(hipMemcpyAsync(c.std_dev, std_host, sizeof(T) * V, hipMemcpyHostToDevice, h->stream));
+        const int64_t n = h->ldx * Mp;
+        const unsigned pg = (unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
+        if (syn)
+            hipLaunchKernelGGL((cov_prep_kernel<T>), dim3(pg), dim3(256), 0, h->stream, (const T*)nullptr, (const T*)nullptr, P<T>(s.D), n, Mp,
+                               (T)(1.0 / (double)h->N), (T*)nullptr, P<T>(c.op_b));
+        else
+            hipLaunchKernelGGL((cov_prep_kernel<T>), dim3(pg), dim3(256), 0, h->stream, P<T>(s.rir), P<T>(s.si), (const T*)nullptr, n, Mp, (T)0,
+                               P<T>(c.op_a), (T*)nullptr);
+        KCHECK();
+        const T* opa = syn ? P<T>(s.xz) : P<T>(c.op_a);
+        const T* opb = syn ? P<T>(c.op_b) : P<T>(c.op_a);
+        const T denom = syn ? (T)1 : (T)(1.0 - eps * eps);
+        T* out = P<T>(out_host);
+        const int64_t nblk = cdiv(nrows, brows);
+        double ksec = 0.0;
+        for (int64_t k = 0; k <= nblk; ++k) {
+            if (k < nblk) {
+                const int b = (int)(k & 1);
+                const int64_t r0 = row0 + k * brows, nr = (nrows - k * brows) < brows ? (nrows - k * brows) : brows;
+                dim3 grid((unsigned)cdiv(V, 64), (unsigned)cdiv(nr, 64));
+                HIPCHECK(hipEventRecord(c.t_a[b], h->stream));
+                hipLaunchKernelGGL((cov_syrk_kernel<T, Mp>), grid, dim3(256), 0, h->stream, opa, opb, P<T>(c.std_dev), V, r0, nr, denom,
+                                   P<T>(c.dev[b]), ldo);
+                KCHECK();
+                HIPCHECK(hipEventRecord(c.t_b[b], h->stream));
+                HIPCHECK(hipEventRecord(c.ev_k[b], h->stream));
+                HIPCHECK(hipStreamWaitEvent(c.copy_stream, c.ev_k[b], 0));
+                HIPCHECK(hipMemcpy2DAsync(c.pin[b], (size_t)V * sizeof(T), c.dev[b], (size_t)ldo * sizeof(T), (size_t)V * sizeof(T), (size_t)nr,
+                                          hipMemcpyDeviceToHost, c.copy_stream));
+                HIPCHECK(hipEventRecord(c.ev_c[b], c.copy_stream));
+            }
+            if (k >= 1) {
+                const int b = (int)((k - 1) & 1);
+                const int64_t nr = (nrows - (k - 1) * brows) < brows ? (nrows - (k - 1) * brows) : brows;
+                HIPCHECK(hipEventSynchronize(c.ev_c[b]));
+                {
+                    float ms = 0.f;
+                    HIPCHECK(hipEventElapsedTime(&ms, c.t_a[b], c.t_b[b]));
+                    ksec += (double)ms * 1e-3;
+                }
+                place_rows(P<T>(c.pin[b]), V, out + (k - 1) * brows * ld_out, ld_out, nr, V);
+            }
+        }
+        c.last_kernel_seconds = ksec;
+        if (kernel_seconds) *kernel_seconds = ksec;
+        return LCX_OK;
+    }
     static int covariance_syn(lcx_ctx* h, const void* std_host, int64_t row0, int64_t nrows, void* out_host) {
         MomentSet& s = h->set[0];
         if (!s.xz) return fail(LCX_ERR_STATE, "synergistic covariance needs lcx_syn_moments_b first");
@@ -928,6 +1129,10 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
 
+    static int covariance_full(lcx_ctx* h, int syn, double eps, const void* std_host, void* out_host, int64_t ld_out, double* ksec) {
+        if (syn && !h->set[0].xz) return fail(LCX_ERR_STATE, "synergistic covariance needs lcx_syn_moments_b first");
+        return covariance_blocks(h, syn != 0, eps, std_host, 0, h->V, out_host, ld_out, ksec);
+    }
     static int covariance(lcx_ctx* h, double eps, const void* std_host, int64_t row0, int64_t nrows, void* out_host) {
         return covariance_blocks(h, false, eps, std_host, row0, nrows, out_host, h->V, nullptr);
     }
@@ -936,8 +1141,9 @@ template <typename T, int CT> struct Impl {
         const int64_t blk = 8192;      // rows per staged block
         const int64_t rows_pad = round_up(n_rows < blk ? n_rows : blk, 64);
         T *xd = nullptr, *yd = nullptr;
-        HIPCHECK(hipMalloc((void**)&xd, sizeof(T) * rows_pad * h->ldx));
-        HIPCHECK(hipMalloc((void**)&yd, sizeof(T) * rows_pad * Mp));
+        DevTemps tmps;
+        LCXCHECK(tmps.get(&xd, sizeof(T) * rows_pad * h->ldx));
+        LCXCHECK(tmps.get(&yd, sizeof(T) * rows_pad * Mp));
         std::vector<T> tmp((size_t)rows_pad * Mp);
         T* out = P<T>(out_host);
         for (int64_t r0 = 0; r0 < n_rows; r0 += blk) {
@@ -951,8 +1157,6 @@ template <typename T, int CT> struct Impl {
             for (int64_t r = 0; r < nr; ++r)
                 for (int j = 0; j < h->M; ++j) out[(r0 + r) * h->M + j] = tmp[r * Mp + j];
         }
-        HIPCHECK(hipFree(xd));
-        HIPCHECK(hipFree(yd));
         return LCX_OK;
     }
 
@@ -981,13 +1185,14 @@ template <typename T, int CT> struct Impl {
         if ((int64_t)RS * 16 > N) RS = (int)(N / 16 > 0 ? N / 16 : 1);
         if (RS < 1) RS = 1;
         double *nobs = nullptr, *imp = nullptr, *mean = nullptr, *stdv = nullptr, *ps = nullptr, *pn = nullptr, *bmax = nullptr;
-        HIPCHECK(hipMalloc((void**)&nobs, sizeof(double) * V));
-        HIPCHECK(hipMalloc((void**)&imp, sizeof(double) * V));
-        HIPCHECK(hipMalloc((void**)&mean, sizeof(double) * V));
-        HIPCHECK(hipMalloc((void**)&stdv, sizeof(double) * V));
-        HIPCHECK(hipMalloc((void**)&ps, sizeof(double) * V * RS));
-        HIPCHECK(hipMalloc((void**)&pn, sizeof(double) * V * RS));
-        HIPCHECK(hipMalloc((void**)&bmax, sizeof(double) * strips * RS));
+        DevTemps tmps;
+        LCXCHECK(tmps.get(&nobs, sizeof(double) * V));
+        LCXCHECK(tmps.get(&imp, sizeof(double) * V));
+        LCXCHECK(tmps.get(&mean, sizeof(double) * V));
+        LCXCHECK(tmps.get(&stdv, sizeof(double) * V));
+        LCXCHECK(tmps.get(&ps, sizeof(double) * V * RS));
+        LCXCHECK(tmps.get(&pn, sizeof(double) * V * RS));
+        LCXCHECK(tmps.get(&bmax, sizeof(double) * strips * RS));
         const dim3 grid((unsigned)strips, (unsigned)RS);
         const unsigned fgrid = (unsigned)cdiv(V, 256);
         T* X = P<T>(h->X);
@@ -1049,8 +1254,6 @@ template <typename T, int CT> struct Impl {
                 for (double v : bm) if (v > *maxabs_out) *maxabs_out = v;
             }
         }
-        void* fr[] = {nobs, imp, mean, stdv, ps, pn, bmax};
-        for (void* q : fr) HIPCHECK(hipFree(q));
         return LCX_OK;
     }
 
@@ -1070,11 +1273,12 @@ template <typename T, int CT> struct Impl {
         double *mean = nullptr, *stdv = nullptr, *bmax = nullptr;
         const int strips = (int)cdiv(h->V, 64);
         const int RS = 8;
-        HIPCHECK(hipMalloc((void**)&xd, sizeof(T) * rows_pad * h->ldx));
-        HIPCHECK(hipMalloc((void**)&yd, sizeof(T) * rows_pad * Mp));
-        HIPCHECK(hipMalloc((void**)&mean, sizeof(double) * h->V));
-        HIPCHECK(hipMalloc((void**)&stdv, sizeof(double) * h->V));
-        HIPCHECK(hipMalloc((void**)&bmax, sizeof(double) * strips * RS));
+        DevTemps tmps;
+        LCXCHECK(tmps.get(&xd, sizeof(T) * rows_pad * h->ldx));
+        LCXCHECK(tmps.get(&yd, sizeof(T) * rows_pad * Mp));
+        LCXCHECK(tmps.get(&mean, sizeof(double) * h->V));
+        LCXCHECK(tmps.get(&stdv, sizeof(double) * h->V));
+        LCXCHECK(tmps.get(&bmax, sizeof(double) * strips * RS));
         if (kind != PP_KIND_NONE) {
             std::vector<double> tmp((size_t)h->V);
             for (int64_t c = 0; c < h->V; ++c) tmp[c] = (double)reinterpret_cast<const T*>(mean_h)[c];
@@ -1100,8 +1304,6 @@ template <typename T, int CT> struct Impl {
             for (int64_t r = 0; r < nr; ++r)
                 for (int j = 0; j < h->M; ++j) out[(r0 + r) * h->M + j] = tmp[r * Mp + j];
         }
-        void* fr[] = {xd, yd, mean, stdv, bmax};
-        for (void* q : fr) HIPCHECK(hipFree(q));
         return LCX_OK;
     }
 
@@ -1147,6 +1349,18 @@ static int ct_for(int m) {
 #define NEED(h)                                            \
     if (!(h)) return fail(LCX_ERR_ARG, "null handle");     \
     HIPCHECK(hipSetDevice((h)->device));
+
+// Every entry point that changes the fit state abandons a speculation of lcx_iterate (its kernels run to completion on
+// buffers only a trial owns; what they leave behind in the shared exchange buffer is remembered in spec_dirty).
+static inline void cancel_speculation(lcx_ctx* h) {
+    if (h->spec_pending) {
+        h->spec_pending = false;
+        h->spec_dirty = true;
+        h->have_direction = false;
+        h->w1_ready = false;
+    }
+}
+#define NEED_MUT(h) NEED(h); cancel_speculation(h)
 
 // ---- isolated GEMM checks -------------------------------------------------------------------------
 template <typename T, int CT>
@@ -1280,7 +1494,10 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     h->have_direction = false;
     h->target_waves = prop.multiProcessorCount * 12;
     h->n_cus = prop.multiProcessorCount;
-    HIPCHECK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(LCX_ERR_HIP, "lcx_create: cannot create a stream");
+    }
     h->stream = h->own_stream;
     hipStream_t st = h->stream;
 
@@ -1289,13 +1506,14 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
         lcx_ctx* hh = h;
         auto geo = [&]() -> int { DISPATCH(hh, geometry, hh); };
         rc = geo();
-        if (rc != LCX_OK) { delete h; return rc; }
+        if (rc != LCX_OK) { (void)lcx_destroy(h); return rc; }
     }
     const size_t es = h->es;
     const size_t mv = (size_t)h->ldx * h->Mp * es;
     const size_t vv = (size_t)h->ldx * es;
     const int Mp = h->Mp;
-#define A_(ptr, bytes) do { int r_ = dev_alloc((void**)&(ptr), (bytes), st); if (r_ != LCX_OK) return r_; } while (0)
+    // a failed allocation releases everything allocated so far (lcx_destroy copes with a half-built handle)
+#define A_(ptr, bytes) do { const size_t b_ = (bytes); int r_ = dev_alloc((void**)&(ptr), b_, st); if (r_ != LCX_OK) { (void)lcx_destroy(h); return r_; } h->bytes_resident += b_ ? b_ : 16; } while (0)
     A_(h->X, (size_t)h->Npad * h->ldx * es);
     A_(h->XT, (size_t)h->Npad * h->ldx * es);
     for (int k = 0; k < 2; ++k) {
@@ -1349,11 +1567,17 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
 #undef A_
     h->set[0].st = h->states;
     h->set[1].st = h->states + 1;
-    HIPCHECK(hipHostMalloc((void**)&h->host_states, sizeof(SetState) * 2, hipHostMallocMapped | hipHostMallocCoherent));
+    if (hipHostMalloc((void**)&h->host_states, sizeof(SetState) * 2, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        (void)lcx_destroy(h);
+        return fail(LCX_ERR_HIP, "lcx_create: cannot allocate the pinned state mirror");
+    }
     memset(h->host_states, 0, sizeof(SetState) * 2);
     {
         SetState* dv = nullptr;
-        HIPCHECK(hipHostGetDevicePointer((void**)&dv, h->host_states, 0));
+        if (hipHostGetDevicePointer((void**)&dv, h->host_states, 0) != hipSuccess) {
+            (void)lcx_destroy(h);
+            return fail(LCX_ERR_HIP, "lcx_create: no device address for the pinned state mirror");
+        }
         for (int k = 0; k < 2; ++k) {
             h->set[k].hst = h->host_states + k;
             h->set[k].hst_dev = dv + k;
@@ -1362,6 +1586,8 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     }
     h->world = 1;
     h->seq_next = 0;
+    h->spec_pending = h->spec_dirty = false;
+    h->spec_eps = 0.0;
     HIPCHECK(hipStreamSynchronize(st));
     *out = h;
     return LCX_OK;
@@ -1370,7 +1596,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
 int lcx_destroy(lcx_ctx* h) {
     if (!h) return LCX_OK;
     (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->X, h->XT, h->Wt[0], h->Wt[1], h->grad, h->update, h->sgrad, h->scratch, h->ydir, h->ddir, h->ybuf_own, h->sbuf_own,
                     h->ypart, h->dpart, h->gpart, h->gpartw, h->tcpart, h->bjpart, h->tanpart, h->detpart, h->ryinv, h->invwork,
                     h->states, h->order_dev, h->ticket};
@@ -1380,16 +1606,32 @@ int lcx_destroy(lcx_ctx* h) {
         void* q[] = {s.Y, s.D, s.rho, s.rir, s.qij, s.si, s.q2, s.hscale, s.uj, s.ry, s.wmag, s.xz, s.x2y, s.cy, s.yj2, s.inv_sd};
         for (void* p : q) (void)hipFree(p);
     }
-    (void)hipHostFree(h->host_states);
+    if (h->host_states) (void)hipHostFree(h->host_states);
+    if (h->cov) {
+        CovStage& c = *h->cov;
+        for (int k = 0; k < 2; ++k) {
+            if (c.dev[k]) (void)hipFree(c.dev[k]);
+            if (c.pin[k]) (void)hipHostFree(c.pin[k]);
+            if (c.ev_k[k]) (void)hipEventDestroy(c.ev_k[k]);
+            if (c.ev_c[k]) (void)hipEventDestroy(c.ev_c[k]);
+            if (c.t_a[k]) (void)hipEventDestroy(c.t_a[k]);
+            if (c.t_b[k]) (void)hipEventDestroy(c.t_b[k]);
+        }
+        if (c.op_a) (void)hipFree(c.op_a);
+        if (c.op_b) (void)hipFree(c.op_b);
+        if (c.std_dev) (void)hipFree(c.std_dev);
+        if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream);
+        delete h->cov;
+    }
     for (auto& tp : h->pool) { (void)hipEventDestroy(tp.a); (void)hipEventDestroy(tp.b); }
     for (auto& tp : h->pending) { (void)hipEventDestroy(tp.a); (void)hipEventDestroy(tp.b); }
-    (void)hipStreamDestroy(h->own_stream);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return LCX_OK;
 }
 
 int lcx_set_stream(lcx_ctx* h, void* s) {
-    NEED(h);
+    NEED_MUT(h);
     HIPCHECK(hipStreamSynchronize(h->stream));
     h->stream = s ? (hipStream_t)s : h->own_stream;
     return LCX_OK;
@@ -1411,7 +1653,7 @@ int lcx_exchange_layout(lcx_ctx* h, int64_t* ye, int64_t* se, void** yd, void** 
 }
 
 int lcx_bind_exchange(lcx_ctx* h, void* y, void* s) {
-    NEED(h);
+    NEED_MUT(h);
     HIPCHECK(hipStreamSynchronize(h->stream));
     h->ybuf = y ? y : h->ybuf_own;
     h->sbuf = s ? (double*)s : h->sbuf_own;
@@ -1422,7 +1664,7 @@ int lcx_bind_exchange(lcx_ctx* h, void* y, void* s) {
 }
 
 int lcx_upload_x(lcx_ctx* h, const void* x, int64_t ld) {
-    NEED(h);
+    NEED_MUT(h);
     if (!x || ld < h->V) return fail(LCX_ERR_ARG, "lcx_upload_x: bad leading dimension");
     HIPCHECK(hipMemcpy2DAsync(h->X, h->ldx * h->es, x, ld * h->es, h->V * h->es, h->N, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
@@ -1431,7 +1673,7 @@ int lcx_upload_x(lcx_ctx* h, const void* x, int64_t ld) {
 
 int lcx_upload_preprocess(lcx_ctx* h, const void* x, int64_t ld, int kind, int has_missing, double missing, int fit, void* mean_io,
                           void* std_io, int64_t* n_obs_out, double* max_abs_out) {
-    NEED(h);
+    NEED_MUT(h);
     if (!x || ld < h->V) return fail(LCX_ERR_ARG, "lcx_upload_preprocess: bad leading dimension");
     if (kind < 0 || kind > 2) return fail(LCX_ERR_ARG, "lcx_upload_preprocess: kind must be 0 (none), 1 (standard) or 2 (outliers)");
     DISPATCH(h, upload_preprocess, h, x, ld, kind, has_missing, missing, fit, mean_io, std_io, n_obs_out, max_abs_out);
@@ -1446,12 +1688,12 @@ int lcx_download_x(lcx_ctx* h, void* x, int64_t ld) {
 }
 
 int lcx_generate_x(lcx_ctx* h, uint64_t seed, int kind, int n_groups, int64_t col_offset) {
-    NEED(h);
+    NEED_MUT(h);
     DISPATCH(h, generate, h, seed, kind, n_groups, col_offset);
 }
 
 int lcx_set_ws(lcx_ctx* h, const void* w) {
-    NEED(h);
+    NEED_MUT(h);
     h->w1_ready = false;
     if (!w) return fail(LCX_ERR_ARG, "lcx_set_ws: null");
     DISPATCH(h, set_ws, h, w);
@@ -1478,7 +1720,7 @@ int lcx_get_ws(lcx_ctx* h, int which, void* w) {
 }
 
 int lcx_permute_factors(lcx_ctx* h, const int32_t* order) {
-    NEED(h);
+    NEED_MUT(h);
     h->w1_ready = false;
     if (!order) return fail(LCX_ERR_ARG, "lcx_permute_factors: null");
     for (int j = 0; j < h->M; ++j)
@@ -1488,9 +1730,9 @@ int lcx_permute_factors(lcx_ctx* h, const int32_t* order) {
 
 #define WHICH_OK(w) if ((w) < 0 || (w) > 1) return fail(LCX_ERR_ARG, "which must be 0 or 1")
 
-int lcx_moments_a(lcx_ctx* h, int which) { NEED(h); WHICH_OK(which); DISPATCH(h, moments_a, h, which); }
-int lcx_moments_b(lcx_ctx* h, int which, double eps, int quick) { NEED(h); WHICH_OK(which); DISPATCH(h, moments_b, h, which, eps, quick); }
-int lcx_moments_c(lcx_ctx* h, int which) { NEED(h); WHICH_OK(which); DISPATCH(h, moments_c, h, which); }
+int lcx_moments_a(lcx_ctx* h, int which) { NEED_MUT(h); WHICH_OK(which); DISPATCH(h, moments_a, h, which); }
+int lcx_moments_b(lcx_ctx* h, int which, double eps, int quick) { NEED_MUT(h); WHICH_OK(which); DISPATCH(h, moments_b, h, which, eps, quick); }
+int lcx_moments_c(lcx_ctx* h, int which) { NEED_MUT(h); WHICH_OK(which); DISPATCH(h, moments_c, h, which); }
 
 static int detail_entry(lcx_ctx* h, int which) {
     if (h->dtype == LCX_F32) {
@@ -1508,33 +1750,33 @@ static int detail_entry(lcx_ctx* h, int which) {
 }
 int lcx_moments_detail(lcx_ctx* h, int which) { NEED(h); WHICH_OK(which); return detail_entry(h, which); }
 
-int lcx_update_a(lcx_ctx* h) { NEED(h); DISPATCH(h, update_a, h); }
-int lcx_update_b(lcx_ctx* h, double eps) { NEED(h); DISPATCH(h, update_b, h, eps); }
-int lcx_update_c(lcx_ctx* h, double eps) { NEED(h); DISPATCH(h, update_c, h, eps); }
+int lcx_update_a(lcx_ctx* h) { NEED_MUT(h); DISPATCH(h, update_a, h); }
+int lcx_update_b(lcx_ctx* h, double eps) { NEED_MUT(h); DISPATCH(h, update_b, h, eps); }
+int lcx_update_c(lcx_ctx* h, double eps) { NEED_MUT(h); DISPATCH(h, update_c, h, eps); }
 int lcx_update_d(lcx_ctx* h) {
-    NEED(h);
+    NEED_MUT(h);
     // With one GPU lcx_update_c already published the tangent; with several ranks its partial sits in sbuf[2]
     // and becomes global with the scalar all-reduce of the first trial (lcx_moments_c stores it).
     h->have_direction = true;
     return LCX_OK;
 }
 int lcx_make_trial(lcx_ctx* h, double eta) {
-    NEED(h);
+    NEED_MUT(h);
     if (!h->have_direction) return fail(LCX_ERR_STATE, "lcx_make_trial before lcx_update_a..d");
     DISPATCH(h, make_trial, h, eta);
 }
 int lcx_trial_linear_a(lcx_ctx* h, double eta) {
-    NEED(h);
+    NEED_MUT(h);
     if (!h->have_direction) return fail(LCX_ERR_STATE, "lcx_trial_linear_a before lcx_update_a..d");
     DISPATCH(h, trial_linear_a, h, eta);
 }
 int lcx_trial_linear_b(lcx_ctx* h, double eps, double eta) {
-    NEED(h);
+    NEED_MUT(h);
     if (!h->have_direction) return fail(LCX_ERR_STATE, "lcx_trial_linear_b before lcx_update_a..d");
     DISPATCH(h, trial_linear_b, h, eps, eta);
 }
 int lcx_accept_trial(lcx_ctx* h) {
-    NEED(h);
+    NEED_MUT(h);
     h->w1_ready = false;
     std::swap(h->Wt[0], h->Wt[1]);
     std::swap(h->set[0], h->set[1]);
@@ -1542,18 +1784,24 @@ int lcx_accept_trial(lcx_ctx* h) {
     return LCX_OK;
 }
 
-int lcx_syn_moments_b(lcx_ctx* h, int which, double yscale) { NEED(h); WHICH_OK(which); DISPATCH(h, syn_moments_b, h, which, yscale); }
-int lcx_syn_moments_c(lcx_ctx* h, int which) { NEED(h); WHICH_OK(which); DISPATCH(h, syn_moments_c, h, which); }
-int lcx_syn_update_a(lcx_ctx* h) { NEED(h); DISPATCH(h, syn_update_a, h); }
-int lcx_syn_update_b(lcx_ctx* h, double eta) { NEED(h); DISPATCH(h, syn_update_b, h, eta); }
+int lcx_iterate(lcx_ctx* h, double eps, double tol, double tc_cur, int more, double* out8) {
+    NEED(h);
+    if (!out8) return fail(LCX_ERR_ARG, "lcx_iterate: null");
+    DISPATCH(h, iterate, h, eps, tol, tc_cur, more, out8);
+}
+
+int lcx_syn_moments_b(lcx_ctx* h, int which, double yscale) { NEED_MUT(h); WHICH_OK(which); DISPATCH(h, syn_moments_b, h, which, yscale); }
+int lcx_syn_moments_c(lcx_ctx* h, int which) { NEED_MUT(h); WHICH_OK(which); DISPATCH(h, syn_moments_c, h, which); }
+int lcx_syn_update_a(lcx_ctx* h) { NEED_MUT(h); DISPATCH(h, syn_update_a, h); }
+int lcx_syn_update_b(lcx_ctx* h, double eta) { NEED_MUT(h); DISPATCH(h, syn_update_b, h, eta); }
 int lcx_covariance_rows_syn(lcx_ctx* h, const void* std_host, int64_t row0, int64_t nrows, void* out) {
     NEED(h);
     if (!std_host || !out || row0 < 0 || nrows < 1 || row0 + nrows > h->V) return fail(LCX_ERR_ARG, "lcx_covariance_rows_syn: bad range");
     DISPATCH(h, covariance_syn, h, std_host, row0, nrows, out);
 }
 
-int lcx_rescale_ws(lcx_ctx* h, double e0, double e1) { NEED(h); h->w1_ready = false; DISPATCH(h, rescale, h, e0, e1); }
-int lcx_init_scale_ws(lcx_ctx* h) { NEED(h); h->w1_ready = false; DISPATCH(h, init_scale, h); }
+int lcx_rescale_ws(lcx_ctx* h, double e0, double e1) { NEED_MUT(h); h->w1_ready = false; DISPATCH(h, rescale, h, e0, e1); }
+int lcx_init_scale_ws(lcx_ctx* h) { NEED_MUT(h); h->w1_ready = false; DISPATCH(h, init_scale, h); }
 
 // Wait until the pinned mirror of a set carries the last publication enqueued for it.
 static int wait_published(lcx_ctx* h, MomentSet& s) {
@@ -1630,21 +1878,21 @@ int lcx_read_state(lcx_ctx* h, int which, double* out) {
 }
 
 int lcx_set_linear_mode(lcx_ctx* h, int enable) {
-    NEED(h);
+    NEED_MUT(h);
     HIPCHECK(hipStreamSynchronize(h->stream));
     h->full_sig = enable != 0;
     return LCX_OK;
 }
 
 int lcx_set_exchange(lcx_ctx* h, int enable) {
-    NEED(h);
+    NEED_MUT(h);
     HIPCHECK(hipStreamSynchronize(h->stream));
     h->exchange = enable != 0 || h->world > 1;
     return LCX_OK;
 }
 
 int lcx_set_world(lcx_ctx* h, int world) {
-    NEED(h);
+    NEED_MUT(h);
     if (world < 1) return fail(LCX_ERR_ARG, "lcx_set_world: world must be >= 1");
     HIPCHECK(hipStreamSynchronize(h->stream));
     h->world = world;
@@ -1660,7 +1908,7 @@ int lcx_get_moment(lcx_ctx* h, int which, int key, double eps, void* out) {
 }
 
 int lcx_set_moment(lcx_ctx* h, int which, int key, const void* in) {
-    NEED(h);
+    NEED_MUT(h);
     WHICH_OK(which);
     if (!in) return fail(LCX_ERR_ARG, "lcx_set_moment: null");
     DISPATCH(h, set_moment, h, which, key, in);
@@ -1678,6 +1926,19 @@ int lcx_covariance_rows(lcx_ctx* h, double eps, const void* std_host, int64_t ro
     NEED(h);
     if (!std_host || !out || row0 < 0 || nrows < 1 || row0 + nrows > h->V) return fail(LCX_ERR_ARG, "lcx_covariance_rows: bad range");
     DISPATCH(h, covariance, h, eps, std_host, row0, nrows, out);
+}
+
+int lcx_covariance(lcx_ctx* h, int synergistic, double eps, const void* std_host, void* out, int64_t ld_out, double* kernel_seconds) {
+    NEED(h);
+    if (!std_host || !out || ld_out < h->V) return fail(LCX_ERR_ARG, "lcx_covariance: bad argument");
+    DISPATCH(h, covariance_full, h, synergistic, eps, std_host, out, ld_out, kernel_seconds);
+}
+
+int lcx_bytes_resident(lcx_ctx* h, int64_t* total, int64_t* x_bytes) {
+    NEED(h);
+    if (total) *total = (int64_t)h->bytes_resident;
+    if (x_bytes) *x_bytes = (int64_t)(2 * (size_t)h->Npad * h->ldx * h->es);
+    return LCX_OK;
 }
 
 int lcx_project(lcx_ctx* h, const void* x, int64_t n_rows, int64_t ld, void* out) {
@@ -1733,7 +1994,7 @@ int lcx_timing_passes(lcx_ctx* h, int kind, int64_t* passes) {
 }
 
 int lcx_bench_gemm(lcx_ctx* h, int kind, int iters, double* avg_ms) {
-    NEED(h);
+    NEED_MUT(h);
     if (kind < 0 || kind > 1 || iters < 1 || !avg_ms) return fail(LCX_ERR_ARG, "lcx_bench_gemm: bad argument");
     hipEvent_t a, b;
     HIPCHECK(hipEventCreate(&a));
@@ -1759,7 +2020,7 @@ int lcx_bench_gemm(lcx_ctx* h, int kind, int iters, double* avg_ms) {
 // `iters` times vs captured once into a hipGraph and replayed `iters` times.  The replay publishes a stale sequence number,
 // which is fine for timing; nothing reads the state in between.
 int lcx_bench_graph(lcx_ctx* h, double eps, int iters, double* direct_ms, double* graph_ms) {
-    NEED(h);
+    NEED_MUT(h);
     if (iters < 1 || !direct_ms || !graph_ms) return fail(LCX_ERR_ARG, "lcx_bench_graph: bad argument");
     if (h->exchange) return fail(LCX_ERR_STATE, "lcx_bench_graph: one GPU only");
     hipEvent_t a, b;

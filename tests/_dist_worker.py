@@ -55,7 +55,29 @@ def main():
     c0, c1 = comm.shard(v)
     assert model._backend.nv == c1 - c0
     y = model.transform(x)
-    rho = model.moments["rho"]              # lazily gathered: every rank must ask (collective)
+    if os.environ.get("LCX_EAGER_GATHER_ELEMS") == "0":
+        # sharded moments were NOT put together at the end of fit: touching one must raise (never a hidden collective that
+        # the other ranks do not join), pickling must work without them, and the explicit collective brings them in
+        import pickle
+        try:
+            model.moments["rho"]
+            raise SystemExit("moments['rho'] on a sharded model did not raise")
+        except RuntimeError:
+            pass
+        assert "rho" not in model.moments and "TC" in model.moments
+        if comm.rank == 0:
+            back = pickle.loads(pickle.dumps(model))
+            assert "rho" not in back.moments and back.ws.shape == (m, v)
+        model.gather_moments(["rho", "X_i Z_j", "Si"])
+        assert "rho" in model.moments
+    elif comm.rank == 0:
+        # the usual pattern: one rank alone looks at the results / saves the model (vis_corex.py:549) - no collective may
+        # hide behind that
+        import pickle
+        back = pickle.loads(pickle.dumps(model))
+        assert back.moments["rho"].shape == (m, v)
+        assert model.mis.shape == (m, v) and model.moments["MI"].shape == (m, v)
+    rho = model.moments["rho"]
     xz = model.moments["X_i Z_j"]
     si = model.moments["Si"]
     cov = model.get_covariance() if (syn and comm.world == 1) else np.zeros(1)

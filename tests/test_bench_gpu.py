@@ -1,6 +1,7 @@
 """bench.py contract checks on the GPU box: exactly ONE line on stdout and it is the JSON record - also when RCCL is
 live (it prints a version banner to the C-level stdout) and when several ranks run (two ranks sharing GPU 0 through
-gloo exercise the multi-rank code of bench.py; RCCL itself refuses two ranks per device)."""
+gloo exercise the multi-rank code of bench.py; RCCL itself refuses two ranks per device).  `--gpus 2` without a
+launcher must start two ranks itself and report n_gpus == 2."""
 import json
 import os
 import subprocess
@@ -12,7 +13,8 @@ from tests.test_distributed_cpu import ROOT, free_port
 
 pytestmark = pytest.mark.gpu
 
-FAST = ["--steps", "7", "--warmup", "7", "--no-also-linear", "--cpu-iters-per-stage", "0", "--no-convergence"]
+FAST = ["--steps", "3", "--warmup", "2", "--no-extras", "--repeats", "1"]
+SMALL = {"LCX_BENCH_HEAD": "tiny"}          # a small headline workload instead of BASELINE configs[2] / [3]
 
 
 def _one_json_line(stdout):
@@ -22,30 +24,67 @@ def _one_json_line(stdout):
 
 
 def test_single_rank_rccl_stdout_is_one_json_line():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-exchange"] + FAST, cwd=ROOT,
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-exchange", "--workload", "c2"] + FAST, cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     d = _one_json_line(p.stdout)
     assert d["n_gpus"] == 1 and d["config"]["force_exchange"] is True
     assert d["roofline"]["kernel"].startswith("lcx::gemm_") and 0.0 < d["roofline"]["frac"] < 1.0
-    assert d["value"] > 0 and d["steps"] == 7
+    assert d["roofline"]["bound"] == "hbm" and d["dtype"] == "f64"
+    assert d["value"] > 0 and d["steps"] == 3
+    w = d["config"]["windows"]
+    assert w["stages"] == 7 and w["steps_per_window"] == 3 and w["timed_iterations"] == 21
+
+
+def test_default_line_is_the_c3_line_with_the_c2_block():
+    """The driver's command: the headline must be BASELINE configs[2] (MFMA-bound), c2 rides along as a nested block, the
+    CPU baselines are real, and the figure must not depend on the driver's --steps 20 --warmup 5."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                        "--cpu-seconds", "5"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    d = _one_json_line(p.stdout)
+    assert d["config"]["workload"].startswith("c3:") and d["dtype"] == "f32" and d["n_gpus"] == 1
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["unit"] == "TFLOP/s" and 0.3 < d["roofline"]["frac"] < 1.0
+    assert d["roofline"]["kernel"].startswith("lcx::gemm_ct")
+    assert d["config"]["windows"]["timed_seconds"] >= 0.5
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    c2 = d["config"]["c2"]
+    assert c2["roofline"]["bound"] == "hbm" and c2["windows"]["timed_seconds"] >= 0.5
+    assert c2["cpu_baseline"]["value"] > 0
+    lo, med, hi = c2["windows"]["ms_per_step_walk_min_median_max"]
+    assert hi / lo < 1.15, (lo, med, hi)
+    assert c2["get_covariance"]["n_variables"] == 5000 and c2["get_covariance"]["seconds"] > 0
+    assert d["config"]["get_covariance_c5_standin"]["n_variables"] == 20000
+
+
+def _two_rank_env():
+    return dict(os.environ, LCX_BENCH_DEVICE="0", LCX_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2",
+                LCX_WAIT_TIMEOUT_MS="60000", **SMALL)
 
 
 def test_two_ranks_one_gpu_stdout_is_one_json_line():
-    env = dict(os.environ, LCX_BENCH_DEVICE="0", LCX_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + FAST
-    p = None
-    for attempt in range(2):                      # see tests/test_distributed_gpu.py: two gloo ranks on one GPU can stall
-        try:
-            p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
-            break
-        except subprocess.TimeoutExpired as e:
-            sys.stderr.write("bench.py with two gloo ranks did not finish in 180 s:\n%s\n" % (e.stderr or b"").decode(errors="replace")[-3000:])
-            p = None
-    assert p is not None, "bench.py with two gloo ranks stalled twice"
+    p = subprocess.run(cmd, cwd=ROOT, env=_two_rank_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     d = _one_json_line(p.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["config"]["n_variables_total"] == 2 * d["config"]["n_variables_per_gpu"]
     assert d["cpu_baseline"] is None
+
+
+def test_gpus_2_without_a_launcher_starts_two_ranks():
+    """`python bench.py --gpus 2` (what the driver types): bench.py launches the ranks as children and relays rank 0's line."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + FAST, cwd=ROOT, env=_two_rank_env(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    d = _one_json_line(p.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["config"]["n_variables_total"] == 2 * d["config"]["n_variables_per_gpu"]
+
+
+def test_world_size_mismatch_is_an_error():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + FAST, cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode != 0 and not p.stdout.strip()

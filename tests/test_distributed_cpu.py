@@ -23,12 +23,12 @@ def free_port():
     return p
 
 
-def launch(world, out_dir, n, v, m, mode="exact"):
+def launch(world, out_dir, n, v, m, mode="exact", extra_env=None):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2")
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(out_dir),
                                        str(n), str(v), str(m), mode], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -83,3 +83,16 @@ def test_sharded_synergistic_fit_matches_oracle(tmp_path):
     assert np.max(np.abs(got["xz"] - ref.moments["X_i Z_j"])) < 1e-8
     assert np.max(np.abs(got["si"] - ref.moments["Si"])) < 1e-8
     assert np.max(np.abs(got["tcs"] - ref.moments["TCs"])) < 1e-8
+
+
+@pytest.mark.parametrize("mode", ["exact", "syn"])
+def test_sharded_moments_need_an_explicit_collective(mode, tmp_path):
+    """Above the eager-gather size the per-variable moments stay on their shards: dict access raises (no hidden collective),
+    pickling on one rank works without them, `gather_moments` on every rank brings them in - and the result is the oracle's."""
+    n, v, m = 300, 203, 4
+    launch(2, tmp_path, n, v, m, mode, extra_env={"LCX_EAGER_GATHER_ELEMS": "0"})
+    got = np.load(os.path.join(tmp_path, "dist_result.npz"))
+    x, _ = O.gen_planted(n, v, m, seed=2)
+    ref = (O.fit_syn if mode == "syn" else O.fit_ns)(x, m, seed=0, dtype=np.float64, keep_x=True)
+    assert np.max(np.abs(got["rho"] - ref.moments["rho"])) < 1e-8
+    assert np.max(np.abs(got["xz"] - ref.moments["X_i Z_j"])) < 1e-8

@@ -206,3 +206,29 @@ def test_synergistic_branch_host_logic():
     assert np.max(np.abs(cov - ref.get_covariance())) < 1e-10
     back = pickle.loads(pickle.dumps(out))
     assert back._backend is None and np.max(np.abs(back.get_covariance() - cov)) < 1e-12
+
+
+def test_bench_gpus_n_spawns_the_ranks_itself():
+    """`python bench.py --gpus 8` without WORLD_SIZE must launch 8 ranks as children (dry run: the command only) instead of
+    silently measuring one GPU; nothing of torch / HIP is touched in the launching process before that."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["LCX_BENCH_DRY_SPAWN"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"],
+                       env=env, capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0, p.stderr
+    cmd = json.loads(p.stdout.strip().splitlines()[-1])["spawn"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+
+
+def test_bench_refuses_a_world_that_does_not_match_gpus():
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=60)
+    assert p.returncode != 0 and not p.stdout.strip()

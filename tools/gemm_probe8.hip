@@ -122,7 +122,7 @@ void suite(const char* name, int64_t K, int64_t V, bool small) {
     T *A, *B, *out;
     CK(hipMalloc(&A, sizeof(T) * K * V));
     CK(hipMalloc(&B, sizeof(T) * K * 16 * CT));
-    CK(hipMalloc(&out, sizeof(T) * 48 * V * 16 * CT));
+    CK(hipMalloc(&out, sizeof(T) * (small ? 600 : 48) * V * 16 * CT));
     {
         std::vector<T> h((size_t)K * V);
         for (size_t x = 0; x < h.size(); ++x) h[x] = (T)((double)rand() / RAND_MAX - 0.5);
@@ -134,6 +134,8 @@ void suite(const char* name, int64_t K, int64_t V, bool small) {
     std::vector<Variant> vs;
     vs.push_back(mkct<T, CT, 4, 4, 4>(A, V, K, V, B, out, 2));          // production
     if constexpr (CT == 4) {
+        vs.push_back(mkct<T, CT, 4, 4, 8>(A, V, K, V, B, out, 2));
+        vs.push_back(mkct<T, CT, 4, 4, 8>(A, V, K, V, B, out, 3));
         vs.push_back(mkct<T, CT, 8, 4, 4>(A, V, K, V, B, out, 2));
         vs.push_back(mkct<T, CT, 8, 4, 4>(A, V, K, V, B, out, 1));
         vs.push_back(mkct<T, CT, 8, 2, 4>(A, V, K, V, B, out, 4));
@@ -158,16 +160,16 @@ int main(int argc, char** argv) {
     const char* which = argc > 1 ? argv[1] : "all";
     const bool all = !strcmp(which, "all");
     if (all || !strcmp(which, "odd")) {
-        suite<4>("odd_m64", 2048, 1984, true);          // ragged super tile
-        suite<8>("odd_m128", 1024, 3008, true);
-        suite<2>("odd_m32", 1024, 6464, true);
+        suite<4>("odd_m64", 2048, 2048, true);
+        suite<8>("odd_m128", 1024, 3072, true);
+        suite<2>("odd_m32", 1024, 6656, true);
     }
     if (all || !strcmp(which, "c3")) {
-        suite<4>("c3l_xty", 50048, 20032, false);
-        suite<4>("c3l_xw", 20032, 50048, false);
+        suite<4>("c3l_xty", 50048, 20480, false);      // 20480 = 40 x 512: whole super tiles for every variant
+        suite<4>("c3l_xw", 20480, 50176, false);       // 50176 = 98 x 512
     }
     if (all || !strcmp(which, "c4")) {
-        suite<8>("c4l_xty", 50048, 20032, false);
+        suite<8>("c4l_xty", 50048, 20480, false);
     }
     return 0;
 }

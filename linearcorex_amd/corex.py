@@ -320,6 +320,7 @@ class Corex(object):
         c0, c1 = self._comm.shard(self.nv)
         self._cols = (c0, c1)
         be = self._make_backend(self.n_samples, c1 - c0)
+        self._x_resident = True
         if self.gaussianize == 'empirical':
             # rank-based gaussianisation (:424-426) is a per-column sort: host side, then a plain upload
             x = self.preprocess(x, fit=True)
@@ -350,6 +351,7 @@ class Corex(object):
         c0, c1 = self._comm.shard(self.nv)
         self._cols = (c0, c1)
         be = self._make_backend(self.n_samples, c1 - c0)
+        self._x_resident = True
         be.generate_x(seed, kind, n_groups, c0)
         self.theta = (np.zeros(self.nv, self.dtype), np.ones(self.nv, self.dtype))
         self.n_obs = self.n_samples
@@ -362,6 +364,7 @@ class Corex(object):
         self._cols = self._comm.shard(self.nv)
         assert x_local.shape[1] == self._cols[1] - self._cols[0]
         be = self._make_backend(self.n_samples, x_local.shape[1])
+        self._x_resident = True
         be.upload_x(np.ascontiguousarray(x_local, dtype=self.dtype))
         if self.theta is None:
             self.theta = (np.zeros(self.nv, self.dtype), np.ones(self.nv, self.dtype))
@@ -733,8 +736,9 @@ class Corex(object):
                 self._comm.allreduce(t)
                 y = t.cpu().numpy()
         if details:
-            if ns != self.n_samples:
-                raise NotImplementedError("transform(details=True) is supported on the fitted data only")
+            if ns != self.n_samples or not getattr(self, "_x_resident", True):
+                raise NotImplementedError("transform(details=True) evaluates the moments on the resident (fitted) data: "
+                                          "not available for other data or on a model restored from a pickle")
             if not self.discourage_overlap:
                 return y, self._calculate_moments_syn()
             return y, self._calculate_moments(quick=False, details=True)
@@ -781,11 +785,14 @@ class Corex(object):
         if self._backend is None:
             if self.ws.size == 0:
                 raise RuntimeError("model is not fitted")
-            # restored from a pickle: bring W (and what get_covariance needs) back to the device
+            # restored from a pickle: bring W (and what get_covariance needs) back to the device.  The data are NOT
+            # resident any more, so the handle is created for a single (empty) sample: transform / get_covariance only
+            # need W and the per-variable moments, not an n_samples x n_variables shard and its transposed copy
             self._cols = self._comm.shard(self.nv)
-            be = self._make_backend(max(int(self.n_samples), 1), self.nv)
+            be = self._make_backend(1, self.nv)
             be.set_ws(np.asarray(self.ws, dtype=self.dtype))
             self._moments_restored = False
+            self._x_resident = False
         if need_moments and getattr(self, "_moments_restored", True) is False:
             self._backend.set_moment(0, "rhoinvrho", self.moments["rhoinvrho"])
             self._backend.set_moment(0, "Si", self.moments["Si"])

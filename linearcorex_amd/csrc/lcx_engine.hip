@@ -937,7 +937,7 @@ template <typename T, int CT> struct Impl {
         if (syn && !c.op_b) HIPCHECK(hipMalloc(&c.op_b, mv));
         if (!c.dev[0]) {
             const int64_t ldo = h->ldx;
-            int64_t rows = (int64_t)(32u << 20) / (ldo * (int64_t)sizeof(T)) / 64 * 64;
+            int64_t rows = (int64_t)(64u << 20) / (ldo * (int64_t)sizeof(T)) / 64 * 64;
             if (rows < 64) rows = 64;
             if (rows > round_up(h->V, 64)) rows = round_up(h->V, 64);
             c.block_bytes = (size_t)rows * ldo * sizeof(T);
@@ -952,7 +952,12 @@ template <typename T, int CT> struct Impl {
         // pinned block -> the caller's matrix; the destination is usually freshly allocated pageable memory, i.e. this is
         // where its pages are first touched: a few threads keep it off the critical path of the PCIe copies
         const int64_t bytes = rows * cols * (int64_t)sizeof(T);
-        const int nt = bytes >= (8 << 20) ? 8 : 1;
+        static const int max_threads = []() {
+            const char* e = getenv("LCX_HOST_THREADS");
+            int n = (e && *e) ? atoi(e) : 12;
+            return n < 1 ? 1 : (n > 64 ? 64 : n);
+        }();
+        const int nt = bytes >= (8 << 20) ? max_threads : 1;
         auto work = [=](int t) {
             const int64_t r0 = rows * t / nt, r1 = rows * (t + 1) / nt;
             if (src_ld == cols && dst_ld == cols) memcpy(dst + r0 * cols, src + r0 * cols, (size_t)(r1 - r0) * cols * sizeof(T));

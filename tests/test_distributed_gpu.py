@@ -44,18 +44,17 @@ def _launch_once(world, out_dir, n, v, m, mode, timeout):
 
 
 def launch_hip(world, out_dir, n, v, m, mode):
-    """A normal run takes ~5 s.  On some boxes the two ranks sharing GPU 0 over gloo have been seen to stall right after
-    the rendezvous (test plumbing: the product's multi-GPU path is RCCL, one rank per GPU); such a run is reported with
-    the ranks' Python stacks and retried once."""
-    import sys
-    timed_out, procs, outs = _launch_once(world, out_dir, n, v, m, mode, 120)
+    """A normal run takes 3-8 s.  No retry: a rank that waits for a state publication longer than LCX_WAIT_TIMEOUT_MS fails
+    with the expected / seen sequence numbers (lcx_read_state -> LCX_ERR_STATE), a rank still alive after
+    LCX_TEST_DUMP_AFTER seconds prints the Python stack of every thread, and both end up in
+    gpurun_out/dist_stall_stacks.log.  (Round 1 saw this launch stall in 2 of ~12 suites and retried it; 60 stress launches
+    and 6 suites of round 2 - profiles/r02_dist_stress_*.txt - never reproduced it.)"""
+    timed_out, procs, outs = _launch_once(world, out_dir, n, v, m, mode, 150)
     if timed_out:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "dist_stall_stacks.log"), "a") as f:
             f.write("==== %s %s ====\n" % (mode, (n, v, m)) + "\n-----\n".join(o[-8000:] for o in outs) + "\n")
-        sys.stderr.write("ranks did not finish in 120 s, retrying once:\n" + "\n-----\n".join(o[-3000:] for o in outs) + "\n")
-        timed_out, procs, outs = _launch_once(world, out_dir, n, v, m, mode, 120)
-    assert not timed_out, "ranks did not finish in 120 s (twice):\n" + "\n-----\n".join(o[-3000:] for o in outs)
+    assert not timed_out, "ranks did not finish in 150 s:\n" + "\n-----\n".join(o[-4000:] for o in outs)
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
 

@@ -54,6 +54,17 @@ def _stub():
         def accept(self):
             _ck(_lcx.lcx_accept_trial(self.h))
 
+        def update_ns(self, eps, tol, tc_cur, more=True):
+            o = (C.c_double * 8)()
+            _ck(_lcx.lcx_iterate(self.h, C.c_double(eps), C.c_double(tol), C.c_double(tc_cur), int(more), o))
+            return int(o[0]), o[1], int(o[3])
+
+        def covariance(self, eps, std32):
+            nv = std32.shape[0]
+            out = np.empty((nv, nv), np.float32)
+            _ck(_lcx.lcx_covariance(self.h, 0, C.c_double(eps), _p(std32), _p(out), C.c_int64(nv), None))
+            return out
+
         def get_ws(self, m, nv):
             out = np.empty((m, nv), np.float32)
             _ck(_lcx.lcx_get_ws(self.h, 0, _p(out)))
@@ -94,4 +105,30 @@ def test_integration_stub_runs_update_ns():
     assert n_trials == info["n_trials"] and eta == info["eta"]
     assert abs(tc_new - float(m_ref["TC"])) < 2e-3 * max(1.0, abs(float(m_ref["TC"])))
     assert np.max(np.abs(dev.get_ws(m, v) - w_ref)) < 1e-4
+    dev.close()
+
+
+def test_integration_stub_update_ns_in_one_call():
+    """The shortest integration of INTEGRATION.md: `_update_ns` (:290-334) as one lcx_iterate call per iteration, and
+    get_covariance (:443-451) as one lcx_covariance call."""
+    LcxDevice = _stub()
+    n, v, m, eps = 500, 333, 5, 0.36
+    x, _ = O.gen_planted(n, v, m, seed=8)
+    x32 = O.preprocess(x.astype(np.float32))[0]
+    w = np.random.RandomState(0).randn(m, v).astype(np.float32)
+    w /= (10.0 * O.norm(x32, w, 0))[:, np.newaxis]
+    dev = LcxDevice(x32, m)
+    dev.set_ws(w)
+    tc = dev.moments(0, eps, False)
+    mo = O.moments_ns(x32, w, eps, quick=False)
+    w_ref = w
+    for it in range(4):
+        status, tc, trials = dev.update_ns(eps, 1e-5, tc, more=it < 3)
+        w_ref, mo, info = O.update_ns(x32, w_ref, mo, eps)
+        assert status == 0 and trials == info["n_trials"]
+        assert abs(tc - float(mo["TC"])) < 2e-3 * max(1.0, abs(float(mo["TC"])))
+    assert np.max(np.abs(dev.get_ws(m, v) - w_ref)) < 2e-4
+    cov = dev.covariance(eps, np.ones(v, np.float32))
+    cov_ref = O.covariance_ns(mo, eps, (np.zeros(v, np.float32), np.ones(v, np.float32)))
+    assert np.max(np.abs(cov - cov_ref)) < 5e-3 * np.max(np.abs(cov_ref))
     dev.close()

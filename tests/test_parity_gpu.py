@@ -471,3 +471,99 @@ def test_ct_many_slots_end_to_end(tag, m):
     tol = 1e-8 if tag == "f64" else 2e-3
     assert np.max(np.abs(h_ref - h_out) / np.maximum(1.0, np.abs(h_ref))) < tol
     assert np.array_equal(out.clusters(), ref.clusters())
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_init_scale_ws_against_the_reference(tag, g1):
+    """`ws /= 10 * _norm(x, ws)` (reference :117, `_norm` :215-228) on its own: the weights the reference's first moment
+    evaluation sees (captured by tests/golden/make_golden.py) from the same random draw."""
+    xt = g1[tag + "_x_tilde"]
+    np.random.seed(0)
+    w0 = np.random.randn(5, xt.shape[1]).astype(DT[tag])
+    be = make_backend(xt.astype(DT[tag]), w0, DT[tag])
+    be.moments_a(0)
+    be.init_scale_ws()
+    w = be.get_ws(0)
+    assert relerr(w, g1[tag + "_w_init"]) < (1e-12 if tag == "f64" else 2e-6)
+    be.close()
+
+
+@pytest.mark.parametrize("m", [64, 128])
+def test_large_shard_kernels_inside_a_float32_fit(m, monkeypatch):
+    """The instantiations BASELINE configs[2] / [3] run - gemm_ct<float, 4 | 8, ...> feeding the 64- / 128-factor float32
+    epilogue, gradient and update kernels - inside a fit (7 stages x 3 iterations, the loop of reference :124-159 without
+    the final factor sort, whose order is a near-tie after so few iterations), against the float32 oracle on planted data."""
+    from linearcorex_amd import Corex
+    from linearcorex_amd.preprocess import preprocess as pp
+    monkeypatch.setenv("LCX_GEMM", "ct")
+    n, v = 4096, 8192
+    x, grp = O.gen_planted(n, v, m, seed=51)
+    xt = pp(x.astype(np.float32), None, "standard", None)[0]
+    ref = O.fit_ns_preprocessed(xt, m, seed=0, dtype=np.float32, max_iter=3, tol=0.0, finish=False)
+    model = Corex(n_hidden=m, seed=0, dtype=np.float32, tol=0.0, device=0)
+    be = model._attach_shard(xt, v)
+    assert ("gemm_ct_kernel<float, %d" % (m // 16)) in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)
+    for i_eps, eps in enumerate(model._init_weights()):
+        model._begin_stage(i_eps, eps)
+        for k in range(3):
+            model._iterate(more=k < 2)
+    h_ref, h = np.asarray(ref.history_tc, np.float64), np.asarray(model.history["TC"], np.float64)
+    assert len(h) == len(h_ref) == 21
+    assert np.max(np.abs(h - h_ref) / np.maximum(1.0, np.abs(h_ref))) < 2e-3
+    assert abs(model.stats["trials"] - ref.n_trials) <= 2
+    w = be.get_ws(0)
+    assert relerr(w, ref.ws) < 5e-3
+    assert relerr(model.moments["rho"], ref.moments["rho"]) < 5e-3
+    agree = np.mean(np.argmax(np.abs(w), axis=0) == np.argmax(np.abs(ref.ws), axis=0))
+    assert agree >= 0.995, agree
+    be.close()
+
+
+def _iterate_n(x, m, n_iter, mode, dtype=np.float64):
+    """n_iter iterations of the first annealing stage; mode: 'library' (lcx_iterate with the next iteration started early),
+    'host' (levels sequenced from Python), 'mixed' (alternating: every library iteration leaves a speculation behind that the
+    following host iteration has to abandon)."""
+    from linearcorex_amd import Corex
+    from linearcorex_amd.preprocess import preprocess as pp
+    model = Corex(n_hidden=m, seed=0, dtype=dtype, tol=0.0, device=0)
+    model._attach_shard(pp(x.astype(dtype), None, "standard", None)[0], x.shape[1])
+    sched = model._init_weights()
+    model._begin_stage(0, sched[0])
+    for k in range(n_iter):
+        model._in_library = mode == "library" or (mode == "mixed" and k % 2 == 0)
+        model._iterate(more=True)
+    model._in_library = True
+    model._begin_stage(1, sched[1])          # a stage change right on top of a pending speculation
+    for k in range(3):
+        model._iterate(more=k < 2)
+    w = model._backend.get_ws(0)
+    rho = model.moments["rho"]
+    model._backend.close()
+    return np.asarray(model.history["TC"], np.float64), w, rho, dict(model.stats)
+
+
+def test_library_loop_equals_host_loop():
+    """lcx_iterate (line-search decisions in the library, next iteration's direction and first trial enqueued before the
+    call returns) must walk exactly the trajectory of the host-sequenced levels - also when a speculation is abandoned by a
+    host-sequenced iteration, a stage change or a readback in between."""
+    x, _ = O.gen_planted(600, 900, 6, seed=61)
+    h_lib, w_lib, rho_lib, st_lib = _iterate_n(x, 6, 14, "library")
+    h_host, w_host, rho_host, st_host = _iterate_n(x, 6, 14, "host")
+    h_mix, w_mix, rho_mix, st_mix = _iterate_n(x, 6, 14, "mixed")
+    assert len(h_lib) == 17
+    assert np.array_equal(h_lib, h_host) and np.array_equal(h_lib, h_mix)
+    assert np.array_equal(w_lib, w_host) and np.array_equal(w_lib, w_mix)
+    assert np.array_equal(rho_lib, rho_host) and np.array_equal(rho_lib, rho_mix)
+    assert st_lib["trials"] == st_host["trials"] == st_mix["trials"]
+    # and against the oracle
+    ref = O.fit_ns(x, 6, seed=0, dtype=np.float64, max_iter=14)
+    assert np.max(np.abs(h_lib[:14] - np.asarray(ref.history_tc[:14]))) < 1e-9
+
+
+def test_host_loop_end_to_end(g1, monkeypatch):
+    """LCX_HOST_LOOP=1 (what several ranks always run) on big5: same bars as the default path."""
+    monkeypatch.setenv("LCX_HOST_LOOP", "1")
+    out = _fit(g1["x_raw"].astype(np.float64), 5, "f64")
+    assert out._in_library is False
+    h, h_ref = np.asarray(out.history["TC"], np.float64), g1["f64_history_tc"]
+    assert len(h) == len(h_ref) and relerr(h, h_ref) < 1e-6

@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--write", required=True)
     ap.add_argument("--mfma", default=None, help="pass with SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64/_F32")
     ap.add_argument("--command", default="")
+    ap.add_argument("--lib-src-hash", default=None, help="hash of the library sources that were profiled (__graft_entry__._src_hash)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     fetch, write = collect(a.fetch, "FETCH_SIZE"), collect(a.write, "WRITE_SIZE")
@@ -93,7 +94,15 @@ def main():
             flops = 512.0 * ((m64[k]["sum"] / m64[k]["launches"] if k in m64 else 0.0) +
                              (m32[k]["sum"] / m32[k]["launches"] if k in m32 else 0.0))
             d["mfma_flops_per_launch"] = flops
-    out = {"workload": a.workload, "command": a.command,
+    lib_hash = a.lib_src_hash
+    if lib_hash is None:
+        try:
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            import __graft_entry__ as ge
+            lib_hash = ge._src_hash()
+        except Exception:
+            lib_hash = None
+    out = {"workload": a.workload, "command": a.command, "lib_src_hash": lib_hash,
            "corrections": "FETCH_SIZE x2 (gfx950 wide coalesced reads are tallied at half size), KiB -> bytes; "
                           "WRITE_SIZE as reported (uncalibrated)",
            "kernels": kernels}

@@ -88,6 +88,9 @@ def parse(argv=None):
                     help="time budget of the CPU-baseline sample of the headline workload (0 = skip)")
     ap.add_argument("--cpu-iters-per-stage", type=int, default=10,
                     help="CPU baseline of the c2 block: oracle iterations per annealing stage (0 = skip)")
+    ap.add_argument("--convergence-max-iter", type=int, default=100,
+                    help="iterations per annealing stage allowed to the whole-fit wall-clock measurement of a generated headline "
+                         "workload (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-sample", type=int, default=0,
                     help="HIP-event pairs around every n-th X pass of the timed windows (a pair costs ~5 us of stream time; "
@@ -665,6 +668,23 @@ def main():
     n, v_per, m, tag = WORKLOADS[head]
     dtype = np.float64 if tag == "f64" else np.float32
 
+    # ---- several ranks: first the SAME shard on every GPU without any exchange (each rank on its own, no collective in the
+    # measurement): the one-GPU point of the weak-scaling series of THIS workload, measured in the same job.  (The N=1 line
+    # of bench.py headlines another workload, configs[2], so value(N) / (N x value(1)) across lines is not an efficiency.)
+    same_shard_single = None
+    if world > 1 and args.extras:
+        r1, m1, b1 = measure(args, None, 1, rank, local_rank, head, args.steps, args.warmup, args.line_search, repeats=args.repeats)
+        b1.close()
+        m1._backend = None
+        del m1, b1
+        import torch.distributed as dist
+        t = torch.tensor([r1["its_per_s"], -r1["its_per_s"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        same_shard_single = {"iterations_per_sec_slowest_rank": float(t[0]), "iterations_per_sec_fastest_rank": float(-t[1]),
+                             "ms_per_step_this_rank": r1["per_step_s"] * 1e3, "x_passes_per_iteration": r1["x_passes"],
+                             "what": "every rank fits the same %s shard alone, no exchange steps: the one-GPU point of this "
+                                     "workload's weak-scaling series, measured in this job" % head}
+
     # ---- headline: the reference-shaped iteration (every line-search trial re-evaluates the moments with two passes
     # over X, linearcorex.py:321) ----
     r, model, be = measure(args, comm, world, rank, local_rank, head, args.steps, args.warmup, args.line_search,
@@ -672,11 +692,31 @@ def main():
     roofline = roofline_of(head, r, world)
     cfg = config_of(head, r, world, args.line_search, args.force_exchange)
     x_head = r.pop("x_host")
+    if same_shard_single is not None:
+        cfg["single_gpu_same_shard"] = same_shard_single
+        cfg["weak_scaling_vs_same_shard"] = r["its_per_s"] / same_shard_single["iterations_per_sec_slowest_rank"]
     if args.extras and world == 1 and comm is None and v_per <= 20000:
         cfg["get_covariance"] = covariance_block(model, be, head)
     be.close()
     model._backend = None
     del model, be
+    if args.extras and world == 1 and comm is None and x_head is None and args.convergence_max_iter > 0:
+        # BASELINE.json's second figure for the headline workload: wall-clock of a whole fit (data generation, 7 stages to
+        # |dTC| < 1e-5 each - capped at --convergence-max-iter iterations per stage - final detail moments and factor sort)
+        from linearcorex_amd import Corex
+        t0 = time.perf_counter()
+        mdl = Corex(n_hidden=m, seed=0, dtype=dtype, device=local_rank, max_iter=args.convergence_max_iter)
+        mdl.fit_generated(n, v_per, seed=1)
+        t1 = time.perf_counter()
+        n_it = len(mdl.history["TC"])
+        cfg["fit_to_convergence"] = {
+            "seconds": t1 - t0, "iterations": n_it, "TC": float(mdl.tc), "tol": 1e-5,
+            "max_iter_per_stage": args.convergence_max_iter, "iterations_by_stage": list(mdl.stage_iterations),
+            "stages_converged_before_the_cap": int(sum(1 for k in mdl.stage_iterations if k < args.convergence_max_iter)),
+            "iterations_per_sec_incl_setup": n_it / (t1 - t0),
+            "trials_per_iteration": mdl.stats["trials"] / max(1, n_it)}
+        mdl._backend.close()
+        del mdl
 
     out = {
         "metric": "corex_fit_iterations_per_sec",

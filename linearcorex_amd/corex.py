@@ -522,14 +522,17 @@ class Corex(object):
     def _fit_resident(self):
         if not self.discourage_overlap:
             return self._fit_resident_syn()
+        self.stage_iterations = []             # iterations spent in each annealing stage (not in the reference; for reports)
         for i_eps, eps in enumerate(self._init_weights()):
             self._begin_stage(i_eps, eps)
             delta = 0.
+            self.stage_iterations.append(0)
             for i_loop in range(self.max_iter):
                 delta = self._iterate(more=i_loop + 1 < self.max_iter)
                 if delta is None:
                     self.ws = self._gather(self._backend.get_ws(0))
                     return self
+                self.stage_iterations[-1] = i_loop + 1
                 if delta < self.tol:
                     if self.verbose:
                         print('{:d} iterations to tol: {:f}, TC={:f}'.format(i_loop, self.tol, self.tc))

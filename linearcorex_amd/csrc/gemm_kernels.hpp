@@ -783,7 +783,8 @@ template <int CT, int RT, int KW, int U, bool SERIAL = false> struct Tn4Lds {
 
 // tile shapes of gemm_ct: 16-byte A loads wherever the accumulators fit (RT*CT*4 registers of T)
 template <typename T, int CT> struct CtShape {
-    static constexpr int RT = (sizeof(T) == 8) ? (CT >= 4 ? 2 : 4) : 4;
+    // 256 padded factors (CT = 16): half the column tile, so that the accumulators stay at 128 registers
+    static constexpr int RT = (sizeof(T) == 8) ? (CT >= 16 ? 1 : (CT >= 4 ? 2 : 4)) : (CT >= 16 ? 2 : 4);
     // measured (tools/gemm_probe4, 50k x 20k float32): KW=4, U=4 gives 122 TF/s at n_hidden 64 and 140 TF/s
     // at 128; KW=8 or U=2 lose 10-20 %
     static constexpr int KW = 4;

@@ -201,6 +201,12 @@ static int timing_collect(lcx_ctx* h) {
     return LCX_OK;
 }
 
+// dynamic LDS above 64 KiB needs an explicit opt-in per kernel
+template <typename F> static int allow_lds(F* f, size_t bytes) {
+    if (bytes > 48 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return LCX_OK;
+}
+
 template <typename T, int CT>
 static int launch_nt(hipStream_t st, const T* X, int64_t ldx, int64_t rows_pad, const T* B, T* out,
                      int S, int KW, const int* skip) {
@@ -220,17 +226,30 @@ static int launch_nt(hipStream_t st, const T* X, int64_t ldx, int64_t rows_pad, 
 }
 
 // out rows (padded "v" count) must be a multiple of 16*RT; K a multiple of 16.
+// 8-wave blocks do not exist for 256 padded factors (512 threads leave 256 registers per lane for a 128-register tile
+// plus its operand buffers): those shapes use at most 4 waves
+template <int CT> struct MaxKw { static constexpr int v = CT >= 16 ? 4 : 8; };
+
 template <typename T, int CT, int RT, bool SCALE, bool NTA = false>
 static int launch_tn(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t vcols_pad, const T* B,
                      const T* rowscale, T* out, int S, int KW, const int* skip) {
     const int kgroups = (int)(K / 16);
     dim3 grid((unsigned)(vcols_pad / (16 * RT)), (unsigned)S);
+    if (KW > 4 && CT >= 16) KW = 4;          // 8 partial tiles of 256 factors do not fit the LDS
     const size_t lds = (size_t)KW * 16 * RT * 16 * CT * sizeof(T);
+    if (lds > 48 * 1024) {
+        switch (KW) {
+            case 1: LCXCHECK(allow_lds(gemm_tn_kernel<T, CT, RT, 1, SCALE, 0, 4, NTA>, lds)); break;
+            case 2: LCXCHECK(allow_lds(gemm_tn_kernel<T, CT, RT, 2, SCALE, 0, 4, NTA>, lds)); break;
+            case 4: LCXCHECK(allow_lds(gemm_tn_kernel<T, CT, RT, 4, SCALE, 0, 4, NTA>, lds)); break;
+            default: LCXCHECK(allow_lds(gemm_tn_kernel<T, CT, RT, MaxKw<CT>::v, SCALE, 0, 4, NTA>, lds)); break;
+        }
+    }
     switch (KW) {
         case 1: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 1, SCALE, 0, 4, NTA>), grid, dim3(64), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
         case 2: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 2, SCALE, 0, 4, NTA>), grid, dim3(128), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
         case 4: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 4, SCALE, 0, 4, NTA>), grid, dim3(256), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
-        default: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 8, SCALE, 0, 4, NTA>), grid, dim3(512), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
+        default: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, MaxKw<CT>::v, SCALE, 0, 4, NTA>), grid, dim3(64 * MaxKw<CT>::v), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
     }
     KCHECK();
     return LCX_OK;
@@ -307,11 +326,6 @@ template <typename T, int CT> struct Geo {
     static constexpr int CH = 4 * (32 / (int)sizeof(T));
 };
 
-// dynamic LDS above 64 KiB needs an explicit opt-in per kernel
-template <typename F> static int allow_lds(F* f, size_t bytes) {
-    if (bytes > 48 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return LCX_OK;
-}
 
 // -------------------------------------------------------------------------------------------------
 // typed implementation
@@ -393,7 +407,7 @@ template <typename T, int CT> struct Impl {
                 case 1: bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, 1, false>, 64, lds); break;
                 case 2: bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, 2, false>, 128, lds); break;
                 case 4: bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, 4, false>, 256, lds); break;
-                default: h->nt_KW = 8; bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, 8, false>, 512, lds); break;
+                default: h->nt_KW = MaxKw<CT>::v; bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, MaxKw<CT>::v, false>, 64 * MaxKw<CT>::v, (size_t)MaxKw<CT>::v * 16 * TN_RT * Mp * sizeof(T)); break;
             }
             h->nt_bpc = bpc;
             h->nt_S = env_int("LCX_NT_S", single_round_split(h->Npad / (16 * TN_RT), (int64_t)bpc * cus, kgv, h->nt_KW, 16));
@@ -415,7 +429,7 @@ template <typename T, int CT> struct Impl {
                 case 1: bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, 1, false>, 64, lds); break;
                 case 2: bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, 2, false>, 128, lds); break;
                 case 4: bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, 4, false>, 256, lds); break;
-                default: h->tn_KW = 8; bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, 8, false>, 512, lds); break;
+                default: h->tn_KW = MaxKw<CT>::v; bpc = blocks_per_cu(gemm_tn_kernel<T, CT, TN_RT, MaxKw<CT>::v, false>, 64 * MaxKw<CT>::v, (size_t)MaxKw<CT>::v * 16 * TN_RT * Mp * sizeof(T)); break;
             }
             h->tn_bpc = bpc;
             h->tn_S = env_int("LCX_TN_S", single_round_split(h->ldx / (16 * TN_RT), (int64_t)bpc * cus, kgn, h->tn_KW, 32));
@@ -588,6 +602,13 @@ template <typename T, int CT> struct Impl {
         GramProblem<T> p0{w, P<T>(h->gpartw), kgv, h->gv_S}, p1{y, P<T>(h->gpart), kgn, h->gn_S};
         dim3 grid((unsigned)(Mp / (16 * RT)), (unsigned)(h->gv_S > h->gn_S ? h->gv_S : h->gn_S), 2);
         const size_t lds = (size_t)kw * 16 * RT * Mp * sizeof(T);
+        if (lds > 48 * 1024) {
+            switch (kw) {
+                case 1: LCXCHECK(allow_lds(gram_pair_kernel<T, CT, RT, 1>, lds)); break;
+                case 2: LCXCHECK(allow_lds(gram_pair_kernel<T, CT, RT, 2>, lds)); break;
+                default: LCXCHECK(allow_lds(gram_pair_kernel<T, CT, RT, 4>, lds)); break;
+            }
+        }
         switch (kw) {
             case 1: hipLaunchKernelGGL((gram_pair_kernel<T, CT, RT, 1>), grid, dim3(64), lds, h->stream, p0, p1); break;
             case 2: hipLaunchKernelGGL((gram_pair_kernel<T, CT, RT, 2>), grid, dim3(128), lds, h->stream, p0, p1); break;
@@ -606,7 +627,7 @@ template <typename T, int CT> struct Impl {
     static int epilogue(lcx_ctx* h, int which, double eps, bool linear, double eta) {
         MomentSet& s = h->set[which];
         const int* skip = &s.st->invalid;
-        const size_t lds = ((size_t)Mp * Mp + (size_t)VPB * Mp) * sizeof(T);
+        const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * Mp : 0) + (size_t)VPB * Mp) * sizeof(T);
         LCXCHECK(allow_lds(moments_epilogue_kernel<T, Mp>, lds));
         hipLaunchKernelGGL((moments_epilogue_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream,
                            P<T>(h->dpart), h->tn_slots, h->ldx * Mp,
@@ -627,6 +648,13 @@ template <typename T, int CT> struct Impl {
             const int kgroups = (int)(h->ldx / 16), kw = pick_kw(kgroups);
             dim3 grid((unsigned)(Mp / (16 * RT)), (unsigned)h->gv_S, 2);
             const size_t glds = (size_t)kw * 16 * RT * Mp * sizeof(T);
+            if (glds > 48 * 1024) {
+                switch (kw) {
+                    case 1: LCXCHECK(allow_lds(gram_tc_kernel<T, CT, RT, 1>, glds)); break;
+                    case 2: LCXCHECK(allow_lds(gram_tc_kernel<T, CT, RT, 2>, glds)); break;
+                    default: LCXCHECK(allow_lds(gram_tc_kernel<T, CT, RT, 4>, glds)); break;
+                }
+            }
             switch (kw) {
                 case 1: hipLaunchKernelGGL((gram_tc_kernel<T, CT, RT, 1>), grid, dim3(64), glds, h->stream, P<T>(s.rir), P<T>(s.hscale), P<T>(h->gpart), kgroups, h->gv_S, skip, tail); break;
                 case 2: hipLaunchKernelGGL((gram_tc_kernel<T, CT, RT, 2>), grid, dim3(128), glds, h->stream, P<T>(s.rir), P<T>(s.hscale), P<T>(h->gpart), kgroups, h->gv_S, skip, tail); break;
@@ -695,7 +723,7 @@ template <typename T, int CT> struct Impl {
             h->spec_dirty = false;
         }
         MomentSet& s = h->set[0];
-        const size_t lds = ((size_t)Mp * (Mp + 1) + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
+        const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * (Mp + 1) : 0) + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
         LCXCHECK(allow_lds(grad_kernel<T, Mp>, lds));
         hipLaunchKernelGGL((grad_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(h->Wt[0]),
                            P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), s.uj, h->sbuf + SB_H, h->V,
@@ -835,7 +863,7 @@ template <typename T, int CT> struct Impl {
         MomentSet& s = h->set[which];
         hipLaunchKernelGGL(invert_kernel, dim3(1), dim3(256), 0, h->stream, s.ry, Mp, h->invwork, h->ryinv);
         KCHECK();
-        const size_t lds = ((size_t)Mp * Mp + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
+        const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * Mp : 0) + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
         LCXCHECK(allow_lds(detail_kernel<T, Mp>, lds));
         hipLaunchKernelGGL((detail_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(s.rho),
                            h->ryinv, h->V, h->M, mi_o, xz_o, x2y_o, h->detpart);
@@ -877,7 +905,7 @@ template <typename T, int CT> struct Impl {
         KCHECK();
         hipLaunchKernelGGL(invert_kernel, dim3(1), dim3(256), 0, h->stream, s.ry, Mp, h->invwork, h->ryinv);
         KCHECK();
-        const size_t lds = ((size_t)Mp * Mp + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
+        const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * Mp : 0) + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
         LCXCHECK(allow_lds(detail_kernel<T, Mp>, lds));
         // X_i Z_j = solve(cy, X_i Y_j^T)^T = (ry^-1 rho)_j / sd_j ; X_i^2|Y = 1 - rho^T ry^-1 rho ; hscale <- 1 / X_i^2|Y
         hipLaunchKernelGGL((detail_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(s.rho), h->ryinv, h->V, h->M,
@@ -909,7 +937,7 @@ template <typename T, int CT> struct Impl {
     // ws' = (1-eta) ws + eta (R - H ws) (:380-382) -> set 1
     static int syn_update_b(lcx_ctx* h, double eta) {
         MomentSet& s = h->set[0];
-        const size_t lds = ((size_t)Mp * (Mp + 1) + (size_t)VPB * Mp) * sizeof(T);
+        const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * (Mp + 1) : 0) + (size_t)VPB * Mp) * sizeof(T);
         LCXCHECK(allow_lds(syn_update_kernel<T, Mp>, lds));
         hipLaunchKernelGGL((syn_update_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(h->Wt[0]), P<T>(s.xz),
                            P<T>(s.hscale), h->sbuf + SB_H, h->V, (T)eta, P<T>(h->Wt[1]));
@@ -1142,10 +1170,27 @@ template <typename T, int CT> struct Impl {
         return covariance_blocks(h, false, eps, std_host, row0, nrows, out_host, h->V, nullptr);
     }
 
+    // y[rows_pad][Mp] = xd[rows_pad][ldx] . W^T for a staged block of new rows (transform, :386-395).  Up to 128 padded
+    // factors: the row-streaming kernel gemm_nt.  256: its register tile does not fit, so the block is transposed and runs
+    // through the column-streaming kernel like the resident passes do.
+    static int project_block(lcx_ctx* h, DevTemps& tmps, T* xd, int64_t rows_pad, T* yd, T** xt_io) {
+        if constexpr (CT <= 8) {
+            (void)tmps; (void)xt_io;
+            return launch_nt<T, CT>(h->stream, xd, h->ldx, rows_pad, P<T>(h->Wt[0]), yd, 1, 4, nullptr);
+        } else {
+            if (!*xt_io) LCXCHECK(tmps.get(xt_io, sizeof(T) * rows_pad * h->ldx));
+            dim3 grid((unsigned)(h->ldx / 64), (unsigned)(rows_pad / 64));
+            hipLaunchKernelGGL((transpose_kernel<T>), grid, dim3(256), 0, h->stream, xd, h->ldx, *xt_io, rows_pad);
+            KCHECK();
+            return launch_tn<T, CT, Geo<T, CT>::TN_RT, false, false>(h->stream, *xt_io, rows_pad, h->ldx, rows_pad, P<T>(h->Wt[0]), nullptr, yd, 1,
+                                                                      4, nullptr);
+        }
+    }
+
     static int project(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, void* out_host) {
         const int64_t blk = 8192;      // rows per staged block
         const int64_t rows_pad = round_up(n_rows < blk ? n_rows : blk, 64);
-        T *xd = nullptr, *yd = nullptr;
+        T *xd = nullptr, *yd = nullptr, *xt_tmp = nullptr;
         DevTemps tmps;
         LCXCHECK(tmps.get(&xd, sizeof(T) * rows_pad * h->ldx));
         LCXCHECK(tmps.get(&yd, sizeof(T) * rows_pad * Mp));
@@ -1156,7 +1201,7 @@ template <typename T, int CT> struct Impl {
             HIPCHECK(hipMemsetAsync(xd, 0, sizeof(T) * rows_pad * h->ldx, h->stream));
             HIPCHECK(hipMemcpy2DAsync(xd, h->ldx * sizeof(T), reinterpret_cast<const T*>(x_host) + r0 * ld, ld * sizeof(T),
                                       h->V * sizeof(T), nr, hipMemcpyHostToDevice, h->stream));
-            LCXCHECK((launch_nt<T, CT>(h->stream, xd, h->ldx, rows_pad, P<T>(h->Wt[0]), yd, 1, 4, nullptr)));
+            LCXCHECK(project_block(h, tmps, xd, rows_pad, yd, &xt_tmp));
             HIPCHECK(hipMemcpyAsync(tmp.data(), yd, sizeof(T) * rows_pad * Mp, hipMemcpyDeviceToHost, h->stream));
             HIPCHECK(hipStreamSynchronize(h->stream));
             for (int64_t r = 0; r < nr; ++r)
@@ -1274,7 +1319,7 @@ template <typename T, int CT> struct Impl {
                            const void* std_h, void* out_host) {
         const int64_t blk = 8192;
         const int64_t rows_pad = round_up(n_rows < blk ? n_rows : blk, 64);
-        T *xd = nullptr, *yd = nullptr;
+        T *xd = nullptr, *yd = nullptr, *xt_tmp = nullptr;
         double *mean = nullptr, *stdv = nullptr, *bmax = nullptr;
         const int strips = (int)cdiv(h->V, 64);
         const int RS = 8;
@@ -1303,7 +1348,7 @@ template <typename T, int CT> struct Impl {
                                    (const double*)nullptr, mean, stdv, kind, bmax);
                 KCHECK();
             }
-            LCXCHECK((launch_nt<T, CT>(h->stream, xd, h->ldx, rows_pad, P<T>(h->Wt[0]), yd, 1, 4, nullptr)));
+            LCXCHECK(project_block(h, tmps, xd, rows_pad, yd, &xt_tmp));
             HIPCHECK(hipMemcpyAsync(tmp.data(), yd, sizeof(T) * rows_pad * Mp, hipMemcpyDeviceToHost, h->stream));
             HIPCHECK(hipStreamSynchronize(h->stream));
             for (int64_t r = 0; r < nr; ++r)
@@ -1331,6 +1376,7 @@ template <typename T, int CT> struct Impl {
                 case 2: return Impl<float, 2>::fn(__VA_ARGS__);                     \
                 case 4: return Impl<float, 4>::fn(__VA_ARGS__);                     \
                 case 8: return Impl<float, 8>::fn(__VA_ARGS__);                     \
+                case 16: return Impl<float, 16>::fn(__VA_ARGS__);                   \
             }                                                                       \
         } else {                                                                    \
             switch ((h)->CT) {                                                      \
@@ -1338,6 +1384,7 @@ template <typename T, int CT> struct Impl {
                 case 2: return Impl<double, 2>::fn(__VA_ARGS__);                    \
                 case 4: return Impl<double, 4>::fn(__VA_ARGS__);                    \
                 case 8: return Impl<double, 8>::fn(__VA_ARGS__);                    \
+                case 16: return Impl<double, 16>::fn(__VA_ARGS__);                  \
             }                                                                       \
         }                                                                           \
         return fail(LCX_ERR_ARG, "unsupported n_hidden padding");                   \
@@ -1348,6 +1395,7 @@ static int ct_for(int m) {
     if (m <= 32) return 2;
     if (m <= 64) return 4;
     if (m <= 128) return 8;
+    if (m <= 256) return 16;
     return 0;
 }
 
@@ -1471,7 +1519,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     if (!out || n_samples < 1 || nv_local < 1 || n_hidden < 1) return fail(LCX_ERR_ARG, "lcx_create: bad sizes");
     if (dtype != LCX_F32 && dtype != LCX_F64) return fail(LCX_ERR_ARG, "lcx_create: dtype must be LCX_F32 or LCX_F64");
     const int ct = ct_for(n_hidden);
-    if (!ct) return fail(LCX_ERR_ARG, "lcx_create: n_hidden > 128 is not supported by this build");
+    if (!ct) return fail(LCX_ERR_ARG, "lcx_create: n_hidden > 256 is not supported by this build");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(LCX_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= ndev) return fail(LCX_ERR_ARG, "lcx_create: device index out of range");
@@ -1709,12 +1757,14 @@ static int get_ws_impl(lcx_ctx* h, int which, void* w) {
         switch (h->CT) { case 1: return Impl<float,1>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
                          case 2: return Impl<float,2>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
                          case 4: return Impl<float,4>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
-                         case 8: return Impl<float,8>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true); }
+                         case 8: return Impl<float,8>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
+                         case 16: return Impl<float,16>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true); }
     } else {
         switch (h->CT) { case 1: return Impl<double,1>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
                          case 2: return Impl<double,2>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
                          case 4: return Impl<double,4>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
-                         case 8: return Impl<double,8>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true); }
+                         case 8: return Impl<double,8>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
+                         case 16: return Impl<double,16>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true); }
     }
     return fail(LCX_ERR_ARG, "bad CT");
 }
@@ -1744,12 +1794,14 @@ static int detail_entry(lcx_ctx* h, int which) {
         switch (h->CT) { case 1: return Impl<float,1>::detail(h, which, nullptr, nullptr, nullptr);
                          case 2: return Impl<float,2>::detail(h, which, nullptr, nullptr, nullptr);
                          case 4: return Impl<float,4>::detail(h, which, nullptr, nullptr, nullptr);
-                         case 8: return Impl<float,8>::detail(h, which, nullptr, nullptr, nullptr); }
+                         case 8: return Impl<float,8>::detail(h, which, nullptr, nullptr, nullptr);
+                         case 16: return Impl<float,16>::detail(h, which, nullptr, nullptr, nullptr); }
     } else {
         switch (h->CT) { case 1: return Impl<double,1>::detail(h, which, nullptr, nullptr, nullptr);
                          case 2: return Impl<double,2>::detail(h, which, nullptr, nullptr, nullptr);
                          case 4: return Impl<double,4>::detail(h, which, nullptr, nullptr, nullptr);
-                         case 8: return Impl<double,8>::detail(h, which, nullptr, nullptr, nullptr); }
+                         case 8: return Impl<double,8>::detail(h, which, nullptr, nullptr, nullptr);
+                         case 16: return Impl<double,16>::detail(h, which, nullptr, nullptr, nullptr); }
     }
     return fail(LCX_ERR_ARG, "bad CT");
 }
@@ -2101,7 +2153,7 @@ int lcx_test_gemm_nt(int dtype, int device, const void* a, int64_t n_rows, int64
         switch (ct) { case 1: return test_nt<double,1>(a,n_rows,k,lda,b,out,fs,fk); case 2: return test_nt<double,2>(a,n_rows,k,lda,b,out,fs,fk);
                       case 4: return test_nt<double,4>(a,n_rows,k,lda,b,out,fs,fk); case 8: return test_nt<double,8>(a,n_rows,k,lda,b,out,fs,fk); }
     }
-    return fail(LCX_ERR_ARG, "m_pad must be 16, 32, 64 or 128");
+    return fail(LCX_ERR_ARG, "m_pad must be 16, 32, 64 or 128 (the row-streaming kernel has no 256-factor form)");
 }
 
 int lcx_test_gemm_tn(int dtype, int device, const void* a, int64_t k, int64_t v, int64_t lda, const void* b, int m_pad,
@@ -2110,10 +2162,12 @@ int lcx_test_gemm_tn(int dtype, int device, const void* a, int64_t k, int64_t v,
     const int ct = m_pad / 16;
     if (dtype == LCX_F32) {
         switch (ct) { case 1: return test_tn<float,1>(a,k,v,lda,b,rs,out,fs,fk); case 2: return test_tn<float,2>(a,k,v,lda,b,rs,out,fs,fk);
-                      case 4: return test_tn<float,4>(a,k,v,lda,b,rs,out,fs,fk); case 8: return test_tn<float,8>(a,k,v,lda,b,rs,out,fs,fk); }
+                      case 4: return test_tn<float,4>(a,k,v,lda,b,rs,out,fs,fk); case 8: return test_tn<float,8>(a,k,v,lda,b,rs,out,fs,fk);
+                      case 16: return test_tn<float,16>(a,k,v,lda,b,rs,out,fs,fk); }
     } else {
         switch (ct) { case 1: return test_tn<double,1>(a,k,v,lda,b,rs,out,fs,fk); case 2: return test_tn<double,2>(a,k,v,lda,b,rs,out,fs,fk);
-                      case 4: return test_tn<double,4>(a,k,v,lda,b,rs,out,fs,fk); case 8: return test_tn<double,8>(a,k,v,lda,b,rs,out,fs,fk); }
+                      case 4: return test_tn<double,4>(a,k,v,lda,b,rs,out,fs,fk); case 8: return test_tn<double,8>(a,k,v,lda,b,rs,out,fs,fk);
+                      case 16: return test_tn<double,16>(a,k,v,lda,b,rs,out,fs,fk); }
     }
     return fail(LCX_ERR_ARG, "m_pad must be 16, 32, 64 or 128");
 }

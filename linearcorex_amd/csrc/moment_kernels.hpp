@@ -19,6 +19,10 @@
 namespace lcx {
 
 constexpr int PV_THREADS = 256;
+// The m x m operators of the per-variable kernels (ry, H, ry^-1) are staged in LDS up to 128 padded factors; above
+// (n_hidden 129..256) Mp^2 elements no longer fit next to the per-variable strips and every thread reads its column of
+// the operator from global memory instead (coalesced over the factor index, served by L2).
+template <int Mp> struct OpInLds { static constexpr bool v = Mp <= 128; };
 
 // state scalars per moment set (mirrors LCX_S_* in include/lcx.h)
 struct SetState {
@@ -77,12 +81,15 @@ __device__ __forceinline__ R group_sum(R v, R* scratch /* [PV_THREADS/64] per us
 #pragma unroll
     for (int off = W / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, W);
     if (Mp > 64) {
-        // two waves per variable: combine through LDS in a fixed order
+        // Mp / 64 waves per variable: combine through LDS in a fixed order
+        constexpr int NW = Mp / 64;
         __syncthreads();
         if ((tid & 63) == 0) scratch[tid >> 6] = v;
         __syncthreads();
-        const int base = (tid >> 6) & ~1;
-        v = scratch[base] + scratch[base + 1];
+        const int base = ((tid >> 6) / NW) * NW;
+        v = scratch[base];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += scratch[base + w];
     }
     return v;
 }
@@ -132,8 +139,8 @@ small_moments_kernel(const T* __restrict__ gy, int nsplit, const T* __restrict__
     // scalars.  One launch instead of reduce + finish; deterministic (no floating-point atomics).
     __shared__ T shy[8][32];
     __shared__ T shw[8][32];
-    __shared__ double lg[128];
-    __shared__ double uu[128];
+    __shared__ double lg[256];
+    __shared__ double uu[256];
     __shared__ int last_s;
     const int tid = threadIdx.x, e = tid & 31, g = tid >> 5;
     const int64_t mm = (int64_t)Mp * Mp;
@@ -172,7 +179,7 @@ small_moments_kernel(const T* __restrict__ gy, int nsplit, const T* __restrict__
     }
     __syncthreads();
     if (!last_s) return;
-    if (tid < 128) {
+    if (tid < 256) {
         double u = -1e300, l = 0.0;
         if (tid < m) {
             u = __hip_atomic_load(&sm.uj[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -224,13 +231,14 @@ moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride
     constexpr int VPB = PV_THREADS / Mp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* ry_s = reinterpret_cast<T*>(smem_raw);
-    T* rir_s = ry_s + Mp * Mp;
+    T* rir_s = ry_s + (OpInLds<Mp>::v ? Mp * Mp : 0);
     __shared__ T gs_scratch[PV_THREADS / 64];
     __shared__ double bs_scratch[PV_THREADS / 64];
     if (skip_flag != nullptr && *skip_flag != 0) return;       // invalid trial (:250-251): the tail block still publishes
 
     const int tid = threadIdx.x, vl = tid / Mp, j = tid % Mp;
-    for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) ry_s[idx] = (T)ry[idx];
+    if (OpInLds<Mp>::v)
+        for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) ry_s[idx] = (T)ry[idx];
     __syncthreads();
 
     const T c1 = (T)(1.0 - eps * eps), c2 = (T)(eps * eps), ns = (T)n_samples;
@@ -260,8 +268,13 @@ moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride
         __syncthreads();
         T qv = (ABL & 1) ? rir : (T)0;
         if (!(ABL & 1)) {
+            if (OpInLds<Mp>::v) {
 #pragma unroll 8
-            for (int k = 0; k < Mp; ++k) qv += ry_s[k * Mp + j] * rir_s[vl * Mp + k];   // ry symmetric
+                for (int k = 0; k < Mp; ++k) qv += ry_s[k * Mp + j] * rir_s[vl * Mp + k];   // ry symmetric
+            } else {
+#pragma unroll 8
+                for (int k = 0; k < Mp; ++k) qv += (T)ry[k * Mp + j] * rir_s[vl * Mp + k];
+            }
         }
         const T q2 = group_sum<Mp, T>(rir * (qv - si * rho), gs_scratch, tid);
         if (ok) {
@@ -410,13 +423,14 @@ grad_kernel(const T* __restrict__ W, const T* __restrict__ rho_i, const T* __res
     constexpr int VPB = PV_THREADS / Mp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* h_s = reinterpret_cast<T*>(smem_raw);        // [Mp][Mp+1]
-    T* w_s = h_s + Mp * (Mp + 1);                   // [VPB][Mp]
+    T* w_s = h_s + (OpInLds<Mp>::v ? Mp * (Mp + 1) : 0);           // [VPB][Mp]
     double* bj_s = reinterpret_cast<double*>(w_s + VPB * Mp + (((VPB * Mp) & 1) ? 1 : 0));
     const int tid = threadIdx.x, vl = tid / Mp, j = tid % Mp;
-    for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) {
-        const int a = idx / Mp, b = idx % Mp;
-        h_s[a * (Mp + 1) + b] = (a == b) ? (T)0 : (T)H[idx];       // fill_diagonal(H, 0), :295
-    }
+    if (OpInLds<Mp>::v)
+        for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) {
+            const int a = idx / Mp, b = idx % Mp;
+            h_s[a * (Mp + 1) + b] = (a == b) ? (T)0 : (T)H[idx];       // fill_diagonal(H, 0), :295
+        }
     const T rj = (T)1 - (T)uj[j];
     __syncthreads();
     double bj = 0.0;
@@ -436,8 +450,14 @@ grad_kernel(const T* __restrict__ W, const T* __restrict__ rho_i, const T* __res
         g -= (T)2 * inv * rir / ((T)1 + si);                                    // :297
         g += inv * inv * (((T)1 + rho * rho) * qij - (T)2 * rho * si) / ((T)1 + q2);   // :298-299
         T hw = (T)0;
+        if (OpInLds<Mp>::v) {
 #pragma unroll 8
-        for (int k = 0; k < Mp; ++k) hw += h_s[j * (Mp + 1) + k] * w_s[vl * Mp + k];
+            for (int k = 0; k < Mp; ++k) hw += h_s[j * (Mp + 1) + k] * w_s[vl * Mp + k];
+        } else {
+            // H is a Gram matrix (symmetric up to rounding): column j is read, coalesced over j
+#pragma unroll 8
+            for (int k = 0; k < Mp; ++k) hw += (k == j ? (T)0 : (T)H[k * Mp + j]) * w_s[vl * Mp + k];
+        }
         g += hw;                                                                // :300
         if (ok) {
             grad_o[o] = g;
@@ -734,12 +754,13 @@ detail_kernel(const T* __restrict__ rho_i, const double* __restrict__ ryinv, int
     constexpr int VPB = PV_THREADS / Mp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* ri_s = reinterpret_cast<T*>(smem_raw);
-    T* rho_s = ri_s + Mp * Mp;
+    T* rho_s = ri_s + (OpInLds<Mp>::v ? Mp * Mp : 0);
     double* acc_s = reinterpret_cast<double*>(rho_s + VPB * Mp + (((VPB * Mp) & 1) ? 1 : 0));
     __shared__ T gs_scratch[PV_THREADS / 64];
     __shared__ double bs_scratch[PV_THREADS / 64];
     const int tid = threadIdx.x, vl = tid / Mp, j = tid % Mp;
-    for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) ri_s[idx] = (T)ryinv[idx];
+    if (OpInLds<Mp>::v)
+        for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) ri_s[idx] = (T)ryinv[idx];
     __syncthreads();
     double col_mi = 0.0, s_max = 0.0, s_ixy = 0.0;
     const int64_t ngroups = (V + VPB - 1) / VPB;
@@ -752,8 +773,14 @@ detail_kernel(const T* __restrict__ rho_i, const double* __restrict__ ryinv, int
         rho_s[vl * Mp + j] = rho;
         __syncthreads();
         T xz = (T)0;
+        if (OpInLds<Mp>::v) {
 #pragma unroll 8
-        for (int k = 0; k < Mp; ++k) xz += ri_s[j * Mp + k] * rho_s[vl * Mp + k];   // (ry^-1 rho)_j
+            for (int k = 0; k < Mp; ++k) xz += ri_s[j * Mp + k] * rho_s[vl * Mp + k];   // (ry^-1 rho)_j
+        } else {
+            // ry^-1 is symmetric up to rounding: column j, coalesced over j
+#pragma unroll 8
+            for (int k = 0; k < Mp; ++k) xz += (T)ryinv[k * Mp + j] * rho_s[vl * Mp + k];
+        }
         const T mi = (T)-0.5 * log1p(-rho * rho);
         const T dot = group_sum<Mp, T>(xz * rho, gs_scratch, tid);
         // max over factors of MI (padded factors have MI = 0 <= every real MI)
@@ -763,11 +790,14 @@ detail_kernel(const T* __restrict__ rho_i, const double* __restrict__ ryinv, int
 #pragma unroll
             for (int off = Wd / 2; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, Wd));
             if (Mp > 64) {
+                constexpr int NW = Mp / 64;
                 __syncthreads();
                 if ((tid & 63) == 0) gs_scratch[tid >> 6] = mx;
                 __syncthreads();
-                const int base = (tid >> 6) & ~1;
-                mx = fmax(gs_scratch[base], gs_scratch[base + 1]);
+                const int base = ((tid >> 6) / NW) * NW;
+                mx = gs_scratch[base];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) mx = fmax(mx, gs_scratch[base + w]);
             }
         }
         T x2y = (T)1 - dot;
@@ -810,8 +840,8 @@ __global__ void __launch_bounds__(256)
 syn_small_kernel(const T* __restrict__ gy, int nsplit, int Mp, int m, double n_samples, double yscale,
                  double* __restrict__ cy, double* __restrict__ yj2, double* __restrict__ ry,
                  double* __restrict__ inv_sd, SetState* st) {
-    __shared__ double sd_s[128];
-    __shared__ double lg_s[128];
+    __shared__ double sd_s[256];
+    __shared__ double lg_s[256];
     const int tid = threadIdx.x;
     const int mm = Mp * Mp;
     for (int idx = tid; idx < mm; idx += blockDim.x) {
@@ -875,12 +905,13 @@ syn_update_kernel(const T* __restrict__ W, const T* __restrict__ xz, const T* __
     constexpr int VPB = PV_THREADS / Mp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* h_s = reinterpret_cast<T*>(smem_raw);
-    T* w_s = h_s + Mp * (Mp + 1);
+    T* w_s = h_s + (OpInLds<Mp>::v ? Mp * (Mp + 1) : 0);
     const int tid = threadIdx.x, vl = tid / Mp, j = tid % Mp;
-    for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) {
-        const int a = idx / Mp, b = idx % Mp;
-        h_s[a * (Mp + 1) + b] = (a == b) ? (T)0 : (T)H[idx];
-    }
+    if (OpInLds<Mp>::v)
+        for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) {
+            const int a = idx / Mp, b = idx % Mp;
+            h_s[a * (Mp + 1) + b] = (a == b) ? (T)0 : (T)H[idx];
+        }
     __syncthreads();
     const int64_t ngroups = (V + VPB - 1) / VPB;
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -892,8 +923,13 @@ syn_update_kernel(const T* __restrict__ W, const T* __restrict__ xz, const T* __
         w_s[vl * Mp + j] = w;
         __syncthreads();
         T s = (T)0;
+        if (OpInLds<Mp>::v) {
 #pragma unroll 8
-        for (int k = 0; k < Mp; ++k) s += h_s[j * (Mp + 1) + k] * w_s[vl * Mp + k];
+            for (int k = 0; k < Mp; ++k) s += h_s[j * (Mp + 1) + k] * w_s[vl * Mp + k];
+        } else {
+#pragma unroll 8
+            for (int k = 0; k < Mp; ++k) s += (k == j ? (T)0 : (T)H[k * Mp + j]) * w_s[vl * Mp + k];
+        }
         if (ok) {
             const T r = xz[o] * inv_x2y[v];
             w_out[o] = ((T)1 - eta) * w + eta * (r - s);

@@ -88,3 +88,19 @@ def test_world_size_mismatch_is_an_error():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + FAST, cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert p.returncode != 0 and not p.stdout.strip()
+
+
+def test_two_ranks_full_line_has_the_same_shard_reference_and_the_c2_block():
+    """The line the driver's multi-GPU run produces (extras on): the headline shard measured on every GPU alone first
+    (`config.single_gpu_same_shard`: the one-GPU point of this workload's weak-scaling series), then sharded; the nested
+    config-2 block with 5 000 variables per GPU."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--repeats", "1"]
+    p = subprocess.run(cmd, cwd=ROOT, env=_two_rank_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    d = _one_json_line(p.stdout)
+    assert d["n_gpus"] == 2 and d["cpu_baseline"] is None
+    ref = d["config"]["single_gpu_same_shard"]
+    assert ref["iterations_per_sec_slowest_rank"] > 0 and d["config"]["weak_scaling_vs_same_shard"] > 0
+    c2 = d["config"]["c2_weak"]
+    assert c2["n_variables_total"] == 10000 and c2["n_variables_per_gpu"] == 5000 and c2["roofline"]["bound"] == "hbm"
+    assert c2["linear_trial_mode"]["fit_iterations_per_sec"] > 0

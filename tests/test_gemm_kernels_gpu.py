@@ -29,7 +29,7 @@ def test_gemm_nt(dtype, m_pad, shape, split, waves):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("m_pad", [16, 32, 64, 128])
+@pytest.mark.parametrize("m_pad", [16, 32, 64, 128, 256])
 @pytest.mark.parametrize("shape,split,waves", [((70, 45), 1, 1), ((300, 257), 1, 4), ((1111, 1000), 3, 4),
                                                ((2048, 64), 2, 8), ((64, 333), 1, 2)])
 def test_gemm_tn(dtype, m_pad, shape, split, waves):
@@ -82,7 +82,7 @@ def test_gemm_linearity_at_config2_size():
 # ---- gemm_ct: column-tiled waves, B through LDS, stream-K balanced blocks --------------------------
 # waves=-1 selects it in the test entry point; split = number of blocks (0: what production would launch).
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("m_pad", [16, 32, 64, 128])
+@pytest.mark.parametrize("m_pad", [16, 32, 64, 128, 256])
 @pytest.mark.parametrize("shape,blocks", [((70, 45), 0), ((300, 257), 3), ((1111, 1000), 0), ((2048, 64), 7),
                                           ((64, 333), 1), ((1000, 1984), 37), ((4096, 640), 512)])
 def test_gemm_ct(dtype, m_pad, shape, blocks):

@@ -61,6 +61,11 @@ CASES = [
     (200, 8000, 6, 0.36, 20),
     (20000, 100, 5, 0.216, 21),
     (448, 6000, 30, 0.0, 22),
+    # 129..256 factors: the m x m operators no longer fit the LDS of the per-variable kernels (read from L2 instead),
+    # 4 wavefronts share a variable, the GEMM tiles shrink to keep 256-wide accumulators in registers
+    (300, 400, 200, 0.36, 23),
+    (200, 333, 256, 0.0, 24),
+    (520, 1100, 129, 0.6, 25),
 ]
 
 
@@ -567,3 +572,36 @@ def test_host_loop_end_to_end(g1, monkeypatch):
     assert out._in_library is False
     h, h_ref = np.asarray(out.history["TC"], np.float64), g1["f64_history_tc"]
     assert len(h) == len(h_ref) and relerr(h, h_ref) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_more_than_128_factors_end_to_end(tag):
+    """n_hidden above 128 (the reference takes any n_hidden, :72): a short fit with 160 factors follows the oracle, clusters
+    bit-exact on planted data in float64; transform (the transposed-block path) and the synergistic branch work as well."""
+    from linearcorex_amd import Corex
+    n, v, m = 700, 1500, 160
+    x, grp = O.gen_planted(n, v, 12, seed=71)
+    ref = O.fit_ns(x, m, seed=0, dtype=DT[tag], max_iter=4, keep_x=True)
+    out = Corex(n_hidden=m, seed=0, max_iter=4, dtype=DT[tag], device=0).fit(x)
+    assert out._backend.geometry()["m_pad"] == 256
+    h_ref, h = np.asarray(ref.history_tc, np.float64), np.asarray(out.history["TC"], np.float64)
+    assert len(h) == len(h_ref)
+    tol = 1e-8 if tag == "f64" else 2e-3
+    assert np.max(np.abs(h - h_ref) / np.maximum(1.0, np.abs(h_ref))) < tol
+    assert relerr(out.transform(x), ref.transform(ref.x_tilde)) < (1e-7 if tag == "f64" else 2e-3)
+    if tag == "f64":
+        assert np.array_equal(out.clusters(), ref.clusters())
+        assert relerr(out.ws, ref.ws) < 1e-6
+        assert relerr(out.get_covariance(), ref.get_covariance()) < 1e-6
+        assert relerr(out.moments["X_i Z_j"], ref.moments["X_i Z_j"]) < 1e-6
+        syn_ref = O.fit_syn(x, m, seed=0, dtype=np.float64, max_iter=5)
+        syn = Corex(n_hidden=m, seed=0, max_iter=5, dtype=np.float64, device=0, discourage_overlap=False).fit(x)
+        hs, hs_ref = np.asarray(syn.history["TC"], np.float64), np.asarray(syn_ref.history_tc)
+        assert len(hs) == len(hs_ref) and np.max(np.abs(hs - hs_ref) / np.maximum(1.0, np.abs(hs_ref))) < 1e-8
+
+
+def test_more_than_256_factors_is_refused():
+    from linearcorex_amd import Corex
+    from linearcorex_amd._abi import LcxError
+    with pytest.raises(LcxError, match="n_hidden > 256"):
+        Corex(n_hidden=257, seed=0, device=0).fit(np.random.RandomState(0).randn(50, 300))

@@ -117,7 +117,7 @@ void check(const char* what, Variant& v, Variant& ref, T* out, int64_t V, int Mp
 }
 
 template <int CT>
-void suite(const char* name, int64_t K, int64_t V, bool small) {
+void suite(const char* name, int64_t K, int64_t V, bool small, bool zero = false) {
     typedef float T;
     T *A, *B, *out;
     CK(hipMalloc(&A, sizeof(T) * K * V));
@@ -126,6 +126,8 @@ void suite(const char* name, int64_t K, int64_t V, bool small) {
     {
         std::vector<T> h((size_t)K * V);
         for (size_t x = 0; x < h.size(); ++x) h[x] = (T)((double)rand() / RAND_MAX - 0.5);
+        // zero: the same instructions on all-zero X - what the pass does when the data paths do not toggle (power headroom)
+        if (zero) CK(hipMemset(A, 0, sizeof(T) * K * V)); else
         CK(hipMemcpy(A, h.data(), sizeof(T) * K * V, hipMemcpyHostToDevice));
         CK(hipMemcpy(B, h.data(), sizeof(T) * K * 16 * CT, hipMemcpyHostToDevice));
     }
@@ -167,6 +169,9 @@ int main(int argc, char** argv) {
     if (all || !strcmp(which, "c3")) {
         suite<4>("c3l_xty", 50048, 20480, false);      // 20480 = 40 x 512: whole super tiles for every variant
         suite<4>("c3l_xw", 20480, 50176, false);       // 50176 = 98 x 512
+    }
+    if (!strcmp(which, "c3zero")) {
+        suite<4>("c3l_xty_zero_X", 50048, 20480, false, true);
     }
     if (all || !strcmp(which, "c4")) {
         suite<8>("c4l_xty", 50048, 20480, false);

@@ -88,7 +88,7 @@ def parse(argv=None):
                     help="time budget of the CPU-baseline sample of the headline workload (0 = skip)")
     ap.add_argument("--cpu-iters-per-stage", type=int, default=10,
                     help="CPU baseline of the c2 block: oracle iterations per annealing stage (0 = skip)")
-    ap.add_argument("--convergence-max-iter", type=int, default=100,
+    ap.add_argument("--convergence-max-iter", type=int, default=60,
                     help="iterations per annealing stage allowed to the whole-fit wall-clock measurement of a generated headline "
                          "workload (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -488,7 +488,8 @@ def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_s
         "x_passes": (be.timing_passes() / timed_iters) if timing else None,
         "trials": totals["trials"] / timed_iters, "invalid": totals["invalid_trials"] / timed_iters,
         "final_tc": float(model.tc), "x_host": x_host, "every": every,
-        "kernel_names": {"gemm_nt": be.kernel_name(0), "gemm_tn": be.kernel_name(1)},
+        "kernel_names": {"gemm_nt": be.kernel_name(0), "gemm_tn": be.kernel_name(1), "gemm_nt2": be.kernel_name(2)},
+        "passes_by_site": ({k: v / timed_iters for k, v in be.timing_passes_by_kind().items()} if timing else None),
         "windows": {
             "stages": n_stages, "steps_per_window": steps, "walks_timed": repeats, "walks_discarded_as_warmup": 1,
             "timed_iterations": timed_iters, "timed_seconds": float(wins.sum()),
@@ -513,12 +514,15 @@ def roofline_of(workload, r, world):
     es = 8 if tag == "f64" else 4
     alg_bytes = es * (n * v_per + m * v_per + n * m)
     alg_flops = 2.0 * n * v_per * m
+    # the merged pass (gemm_nt2) contracts X with 2 x n_hidden columns in one read of X: twice the flops, the X bytes once
+    site_bytes = {"gemm_nt2": es * (n * v_per + 2 * m * v_per + 2 * n * m)}
+    site_flops = {"gemm_nt2": 2.0 * alg_flops}
     kernels = {}
     for name, (cnt, ms) in r["timing"].items():
         if cnt:
             avg = ms / cnt * 1e-3
-            kernels[name] = {"launches": cnt, "avg_us": avg * 1e6, "GBps": alg_bytes / avg / 1e9,
-                             "TFLOPs": alg_flops / avg / 1e12}
+            kernels[name] = {"launches": cnt, "avg_us": avg * 1e6, "GBps": site_bytes.get(name, alg_bytes) / avg / 1e9,
+                             "TFLOPs": site_flops.get(name, alg_flops) / avg / 1e12}
     if not kernels:
         return None
     # use sites -> kernel function (rocprofv3 row).  X.B^T ("gemm_nt", :247/:210) and X^T.Y ("gemm_tn", :259/:211)
@@ -532,8 +536,13 @@ def roofline_of(workload, r, world):
         d["use_sites"].append(name)
     for fn, d in by_fn.items():
         avg = d["total_us"] / d["launches"] * 1e-6
-        d.update(avg_us=avg * 1e6, GBps=alg_bytes / avg / 1e9, TFLOPs=alg_flops / avg / 1e12)
+        wide = d["use_sites"] == ["gemm_nt2"]
+        d.update(avg_us=avg * 1e6, GBps=(site_bytes["gemm_nt2"] if wide else alg_bytes) / avg / 1e9,
+                 TFLOPs=(site_flops["gemm_nt2"] if wide else alg_flops) / avg / 1e12)
     dom = max(by_fn, key=lambda k: by_fn[k]["total_us"])
+    dom_wide = by_fn[dom]["use_sites"] == ["gemm_nt2"]
+    if dom_wide:
+        alg_bytes, alg_flops = site_bytes["gemm_nt2"], site_flops["gemm_nt2"]
     intensity = alg_flops / alg_bytes
     mfma_peak = FP64_MFMA_PEAK_TFLOPS if tag == "f64" else FP32_MFMA_PEAK_TFLOPS
     traffic, tinfo = load_pmc_traffic(workload, dom)
@@ -556,11 +565,15 @@ def roofline_of(workload, r, world):
     roofline.update(rocprofv3_avg_kernel_us=rp_us, rocprofv3_source=rp_src)
     # whole-iteration view: algorithmic bytes / flops of the X passes an iteration makes over the iteration time
     if r["x_passes"]:
-        roofline["iteration"] = {"x_passes": r["x_passes"],
-                                 "achieved_GBps": r["x_passes"] * alg_bytes / r["per_step_s"] / 1e9,
-                                 "achieved_TFLOPs": r["x_passes"] * alg_flops / r["per_step_s"] / 1e12,
-                                 "fraction_of_step_inside_the_dominant_kernel":
-                                     r["x_passes"] * by_fn[dom]["avg_us"] * 1e-6 / r["per_step_s"]}
+        ps = r.get("passes_by_site") or {}
+        base_b, base_f = es * (n * v_per + m * v_per + n * m), 2.0 * n * v_per * m
+        it_bytes = sum(ps.get(k, 0.0) * site_bytes.get(k, base_b) for k in ("gemm_nt", "gemm_tn", "gemm_nt2"))
+        it_flops = sum(ps.get(k, 0.0) * site_flops.get(k, base_f) for k in ("gemm_nt", "gemm_tn", "gemm_nt2"))
+        in_pass = sum(ps.get(k, 0.0) * kernels[k]["avg_us"] for k in kernels) * 1e-6
+        roofline["iteration"] = {"x_passes": r["x_passes"], "x_passes_by_site": ps,
+                                 "achieved_GBps": it_bytes / r["per_step_s"] / 1e9,
+                                 "achieved_TFLOPs": it_flops / r["per_step_s"] / 1e12,
+                                 "fraction_of_step_inside_the_x_passes": in_pass / r["per_step_s"]}
     return roofline
 
 
@@ -582,18 +595,23 @@ def config_of(workload, r, world, line_search, force_exchange=False):
 
 
 def covariance_block(model, be, label):
-    """get_covariance() (reference :443-451) of the resident solution: seconds and achieved write rate."""
+    """get_covariance() (reference :443-451) of the resident solution: seconds (median of 3 calls, each into a freshly
+    allocated NumPy matrix) and the device time of the product kernels."""
     import numpy as np
-    t0 = time.perf_counter()
-    cov = model.get_covariance()
-    t1 = time.perf_counter()
-    cov = model.get_covariance()
-    t2 = time.perf_counter()
-    nv = cov.shape[0]
-    nbytes = cov.nbytes
-    dev_s = be.last_covariance_device_seconds() if hasattr(be, "last_covariance_device_seconds") else None
+    secs, dev = [], []
+    cov = None
+    for _ in range(3):
+        del cov
+        t0 = time.perf_counter()
+        cov = model.get_covariance()
+        secs.append(time.perf_counter() - t0)
+        d = be.last_covariance_device_seconds() if hasattr(be, "last_covariance_device_seconds") else None
+        if d:
+            dev.append(d)
+    nv, nbytes = cov.shape[0], cov.nbytes
+    sec, dev_s = float(np.median(secs)), (float(np.median(dev)) if dev else None)
     out = {"workload": label, "n_variables": int(nv), "dtype": cov.dtype.name, "output_bytes": int(nbytes),
-           "seconds_first_call": t1 - t0, "seconds": t2 - t1, "host_GBps": nbytes / (t2 - t1) / 1e9,
+           "seconds": sec, "seconds_each_call": secs, "host_GBps": nbytes / sec / 1e9,
            "kernel_seconds": dev_s, "kernel_write_GBps": (nbytes / dev_s / 1e9) if dev_s else None,
            "diag_is_var": bool(np.allclose(np.diag(cov), np.asarray(model.theta[1], dtype=cov.dtype) ** 2))}
     del cov

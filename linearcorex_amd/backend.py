@@ -78,7 +78,8 @@ class HipBackend:
 
     def timing_read(self):
         out = {}
-        for kind, name in ((0, "gemm_nt"), (1, "gemm_tn")):
+        # gemm_nt2: the merged pass X.[grad | ws + update]^T (2 x n_hidden columns, one read of X; float32 large shards)
+        for kind, name in ((0, "gemm_nt"), (1, "gemm_tn"), (2, "gemm_nt2")):
             n, ms = C.c_int64(), C.c_double()
             _abi.check(self.lib.lcx_timing_read(self.h, kind, C.byref(n), C.byref(ms)))
             out[name] = (n.value, ms.value)
@@ -88,10 +89,18 @@ class HipBackend:
         """X passes issued while timing was on (every pass, whatever `timing_sample` says)."""
         n = C.c_int64()
         tot = 0
-        for kind in (0, 1):
+        for kind in (0, 1, 2):
             _abi.check(self.lib.lcx_timing_passes(self.h, kind, C.byref(n)))
             tot += n.value
         return tot
+
+    def timing_passes_by_kind(self):
+        out = {}
+        n = C.c_int64()
+        for kind, name in ((0, "gemm_nt"), (1, "gemm_tn"), (2, "gemm_nt2")):
+            _abi.check(self.lib.lcx_timing_passes(self.h, kind, C.byref(n)))
+            out[name] = n.value
+        return out
 
     def kernel_name(self, kind):
         buf = C.create_string_buffer(256)

@@ -11,6 +11,8 @@
 #include <stdlib.h>
 #include <sched.h>
 #include <time.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <string>
 #include <thread>
@@ -114,6 +116,11 @@ struct lcx_ctx {
     bool full_sig;              // run the second pass of _sig (X^T.Y_g): the linear trial mode needs D(update)
     bool exchange;              // the exchange steps are live (several ranks, or forced for testing)
     bool w1_ready;              // Wt[1] already holds ws + update (written by update_kernel)
+    // merged pass (float32 large shards with <= 64 padded factors): X.grad^T and the first trial's X.(ws+update)^T as ONE
+    // pass over X with 2 Mp columns - half the X traffic of the two and the more efficient wide kernel
+    bool merged_ok, y1_ready;   // y1_ready: ybuf / set[1].Y already hold Y of the eta = 1 trial
+    void *gw, *y2part, *ygbuf;  // [Vp][2 Mp] operand [grad | ws + update]; partial slots [S][Npad][2 Mp]; Y_g [Npad][Mp]
+    int nt2_nb, nt2_nsuper, nt2_S;
     // launch geometry
     int nt_S, nt_KW, tn_S, tn_KW, gn_S, gv_S, pv_grid, target_waves, n_cus, nt_bpc, tn_bpc;
     int tan_blocks;             // per-block partials of update_tangent waiting in tanpart (summed by the next evaluation's tail)
@@ -127,9 +134,9 @@ struct lcx_ctx {
     int t_every, t_count;       // HIP-event timing samples every t_every-th X pass (an event pair costs ~5 us of stream time)
     std::vector<TimingPair> pending;
     std::vector<TimingPair> pool;
-    int64_t t_launch[2];
-    int64_t t_pass[2];          // every X pass issued while timing is on (sampled or not)
-    double t_ms[2];
+    int64_t t_launch[3];        // kind 0 = X.B^T, 1 = X^T.Y, 2 = the merged X.[grad | ws+update]^T pass (2 Mp columns)
+    int64_t t_pass[3];          // every X pass issued while timing is on (sampled or not)
+    double t_ms[3];
     bool have_direction;
     int world;                  // ranks sharing the variables axis (1: no exchange between levels)
     unsigned int seq_next;
@@ -465,6 +472,16 @@ template <typename T, int CT> struct Impl {
             h->tn_ct = force ? !strcmp(force, "ct") : use_ct(sl, h->Npad);
             if (h->tn_ct) { h->tn_nb = nb; h->tn_nsuper = ns; h->tn_S = sl; h->tn_KW = CtShape<T, CT>::KW; }
         }
+        // merged pass: float32, 32 / 64 padded factors, large shards (the 2 Mp-wide gemm_ct does the flops of both passes at
+        // a higher rate and reads X once); LCX_MERGED_PASS=0 turns it off
+        h->merged_ok = false;
+        if constexpr (sizeof(T) == 4 && CT >= 2 && CT <= 4) {
+            if (h->nt_ct && env_int("LCX_MERGED_PASS", 1) != 0) {
+                int nb, ns, sl;
+                ct_geometry<T, 2 * CT>(cus, h->ldx, h->Npad, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
+                if (sl <= 8) { h->merged_ok = true; h->nt2_nb = nb; h->nt2_nsuper = ns; h->nt2_S = sl; }
+            }
+        }
         h->gn_S = pick_split(Mp / (16 * Geo<T, CT>::G_RT), pick_kw(kgn), kgn, h->target_waves / 4, 64);
         h->gv_S = pick_split(Mp / (16 * Geo<T, CT>::G_RT), pick_kw(kgv), kgv, h->target_waves / 4, 64);
         int64_t groups = cdiv(h->V, VPB);
@@ -568,6 +585,11 @@ template <typename T, int CT> struct Impl {
     }
 
     static int moments_a(lcx_ctx* h, int which) {
+        if (which == 1 && h->y1_ready && use_merged(h)) {       // the merged pass of lcx_update_b left it in ybuf / set 1
+            h->y1_ready = false;
+            return LCX_OK;
+        }
+        h->y1_ready = false;
         T* w = P<T>(h->Wt[which]);
         // without an exchange the summed Y is final: the set's own copy is written by the same reduction
         LCXCHECK(nt_big(h, w, nullptr, false, (!h->exchange && h->nt_S > 1) ? P<T>(h->set[which].Y) : (T*)nullptr));
@@ -725,21 +747,61 @@ template <typename T, int CT> struct Impl {
         MomentSet& s = h->set[0];
         const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * (Mp + 1) : 0) + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
         LCXCHECK(allow_lds(grad_kernel<T, Mp>, lds));
+        const bool merged = use_merged(h);
         hipLaunchKernelGGL((grad_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(h->Wt[0]),
                            P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), s.uj, h->sbuf + SB_H, h->V,
-                           P<T>(h->grad), h->bjpart);
+                           P<T>(h->grad), h->bjpart, merged ? P<T>(h->gw) : (T*)nullptr);
         KCHECK();
-        return nt_big(h, P<T>(h->grad), nullptr, true);
+        if (!merged) return nt_big(h, P<T>(h->grad), nullptr, true);
+        if constexpr (sizeof(T) == 4 && CT >= 2 && CT <= 4) {
+            // Bj (:302) does not wait for the pass: sum its per-block partials now, form update and ws + update (:303, :320) and
+            // put both B operands side by side, then ONE pass over X for [Y_g | Y of the first trial]
+            const int64_t n = h->Npad * Mp;
+            hipLaunchKernelGGL((reduce_y_bj_kernel<T, false>), dim3(Mp), dim3(PV_THREADS), 0, h->stream, P<T>(h->ypart), 1, n,
+                               P<T>(h->ybuf), 0, h->bjpart, h->pv_grid, Mp, P<T>(h->ybuf) + n);
+            KCHECK();
+            const int grid = update_grid(h);
+            hipLaunchKernelGGL((update_kernel<T, Mp>), dim3(grid), dim3(PV_THREADS), 0, h->stream, P<T>(h->dpart), 0, h->ldx * Mp,
+                               P<T>(h->grad), P<T>(h->Wt[0]), s.uj, P<T>(h->ybuf) + n, h->V, (double)h->N, eps, P<T>(h->update),
+                               P<T>(h->sgrad), h->tanpart, (const T*)nullptr, (T*)nullptr, grid, (const T*)nullptr, (const T*)nullptr,
+                               (int64_t)0, (T*)nullptr, P<T>(h->Wt[1]), h->world, P<T>(h->gw), 0);
+            KCHECK();
+            TimingPair tp;
+            LCXCHECK(timing_begin(h, 2, &tp));
+            LCXCHECK((launch_ct<T, 2 * CT>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, P<T>(h->gw), P<T>(h->y2part), h->nt2_nb,
+                                           h->nt2_nsuper, h->nt2_S, nullptr)));
+            LCXCHECK(timing_end(h, 2, &tp));
+            const int64_t n2 = 2 * n;
+            hipLaunchKernelGGL((reduce_split_kernel<T>), dim3((unsigned)(cdiv(n2, 256) < 2048 ? cdiv(n2, 256) : 2048)), dim3(256), 0,
+                               h->stream, P<T>(h->y2part), h->nt2_S, n2, Mp, P<T>(h->ygbuf), P<T>(h->ybuf), P<T>(h->set[1].Y));
+            KCHECK();
+            h->w1_ready = h->y1_ready = true;
+        }
+        return LCX_OK;
     }
+    // the merged pass needs: its buffers, one GPU (the exchange would have to carry both Y), and the Y-space tangent
+    static bool use_merged(const lcx_ctx* h) { return h->merged_ok && !h->exchange && !h->full_sig && h->gw != nullptr; }
+    static int update_grid(const lcx_ctx* h) { return (int)(cdiv(h->V * Mp, PV_THREADS) < 1536 ? cdiv(h->V * Mp, PV_THREADS) : 1536); }
 
     static int update_c(lcx_ctx* h, double eps) {
         MomentSet& s = h->set[0];
         // The second pass of _sig (X^T.Y_g, :211) only feeds update_tangent, which is available in Y space after
         // the first pass (see update_kernel); it is run when the linear trial mode needs D(update) as well.
         if (h->full_sig) LCXCHECK(tn_big(h, nullptr));
-        const int grid = (int)(cdiv(h->V * Mp, PV_THREADS) < 1536 ? cdiv(h->V * Mp, PV_THREADS) : 1536);
+        const int grid = update_grid(h);
         const int64_t ny = h->Npad * Mp;
         const int gridy = (int)(cdiv(ny, PV_THREADS) < 512 ? cdiv(ny, PV_THREADS) : 512);
+        if (h->y1_ready && use_merged(h)) {
+            // merged flow: update / ws + update were formed before the pass (lcx_update_b); what is left is the Y-space part -
+            // Y(update) and the Y term of update_tangent - from Y_g, which sits in its own buffer
+            hipLaunchKernelGGL((update_kernel<T, Mp>), dim3(gridy), dim3(PV_THREADS), 0, h->stream, P<T>(h->dpart), 0, h->ldx * Mp,
+                               P<T>(h->grad), P<T>(h->Wt[0]), s.uj, P<T>(h->ybuf) + h->Npad * Mp, h->V, (double)h->N, eps, P<T>(h->update),
+                               P<T>(h->sgrad), h->tanpart, (const T*)nullptr, (T*)nullptr, 0, P<T>(h->ygbuf), P<T>(s.Y), ny, P<T>(h->ydir),
+                               (T*)nullptr, h->world, (T*)nullptr, grid);
+            KCHECK();
+            h->tan_blocks = grid + gridy;
+            return LCX_OK;
+        }
         hipLaunchKernelGGL((update_kernel<T, Mp>), dim3(grid + gridy), dim3(PV_THREADS), 0, h->stream, P<T>(h->dpart),
                            h->full_sig ? h->tn_slots : 0, h->ldx * Mp, P<T>(h->grad), P<T>(h->Wt[0]), s.uj, P<T>(h->ybuf) + h->Npad * Mp, h->V,
                            (double)h->N, eps, P<T>(h->update), P<T>(h->sgrad), h->tanpart,
@@ -753,6 +815,7 @@ template <typename T, int CT> struct Impl {
 
     static int make_trial(lcx_ctx* h, double eta) {
         if (eta == 1.0 && h->w1_ready) return LCX_OK;        // update_kernel already wrote ws + update
+        h->y1_ready = false;
         const int64_t n = h->V * Mp;
         hipLaunchKernelGGL((axpy_kernel<T>), dim3((unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048)), dim3(256), 0,
                            h->stream, P<T>(h->Wt[0]), P<T>(h->update), (T)eta, n, P<T>(h->Wt[1]));
@@ -797,7 +860,7 @@ template <typename T, int CT> struct Impl {
                 if (tangent >= 0) {                                              // :306-311: keep ws, discard the trial
                     LCXCHECK(update_a(h));                                       // its H went to sbuf: restore set 0's
                     h->have_direction = false;
-                    h->w1_ready = false;
+                    h->w1_ready = h->y1_ready = false;
                     out[0] = 1; out[1] = tc_cur; out[2] = tangent; out[3] = trials - 1; out[4] = 0; out[5] = 0; out[6] = trials; out[7] = 0;
                     return LCX_OK;
                 }
@@ -810,7 +873,7 @@ template <typename T, int CT> struct Impl {
             break;
         }
         // self.ws, self.moments = w_update, m_update (:139, :334)
-        h->w1_ready = false;
+        h->w1_ready = h->y1_ready = false;
         std::swap(h->Wt[0], h->Wt[1]);
         std::swap(h->set[0], h->set[1]);
         h->have_direction = false;
@@ -1014,6 +1077,17 @@ template <typename T, int CT> struct Impl {
             hipLaunchKernelGGL((cov_prep_kernel<T>), dim3(pg), dim3(256), 0, h->stream, P<T>(s.rir), P<T>(s.si), (const T*)nullptr, n, Mp, (T)0,
                                P<T>(c.op_a), (T*)nullptr);
         KCHECK();
+        // The destination is usually a freshly allocated, never touched NumPy array: its first-touch page faults are
+        // what the end-to-end time of a large matrix is made of.  Ask for huge pages on the page-aligned interior of the
+        // borrowed buffer (a hint; ignored where transparent huge pages are off).
+        {
+            const size_t bytes = (size_t)nrows * (size_t)ld_out * sizeof(T);
+            if (bytes >= ((size_t)8 << 20)) {
+                const uintptr_t pg = (uintptr_t)2 << 20;
+                const uintptr_t a0 = ((uintptr_t)out_host + pg - 1) & ~(pg - 1), a1 = ((uintptr_t)out_host + bytes) & ~(pg - 1);
+                if (a1 > a0) (void)madvise((void*)a0, (size_t)(a1 - a0), MADV_HUGEPAGE);
+            }
+        }
         const T* opa = syn ? P<T>(s.xz) : P<T>(c.op_a);
         const T* opb = syn ? P<T>(c.op_b) : P<T>(c.op_a);
         const T denom = syn ? (T)1 : (T)(1.0 - eps * eps);
@@ -1213,6 +1287,13 @@ template <typename T, int CT> struct Impl {
     // Name of the kernel instantiation behind the two X-streaming passes, as rocprofv3 prints it (both
     // passes run the same function: X.B^T contracts over the rows of the transposed copy).
     static int kernel_name(lcx_ctx* h, int kind, char* buf, int64_t len) {
+        if (kind == 2) {
+            if (!h->merged_ok) { buf[0] = 0; return LCX_OK; }
+            if constexpr (CT <= 4)
+                snprintf(buf, (size_t)len, "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true, 0>", sizeof(T) == 8 ? "double" : "float", 2 * CT,
+                         CtShape<T, 2 * CT>::RT, CtShape<T, 2 * CT>::KW, CtShape<T, 2 * CT>::U);
+            return LCX_OK;
+        }
         if (kind == 0 ? h->nt_ct : h->tn_ct)
             snprintf(buf, (size_t)len, "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true, 0>", sizeof(T) == 8 ? "double" : "float", CT,
                      CtShape<T, CT>::RT, CtShape<T, CT>::KW, CtShape<T, CT>::U);
@@ -1410,7 +1491,7 @@ static inline void cancel_speculation(lcx_ctx* h) {
         h->spec_pending = false;
         h->spec_dirty = true;
         h->have_direction = false;
-        h->w1_ready = false;
+        h->w1_ready = h->y1_ready = false;
     }
 }
 #define NEED_MUT(h) NEED(h); cancel_speculation(h)
@@ -1541,9 +1622,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     h->timing = false;
     h->t_every = 1;
     h->t_count = 0;
-    h->t_launch[0] = h->t_launch[1] = 0;
-    h->t_pass[0] = h->t_pass[1] = 0;
-    h->t_ms[0] = h->t_ms[1] = 0.0;
+    for (int k = 0; k < 3; ++k) { h->t_launch[k] = 0; h->t_pass[k] = 0; h->t_ms[k] = 0.0; }
     h->have_direction = false;
     h->target_waves = prop.multiProcessorCount * 12;
     h->n_cus = prop.multiProcessorCount;
@@ -1591,10 +1670,17 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     A_(h->scratch, mv);
     A_(h->ydir, (size_t)h->Npad * Mp * es);
     A_(h->ddir, mv);
+    h->gw = h->y2part = h->ygbuf = nullptr;
+    h->y1_ready = false;
+    if (h->merged_ok) {
+        A_(h->gw, 2 * mv);
+        A_(h->ygbuf, (size_t)h->Npad * Mp * es);
+        A_(h->y2part, (size_t)h->nt2_S * h->Npad * 2 * Mp * es);
+    }
     h->have_linear = false;
     h->full_sig = true;
     h->exchange = false;
-    h->w1_ready = false;
+    h->w1_ready = h->y1_ready = false;
     h->ybuf_elems = h->Npad * Mp + (int64_t)Mp * Mp;
     h->sbuf_elems = (int64_t)SB_H + (int64_t)Mp * Mp + Mp + 8;
     A_(h->ybuf_own, (size_t)h->ybuf_elems * es);
@@ -1651,6 +1737,7 @@ int lcx_destroy(lcx_ctx* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->X, h->XT, h->Wt[0], h->Wt[1], h->grad, h->update, h->sgrad, h->scratch, h->ydir, h->ddir, h->ybuf_own, h->sbuf_own,
+                    h->gw, h->y2part, h->ygbuf,
                     h->ypart, h->dpart, h->gpart, h->gpartw, h->tcpart, h->bjpart, h->tanpart, h->detpart, h->ryinv, h->invwork,
                     h->states, h->order_dev, h->ticket};
     for (void* p : ptrs) (void)hipFree(p);
@@ -1747,7 +1834,7 @@ int lcx_generate_x(lcx_ctx* h, uint64_t seed, int kind, int n_groups, int64_t co
 
 int lcx_set_ws(lcx_ctx* h, const void* w) {
     NEED_MUT(h);
-    h->w1_ready = false;
+    h->w1_ready = h->y1_ready = false;
     if (!w) return fail(LCX_ERR_ARG, "lcx_set_ws: null");
     DISPATCH(h, set_ws, h, w);
 }
@@ -1776,7 +1863,7 @@ int lcx_get_ws(lcx_ctx* h, int which, void* w) {
 
 int lcx_permute_factors(lcx_ctx* h, const int32_t* order) {
     NEED_MUT(h);
-    h->w1_ready = false;
+    h->w1_ready = h->y1_ready = false;
     if (!order) return fail(LCX_ERR_ARG, "lcx_permute_factors: null");
     for (int j = 0; j < h->M; ++j)
         if (order[j] < 0 || order[j] >= h->M) return fail(LCX_ERR_ARG, "lcx_permute_factors: index out of range");
@@ -1834,7 +1921,7 @@ int lcx_trial_linear_b(lcx_ctx* h, double eps, double eta) {
 }
 int lcx_accept_trial(lcx_ctx* h) {
     NEED_MUT(h);
-    h->w1_ready = false;
+    h->w1_ready = h->y1_ready = false;
     std::swap(h->Wt[0], h->Wt[1]);
     std::swap(h->set[0], h->set[1]);
     h->have_direction = false;
@@ -1857,8 +1944,8 @@ int lcx_covariance_rows_syn(lcx_ctx* h, const void* std_host, int64_t row0, int6
     DISPATCH(h, covariance_syn, h, std_host, row0, nrows, out);
 }
 
-int lcx_rescale_ws(lcx_ctx* h, double e0, double e1) { NEED_MUT(h); h->w1_ready = false; DISPATCH(h, rescale, h, e0, e1); }
-int lcx_init_scale_ws(lcx_ctx* h) { NEED_MUT(h); h->w1_ready = false; DISPATCH(h, init_scale, h); }
+int lcx_rescale_ws(lcx_ctx* h, double e0, double e1) { NEED_MUT(h); h->w1_ready = h->y1_ready = false; DISPATCH(h, rescale, h, e0, e1); }
+int lcx_init_scale_ws(lcx_ctx* h) { NEED_MUT(h); h->w1_ready = h->y1_ready = false; DISPATCH(h, init_scale, h); }
 
 // Wait until the pinned mirror of a set carries the last publication enqueued for it.
 static int wait_published(lcx_ctx* h, MomentSet& s) {
@@ -2027,7 +2114,7 @@ int lcx_timing_sample(lcx_ctx* h, int every) {
 }
 int lcx_timing_read(lcx_ctx* h, int kind, int64_t* launches, double* total_ms) {
     NEED(h);
-    if (kind < 0 || kind > 1) return fail(LCX_ERR_ARG, "kind must be 0 or 1");
+    if (kind < 0 || kind > 2) return fail(LCX_ERR_ARG, "kind must be 0, 1 or 2");
     HIPCHECK(hipStreamSynchronize(h->stream));
     LCXCHECK(timing_collect(h));
     if (launches) *launches = h->t_launch[kind];
@@ -2038,14 +2125,12 @@ int lcx_timing_reset(lcx_ctx* h) {
     NEED(h);
     HIPCHECK(hipStreamSynchronize(h->stream));
     LCXCHECK(timing_collect(h));
-    h->t_launch[0] = h->t_launch[1] = 0;
-    h->t_pass[0] = h->t_pass[1] = 0;
-    h->t_ms[0] = h->t_ms[1] = 0.0;
+    for (int k = 0; k < 3; ++k) { h->t_launch[k] = 0; h->t_pass[k] = 0; h->t_ms[k] = 0.0; }
     return LCX_OK;
 }
 int lcx_timing_passes(lcx_ctx* h, int kind, int64_t* passes) {
     NEED(h);
-    if (kind < 0 || kind > 1 || !passes) return fail(LCX_ERR_ARG, "lcx_timing_passes: bad argument");
+    if (kind < 0 || kind > 2 || !passes) return fail(LCX_ERR_ARG, "lcx_timing_passes: bad argument");
     *passes = h->t_pass[kind];
     return LCX_OK;
 }
@@ -2138,7 +2223,7 @@ int lcx_geometry(lcx_ctx* h, int64_t* n_pad, int64_t* ldx, int* m_pad, int64_t* 
 
 int lcx_kernel_name(lcx_ctx* h, int kind, char* buf, int64_t len) {
     if (!h) return fail(LCX_ERR_ARG, "null handle");
-    if (kind < 0 || kind > 1 || !buf || len < 16) return fail(LCX_ERR_ARG, "lcx_kernel_name: bad argument");
+    if (kind < 0 || kind > 2 || !buf || len < 16) return fail(LCX_ERR_ARG, "lcx_kernel_name: bad argument");
     DISPATCH(h, kernel_name, h, kind, buf, len);
 }
 

@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(PV_THREADS)
 grad_kernel(const T* __restrict__ W, const T* __restrict__ rho_i, const T* __restrict__ rir_i,
             const T* __restrict__ qij_i, const T* __restrict__ si_i, const T* __restrict__ q2_i,
             const double* __restrict__ uj, const double* __restrict__ H /* sbuf, diag ignored */,
-            int64_t V, T* __restrict__ grad_o, double* __restrict__ bjpart) {
+            int64_t V, T* __restrict__ grad_o, double* __restrict__ bjpart, T* __restrict__ grad2_o = nullptr) {
     constexpr int VPB = PV_THREADS / Mp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* h_s = reinterpret_cast<T*>(smem_raw);        // [Mp][Mp+1]
@@ -461,6 +461,7 @@ grad_kernel(const T* __restrict__ W, const T* __restrict__ rho_i, const T* __res
         g += hw;                                                                // :300
         if (ok) {
             grad_o[o] = g;
+            if (grad2_o != nullptr) grad2_o[v * (2 * Mp) + j] = g;          // columns [0, Mp) of the merged operand [V][2 Mp]
             bj += (double)(rho * g);
         }
     }
@@ -484,7 +485,8 @@ update_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, const T*
               T* __restrict__ sgrad_o, double* __restrict__ tanpart,
               const T* __restrict__ d_cur, T* __restrict__ d_dir_o,
               int update_blocks, const T* __restrict__ yg, const T* __restrict__ ycur, int64_t ny,
-              T* __restrict__ ydir_o, T* __restrict__ w1_o, int n_ranks) {
+              T* __restrict__ ydir_o, T* __restrict__ w1_o, int n_ranks, T* __restrict__ w1b_o = nullptr,
+              int tan_offset = 0) {
     __shared__ double bs_scratch[PV_THREADS / 64];
     const int tid = threadIdx.x;
     const T c1 = (T)(1.0 - eps * eps), c2 = (T)(eps * eps), ns = (T)n_samples;
@@ -517,6 +519,7 @@ update_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, const T*
             const T up = -rj * (g - (T)2 * W[o] / ((T)2 - rj) * bj_tail[j]);         // :303
             update_o[o] = up;
             if (w1_o != nullptr) w1_o[o] = W[o] + up;                               // :320 at eta = 1 (the first trial)
+            if (w1b_o != nullptr) w1b_o[(o / Mp) * (2 * Mp) + Mp + j] = W[o] + up;   // columns [Mp, 2 Mp) of the merged operand
             if (yspace) {
                 tan += (double)(c2 * g * up);
             } else {
@@ -534,7 +537,24 @@ update_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride, const T*
     // per-block partial of update_tangent: summed by the tail block of the first trial's evaluation (gram_tc_kernel),
     // or by tangent_finalize_kernel when somebody asks for the state before that
     tan = block_sum<double>(tan, bs_scratch, tid);
-    if (tid == 0) tanpart[blockIdx.x] = tan;
+    if (tid == 0) tanpart[tan_offset + blockIdx.x] = tan;
+}
+
+// Merged pass (one read of X for X.grad^T and X.(ws + update)^T): sum the partial slots of Y2 [slots][Npad][2 Mp] and
+// split the columns: [0, Mp) -> Y_g = X.grad^T (:210), [Mp, 2 Mp) -> Y of the first trial (:321), the latter into the
+// exchange buffer and into the trial set's own copy.
+template <typename T>
+__global__ void reduce_split_kernel(const T* __restrict__ in, int nsplit, int64_t n2, int Mp, T* __restrict__ yg,
+                                    T* __restrict__ y1, T* __restrict__ y1b) {
+    const int w = 2 * Mp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+        T s = in[i];
+        for (int k = 1; k < nsplit; ++k) s += in[k * n2 + i];
+        const int64_t r = i / w;
+        const int c = (int)(i - r * w);
+        if (c < Mp) yg[r * Mp + c] = s;
+        else { y1[r * Mp + c - Mp] = s; y1b[r * Mp + c - Mp] = s; }
+    }
 }
 
 

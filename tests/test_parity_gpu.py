@@ -605,3 +605,27 @@ def test_more_than_256_factors_is_refused():
     from linearcorex_amd._abi import LcxError
     with pytest.raises(LcxError, match="n_hidden > 256"):
         Corex(n_hidden=257, seed=0, device=0).fit(np.random.RandomState(0).randn(50, 300))
+
+
+@pytest.mark.parametrize("m", [24, 64])
+def test_merged_pass_equals_separate_passes(m, monkeypatch):
+    """float32 shards on gemm_ct with <= 64 padded factors run X.grad^T (:210) and the first trial's X.(ws + update)^T (:321) as
+    ONE pass over X with twice the columns.  Same arithmetic per element up to the summation split of the wider kernel: the
+    fit must follow the two-pass path (LCX_MERGED_PASS=0) to float32 rounding, and the float32 oracle within the usual bar."""
+    from linearcorex_amd import Corex
+    monkeypatch.setenv("LCX_GEMM", "ct")
+    x, _ = O.gen_planted(19200, 1280, 8, seed=81)      # 75 super tiles of samples: the merged pass splits into <= 8 slots
+    runs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LCX_MERGED_PASS", flag)
+        out = Corex(n_hidden=m, seed=0, max_iter=6, dtype=np.float32, device=0).fit(x)
+        assert bool(out._backend.kernel_name(2)) == (flag == "1")
+        runs[flag] = (np.asarray(out.history["TC"], np.float64), out.stats["trials"], out.ws.copy(), out.clusters())
+        out._backend.close()
+    h1, h0 = runs["1"][0], runs["0"][0]
+    assert len(h1) == len(h0) == 42 and runs["1"][1] == runs["0"][1]
+    assert np.max(np.abs(h1 - h0) / np.maximum(1.0, np.abs(h0))) < 5e-5
+    assert relerr(runs["1"][2], runs["0"][2]) < 1e-3
+    ref = O.fit_ns(x, m, seed=0, dtype=np.float32, max_iter=6)
+    h_ref = np.asarray(ref.history_tc, np.float64)
+    assert len(h_ref) == len(h1) and np.max(np.abs(h1 - h_ref) / np.maximum(1.0, np.abs(h_ref))) < 2e-3

@@ -412,12 +412,15 @@ gemm_ct_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T*
             Pk<T, CT> bb[U];                                                              \
             _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
                 bb[st] = *reinterpret_cast<const Pk<T, CT>*>(&Bs[BUF][(4 * st + q) * Mp + i * CT]); \
-            if (PRIO) __builtin_amdgcn_s_setprio(PRIO);                                   \
+            /* PRIO 1, 2: s_setprio around the MFMA burst; 3, 4: scheduler hints (iglp_opt 0 / 1) - probe variants */ \
+            if (PRIO == 1 || PRIO == 2) __builtin_amdgcn_s_setprio(PRIO);                 \
+            if (PRIO == 3) __builtin_amdgcn_iglp_opt(0);                                  \
+            if (PRIO == 4) __builtin_amdgcn_iglp_opt(1);                                  \
             _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
             _Pragma("unroll") for (int t = 0; t < RT; ++t)                                \
             _Pragma("unroll") for (int u = 0; u < CT; ++u)                                \
                 acc[t][u] = MF<T>::mma(AA[st][t], bb[st].v[u], acc[t][u]);                \
-            if (PRIO) __builtin_amdgcn_s_setprio(0);                                      \
+            if (PRIO == 1 || PRIO == 2) __builtin_amdgcn_s_setprio(0);                    \
         }
 
         LCX_CT_LOADA(0, a0);

@@ -543,26 +543,37 @@ def _iterate_n(x, m, n_iter, mode, dtype=np.float64):
         model._iterate(more=k < 2)
     w = model._backend.get_ws(0)
     rho = model.moments["rho"]
+    stats = dict(model.stats, merged_kernel=model._backend.kernel_name(2))
     model._backend.close()
-    return np.asarray(model.history["TC"], np.float64), w, rho, dict(model.stats)
+    return np.asarray(model.history["TC"], np.float64), w, rho, stats
 
 
-def test_library_loop_equals_host_loop():
+@pytest.mark.parametrize("case", ["f64", "f32_merged_pass"])
+def test_library_loop_equals_host_loop(case, monkeypatch):
     """lcx_iterate (line-search decisions in the library, next iteration's direction and first trial enqueued before the
     call returns) must walk exactly the trajectory of the host-sequenced levels - also when a speculation is abandoned by a
-    host-sequenced iteration, a stage change or a readback in between."""
-    x, _ = O.gen_planted(600, 900, 6, seed=61)
-    h_lib, w_lib, rho_lib, st_lib = _iterate_n(x, 6, 14, "library")
-    h_host, w_host, rho_host, st_host = _iterate_n(x, 6, 14, "host")
-    h_mix, w_mix, rho_mix, st_mix = _iterate_n(x, 6, 14, "mixed")
+    host-sequenced iteration, a stage change or a readback in between.  Second case: a float32 shard on the merged pass
+    (Y of the first trial already there when its evaluation starts)."""
+    if case == "f64":
+        x, _ = O.gen_planted(600, 900, 6, seed=61)
+        dtype = np.float64
+    else:
+        monkeypatch.setenv("LCX_GEMM", "ct")
+        x, _ = O.gen_planted(19200, 640, 6, seed=62)
+        dtype = np.float32
+    h_lib, w_lib, rho_lib, st_lib = _iterate_n(x, 6 if case == "f64" else 20, 14, "library", dtype)
+    h_host, w_host, rho_host, st_host = _iterate_n(x, 6 if case == "f64" else 20, 14, "host", dtype)
+    h_mix, w_mix, rho_mix, st_mix = _iterate_n(x, 6 if case == "f64" else 20, 14, "mixed", dtype)
     assert len(h_lib) == 17
+    assert bool(st_lib["merged_kernel"]) == (case != "f64")
     assert np.array_equal(h_lib, h_host) and np.array_equal(h_lib, h_mix)
     assert np.array_equal(w_lib, w_host) and np.array_equal(w_lib, w_mix)
     assert np.array_equal(rho_lib, rho_host) and np.array_equal(rho_lib, rho_mix)
     assert st_lib["trials"] == st_host["trials"] == st_mix["trials"]
     # and against the oracle
-    ref = O.fit_ns(x, 6, seed=0, dtype=np.float64, max_iter=14)
-    assert np.max(np.abs(h_lib[:14] - np.asarray(ref.history_tc[:14]))) < 1e-9
+    if case == "f64":
+        ref = O.fit_ns(x, 6, seed=0, dtype=np.float64, max_iter=14)
+        assert np.max(np.abs(h_lib[:14] - np.asarray(ref.history_tc[:14]))) < 1e-9
 
 
 def test_host_loop_end_to_end(g1, monkeypatch):

@@ -24,9 +24,9 @@ __global__ void clock_sampler(long long* out, long long wall_ticks) {
 
 struct Variant { std::string name; std::function<void()> launch; std::vector<float> ms; int maxslots; };
 
-template <typename T, int CT, int RT, int KW, int U, bool NT = true>
+template <typename T, int CT, int RT, int KW, int U, bool NT = true, int PRIO = 0>
 Variant mkct(const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* out, int bpc_use = 0) {
-    auto kern = gemm_ct_kernel<T, CT, RT, KW, U, NT, 0>;
+    auto kern = gemm_ct_kernel<T, CT, RT, KW, U, NT, PRIO>;
     int bpc = 0;
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, 0));
     const int use = bpc_use > 0 && bpc_use < bpc ? bpc_use : bpc;
@@ -38,7 +38,7 @@ Variant mkct(const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* o
     const int maxslots = (nb + nsuper - 1) / nsuper + 1;
     hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, (const void*)kern));
     char buf[240];
-    snprintf(buf, 240, "ct   RT=%d KW=%d U=%d bpc=%d(use %d) nb=%d nsuper=%d slots=%d regs=%d", RT, KW, U, bpc, use, nb, nsuper, maxslots, fa.numRegs);
+    snprintf(buf, 240, "ct   RT=%d KW=%d U=%d hint=%d bpc=%d(use %d) nb=%d nsuper=%d slots=%d regs=%d", RT, KW, U, PRIO, bpc, use, nb, nsuper, maxslots, fa.numRegs);
     return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, A, lda, B, out, vcols, vcols, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
 }
 
@@ -169,6 +169,28 @@ int main(int argc, char** argv) {
     if (all || !strcmp(which, "c3")) {
         suite<4>("c3l_xty", 50048, 20480, false);      // 20480 = 40 x 512: whole super tiles for every variant
         suite<4>("c3l_xw", 20480, 50176, false);       // 50176 = 98 x 512
+    }
+    if (!strcmp(which, "c3hint")) {
+        typedef float T;
+        const int64_t K = 50048, V = 20480;
+        T *A, *B, *out;
+        CK(hipMalloc(&A, sizeof(T) * K * V)); CK(hipMalloc(&B, sizeof(T) * K * 64)); CK(hipMalloc(&out, sizeof(T) * 48 * V * 64));
+        {
+            std::vector<T> h((size_t)K * V);
+            for (size_t x = 0; x < h.size(); ++x) h[x] = (T)((double)rand() / RAND_MAX - 0.5);
+            CK(hipMemcpy(A, h.data(), sizeof(T) * K * V, hipMemcpyHostToDevice));
+            CK(hipMemcpy(B, h.data(), sizeof(T) * K * 64, hipMemcpyHostToDevice));
+        }
+        printf("== c3l_xty scheduler hints: K=%ld V=%ld Mp=64 float32\n", (long)K, (long)V);
+        std::vector<Variant> vs;
+        vs.push_back(mkct<T, 4, 4, 4, 4, true, 0>(A, V, K, V, B, out, 2));
+        vs.push_back(mkct<T, 4, 4, 4, 4, true, 3>(A, V, K, V, B, out, 2));
+        vs.push_back(mkct<T, 4, 4, 4, 4, true, 4>(A, V, K, V, B, out, 2));
+        vs.push_back(mkct<T, 4, 4, 4, 8, true, 0>(A, V, K, V, B, out, 2));
+        vs.push_back(mkct<T, 4, 4, 4, 8, true, 3>(A, V, K, V, B, out, 2));
+        vs.push_back(mkct<T, 4, 4, 4, 4, true, 1>(A, V, K, V, B, out, 2));
+        for (size_t k = 1; k < vs.size(); ++k) check<T>("hint", vs[k], vs[0], out, V, 64, 2e-5);
+        bench(vs, sizeof(T) * ((double)K * V + 64.0 * (K + V)) / 1e9, 2.0 * K * V * 64 / 1e12, 7, 5);
     }
     if (!strcmp(which, "c3zero")) {
         suite<4>("c3l_xty_zero_X", 50048, 20480, false, true);

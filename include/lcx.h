@@ -95,7 +95,8 @@ int         lcx_device_count(int* out_count);
 
 /* ---- handle -------------------------------------------------------------------------------- */
 /* Replaces cm.cublas_init() (:85-86).  Allocates all device state for an
- * (n_samples x nv_local) shard with n_hidden factors on HIP device `device`. */
+ * (n_samples x nv_local) shard with n_hidden factors on HIP device `device`.  n_hidden <= 256 (padded to 16 / 32 / 64 /
+ * 128 / 256 columns).  A failed allocation releases what was allocated before it. */
 int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
                int dtype, int device);
 int lcx_destroy(lcx_ctx* h);
@@ -173,7 +174,9 @@ int lcx_moments_detail(lcx_ctx* h, int which);
  *    of the set they evaluate there, so a fit only needs this call to restore it after a discarded trial.   */
 int lcx_update_a(lcx_ctx* h);
 /* b: grad (:296-300), Bj partial (:302), Y_g partial = X.grad^T (first half of _sig, :210)
- *    -> ybuf (Bj in the tail)                                                                    */
+ *    -> ybuf (Bj in the tail).  Merged form (see lcx_timing_read, kind 2): Bj, update (:303) and ws + update (:320) are
+ *    formed first, then ONE pass over X yields Y_g (kept in a buffer of its own) and the Y of the eta = 1 trial (-> ybuf and
+ *    set 1); lcx_update_c then only adds the Y-space half, and lcx_make_trial(1.0) + lcx_moments_a(1) launch nothing.    */
 int lcx_update_b(lcx_ctx* h, double eps);
 /* c: X^T.Y_g, sig_grad (:211-212), update (:303), per-block partials of update_tangent (:305).  They are summed
  *    into sbuf[2] by the tail of the NEXT lcx_moments_b / lcx_trial_linear_b (the first trial of the direction), which
@@ -279,7 +282,9 @@ int lcx_project_raw(lcx_ctx* h, const void* x_raw_host, int64_t n_rows, int64_t 
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* HIP-event timing of the two X-streaming GEMM kernels on the handle's stream.
- * kind 0 = X.B^T ("nt", :247/:210), kind 1 = X^T.Y ("tn", :259/:211). */
+ * kind 0 = X.B^T ("nt", :247/:210), kind 1 = X^T.Y ("tn", :259/:211), kind 2 = the merged pass
+ * X.[grad | ws + update]^T (the :210 pass and the first trial's :321 pass as one launch with 2 x m_padded columns;
+ * float32 shards on the column-tiled kernel with <= 64 padded factors, one GPU - see lcx_update_b). */
 int lcx_timing_enable(lcx_ctx* h, int enable);
 /* time only every `every`-th X pass (an event pair costs ~5 us of stream time; default 1 = all) */
 int lcx_timing_sample(lcx_ctx* h, int every);

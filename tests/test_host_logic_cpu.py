@@ -232,3 +232,27 @@ def test_bench_refuses_a_world_that_does_not_match_gpus():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
                        timeout=60)
     assert p.returncode != 0 and not p.stdout.strip()
+
+
+def test_bench_roofline_accounting_with_the_merged_pass():
+    """bench.roofline_of: a merged launch (X.[grad | ws+update]^T) carries twice the flops and the X bytes once; the dominant
+    function is the one with the most time; nothing is quoted from a profile taken from other library sources."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    n, v, m, _ = bench.WORKLOADS["c3"]
+    r = {"timing": {"gemm_nt": (63, 63 * 5.2), "gemm_tn": (163, 163 * 5.2), "gemm_nt2": (100, 100 * 9.7)},
+         "kernel_names": {"gemm_nt": "lcx::gemm_ct_kernel<float, 4, 4, 4, 4, true, 0>", "gemm_tn": "lcx::gemm_ct_kernel<float, 4, 4, 4, 4, true, 0>",
+                          "gemm_nt2": "lcx::gemm_ct_kernel<float, 8, 4, 4, 4, true, 0>"},
+         "every": 1, "x_passes": 3.26, "per_step_s": 22.0e-3,
+         "passes_by_site": {"gemm_nt": 0.63, "gemm_tn": 1.63, "gemm_nt2": 1.0}}
+    rf = bench.roofline_of("c3", r, 1)
+    assert rf["bound"] == "mfma" and rf["kernel"].startswith("lcx::gemm_ct_kernel<float, 4,")
+    flops = 2.0 * n * v * m
+    assert abs(rf["achieved"] - flops / 5.2e-3 / 1e12) < 1e-6 * rf["achieved"]
+    assert abs(rf["use_sites"]["gemm_nt2"]["TFLOPs"] - 2 * flops / 9.7e-3 / 1e12) < 1e-6 * rf["use_sites"]["gemm_nt2"]["TFLOPs"]
+    it = rf["iteration"]
+    assert abs(it["achieved_TFLOPs"] - (0.63 + 1.63 + 2 * 1.0) * flops / 22.0e-3 / 1e12) < 1e-6 * it["achieved_TFLOPs"]
+    assert 0.9 < it["fraction_of_step_inside_the_x_passes"] < 1.0
+    # committed profiles are only quoted for the library they were taken from
+    assert rf["traffic"] is None or rf["traffic_profile_matches_library"] is True

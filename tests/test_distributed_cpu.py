@@ -45,7 +45,7 @@ def launch(world, out_dir, n, v, m, mode="exact", extra_env=None):
         assert p.returncode == 0, o[-3000:]
 
 
-@pytest.mark.parametrize("world,mode", [(2, "exact"), (3, "exact"), (2, "linear")])
+@pytest.mark.parametrize("world,mode", [(2, "exact"), (3, "exact"), (2, "linear"), (8, "exact")])
 def test_sharded_fit_matches_oracle(world, mode, tmp_path):
     n, v, m = 300, 203, 4               # 203 variables: uneven shards
     launch(world, tmp_path, n, v, m, mode)

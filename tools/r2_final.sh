@@ -15,6 +15,18 @@ T0=$(date +%s)
 python bench.py --gpus 1 --steps 20 --warmup 5 2>gpurun_out/r02_bench_default.err | tail -1 > gpurun_out/r02_bench_default.json
 echo "bench default: $(( $(date +%s) - T0 )) s"; tail -3 gpurun_out/r02_bench_default.err
 python bench.py --workload c4shard --no-extras 2>/dev/null | tail -1 > gpurun_out/r02_bench_c4shard.json
+# the figures must not move with the driver's step count: the same lines at --steps 5 and --steps 70
+{
+  for SW in "5 1" "20 5" "70 7"; do
+    set -- $SW
+    python bench.py --workload c3 --no-extras --steps $1 --warmup $2 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); w=d['config']['windows']
+print('c3 --steps %3d --warmup %d: %.2f it/s, %.3f ms per step, frac %.3f, %d timed iterations in %.2f s' % (d['steps'], d['warmup'], d['value'], d['ms_per_step'], d['roofline']['frac'], w['timed_iterations'], w['timed_seconds']))"
+    python bench.py --workload c2 --no-extras --steps $1 --warmup $2 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); w=d['config']['windows']
+print('c2 --steps %3d --warmup %d: %.1f it/s, %.4f ms per step, frac %.3f, %d timed iterations in %.2f s, %d walks' % (d['steps'], d['warmup'], d['value'], d['ms_per_step'], d['roofline']['frac'], w['timed_iterations'], w['timed_seconds'], w['walks_timed']))"
+  done
+} | tee gpurun_out/r02_step_count_independence.txt
 python -c "
 import json
 d=json.load(open('gpurun_out/r02_bench_default.json')); c=d['config']['c2']; r=d['roofline']

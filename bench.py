@@ -94,7 +94,7 @@ def parse(argv=None):
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-sample", type=int, default=0,
                     help="HIP-event pairs around every n-th X pass of the timed windows (a pair costs ~5 us of stream time; "
-                         "0 = 1 for passes above 1 ms, 5 below)")
+                         "0 = 1 for passes above 1 ms, 16 below)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="1 GPU only: run the multi-rank device path (world>1 kernels + RCCL all-reduces in a group of "
                          "one rank) to measure the fixed cost of the exchange steps")
@@ -424,7 +424,7 @@ def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_s
     pass_ms = be.bench_gemm(1, 2)
     while time.perf_counter() - t0 < 0.25:
         be.bench_gemm(1, max(2, int(20.0 / max(pass_ms, 1e-3))) if pass_ms < 1.0 else 4)
-    every = args.timing_sample if args.timing_sample > 0 else (1 if pass_ms >= 1.0 else 5)
+    every = args.timing_sample if args.timing_sample > 0 else (1 if pass_ms >= 1.0 else 16)
     timing = kernel_timing and not args.no_kernel_timing
     if timing:
         be.timing_reset()

@@ -21,7 +21,7 @@ python bench.py --workload c4shard --no-extras 2>/dev/null | tail -1 > gpurun_ou
     set -- $SW
     python bench.py --workload c3 --no-extras --steps $1 --warmup $2 2>/dev/null | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); w=d['config']['windows']
-print('c3 --steps %3d --warmup %d: %.2f it/s, %.3f ms per step, frac %.3f, %d timed iterations in %.2f s' % (d['steps'], d['warmup'], d['value'], d['ms_per_step'], d['roofline']['frac'], w['timed_iterations'], w['timed_seconds']))"
+print('c3 --steps %3d --warmup %d: %.2f it/s, %.3f ms per step (%.2f X passes, %.2f trials per iteration), frac %.3f, %d timed iterations in %.2f s' % (d['steps'], d['warmup'], d['value'], d['ms_per_step'], d['config']['x_passes_per_iteration'], d['config']['line_search_trials_per_iteration'], d['roofline']['frac'], w['timed_iterations'], w['timed_seconds']))"
     python bench.py --workload c2 --no-extras --steps $1 --warmup $2 2>/dev/null | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); w=d['config']['windows']
 print('c2 --steps %3d --warmup %d: %.1f it/s, %.4f ms per step, frac %.3f, %d timed iterations in %.2f s, %d walks' % (d['steps'], d['warmup'], d['value'], d['ms_per_step'], d['roofline']['frac'], w['timed_iterations'], w['timed_seconds'], w['walks_timed']))"

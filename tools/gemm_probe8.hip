@@ -11,7 +11,7 @@
 #include <functional>
 #include <string>
 #include <string.h>
-#include "../linearcorex_amd/csrc/gemm_kernels.hpp"
+#include "probe_kernels.hpp"
 using namespace lcx;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
@@ -39,6 +39,24 @@ Variant mkct(const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* o
     hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, (const void*)kern));
     char buf[240];
     snprintf(buf, 240, "ct   RT=%d KW=%d U=%d hint=%d bpc=%d(use %d) nb=%d nsuper=%d slots=%d regs=%d", RT, KW, U, PRIO, bpc, use, nb, nsuper, maxslots, fa.numRegs);
+    return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, A, lda, B, out, vcols, vcols, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
+}
+
+template <typename T, int CT, int RT, int KW, int U>
+Variant mkct3(const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* out, int bpc_use = 0) {
+    auto kern = gemm_ct3_kernel<T, CT, RT, KW, U, true>;
+    int bpc = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, 0));
+    const int use = bpc_use > 0 && bpc_use < bpc ? bpc_use : bpc;
+    const int ng = (int)(K / (4 * U));
+    const int nsuper = (int)((vcols + KW * 16 * RT - 1) / (KW * 16 * RT));
+    int64_t total = (int64_t)nsuper * ng;
+    int nb = 256 * use;
+    if (nb > total) nb = (int)total;
+    const int maxslots = (nb + nsuper - 1) / nsuper + 1;
+    hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, (const void*)kern));
+    char buf[240];
+    snprintf(buf, 240, "ct3  RT=%d KW=%d U=%d (A two groups ahead) bpc=%d(use %d) nb=%d nsuper=%d slots=%d regs=%d", RT, KW, U, bpc, use, nb, nsuper, maxslots, fa.numRegs);
     return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, A, lda, B, out, vcols, vcols, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
 }
 
@@ -189,6 +207,9 @@ int main(int argc, char** argv) {
         vs.push_back(mkct<T, 4, 4, 4, 8, true, 0>(A, V, K, V, B, out, 2));
         vs.push_back(mkct<T, 4, 4, 4, 8, true, 3>(A, V, K, V, B, out, 2));
         vs.push_back(mkct<T, 4, 4, 4, 4, true, 1>(A, V, K, V, B, out, 2));
+        vs.push_back(mkct3<T, 4, 4, 4, 4>(A, V, K, V, B, out, 2));
+        vs.push_back(mkct3<T, 4, 4, 4, 4>(A, V, K, V, B, out, 3));
+        vs.push_back(mkct3<T, 4, 4, 4, 2>(A, V, K, V, B, out, 2));
         for (size_t k = 1; k < vs.size(); ++k) check<T>("hint", vs[k], vs[0], out, V, 64, 2e-5);
         bench(vs, sizeof(T) * ((double)K * V + 64.0 * (K + V)) / 1e9, 2.0 * K * V * 64 / 1e12, 7, 5);
     }

@@ -52,7 +52,7 @@ def test_default_line_is_the_c3_line_with_the_c2_block():
     assert c2["roofline"]["bound"] == "hbm" and c2["windows"]["timed_seconds"] >= 0.5
     assert c2["cpu_baseline"]["value"] > 0
     lo, med, hi = c2["windows"]["ms_per_step_walk_min_median_max"]
-    assert hi / lo < 1.15, (lo, med, hi)
+    assert hi / lo < 1.25, (lo, med, hi)
     assert c2["get_covariance"]["n_variables"] == 5000 and c2["get_covariance"]["seconds"] > 0
     assert d["config"]["get_covariance_c5_standin"]["n_variables"] == 20000
 

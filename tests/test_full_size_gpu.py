@@ -84,3 +84,22 @@ def test_config2_full_fit_vs_oracle():
     cov, cov_ref = out.get_covariance(), ref.get_covariance()
     assert np.max(np.abs(cov - cov_ref)) < 1e-6 * np.max(np.abs(cov_ref))
     assert np.max(np.abs(np.asarray(out.tcs) - np.asarray(ref.moments["TCs"]))) < 1e-6 * max(1.0, float(np.max(np.abs(ref.moments["TCs"]))))
+
+
+def test_config3_merged_pass_matches_separate_passes(monkeypatch):
+    """BASELINE configs[2] at full size: the merged X.[grad | ws+update]^T pass (gemm_ct<float, 8> on 128 columns, 4 slots) against
+    the two separate 64-column passes - same trajectory to float32 rounding, same number of line-search trials."""
+    from linearcorex_amd import Corex
+    runs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LCX_MERGED_PASS", flag)
+        mdl = Corex(n_hidden=64, seed=0, dtype=np.float32, device=0, max_iter=3)
+        mdl.fit_generated(50000, 100000, seed=1, kind=1, n_groups=64)
+        assert bool(mdl._backend.kernel_name(2)) == (flag == "1")
+        runs[flag] = (np.asarray(mdl.history["TC"], np.float64), mdl.stats["trials"], float(np.max(np.abs(mdl.ws))))
+        mdl._backend.close()
+    h1, h0 = runs["1"][0], runs["0"][0]
+    assert len(h1) == len(h0) == 21
+    assert np.max(np.abs(h1 - h0) / np.maximum(1.0, np.abs(h0))) < 1e-4
+    assert abs(runs["1"][1] - runs["0"][1]) <= 1
+    assert abs(runs["1"][2] - runs["0"][2]) < 1e-3 * runs["0"][2]

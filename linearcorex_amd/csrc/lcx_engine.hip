@@ -14,8 +14,11 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/lcx.h"
@@ -208,9 +211,20 @@ static int timing_collect(lcx_ctx* h) {
     return LCX_OK;
 }
 
-// dynamic LDS above 64 KiB needs an explicit opt-in per kernel
+// Dynamic LDS above 48 KiB needs an explicit opt-in per kernel - once per (device, function, size), not per launch: the
+// attribute call is a driver round trip on the path between a trial's result and the next launch.
 template <typename F> static int allow_lds(F* f, size_t bytes) {
-    if (bytes > 48 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (bytes <= 48 * 1024) return LCX_OK;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> done;
+    int dev = 0;
+    HIPCHECK(hipGetDevice(&dev));
+    const std::pair<int, const void*> key(dev, (const void*)f);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return LCX_OK;
+    HIPCHECK(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done[key] = bytes;
     return LCX_OK;
 }
 
@@ -271,11 +285,11 @@ static int launch_tn4(hipStream_t st, const double* A, int64_t lda, int64_t K, i
     const int kgroups = (int)(K / 16);
     if (KW == 2) {
         const size_t lds = Tn4Lds<CT, RT, 2, U>::bytes;
-        if (lds > 48 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)gemm_tn4_kernel<CT, RT, 2, U, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LCXCHECK(allow_lds(gemm_tn4_kernel<CT, RT, 2, U, true>, lds));
         hipLaunchKernelGGL((gemm_tn4_kernel<CT, RT, 2, U, true>), grid, dim3(128), lds, st, A, lda, B, out, vcols_pad, kgroups, S, skip);
     } else {
         const size_t lds = Tn4Lds<CT, RT, 4, U>::bytes;
-        if (lds > 48 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)gemm_tn4_kernel<CT, RT, 4, U, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LCXCHECK(allow_lds(gemm_tn4_kernel<CT, RT, 4, U, true>, lds));
         hipLaunchKernelGGL((gemm_tn4_kernel<CT, RT, 4, U, true>), grid, dim3(256), lds, st, A, lda, B, out, vcols_pad, kgroups, S, skip);
     }
     KCHECK();

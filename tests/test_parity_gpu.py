@@ -6,8 +6,11 @@ Tolerances (stated per SURVEY.md §8c / BASELINE.md §4):
                                history/cov <= 1e-6 relative (north_star), clusters bit-exact;
   float32 build vs oracle-32 : step level 2e-4 of the array scale (the reference itself is only
                                self-consistent to ~2e-5 under summation-order changes and loses
-                               more through 1/(1-rho^2)); end to end TC within 1e-3 relative,
-                               clusters bit-exact on structured inputs, iteration count within 15%.
+                               more through 1/(1-rho^2)); end to end (measured with tools/f32_deviation.py:
+                               iteration counts 259/263, 169/162, 225/220, final TC 1e-7..7e-7, covariance
+                               3e-5..6e-4) final TC within 5e-5 relative, covariance within 2e-3 (big5) /
+                               5e-4 (planted), iteration count within 6 %, clusters bit-exact on structured
+                               inputs.  The reference itself moves by +-2 iterations between BLAS builds.
 """
 import numpy as np
 import pytest
@@ -175,10 +178,10 @@ def test_big5_end_to_end(tag, g1):
         assert abs(out.moments["additivity"] - float(g1["f64_mom_additivity"])) < 1e-6
         assert abs(out.moments["TC_no_overlap"] - float(g1["f64_mom_TC_no_overlap"])) < 1e-6
     else:
-        assert abs(len(h) - len(h_ref)) <= 0.15 * len(h_ref)
-        assert abs(float(out.tc) - float(g1["f32_tc"])) < 1e-3 * float(g1["f32_tc"])
-        assert relerr(out.get_covariance(), g1["f32_cov"]) < 5e-3
-        assert relerr(out.moments["TCs"], g1["f32_mom_TCs"]) < 5e-3
+        assert abs(len(h) - len(h_ref)) <= 0.06 * len(h_ref)
+        assert abs(float(out.tc) - float(g1["f32_tc"])) < 5e-5 * float(g1["f32_tc"])
+        assert relerr(out.get_covariance(), g1["f32_cov"]) < 2e-3
+        assert relerr(out.moments["TCs"], g1["f32_mom_TCs"]) < 2e-3
 
 
 @pytest.mark.parametrize("tag", ["f32", "f64"])
@@ -200,9 +203,9 @@ def test_planted_small_end_to_end(tag, g2_small):
         assert abs(np.linalg.norm(cov) - float(g["f64_cov_fro"])) < 1e-6 * float(g["f64_cov_fro"])
         assert relerr(cov[-4:], g["f64_cov_lastrows"]) < 1e-6
     else:
-        assert abs(len(h) - len(h_ref)) <= 0.15 * len(h_ref)
-        assert abs(h[-1] - h_ref[-1]) < 1e-3 * abs(h_ref[-1])
-        assert relerr(cov[:256, :256], g["f32_cov_block"]) < 5e-3
+        assert abs(len(h) - len(h_ref)) <= 0.06 * len(h_ref)
+        assert abs(h[-1] - h_ref[-1]) < 5e-5 * abs(h_ref[-1])
+        assert relerr(cov[:256, :256], g["f32_cov_block"]) < 5e-4
 
 
 @pytest.mark.parametrize("tag", ["f32", "f64"])
@@ -248,9 +251,9 @@ def test_column_tiled_gemm_end_to_end(tag, g2_small, monkeypatch):
         assert relerr(h, h_ref) < 1e-6
         assert relerr(cov[:256, :256], g["f64_cov_block"]) < 1e-6
     else:
-        assert abs(len(h) - len(h_ref)) <= 0.15 * len(h_ref)
-        assert abs(h[-1] - h_ref[-1]) < 1e-3 * abs(h_ref[-1])
-        assert relerr(cov[:256, :256], g["f32_cov_block"]) < 5e-3
+        assert abs(len(h) - len(h_ref)) <= 0.06 * len(h_ref)
+        assert abs(h[-1] - h_ref[-1]) < 5e-5 * abs(h_ref[-1])
+        assert relerr(cov[:256, :256], g["f32_cov_block"]) < 5e-4
 
 
 def test_f64_kernel_choice_and_fallback(g2_small, monkeypatch):

@@ -33,6 +33,9 @@ using namespace lcx;
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
     g_err = msg;
+    // HIP keeps the last error per thread until somebody reads it: a failed hipMalloc reported here would otherwise
+    // resurface at the next kernel launch check (hipGetLastError) of a perfectly good call
+    if (code == LCX_ERR_HIP) (void)hipGetLastError();
     return code;
 }
 #define HIPCHECK(expr)                                                                         \
@@ -1494,9 +1497,12 @@ static int ct_for(int m) {
     return 0;
 }
 
+// (the read of the per-thread last error drops whatever an earlier, unrelated HIP call of this thread left behind: the
+// launch checks of this call must only see this call's errors)
 #define NEED(h)                                            \
     if (!(h)) return fail(LCX_ERR_ARG, "null handle");     \
-    HIPCHECK(hipSetDevice((h)->device));
+    HIPCHECK(hipSetDevice((h)->device));                   \
+    (void)hipGetLastError();
 
 // Every entry point that changes the fit state abandons a speculation of lcx_iterate (its kernels run to completion on
 // buffers only a trial owns; what they leave behind in the shared exchange buffer is remembered in spec_dirty).

@@ -50,3 +50,63 @@ def test_nan_cells_without_missing_values_poison_tc_like_the_reference(capsys):
     out = Corex(n_hidden=2, seed=0, dtype=np.float64, device=0, max_iter=3).fit(x)
     assert len(out.history["TC"]) == 21 and not np.isfinite(out.history["TC"][-1])
     assert "TC is no longer finite" in capsys.readouterr().out
+
+
+def test_out_of_memory_in_create_is_an_error_and_leaks_nothing():
+    """A shard that cannot be allocated (X and its transposed copy alone would be 2 x 16 TB) fails with LcxError, releases what
+    it had allocated (the same request can be repeated without the device filling up) and leaves the library usable."""
+    import ctypes as C
+    from linearcorex_amd import Corex, _abi
+    from linearcorex_amd.backend import HipBackend
+    lib = _abi.load()
+    free0, total = C.c_size_t(), C.c_size_t()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemGetInfo(C.byref(free0), C.byref(total))
+    for _ in range(3):
+        with pytest.raises(_abi.LcxError, match="hipMalloc|out of memory|memory"):
+            HipBackend(2_000_000, 2_000_000, 64, np.float32, 0)
+    free1 = C.c_size_t()
+    hip.hipMemGetInfo(C.byref(free1), C.byref(total))
+    assert free0.value - free1.value < (256 << 20), (free0.value, free1.value)
+    x, _ = O.gen_planted(200, 60, 3, seed=5)
+    out = Corex(n_hidden=3, seed=0, dtype=np.float64, device=0, max_iter=5).fit(x)
+    ref = O.fit_ns(x, 3, seed=0, dtype=np.float64, max_iter=5)
+    assert np.max(np.abs(np.asarray(out.history["TC"], np.float64) - np.asarray(ref.history_tc))) < 1e-9
+    assert lib.lcx_abi_version() == 1
+
+
+def test_abi_misuse_returns_status_codes():
+    """Plain-C callers get status codes, never a crash: null handles and pointers, out-of-range arguments, calls out of
+    sequence (the error conventions table of INTEGRATION.md)."""
+    import ctypes as C
+    from linearcorex_amd import _abi
+    from linearcorex_amd.backend import HipBackend
+    lib = _abi.load()
+    ARG, STATE = 1, 4
+    assert lib.lcx_moments_a(None, 0) == ARG and b"null handle" in lib.lcx_last_error()
+    assert lib.lcx_destroy(None) == 0
+    h = C.c_void_p()
+    assert lib.lcx_create(C.byref(h), 0, 10, 2, 0, 0) == ARG                 # no samples
+    assert lib.lcx_create(C.byref(h), 10, 10, 2, 7, 0) == ARG                # unknown dtype
+    assert lib.lcx_create(C.byref(h), 10, 10, 2, 0, 99) == ARG               # no such device
+    assert lib.lcx_create(C.byref(h), 10, 10, 300, 0, 0) == ARG              # more than 256 factors
+    be = HipBackend(64, 40, 3, np.float64, 0)
+    assert lib.lcx_moments_a(be.h, 2) == ARG                                  # which must be 0 or 1
+    assert lib.lcx_make_trial(be.h, C.c_double(1.0)) == STATE                 # no direction yet
+    assert lib.lcx_set_ws(be.h, None) == ARG
+    assert lib.lcx_upload_x(be.h, None, 40) == ARG
+    assert lib.lcx_read_state(be.h, 0, None) == ARG
+    out = (C.c_double * 8)()
+    assert lib.lcx_covariance_rows(be.h, C.c_double(0.0), None, 0, 1, None) == ARG
+    assert lib.lcx_covariance_rows(be.h, C.c_double(0.0), C.cast(out, C.c_void_p), 39, 5, C.cast(out, C.c_void_p)) == ARG   # rows past the end
+    assert lib.lcx_timing_read(be.h, 5, None, None) == ARG
+    assert lib.lcx_syn_update_a(be.h) == STATE                                # before any synergistic moments
+    buf = C.create_string_buffer(8)
+    assert lib.lcx_kernel_name(be.h, 0, buf, 8) == ARG                        # buffer too small
+    # the handle is still good after all of that
+    x = np.random.RandomState(0).randn(64, 40)
+    be.upload_x(x - x.mean(0))
+    be.set_ws(np.random.RandomState(1).randn(3, 40) * 0.01)
+    be.moments_a(0); be.moments_b(0, 0.0, 0); be.moments_c(0)
+    assert np.isfinite(be.read_state(0)[0])
+    be.close()

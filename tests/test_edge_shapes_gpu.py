@@ -110,3 +110,49 @@ def test_abi_misuse_returns_status_codes():
     be.moments_a(0); be.moments_b(0, 0.0, 0); be.moments_c(0)
     assert np.isfinite(be.read_state(0)[0])
     be.close()
+
+
+def test_repeated_fits_release_their_device_memory():
+    """Fit / get_covariance / transform / close in a loop (both branches, merged-pass buffers, covariance staging, synergistic
+    buffers): free device memory after the loop is what it was before it, and refitting one object with another shape works."""
+    import ctypes as C
+    from linearcorex_amd import Corex
+    hip = C.CDLL("libamdhip64.so")
+    free0, free1, total = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    rng = np.random.RandomState(0)
+    warm = Corex(n_hidden=3, seed=0, dtype=np.float32, device=0, max_iter=2).fit(rng.randn(100, 50))
+    warm.get_covariance()
+    warm._backend.close()
+    hip.hipMemGetInfo(C.byref(free0), C.byref(total))
+    for k in range(12):
+        syn = k % 3 == 2
+        x = rng.randn(300 + 37 * k, 200 + 61 * k)
+        mdl = Corex(n_hidden=4 + k, seed=0, dtype=np.float32 if k % 2 else np.float64, device=0, max_iter=3,
+                    discourage_overlap=not syn).fit(x)
+        assert mdl.get_covariance().shape == (x.shape[1], x.shape[1])
+        assert mdl.transform(x[:17]).shape == (17, 4 + k)
+        if k % 4 == 0:                                   # the same object again, another shape
+            x2 = rng.randn(150, 90)
+            mdl.ws = np.zeros((0, 0))
+            mdl.fit(x2)
+            assert mdl.ws.shape == (4 + k, 90)
+        mdl._backend.close()
+    hip.hipMemGetInfo(C.byref(free1), C.byref(total))
+    assert abs(int(free0.value) - int(free1.value)) < (64 << 20), (free0.value, free1.value)
+
+
+def test_empirical_gaussianize_goes_through_the_host_rank_transform(capsys):
+    """gaussianize='empirical' (reference :424-426: rank transform per column, done on the host like the reference does) must
+    give the fit of the rank-transformed data; 'none' (and any unknown name, :404-405) passes the data through."""
+    from linearcorex_amd import Corex
+    from linearcorex_amd.preprocess import preprocess as pp
+    x = np.random.RandomState(9).lognormal(size=(300, 40))
+    out = Corex(n_hidden=3, seed=0, dtype=np.float64, device=0, max_iter=6, gaussianize="empirical").fit(x)
+    assert "empirical gauss transform not implemented" in capsys.readouterr().out      # the reference's own warning (:425)
+    xr = pp(x, None, "empirical", None)[0]
+    ref = Corex(n_hidden=3, seed=0, dtype=np.float64, device=0, max_iter=6, gaussianize="none").fit(xr)
+    h, hr = np.asarray(out.history["TC"], np.float64), np.asarray(ref.history["TC"], np.float64)
+    assert len(h) == len(hr) and np.array_equal(h, hr)
+    orc = O.fit_ns(xr, 3, seed=0, dtype=np.float64, max_iter=6, gaussianize="none")
+    assert np.max(np.abs(h - np.asarray(orc.history_tc))) < 1e-9
+    assert out.transform(x).shape == (300, 3)

@@ -608,6 +608,11 @@ def test_more_than_128_factors_end_to_end(tag):
         assert relerr(out.ws, ref.ws) < 1e-6
         assert relerr(out.get_covariance(), ref.get_covariance()) < 1e-6
         assert relerr(out.moments["X_i Z_j"], ref.moments["X_i Z_j"]) < 1e-6
+        lin = Corex(n_hidden=m, seed=0, max_iter=4, dtype=np.float64, device=0, line_search="linear").fit(x)
+        hl = np.asarray(lin.history["TC"], np.float64)
+        assert len(hl) == len(h_ref) and np.max(np.abs(hl - h_ref) / np.maximum(1.0, np.abs(h_ref))) < 1e-6
+        y_det, mom = out.transform(x, details=True)
+        assert relerr(y_det, ref.transform(ref.x_tilde)) < 1e-7 and relerr(mom["TCs"], ref.moments["TCs"]) < 1e-6
         syn_ref = O.fit_syn(x, m, seed=0, dtype=np.float64, max_iter=5)
         syn = Corex(n_hidden=m, seed=0, max_iter=5, dtype=np.float64, device=0, discourage_overlap=False).fit(x)
         hs, hs_ref = np.asarray(syn.history["TC"], np.float64), np.asarray(syn_ref.history_tc)

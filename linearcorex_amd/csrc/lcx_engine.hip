@@ -150,6 +150,10 @@ struct lcx_ctx {
     // lcx_iterate: the direction and first trial of the NEXT iteration are already enqueued (speculation); spec_dirty: a
     // speculation was abandoned, i.e. sbuf holds the H of a trial that was never accepted instead of the H of set 0
     bool spec_pending, spec_dirty;
+    // lcx_iterate computes the gradient of every trial right behind its evaluation (early_grad: `grad` / `bjpart` hold the
+    // gradient of set 1); when the trial is accepted it IS the next iteration's gradient (grad_ready) and the GPU did not
+    // wait for the host's decision to start on it
+    bool early_grad, grad_ready;
     double spec_eps;
     size_t bytes_resident;      // device bytes owned by the handle (X, its transposed copy, moments, work space)
 };
@@ -754,6 +758,17 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
 
+    // grad (:296-300) and the per-block Bj partials (:302) of set `which`, from its moments and the H its evaluation left in sbuf
+    static int launch_grad(lcx_ctx* h, int which) {
+        MomentSet& s = h->set[which];
+        const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * (Mp + 1) : 0) + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
+        LCXCHECK(allow_lds(grad_kernel<T, Mp>, lds));
+        hipLaunchKernelGGL((grad_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(h->Wt[which]),
+                           P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), s.uj, h->sbuf + SB_H, h->V,
+                           P<T>(h->grad), h->bjpart, use_merged(h) ? P<T>(h->gw) : (T*)nullptr);
+        KCHECK();
+        return LCX_OK;
+    }
     static int update_b(lcx_ctx* h, double eps) {
         (void)eps;
         if (h->spec_dirty) {                            // an abandoned speculation overwrote the H of set 0 in sbuf
@@ -762,13 +777,9 @@ template <typename T, int CT> struct Impl {
             h->spec_dirty = false;
         }
         MomentSet& s = h->set[0];
-        const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * (Mp + 1) : 0) + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
-        LCXCHECK(allow_lds(grad_kernel<T, Mp>, lds));
         const bool merged = use_merged(h);
-        hipLaunchKernelGGL((grad_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(h->Wt[0]),
-                           P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), s.uj, h->sbuf + SB_H, h->V,
-                           P<T>(h->grad), h->bjpart, merged ? P<T>(h->gw) : (T*)nullptr);
-        KCHECK();
+        if (h->grad_ready) h->grad_ready = false;       // lcx_iterate already computed it behind the accepted trial's evaluation
+        else LCXCHECK(launch_grad(h, 0));
         if (!merged) return nt_big(h, P<T>(h->grad), nullptr, true);
         if constexpr (sizeof(T) == 4 && CT >= 2 && CT <= 4) {
             // Bj (:302) does not wait for the pass: sum its per-block partials now, form update and ws + update (:303, :320) and
@@ -841,13 +852,24 @@ template <typename T, int CT> struct Impl {
     }
 
     // ---- one whole fixed-point iteration with its back-tracking line search (:290-334), one GPU -------------------
+    // :321 for the weights in set 1, and right behind it the gradient those weights would need next (:296-300): if the trial
+    // is accepted that gradient is already there when the host has decided, if not it is overwritten by the next trial's
+    static int evaluate_trial(lcx_ctx* h, double eps) {
+        LCXCHECK(moments_a(h, 1));
+        LCXCHECK(moments_b(h, 1, eps, 1));
+        h->early_grad = false;
+        if (!h->full_sig) {                          // (the linear trial mode keeps grad / sig_grad of the direction in flight)
+            LCXCHECK(launch_grad(h, 1));
+            h->early_grad = true;
+        }
+        return LCX_OK;
+    }
     static int direction_and_trial(lcx_ctx* h, double eps) {
         LCXCHECK(update_b(h, eps));                  // grad (:296-300), Y_g = X.grad^T (:210), Bj (:302)
         LCXCHECK(update_c(h, eps));                  // update (:303), update_tangent partials (:305), ws + update
         h->have_direction = true;
         LCXCHECK(make_trial(h, 1.0));                // :320 at eta = 1 (update_kernel wrote it already)
-        LCXCHECK(moments_a(h, 1));                   // :321
-        return moments_b(h, 1, eps, 1);
+        return evaluate_trial(h, eps);
     }
     static int iterate(lcx_ctx* h, double eps, double tol, double tc_cur, int more, double* out) {
         if (h->exchange)
@@ -865,8 +887,7 @@ template <typename T, int CT> struct Impl {
             if (!first) {
                 if (eta < eta_min) { too_small = 1; break; }                     // :316-319
                 LCXCHECK(make_trial(h, eta));                                    // :320
-                LCXCHECK(moments_a(h, 1));                                       // :321
-                LCXCHECK(moments_b(h, 1, eps, 1));
+                LCXCHECK(evaluate_trial(h, eps));                                // :321
             }
             ++trials;
             LCXCHECK(wait_published(h, h->set[1]));
@@ -876,6 +897,7 @@ template <typename T, int CT> struct Impl {
                 tangent = st.tangent;                                            // :305, summed by the first trial's tail
                 if (tangent >= 0) {                                              // :306-311: keep ws, discard the trial
                     LCXCHECK(update_a(h));                                       // its H went to sbuf: restore set 0's
+                    h->early_grad = h->grad_ready = false;
                     h->have_direction = false;
                     h->w1_ready = h->y1_ready = false;
                     out[0] = 1; out[1] = tc_cur; out[2] = tangent; out[3] = trials - 1; out[4] = 0; out[5] = 0; out[6] = trials; out[7] = 0;
@@ -895,6 +917,8 @@ template <typename T, int CT> struct Impl {
         std::swap(h->set[0], h->set[1]);
         h->have_direction = false;
         const bool ok = have_last && !last_invalid;
+        h->grad_ready = ok && h->early_grad && !too_small;   // the gradient of the accepted trial = the next iteration's gradient
+        h->early_grad = false;
         int speculated = 0;
         if (ok && more) {
             const double delta = last_tc > tc_cur ? last_tc - tc_cur : tc_cur - last_tc;
@@ -1509,12 +1533,13 @@ static int ct_for(int m) {
 static inline void cancel_speculation(lcx_ctx* h) {
     if (h->spec_pending) {
         h->spec_pending = false;
+        h->early_grad = h->grad_ready = false;
         h->spec_dirty = true;
         h->have_direction = false;
         h->w1_ready = h->y1_ready = false;
     }
 }
-#define NEED_MUT(h) NEED(h); cancel_speculation(h)
+#define NEED_MUT(h) NEED(h); cancel_speculation(h); (h)->early_grad = (h)->grad_ready = false
 
 // ---- isolated GEMM checks -------------------------------------------------------------------------
 template <typename T, int CT>
@@ -1746,6 +1771,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     h->world = 1;
     h->seq_next = 0;
     h->spec_pending = h->spec_dirty = false;
+    h->early_grad = h->grad_ready = false;
     h->spec_eps = 0.0;
     HIPCHECK(hipStreamSynchronize(st));
     *out = h;

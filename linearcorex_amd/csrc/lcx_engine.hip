@@ -858,7 +858,10 @@ template <typename T, int CT> struct Impl {
         LCXCHECK(moments_a(h, 1));
         LCXCHECK(moments_b(h, 1, eps, 1));
         h->early_grad = false;
-        if (!h->full_sig) {                          // (the linear trial mode keeps grad / sig_grad of the direction in flight)
+        // Worth it while the gradient kernel is shorter than the host's decision latency (~20 us): up to ~1M (variable, factor)
+        // pairs (config 2: 5 us).  On large shards a rejected trial would waste more than the gap it hides (config 4 shard: 289 us).
+        // (The linear trial mode keeps grad / sig_grad of the direction in flight.)
+        if (!h->full_sig && h->V * (int64_t)Mp <= ((int64_t)1 << 20)) {
             LCXCHECK(launch_grad(h, 1));
             h->early_grad = true;
         }

@@ -91,6 +91,8 @@ def parse(argv=None):
     ap.add_argument("--convergence-max-iter", type=int, default=60,
                     help="iterations per annealing stage allowed to the whole-fit wall-clock measurement of a generated headline "
                          "workload (0 = skip)")
+    ap.add_argument("--convergence-planted-max-iter", type=int, default=2000,
+                    help="iterations per annealing stage allowed to the whole-fit wall-clock measurement on planted data")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-sample", type=int, default=0,
                     help="HIP-event pairs around every n-th X pass of the timed windows (a pair costs ~5 us of stream time; "
@@ -237,14 +239,7 @@ def _host_gaussian(n, v, dtype, seed):
     return x
 
 
-def cpu_baseline_generated(n, v, m, dtype, budget_s, label):
-    """Large workloads (c3, c4 shard): X cannot be taken from the GPU run (it is generated on the device), so an iid
-    Gaussian X of the same shape is drawn on the host (fewer variables if the host's memory cannot hold it: the
-    iteration cost is linear in n_variables and the scale is stated), and the oracle's loop (reference :136-155) is
-    timed for at least 3 iterations, one per annealing stage while the budget lasts."""
-    import numpy as np
-    from oracle import corex_oracle as O
-    es = np.dtype(dtype).itemsize
+def _host_memory_available():
     avail = None
     try:
         with open("/proc/meminfo") as f:
@@ -266,49 +261,72 @@ def cpu_baseline_generated(n, v, m, dtype, budget_s, label):
                 avail = min(avail, int(lim) - used) if avail is not None else int(lim) - used
     except Exception:
         pass
-    v_cpu = v
+    return avail
+
+
+def cpu_baseline_generated(n, v, m, dtype, budget_s, label, also=()):
+    """Large workloads (c3, c4 shard): X cannot be taken from the GPU run (it is generated on the device), so an iid
+    Gaussian X of the same shape is drawn on the host (fewer variables if the host's memory cannot hold it, and never
+    more than 10^5 - BASELINE.md section 3: the iteration cost is linear in n_variables and the scale is stated), and the
+    oracle's loop (reference :136-155) is timed for at least 3 iterations, one per annealing stage while the budget lasts.
+    also: further (label, n_hidden, n_variables of that workload) timed on the same host matrix; the return value is then
+    a list, the first entry being the one described by the positional arguments."""
+    import numpy as np
+    from oracle import corex_oracle as O
+    es = np.dtype(dtype).itemsize
+    avail = _host_memory_available()
+    v_cpu = min(v, 100000)
     if avail is not None:
         fit = int(0.6 * avail / (n * es))
-        if fit < v:
+        if fit < v_cpu:
             v_cpu = max(1000, fit // 1000 * 1000)
     t_gen = time.perf_counter()
     x = _host_gaussian(n, v_cpu, dtype, seed=1)
     t_gen = time.perf_counter() - t_gen
-    with _BlasPool() as pool:
-        threads, vendor = pool.threads, pool.vendor
-        w = O.initial_weights(0, m, v_cpu, dtype)
-        w /= (10.0 * O.norm(x, w, 0))[:, np.newaxis]
-        mo = O.moments_ns(x, w, 0, quick=True)
-        eps, n_it, trials, t_iter, t_stage, stages = 0, 0, 0, 0.0, 0.0, 0
-        t_begin = time.perf_counter()
-        for stage, eps_new in enumerate(O.anneal_schedule(True)):
-            t0 = time.perf_counter()
-            eps_old, eps = eps, eps_new
-            if stage > 0:
-                w = O.rescale_for_stage(w, mo["uj"], eps_old, eps)
-            mo = O.moments_ns(x, w, eps, quick=False)
-            t1 = time.perf_counter()
-            w, mo, info = O.update_ns(x, w, mo, eps, 0.0)
-            t2 = time.perf_counter()
-            t_stage += t1 - t0
-            t_iter += t2 - t1
-            n_it += 1
-            stages += 1
-            trials += info["n_trials"]
-            if n_it >= 3 and (time.perf_counter() - t_begin) > budget_s:
-                break
-    its = n_it / t_iter
-    scale = float(v_cpu) / float(v)
-    del x
-    return {"value": its * scale, "unit": "iterations/s", "cores": threads, "kind": "port",
+    results = []
+    for lab, mm, v_work in [(label, m, v)] + list(also):
+        with _BlasPool() as pool:
+            threads, vendor = pool.threads, pool.vendor
+            w = O.initial_weights(0, mm, v_cpu, dtype)
+            w /= (10.0 * O.norm(x, w, 0))[:, np.newaxis]
+            mo = O.moments_ns(x, w, 0, quick=True)
+            eps, n_it, trials, invalid, t_iter, t_stage, stages = 0, 0, 0, 0, 0.0, 0.0, 0
+            t_begin = time.perf_counter()
+            for stage, eps_new in enumerate(O.anneal_schedule(True)):
+                t0 = time.perf_counter()
+                eps_old, eps = eps, eps_new
+                if stage > 0:
+                    w = O.rescale_for_stage(w, mo["uj"], eps_old, eps)
+                mo = O.moments_ns(x, w, eps, quick=False)
+                t1 = time.perf_counter()
+                w, mo, info = O.update_ns(x, w, mo, eps, 0.0)
+                t2 = time.perf_counter()
+                t_stage += t1 - t0
+                t_iter += t2 - t1
+                n_it += 1
+                stages += 1
+                trials += info["n_trials"]
+                invalid += info["n_invalid"]
+                if n_it >= 3 and (time.perf_counter() - t_begin) > budget_s:
+                    break
+        its = n_it / t_iter
+        scale = float(v_cpu) / float(v_work)
+        results.append({
+            "value": its * scale, "unit": "iterations/s", "cores": threads, "kind": "port",
             "sample": "%s: %d iterations of the oracle loop (reference linearcorex.py:136-155), the first one of each of the "
                       "first %d annealing stages, on host-generated iid Gaussian X %d x %d %s, n_hidden %d; %.1f s in the "
                       "iterations (%.2f s each), %.1f s in the %d stage changes, %.1f s to draw X; NumPy %s / %s, BLAS threads=%d"
-                      % (label, n_it, stages, n, v_cpu, np.dtype(dtype).name, m, t_iter, t_iter / n_it, t_stage, stages, t_gen,
+                      % (lab, n_it, stages, n, v_cpu, np.dtype(dtype).name, mm, t_iter, t_iter / n_it, t_stage, stages, t_gen,
                          np.__version__, vendor, threads),
-            "n_variables_timed": v_cpu, "n_variables_workload": v,
+            "n_variables_timed": v_cpu, "n_variables_workload": v_work,
             "scaled_linearly_in_n_variables_by": scale, "measured_iterations_per_sec_at_timed_size": its,
-            "trials_per_iteration": trials / max(1, n_it)}
+            "trials_per_iteration": trials / max(1, n_it),
+            "x_passes_per_iteration": (2 * n_it + 2 * trials - invalid) / max(1, n_it),
+            "not_the_same_work_as_value": "the oracle makes the reference's 2 + 2T - E passes over X per iteration (T trials, E "
+                                          "early exits; first iterations of the stages), the device path elides the second _sig "
+                                          "pass and merges passes (config.x_passes_per_iteration): a reported baseline, not a ratio"})
+    del x
+    return results if also else results[0]
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -396,7 +414,7 @@ def make_model(workload, comm, world, rank, local_rank, line_search, keep_x=Fals
 
 
 def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_search, keep_x=False, repeats=0,
-            kernel_timing=True):
+            kernel_timing=True, min_repeats=1):
     """Walk the 7-stage schedule; per stage: the stage change (timed on its own), then a window of exactly `steps`
     iterations (barrier + synchronize on both sides).  Repeat the walk from the same start until MIN_TIMED_SECONDS
     of windows have been timed."""
@@ -471,6 +489,7 @@ def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_s
     est = sum(first_win)
     if repeats <= 0:
         repeats = 1 if est >= MIN_TIMED_SECONDS else min(60, int(math.ceil(MIN_TIMED_SECONDS / max(est, 1e-6))))
+        repeats = max(repeats, min_repeats)
     wins, chgs = [], []
     for _ in range(repeats):
         w, c = walk(record=True)
@@ -594,6 +613,66 @@ def config_of(workload, r, world, line_search, force_exchange=False):
             "bytes_resident": r["bytes_resident"], "force_exchange": bool(force_exchange)}
 
 
+def linear_mode_block(workload, r3, world):
+    """The same iterations with the linear trial mode (SURVEY.md section 7 'linearity shortcut'): trials cost no
+    pass over X.  Reported beside the reference-shaped figure, never as `value`; the roofline is computed from the flops
+    this mode actually executes."""
+    rl = roofline_of(workload, r3, world) or {}
+    it = rl.get("iteration") or {}
+    return {"fit_iterations_per_sec": r3["its_per_s"], "ms_per_step": r3["per_step_s"] * 1e3,
+            "x_passes_per_iteration": r3["x_passes"], "line_search_trials_per_iteration": r3["trials"],
+            "final_TC": r3["final_tc"], "refresh_every": 16,
+            "ms_per_step_walk_min_median_max": r3["windows"]["ms_per_step_walk_min_median_max"],
+            "roofline": {k: rl.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_us", "launches")},
+            "iteration_executed_TFLOPs": it.get("achieved_TFLOPs"), "iteration_executed_GBps": it.get("achieved_GBps")}
+
+
+def planted_groups(seed, n_variables, n_groups, col_offset=0):
+    """Group of every column of lcx_generate_x(kind=1) (moment_kernels.hpp generate_kernel: mix64(seed*31 + column) mod groups)."""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) * np.uint64(31) + (np.arange(n_variables, dtype=np.uint64) + np.uint64(col_offset))
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z % np.uint64(n_groups)).astype(np.int64)
+
+
+def cluster_purity(clusters, groups, n_groups):
+    """fraction of variables whose cluster's majority planted group is their own"""
+    import numpy as np
+    table = np.zeros((int(clusters.max()) + 1, n_groups), np.int64)
+    np.add.at(table, (clusters, groups), 1)
+    return float(table.max(axis=1).sum() / len(clusters))
+
+
+def convergence_block(n, v, m, dtype, device, kind, max_iter, seed=1):
+    """BASELINE.json's second figure: wall-clock of a whole fit() of a generated workload - data generation and
+    standardisation on the device, 7 annealing stages each to |dTC| < tol = 1e-5 (reference defaults :72-74, :152-155)
+    or `max_iter` iterations, final detail moments and factor sort (:160-163)."""
+    import numpy as np
+    from linearcorex_amd import Corex
+    t0 = time.perf_counter()
+    mdl = Corex(n_hidden=m, seed=0, dtype=dtype, device=device, max_iter=max_iter)
+    mdl.fit_generated(n, v, seed=seed, kind=kind, n_groups=m)
+    t1 = time.perf_counter()
+    n_it = len(mdl.history["TC"])
+    blk = {"data": "planted: %d latent groups + unit noise per variable (lcx_generate_x kind 1)" % m if kind == 1
+                   else "iid N(0,1) (lcx_generate_x kind 0): no structure to converge to",
+           "seconds": t1 - t0, "iterations": n_it, "TC": float(mdl.tc), "tol": 1e-5,
+           "max_iter_per_stage": max_iter, "iterations_by_stage": list(mdl.stage_iterations),
+           "stages_converged_before_the_cap": int(sum(1 for k in mdl.stage_iterations if k < max_iter)),
+           "iterations_per_sec_incl_setup": n_it / (t1 - t0),
+           "trials_per_iteration": mdl.stats["trials"] / max(1, n_it)}
+    if kind == 1:
+        blk["cluster_purity_vs_planted_groups"] = cluster_purity(mdl.clusters(), planted_groups(seed, v, m), m)
+        blk["distinct_clusters"] = int(len(np.unique(mdl.clusters())))
+    mdl._backend.close()
+    del mdl
+    return blk
+
+
 def covariance_block(model, be, label):
     """get_covariance() (reference :443-451) of the resident solution: seconds (median of 3 calls, each into a freshly
     allocated NumPy matrix) and the device time of the product kernels."""
@@ -706,7 +785,7 @@ def main():
     # ---- headline: the reference-shaped iteration (every line-search trial re-evaluates the moments with two passes
     # over X, linearcorex.py:321) ----
     r, model, be = measure(args, comm, world, rank, local_rank, head, args.steps, args.warmup, args.line_search,
-                           keep_x=True, repeats=args.repeats)
+                           keep_x=True, repeats=args.repeats, min_repeats=3 if args.extras else 1)
     roofline = roofline_of(head, r, world)
     cfg = config_of(head, r, world, args.line_search, args.force_exchange)
     x_head = r.pop("x_host")
@@ -718,23 +797,21 @@ def main():
     be.close()
     model._backend = None
     del model, be
-    if args.extras and world == 1 and comm is None and x_head is None and args.convergence_max_iter > 0:
-        # BASELINE.json's second figure for the headline workload: wall-clock of a whole fit (data generation, 7 stages to
-        # |dTC| < 1e-5 each - capped at --convergence-max-iter iterations per stage - final detail moments and factor sort)
-        from linearcorex_amd import Corex
-        t0 = time.perf_counter()
-        mdl = Corex(n_hidden=m, seed=0, dtype=dtype, device=local_rank, max_iter=args.convergence_max_iter)
-        mdl.fit_generated(n, v_per, seed=1)
-        t1 = time.perf_counter()
-        n_it = len(mdl.history["TC"])
-        cfg["fit_to_convergence"] = {
-            "seconds": t1 - t0, "iterations": n_it, "TC": float(mdl.tc), "tol": 1e-5,
-            "max_iter_per_stage": args.convergence_max_iter, "iterations_by_stage": list(mdl.stage_iterations),
-            "stages_converged_before_the_cap": int(sum(1 for k in mdl.stage_iterations if k < args.convergence_max_iter)),
-            "iterations_per_sec_incl_setup": n_it / (t1 - t0),
-            "trials_per_iteration": mdl.stats["trials"] / max(1, n_it)}
-        mdl._backend.close()
-        del mdl
+    generated = x_head is None
+    if args.extras and generated and args.line_search == "exact":
+        # the linear trial mode where a trial costs two 5-11 ms passes: reported beside the headline, never as `value`
+        r3, model3, be3 = measure(args, comm, world, rank, local_rank, head, args.steps, args.warmup, "linear")
+        cfg["linear_trial_mode"] = linear_mode_block(head, r3, world)
+        be3.close()
+        model3._backend = None
+        del model3, be3
+    if args.extras and world == 1 and comm is None and generated and args.convergence_max_iter > 0:
+        # BASELINE.json's second figure for the headline workload.  On the iid matrix of the throughput run there is nothing to
+        # converge to (every stage runs into the cap): that run is labelled as capped, and the convergence measurement proper is
+        # the planted matrix of the same shape, each stage to |dTC| < 1e-5
+        cfg["fit_to_convergence"] = convergence_block(n, v_per, m, dtype, local_rank, 0, args.convergence_max_iter)
+        cfg["fit_to_convergence"]["capped"] = True
+        cfg["fit_to_convergence_planted"] = convergence_block(n, v_per, m, dtype, local_rank, 1, args.convergence_planted_max_iter)
 
     out = {
         "metric": "corex_fit_iterations_per_sec",
@@ -797,12 +874,41 @@ def main():
         out["config"]["c2" if world == 1 else "c2_weak"] = blk
         del x2
 
-        # ---- CPU baseline of the headline workload, rank 0 at N=1 only ----
-        if rank == 0 and world == 1 and comm is None and args.cpu_seconds > 0:
+        # ---- N=1, default workload: the one-GPU point of the weak-scaling series the --gpus N lines headline (configs[3]'s
+        # shard), so that the series 1 -> 8 is self-contained in the driver's records ----
+        c4 = None
+        if auto and world == 1 and comm is None and head == "c3":
+            r4, model4, be4 = measure(args, comm, world, rank, local_rank, "c4shard", 10, 3, "exact")
+            c4 = config_of("c4shard", r4, world, "exact")
+            c4["value"] = r4["its_per_s"]
+            c4["ms_per_step"] = r4["per_step_s"] * 1e3
+            c4["dtype"] = "f32"
+            c4["roofline"] = roofline_of("c4shard", r4, world)
+            c4["what"] = ("the workload `python bench.py --gpus N` headlines for N > 1, on one GPU without exchange steps: "
+                          "value(N) / (N x this value) is the weak-scaling efficiency of that series")
+            be4.close()
+            model4._backend = None
+            del model4, be4
+            r5, model5, be5 = measure(args, comm, world, rank, local_rank, "c4shard", 10, 3, "linear")
+            c4["linear_trial_mode"] = linear_mode_block("c4shard", r5, world)
+            be5.close()
+            model5._backend = None
+            del model5, be5
+            out["config"]["c4shard"] = c4
+
+        # ---- CPU baseline of the headline workload: rank 0, the other ranks wait in the barrier below ----
+        if rank == 0 and args.cpu_seconds > 0 and (world == 1 and comm is None or world > 1):
             if x_head is not None:
                 out["cpu_baseline"] = cpu_baseline_resident(x_head, m, dtype, max(1, args.cpu_iters_per_stage))
+            elif c4 is not None:
+                n4, v4, m4, _ = WORKLOADS["c4shard"]
+                both = cpu_baseline_generated(n, v_per, m, dtype, args.cpu_seconds, head, also=[("c4shard", m4, v4)])
+                out["cpu_baseline"], c4["cpu_baseline"] = both
             else:
                 out["cpu_baseline"] = cpu_baseline_generated(n, v_per, m, dtype, args.cpu_seconds, head)
+            if world > 1:
+                out["cpu_baseline"]["sample"] += ("; one shard's iteration (n_variables per GPU = %d): `value` counts every "
+                                                  "rank's shard iterations, so the two are in the same unit" % v_per)
 
     # tear the process group down first and push out whatever C-level stdio still buffers (now on stderr), so that the JSON
     # line is the last thing this job writes even when the caller merges the two streams

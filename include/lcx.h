@@ -280,6 +280,18 @@ int lcx_project(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, void
 int lcx_project_raw(lcx_ctx* h, const void* x_raw_host, int64_t n_rows, int64_t ld, int kind, const void* mean,
                     const void* std, void* out_host);
 
+/* predict (:440-441): out (n_rows x nv_local, row-major, leading dimension ld_out) = invert(y . X_i Z_j^T) for
+ * y_host (n_rows x n_hidden, row-major): the rank-m_padded product on MFMA in row blocks with `invert` (:431-438) as its
+ * epilogue - out = std_c f(.) + mean_c, f = identity (kind 1 'standard') or g_inv (:490-494; kind 2 'outliers'); kind 0
+ * returns the product itself - staged to the host like lcx_covariance.  X_i Z_j: xz_host (nv_local x n_hidden, row-major) if
+ * given (a model restored from a pickle), else the resident moments of set 0 (synergistic == 0: solve(ry, rho)^T of :280;
+ * != 0: the X_i Z_j of lcx_syn_moments_b, :367).  kernel_seconds (may be NULL): device time of the product kernels. */
+int lcx_predict(lcx_ctx* h, const void* y_host, int64_t n_rows, int synergistic, const void* xz_host, int kind, const void* mean,
+                const void* std, void* out_host, int64_t ld_out, double* kernel_seconds);
+/* invert (:431-438) of host rows x (n_rows x nv_local, ld): out = std_c f(x) + mean_c (kind / theta as above) */
+int lcx_invert(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, int kind, const void* mean, const void* std,
+               void* out_host, int64_t ld_out);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* HIP-event timing of the two X-streaming GEMM kernels on the handle's stream.
  * kind 0 = X.B^T ("nt", :247/:210), kind 1 = X^T.Y ("tn", :259/:211), kind 2 = the merged pass

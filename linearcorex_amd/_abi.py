@@ -41,6 +41,8 @@ SIGNATURES = {
     "lcx_upload_x": [_vp, _vp, _i64],
     "lcx_upload_preprocess": [_vp, _vp, _i64, _i32, _i32, _dbl, _i32, _vp, _vp, C.POINTER(_i64), C.POINTER(_dbl)],
     "lcx_project_raw": [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp],
+    "lcx_predict": [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i64, C.POINTER(_dbl)],
+    "lcx_invert": [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64],
     "lcx_generate_x": [_vp, C.c_uint64, _i32, _i32, _i64],
     "lcx_download_x": [_vp, _vp, _i64],
     "lcx_set_ws": [_vp, _vp],

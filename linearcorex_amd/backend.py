@@ -356,6 +356,42 @@ class HipBackend:
         _abi.check(self.lib.lcx_bytes_resident(self.h, C.byref(tot), C.byref(xb)))
         return {"total": tot.value, "x_and_transposed_copy": xb.value}
 
+    def predict(self, y, xz=None, syn=False, gaussianize=None, theta=None):
+        """predict (linearcorex.py:440-441) for this shard: invert(y . X_i Z_j^T), (n_rows, nv_local).  xz: X_i Z_j
+        (nv_local, m) of a restored model, None = the resident moments."""
+        y, py = self._a(y)
+        assert y.ndim == 2 and y.shape[1] == self.m, y.shape
+        kind = self.PP_KINDS.get(gaussianize, 0)
+        mean = std = None
+        if kind:
+            mean, std = np.ascontiguousarray(theta[0], self.dtype), np.ascontiguousarray(theta[1], self.dtype)
+            assert mean.shape == std.shape == (self.nv,)
+        pxz = None
+        if xz is not None:
+            xz, pxz = self._a(xz)
+            assert xz.shape == (self.nv, self.m), xz.shape
+        out = np.empty((y.shape[0], self.nv), dtype=self.dtype)
+        ksec = C.c_double()
+        _abi.check(self.lib.lcx_predict(self.h, py, y.shape[0], 1 if syn else 0, pxz, kind,
+                                        None if mean is None else _abi.np_ptr(mean), None if std is None else _abi.np_ptr(std),
+                                        _abi.np_ptr(out), self.nv, C.byref(ksec)))
+        self._predict_kernel_seconds = ksec.value
+        return out
+
+    def invert(self, x, gaussianize, theta):
+        """invert (linearcorex.py:431-438) of host rows (n_rows, nv_local)."""
+        x, px = self._a(x)
+        assert x.ndim == 2 and x.shape[1] == self.nv, x.shape
+        kind = self.PP_KINDS.get(gaussianize, 0)
+        mean = std = None
+        if kind:
+            mean, std = np.ascontiguousarray(theta[0], self.dtype), np.ascontiguousarray(theta[1], self.dtype)
+        out = np.empty_like(x)
+        _abi.check(self.lib.lcx_invert(self.h, px, x.shape[0], x.shape[1], kind,
+                                       None if mean is None else _abi.np_ptr(mean), None if std is None else _abi.np_ptr(std),
+                                       _abi.np_ptr(out), x.shape[1]))
+        return out
+
     def project(self, x):
         x, p = self._a(x)
         assert x.ndim == 2 and x.shape[1] == self.nv

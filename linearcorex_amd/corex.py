@@ -44,7 +44,7 @@ class DeviceMoments(dict):
         be = self._owner._backend if self._owner is not None else None
         return be is not None and be.generation == self._gen
 
-    def _fetch(self, key, collective=False):
+    def _fetch(self, key, collective=False, for_key=None):
         if not self._resident():
             raise KeyError("%r: these moments are no longer resident on the device" % key)
         o, be = self._owner, self._owner._backend
@@ -55,17 +55,22 @@ class DeviceMoments(dict):
         if key == "I(X_i ; Y)":
             return -0.5 * np.log(self._get(key, "X_i^2 | Y", collective))                   # :283
         if key not in self._REPLICATED and o._comm.world > 1 and not collective:
-            raise RuntimeError("moments[%r] is sharded over %d ranks: call model.gather_moments([%r]) on every rank first "
-                               "(dict access never issues a collective)" % (key, o._comm.world, key))
+            raise self._sharded_error(for_key or key)
         val = be.get_moment(0, key, self._eps)
         if key not in self._REPLICATED:
             val = o._gather(val, key)
         return val
 
+    def _sharded_error(self, key):
+        return RuntimeError("moments[%r] is sharded over %d ranks: call model.gather_moments([%r]) on every rank first "
+                            "(dict access never issues a collective)" % (key, self._owner._comm.world, key))
+
+    _DERIVED = {"X_i Y_j": "rho", "I(X_i ; Y)": "X_i^2 | Y"}       # derived key -> the device array it is computed from
+
     def _get(self, for_key, key, collective):
         if dict.__contains__(self, key):
             return dict.__getitem__(self, key)
-        val = self._fetch(key, collective)
+        val = self._fetch(key, collective, for_key=for_key)
         dict.__setitem__(self, key, val)
         return val
 
@@ -89,12 +94,15 @@ class DeviceMoments(dict):
         if key not in self._lazy or not self._resident():
             return False
         single = self._owner._comm.world == 1
-        return single or key in self._REPLICATED or key == "Y_j^2"
+        if single or key in self._REPLICATED or key == "Y_j^2":
+            return True
+        # several ranks: a derived key is there without a collective once the array it is computed from was gathered
+        return key in self._DERIVED and dict.__contains__(self, self._DERIVED[key])
 
     def get(self, key, default=None):
         try:
             return self[key]
-        except KeyError:
+        except (KeyError, RuntimeError):       # RuntimeError: sharded and not gathered - absent as far as dict.get goes
             return default
 
     def materialize(self, keys=None):
@@ -123,14 +131,15 @@ class SynMoments(DeviceMoments):
 
     _REPLICATED = ("cy", "Y_j^2", "ry")
 
-    def _fetch(self, key, collective=False):
+    _DERIVED = {"invrho": "rho", "MI": "rho", "Si": "rho", "rhoinvrho": "rho", "Qij": "rho", "Qi": "rho"}
+
+    def _fetch(self, key, collective=False, for_key=None):
         if not self._resident():
             raise KeyError("%r: these moments are no longer resident on the device" % key)
         o, be = self._owner, self._owner._backend
         if key in self._SYN_DEVICE:
             if key not in self._REPLICATED and o._comm.world > 1 and not collective:
-                raise RuntimeError("moments[%r] is sharded over %d ranks: call model.gather_moments([%r]) on every rank first "
-                                   "(dict access never issues a collective)" % (key, o._comm.world, key))
+                raise self._sharded_error(for_key or key)
             val = be.get_moment(0, self._SYN_DEVICE[key])
             if key in ("X_i Y_j", "X_i Z_j"):                # (nv_local, m): shard axis first
                 return o._gather(np.ascontiguousarray(val.T)).T
@@ -155,7 +164,9 @@ class SynMoments(DeviceMoments):
             return True
         if key not in self._lazy or not self._resident():
             return False
-        return self._owner._comm.world == 1 or key in self._REPLICATED
+        if self._owner._comm.world == 1 or key in self._REPLICATED:
+            return True
+        return key in self._DERIVED and dict.__contains__(self, self._DERIVED[key])
 
 
 class Corex(object):
@@ -754,32 +765,55 @@ class Corex(object):
                                         self.missing_values, verbose=self.verbose)
         return x
 
+    def _theta_local(self):
+        c0, c1 = self._cols
+        if self.gaussianize in ('standard', 'outliers'):
+            return (np.asarray(self.theta[0])[c0:c1], np.asarray(self.theta[1])[c0:c1])
+        return None
+
     def invert(self, x):
-        """Undo the preprocessing (:431-438)."""
-        if self.gaussianize == 'standard':
-            return self.theta[1] * x + self.theta[0]
-        elif self.gaussianize == 'outliers':
-            return self.theta[1] * g_inv(x) + self.theta[0]
-        return x
+        """Undo the preprocessing (:431-438), on the device (rows staged through the shard's GPU).  Several ranks: a
+        collective, like every call that returns a full (.., n_variables) array."""
+        if self.gaussianize not in ('standard', 'outliers'):
+            return x
+        x = np.asarray(x, dtype=self.dtype)
+        if x.ndim == 1:
+            return self.invert(x[np.newaxis])[0]
+        be = self._resident_backend()
+        c0, c1 = self._cols
+        return self._gather(be.invert(np.ascontiguousarray(x[:, c0:c1]), self.gaussianize, self._theta_local()))
 
     def predict(self, y):
-        """:440-441."""
-        return self.invert(np.dot(self.moments["X_i Z_j"], np.asarray(y).T).T)
+        """:440-441: invert(y . X_i Z_j^T) - the rank-n_hidden product and the inverse marginal map run on the device
+        (lcx_predict), the (n_rows, n_variables) result is staged back in row blocks."""
+        y = np.asarray(y, dtype=self.dtype)
+        if y.ndim == 1:
+            return self.predict(y[np.newaxis])[0]
+        be = self._resident_backend()
+        c0, c1 = self._cols
+        live = isinstance(self.moments, DeviceMoments) and self.moments._resident() and getattr(self, "_x_resident", True)
+        xz = None if live else np.ascontiguousarray(self._host_moment("X_i Z_j")[c0:c1])
+        out = be.predict(y, xz, syn=not self.discourage_overlap, gaussianize=self.gaussianize, theta=self._theta_local())
+        return self._gather(out)
+
+    def _host_moment(self, key):
+        """A moment a restored (unpickled) model needs on the host; absent if the fit was sharded and the key never gathered."""
+        m = self.moments
+        if isinstance(m, DeviceMoments) or key in m:
+            return m[key]
+        raise RuntimeError("moments[%r] is not part of this model: it was fitted on several ranks and pickled before "
+                           "model.gather_moments([%r]) was called on every rank (sharded moments are not gathered "
+                           "implicitly above LCX_EAGER_GATHER_ELEMS elements)" % (key, key))
 
     def get_covariance(self):
-        """Covariance estimate of the non-synergistic model (:443-451), nv x nv."""
+        """Covariance estimate (:443-455), nv x nv: a rank-n_hidden product on the device for both branches."""
         if self._comm.world > 1:
             raise NotImplementedError("get_covariance() needs all variables on one GPU (nv x nv output)")
-        if not self.discourage_overlap:                                        # :452-455
-            if self._backend is None:
-                # restored from a pickle: a rank-m product of two host arrays, as the reference computes it
-                m = self.moments
-                cov = np.einsum('ij,kj->ik', m["X_i Z_j"], m["X_i Y_j"])
-                np.fill_diagonal(cov, 1)
-                return self.theta[1][:, np.newaxis] * self.theta[1] * cov
-            return self._backend.covariance_syn(np.asarray(self.theta[1], dtype=self.dtype))
         be = self._resident_backend(need_moments=True)
-        return be.covariance(self.eps, np.asarray(self.theta[1], dtype=self.dtype))
+        std = np.asarray(self.theta[1], dtype=self.dtype)
+        if not self.discourage_overlap:                                        # :452-455
+            return be.covariance_syn(std)
+        return be.covariance(self.eps, std)
 
     # ------------------------------------------------------------------------------------------
     # persistence (vis_corex.py:549 pickles the model)
@@ -797,8 +831,12 @@ class Corex(object):
             self._moments_restored = False
             self._x_resident = False
         if need_moments and getattr(self, "_moments_restored", True) is False:
-            self._backend.set_moment(0, "rhoinvrho", self.moments["rhoinvrho"])
-            self._backend.set_moment(0, "Si", self.moments["Si"])
+            if self.discourage_overlap:                                        # what :447 reads
+                self._backend.set_moment(0, "rhoinvrho", self._host_moment("rhoinvrho"))
+                self._backend.set_moment(0, "Si", self._host_moment("Si"))
+            else:                                                              # what :453 reads
+                self._backend.set_moment(0, "syn X_i Z_j", self._host_moment("X_i Z_j"))
+                self._backend.set_moment(0, "syn X_i Y_j", self._host_moment("X_i Y_j"))
             self._moments_restored = True
         return self._backend
 

@@ -86,7 +86,8 @@ struct CovStage {
     void* dev[2] = {nullptr, nullptr};
     void* pin[2] = {nullptr, nullptr};
     size_t block_bytes = 0;
-    void *op_a = nullptr, *op_b = nullptr, *std_dev = nullptr;
+    int64_t block_rows = 0;
+    void *op_a = nullptr, *op_b = nullptr, *std_dev = nullptr, *mean_dev = nullptr;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_k[2] = {nullptr, nullptr}, ev_c[2] = {nullptr, nullptr}, t_a[2] = {nullptr, nullptr}, t_b[2] = {nullptr, nullptr};
     double last_kernel_seconds = 0.0;
@@ -875,6 +876,17 @@ template <typename T, int CT> struct Impl {
         return evaluate_trial(h, eps);
     }
     static int iterate(lcx_ctx* h, double eps, double tol, double tc_cur, int more, double* out) {
+        const int rc = iterate_body(h, eps, tol, tc_cur, more, out);
+        if (rc != LCX_OK) {
+            // a failure part-way (a launch error, a publication that never arrived) leaves sbuf with the H of some trial and the
+            // direction / trial flags half set: make the level API start over (lcx_update_b then restores the H of set 0)
+            h->spec_pending = false;
+            h->spec_dirty = true;
+            h->early_grad = h->grad_ready = h->have_direction = h->w1_ready = h->y1_ready = false;
+        }
+        return rc;
+    }
+    static int iterate_body(lcx_ctx* h, double eps, double tol, double tc_cur, int more, double* out) {
         if (h->exchange)
             return fail(LCX_ERR_STATE, "lcx_iterate drives one GPU; with several ranks the caller exchanges between the levels "
                                        "(lcx_update_b ... lcx_moments_c)");
@@ -1052,34 +1064,41 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
     // get_covariance rows [row0, row0 + nrows) -> out_host (row-major, leading dimension ld_out elements); see CovStage
-    static int cov_stage(lcx_ctx* h, bool syn) {
+    // Staging shared by get_covariance and predict.  Every resource is created on its own guard: a call that failed half
+    // way (say a locked-memory limit on the pinned blocks) leaves the stage retryable instead of half built.
+    static int cov_stage(lcx_ctx* h, bool need_op_a, bool need_op_b) {
         if (!h->cov) h->cov = new CovStage();
         CovStage& c = *h->cov;
         const size_t mv = (size_t)h->ldx * Mp * sizeof(T);
-        if (!c.copy_stream) {
-            HIPCHECK(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
-            for (int k = 0; k < 2; ++k) {
-                HIPCHECK(hipEventCreateWithFlags(&c.ev_k[k], hipEventDisableTiming));
-                HIPCHECK(hipEventCreateWithFlags(&c.ev_c[k], hipEventDisableTiming));
-            }
-            for (int k = 0; k < 2; ++k) {
-                HIPCHECK(hipEventCreate(&c.t_a[k]));
-                HIPCHECK(hipEventCreate(&c.t_b[k]));
-            }
-            HIPCHECK(hipMalloc(&c.std_dev, (size_t)h->ldx * sizeof(T)));
-            HIPCHECK(hipMalloc(&c.op_a, mv));
+        auto dmalloc = [&](void** p, size_t bytes) -> int {
+            if (*p) return LCX_OK;
+            HIPCHECK(hipMalloc(p, bytes));
+            h->bytes_resident += bytes;
+            return LCX_OK;
+        };
+        if (!c.copy_stream) HIPCHECK(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            if (!c.ev_k[k]) HIPCHECK(hipEventCreateWithFlags(&c.ev_k[k], hipEventDisableTiming));
+            if (!c.ev_c[k]) HIPCHECK(hipEventCreateWithFlags(&c.ev_c[k], hipEventDisableTiming));
+            if (!c.t_a[k]) HIPCHECK(hipEventCreate(&c.t_a[k]));
+            if (!c.t_b[k]) HIPCHECK(hipEventCreate(&c.t_b[k]));
         }
-        if (syn && !c.op_b) HIPCHECK(hipMalloc(&c.op_b, mv));
-        if (!c.dev[0]) {
+        LCXCHECK(dmalloc(&c.std_dev, (size_t)h->ldx * sizeof(T)));
+        LCXCHECK(dmalloc(&c.mean_dev, (size_t)h->ldx * sizeof(T)));
+        if (need_op_a) LCXCHECK(dmalloc(&c.op_a, mv));
+        if (need_op_b) LCXCHECK(dmalloc(&c.op_b, mv));
+        if (!c.block_bytes) {
             const int64_t ldo = h->ldx;
             int64_t rows = (int64_t)(64u << 20) / (ldo * (int64_t)sizeof(T)) / 64 * 64;
             if (rows < 64) rows = 64;
-            if (rows > round_up(h->V, 64)) rows = round_up(h->V, 64);
+            const int64_t cap = round_up(h->V, 64) > 8192 ? round_up(h->V, 64) : 8192;     // covariance blocks never exceed V rows
+            if (rows > cap) rows = cap;
+            c.block_rows = rows;
             c.block_bytes = (size_t)rows * ldo * sizeof(T);
-            for (int k = 0; k < 2; ++k) {
-                HIPCHECK(hipMalloc(&c.dev[k], c.block_bytes));
-                HIPCHECK(hipHostMalloc(&c.pin[k], c.block_bytes, hipHostMallocDefault));
-            }
+        }
+        for (int k = 0; k < 2; ++k) {
+            LCXCHECK(dmalloc(&c.dev[k], c.block_bytes));
+            if (!c.pin[k]) HIPCHECK(hipHostMalloc(&c.pin[k], c.block_bytes, hipHostMallocDefault));
         }
         return LCX_OK;
     }
@@ -1107,10 +1126,10 @@ template <typename T, int CT> struct Impl {
     static int covariance_blocks(lcx_ctx* h, bool syn, double eps, const void* std_host, int64_t row0, int64_t nrows, void* out_host,
                                  int64_t ld_out, double* kernel_seconds) {
         MomentSet& s = h->set[0];
-        LCXCHECK(cov_stage(h, syn));
+        LCXCHECK(cov_stage(h, !syn, syn));
         CovStage& c = *h->cov;
         const int64_t V = h->V, ldo = h->ldx;
-        const int64_t brows = (int64_t)(c.block_bytes / ((size_t)ldo * sizeof(T)));
+        const int64_t brows = c.block_rows;
         HIPCHECK(hipMemcpyAsync(c.std_dev, std_host, sizeof(T) * V, hipMemcpyHostToDevice, h->stream));
         const int64_t n = h->ldx * Mp;
         const unsigned pg = (unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
@@ -1144,8 +1163,8 @@ template <typename T, int CT> struct Impl {
                 const int64_t r0 = row0 + k * brows, nr = (nrows - k * brows) < brows ? (nrows - k * brows) : brows;
                 dim3 grid((unsigned)cdiv(V, 64), (unsigned)cdiv(nr, 64));
                 HIPCHECK(hipEventRecord(c.t_a[b], h->stream));
-                hipLaunchKernelGGL((cov_syrk_kernel<T, Mp>), grid, dim3(256), 0, h->stream, opa, opb, P<T>(c.std_dev), V, r0, nr, denom,
-                                   P<T>(c.dev[b]), ldo);
+                hipLaunchKernelGGL((cov_syrk_kernel<T, Mp, 0>), grid, dim3(256), 0, h->stream, opa, opb, P<T>(c.std_dev), V, r0, nr, denom,
+                                   P<T>(c.dev[b]), ldo, (const T*)nullptr, 0);
                 KCHECK();
                 HIPCHECK(hipEventRecord(c.t_b[b], h->stream));
                 HIPCHECK(hipEventRecord(c.ev_k[b], h->stream));
@@ -1261,7 +1280,17 @@ template <typename T, int CT> struct Impl {
             HIPCHECK(hipStreamSynchronize(h->stream));
             return LCX_OK;
         }
-        if (key != LCX_M_RHOINVRHO) return fail(LCX_ERR_ARG, "lcx_set_moment: only RHOINVRHO and SI can be restored");
+        if (key == LCX_M_SYN_XIZJ || key == LCX_M_SYN_XIYJ) {       // (nv, m) host arrays of the synergistic branch (:453)
+            LCXCHECK(syn_alloc(h));
+            std::vector<T> tmp((size_t)h->ldx * Mp, (T)0);
+            const T scale = key == LCX_M_SYN_XIYJ ? (T)h->N : (T)1;  // kept as X^T.Y = N * X_i Y_j (:355)
+            for (int64_t v = 0; v < h->V; ++v)
+                for (int j = 0; j < h->M; ++j) tmp[v * Mp + j] = src[v * h->M + j] * scale;
+            HIPCHECK(hipMemcpyAsync(key == LCX_M_SYN_XIZJ ? s.xz : s.D, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+            HIPCHECK(hipStreamSynchronize(h->stream));
+            return LCX_OK;
+        }
+        if (key != LCX_M_RHOINVRHO) return fail(LCX_ERR_ARG, "lcx_set_moment: only RHOINVRHO, SI, SYN_XIZJ and SYN_XIYJ can be restored");
         std::vector<T> tmp((size_t)h->ldx * Mp, (T)0);
         for (int j = 0; j < h->M; ++j)
             for (int64_t v = 0; v < h->V; ++v) tmp[v * Mp + j] = src[(int64_t)j * h->V + v];
@@ -1286,6 +1315,123 @@ template <typename T, int CT> struct Impl {
     }
     static int covariance(lcx_ctx* h, double eps, const void* std_host, int64_t row0, int64_t nrows, void* out_host) {
         return covariance_blocks(h, false, eps, std_host, row0, nrows, out_host, h->V, nullptr);
+    }
+
+    // theta = (mean, std) of the working dtype -> the stage's device vectors (kind 0: unused)
+    static int stage_theta(lcx_ctx* h, int kind, const void* mean_h, const void* std_h) {
+        CovStage& c = *h->cov;
+        if (kind == PP_KIND_NONE) return LCX_OK;
+        HIPCHECK(hipMemcpyAsync(c.mean_dev, mean_h, sizeof(T) * h->V, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(hipMemcpyAsync(c.std_dev, std_h, sizeof(T) * h->V, hipMemcpyHostToDevice, h->stream));
+        return LCX_OK;
+    }
+
+    // predict (:440-441): out (n_rows x V) = invert(y . X_i Z_j^T), produced in row blocks like get_covariance: the
+    // rank-Mp product + the inverse marginal map on the device, two pinned staging blocks, the host-side placement of
+    // block k-1 under the kernel of block k+1 and the copy of block k.
+    static int predict(lcx_ctx* h, const void* y_host, int64_t n_rows, int syn, const void* xz_host, int kind, const void* mean_h,
+                       const void* std_h, void* out_host, int64_t ld_out, double* kernel_seconds) {
+        MomentSet& s = h->set[0];
+        LCXCHECK(cov_stage(h, true, false));
+        CovStage& c = *h->cov;
+        const int64_t V = h->V, ldo = h->ldx, brows = c.block_rows;
+        LCXCHECK(stage_theta(h, kind, mean_h, std_h));
+        // operand B = X_i Z_j [Vp][Mp]
+        const T* xz = nullptr;
+        if (xz_host) {                                            // restored model: the caller's (V x m) matrix
+            std::vector<T> tmp((size_t)h->ldx * Mp, (T)0);
+            const T* src = reinterpret_cast<const T*>(xz_host);
+            for (int64_t v = 0; v < V; ++v)
+                for (int j = 0; j < h->M; ++j) tmp[v * Mp + j] = src[v * h->M + j];
+            HIPCHECK(hipMemcpyAsync(c.op_a, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+            HIPCHECK(hipStreamSynchronize(h->stream));
+            xz = P<T>(c.op_a);
+        } else if (syn) {
+            if (!s.xz) return fail(LCX_ERR_STATE, "lcx_predict: no synergistic moments resident (lcx_syn_moments_b)");
+            xz = P<T>(s.xz);
+        } else {
+            LCXCHECK(detail(h, 0, nullptr, P<T>(c.op_a), nullptr));      // solve(ry, rho)^T of the resident set 0 (:280)
+            xz = P<T>(c.op_a);
+        }
+        // operand A = Y, padded to Mp columns, whole on the device (n_rows x Mp elements: small beside the output)
+        DevTemps tmps;
+        T* yd = nullptr;
+        const int64_t rows_pad = round_up(n_rows, 64);
+        LCXCHECK(tmps.get(&yd, sizeof(T) * rows_pad * Mp));
+        {
+            std::vector<T> tmp((size_t)rows_pad * Mp, (T)0);
+            const T* src = reinterpret_cast<const T*>(y_host);
+            for (int64_t r = 0; r < n_rows; ++r)
+                for (int j = 0; j < h->M; ++j) tmp[r * Mp + j] = src[r * h->M + j];
+            HIPCHECK(hipMemcpyAsync(yd, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+            HIPCHECK(hipStreamSynchronize(h->stream));
+        }
+        {
+            const size_t bytes = (size_t)n_rows * (size_t)ld_out * sizeof(T);
+            if (bytes >= ((size_t)8 << 20)) {
+                const uintptr_t pg = (uintptr_t)2 << 20;
+                const uintptr_t a0 = ((uintptr_t)out_host + pg - 1) & ~(pg - 1), a1 = ((uintptr_t)out_host + bytes) & ~(pg - 1);
+                if (a1 > a0) (void)madvise((void*)a0, (size_t)(a1 - a0), MADV_HUGEPAGE);
+            }
+        }
+        T* out = P<T>(out_host);
+        const int64_t nblk = cdiv(n_rows, brows);
+        double ksec = 0.0;
+        for (int64_t k = 0; k <= nblk; ++k) {
+            if (k < nblk) {
+                const int b = (int)(k & 1);
+                const int64_t r0 = k * brows, nr = (n_rows - r0) < brows ? (n_rows - r0) : brows;
+                dim3 grid((unsigned)cdiv(V, 64), (unsigned)cdiv(nr, 64));
+                HIPCHECK(hipEventRecord(c.t_a[b], h->stream));
+                hipLaunchKernelGGL((cov_syrk_kernel<T, Mp, 1>), grid, dim3(256), 0, h->stream, yd + r0 * Mp, xz, P<T>(c.std_dev), V, (int64_t)0, nr,
+                                   (T)1, P<T>(c.dev[b]), ldo, P<T>(c.mean_dev), kind);
+                KCHECK();
+                HIPCHECK(hipEventRecord(c.t_b[b], h->stream));
+                HIPCHECK(hipEventRecord(c.ev_k[b], h->stream));
+                HIPCHECK(hipStreamWaitEvent(c.copy_stream, c.ev_k[b], 0));
+                HIPCHECK(hipMemcpy2DAsync(c.pin[b], (size_t)V * sizeof(T), c.dev[b], (size_t)ldo * sizeof(T), (size_t)V * sizeof(T), (size_t)nr,
+                                          hipMemcpyDeviceToHost, c.copy_stream));
+                HIPCHECK(hipEventRecord(c.ev_c[b], c.copy_stream));
+            }
+            if (k >= 1) {
+                const int b = (int)((k - 1) & 1);
+                const int64_t nr = (n_rows - (k - 1) * brows) < brows ? (n_rows - (k - 1) * brows) : brows;
+                HIPCHECK(hipEventSynchronize(c.ev_c[b]));
+                {
+                    float ms = 0.f;
+                    HIPCHECK(hipEventElapsedTime(&ms, c.t_a[b], c.t_b[b]));
+                    ksec += (double)ms * 1e-3;
+                }
+                place_rows(P<T>(c.pin[b]), V, out + (k - 1) * brows * ld_out, ld_out, nr, V);
+            }
+        }
+        c.last_kernel_seconds = ksec;
+        if (kernel_seconds) *kernel_seconds = ksec;
+        return LCX_OK;
+    }
+
+    // invert (:431-438) of host rows: staged blocks, elementwise on the device
+    static int invert_rows(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, int kind, const void* mean_h, const void* std_h,
+                           void* out_host, int64_t ld_out) {
+        LCXCHECK(cov_stage(h, false, false));
+        CovStage& c = *h->cov;
+        const int64_t V = h->V, ldo = h->ldx, brows = c.block_rows;
+        LCXCHECK(stage_theta(h, kind, mean_h, std_h));
+        const T* x = reinterpret_cast<const T*>(x_host);
+        T* out = P<T>(out_host);
+        for (int64_t r0 = 0; r0 < n_rows; r0 += brows) {
+            const int64_t nr = (n_rows - r0) < brows ? (n_rows - r0) : brows;
+            HIPCHECK(hipMemcpy2DAsync(c.dev[0], (size_t)ldo * sizeof(T), x + r0 * ld, (size_t)ld * sizeof(T), (size_t)V * sizeof(T), (size_t)nr,
+                                      hipMemcpyHostToDevice, h->stream));
+            const int64_t total = nr * V;
+            hipLaunchKernelGGL((invert_rows_kernel<T>), dim3((unsigned)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096)), dim3(256), 0, h->stream,
+                               P<T>(c.dev[0]), nr, V, ldo, P<T>(c.mean_dev), P<T>(c.std_dev), kind, P<T>(c.dev[0]));
+            KCHECK();
+            HIPCHECK(hipMemcpy2DAsync(out + r0 * ld_out, (size_t)ld_out * sizeof(T), c.dev[0], (size_t)ldo * sizeof(T), (size_t)V * sizeof(T),
+                                      (size_t)nr, hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(hipStreamSynchronize(h->stream));
+        }
+        return LCX_OK;
     }
 
     // y[rows_pad][Mp] = xd[rows_pad][ldx] . W^T for a staged block of new rows (transform, :386-395).  Up to 128 padded
@@ -1809,6 +1955,7 @@ int lcx_destroy(lcx_ctx* h) {
         if (c.op_a) (void)hipFree(c.op_a);
         if (c.op_b) (void)hipFree(c.op_b);
         if (c.std_dev) (void)hipFree(c.std_dev);
+        if (c.mean_dev) (void)hipFree(c.mean_dev);
         if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream);
         delete h->cov;
     }
@@ -2125,6 +2272,22 @@ int lcx_covariance(lcx_ctx* h, int synergistic, double eps, const void* std_host
     NEED(h);
     if (!std_host || !out || ld_out < h->V) return fail(LCX_ERR_ARG, "lcx_covariance: bad argument");
     DISPATCH(h, covariance_full, h, synergistic, eps, std_host, out, ld_out, kernel_seconds);
+}
+
+int lcx_predict(lcx_ctx* h, const void* y_host, int64_t n_rows, int synergistic, const void* xz_host, int kind, const void* mean,
+                const void* stdv, void* out, int64_t ld_out, double* kernel_seconds) {
+    NEED(h);
+    if (!y_host || !out || n_rows < 1 || ld_out < h->V) return fail(LCX_ERR_ARG, "lcx_predict: bad argument");
+    if (kind < 0 || kind > 2 || (kind != 0 && (!mean || !stdv))) return fail(LCX_ERR_ARG, "lcx_predict: bad kind / theta");
+    DISPATCH(h, predict, h, y_host, n_rows, synergistic, xz_host, kind, mean, stdv, out, ld_out, kernel_seconds);
+}
+
+int lcx_invert(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, int kind, const void* mean, const void* stdv, void* out,
+               int64_t ld_out) {
+    NEED(h);
+    if (!x_host || !out || n_rows < 1 || ld < h->V || ld_out < h->V) return fail(LCX_ERR_ARG, "lcx_invert: bad argument");
+    if (kind < 0 || kind > 2 || (kind != 0 && (!mean || !stdv))) return fail(LCX_ERR_ARG, "lcx_invert: bad kind / theta");
+    DISPATCH(h, invert_rows, h, x_host, n_rows, ld, kind, mean, stdv, out, ld_out);
 }
 
 int lcx_bytes_resident(lcx_ctx* h, int64_t* total, int64_t* x_bytes) {

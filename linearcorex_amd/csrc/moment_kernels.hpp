@@ -985,10 +985,24 @@ __global__ void cov_prep_kernel(const T* __restrict__ src_a, const T* __restrict
     }
 }
 
-template <typename T, int Mp>
+// MODE 0: get_covariance (rows are variables, symmetric scaling std_r std_c, unit diagonal).
+// MODE 1: predict (:440-441) - rows are the n_rows samples of a staged block of Y (A = Y [rows][Mp], B = X_i Z_j [V][Mp]),
+//         and the epilogue is `invert` (:431-438): out[r][c] = std_c f(y_r . xz_c) + mean_c with f = identity ('standard',
+//         kind 1) or g_inv (:490-494; 'outliers', kind 2); kind 0 writes the product unchanged.  aux = mean.
+template <typename T>
+__device__ __forceinline__ T g_inv_dev(T x) {
+    const T t = (T)4;
+    const T xp = x < -t ? -t : (x > t ? t : x);
+    const T lo = (T)(-1 + 1e-10), hi = (T)(1 - 1e-10);          // as the reference clips, in the working precision
+    T d = x - xp;
+    d = d < lo ? lo : (d > hi ? hi : d);
+    return xp + (T)atanh((double)d);
+}
+
+template <typename T, int Mp, int MODE>
 __global__ void __launch_bounds__(256)
 cov_syrk_kernel(const T* __restrict__ A, const T* __restrict__ B, const T* __restrict__ stdv, int64_t V, int64_t row0,
-                int64_t nrows, T denom, T* __restrict__ out, int64_t ldo) {
+                int64_t nrows, T denom, T* __restrict__ out, int64_t ldo, const T* __restrict__ aux, int kind) {
     constexpr int KC = Mp < 32 ? Mp : 32;
     constexpr int LDS_LD = KC + 2;
     typedef typename MF<T>::acc_t acc_t;
@@ -1005,7 +1019,7 @@ cov_syrk_kernel(const T* __restrict__ A, const T* __restrict__ B, const T* __res
         for (int idx = tid; idx < 64 * KC; idx += 256) {
             const int a = idx / KC, j = idx % KC;
             const int64_t vr = rb + a, vc = cb + a;
-            As[a][j] = (vr < V && vr < row0 + nrows) ? A[vr * Mp + j0 + j] : (T)0;
+            As[a][j] = ((MODE == 1 || vr < V) && vr < row0 + nrows) ? A[vr * Mp + j0 + j] : (T)0;
             Bs[(a & 3) * 16 + (a >> 2)][j] = (vc < V) ? B[vc * Mp + j0 + j] : (T)0;      // column 4 j + u -> row 16 u + j
         }
         __syncthreads();
@@ -1016,25 +1030,46 @@ cov_syrk_kernel(const T* __restrict__ A, const T* __restrict__ B, const T* __res
             for (int u = 0; u < 4; ++u) acc[u] = MF<T>::mma(av, Bs[16 * u + i][4 * s + q], acc[u]);
         }
     }
-    Pk<T, 4> sc;
+    Pk<T, 4> sc, mu;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int64_t c = cb + 4 * i + u;
-        sc.v[u] = c < V ? stdv[c] : (T)0;
+        sc.v[u] = (c < V && (MODE == 0 || kind != 0)) ? stdv[c] : (T)(MODE == 0 ? 0 : 1);
+        mu.v[u] = (MODE == 1 && kind != 0 && c < V) ? aux[c] : (T)0;
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int64_t r = rb + 16 * wave + MF<T>::row(lane, g);
-        if (r >= V || r >= row0 + nrows) continue;
-        const T sr = stdv[r];
+        if ((MODE == 0 && r >= V) || r >= row0 + nrows) continue;
         Pk<T, 4> o;
+        if (MODE == 0) {
+            const T sr = stdv[r];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t c = cb + 4 * i + u;
-            const T val = (r == c) ? (T)1 : acc[u][g] / denom;
-            o.v[u] = sr * sc.v[u] * val;
+            for (int u = 0; u < 4; ++u) {
+                const int64_t c = cb + 4 * i + u;
+                const T val = (r == c) ? (T)1 : acc[u][g] / denom;
+                o.v[u] = sr * sc.v[u] * val;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T val = (T)acc[u][g];
+                o.v[u] = sc.v[u] * (kind == 2 ? g_inv_dev<T>(val) : val) + mu.v[u];
+            }
         }
         *reinterpret_cast<Pk<T, 4>*>(out + (r - row0) * ldo + cb + 4 * i) = o;
+    }
+}
+
+// invert (:431-438) of a staged block of rows, elementwise: out = std_c f(x) + mean_c (f as in cov_syrk_kernel MODE 1)
+template <typename T>
+__global__ void invert_rows_kernel(const T* __restrict__ x, int64_t nrows, int64_t V, int64_t ld, const T* __restrict__ mean,
+                                   const T* __restrict__ stdv, int kind, T* __restrict__ out) {
+    const int64_t total = nrows * V;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = k / V, c = k % V;
+        const T v = x[r * ld + c];
+        out[r * ld + c] = kind == 0 ? v : stdv[c] * (kind == 2 ? g_inv_dev<T>(v) : v) + mean[c];
     }
 }
 

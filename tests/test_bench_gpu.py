@@ -40,7 +40,7 @@ def test_default_line_is_the_c3_line_with_the_c2_block():
     """The driver's command: the headline must be BASELINE configs[2] (MFMA-bound), c2 rides along as a nested block, the
     CPU baselines are real, and the figure must not depend on the driver's --steps 20 --warmup 5."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
-                        "--cpu-seconds", "5"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                        "--cpu-seconds", "5"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     d = _one_json_line(p.stdout)
     assert d["config"]["workload"].startswith("c3:") and d["dtype"] == "f32" and d["n_gpus"] == 1
@@ -55,6 +55,26 @@ def test_default_line_is_the_c3_line_with_the_c2_block():
     assert hi / lo < 1.25, (lo, med, hi)
     assert c2["get_covariance"]["n_variables"] == 5000 and c2["get_covariance"]["seconds"] > 0
     assert d["config"]["get_covariance_c5_standin"]["n_variables"] == 20000
+    # the headline is timed over >= 3 walks of the schedule and says how far they are apart
+    w = d["config"]["windows"]
+    assert w["walks_timed"] >= 3
+    lo, med, hi = w["ms_per_step_walk_min_median_max"]
+    assert lo <= med <= hi and hi / lo < 1.15, (lo, med, hi)
+    # the one-GPU point of the weak-scaling series that --gpus N headlines
+    c4 = d["config"]["c4shard"]
+    assert c4["value"] > 0 and c4["n_hidden"] == 128 and c4["n_variables_per_gpu"] == 125000
+    assert c4["roofline"]["bound"] == "mfma" and 0.3 < c4["roofline"]["frac"] < 1.0
+    assert c4["cpu_baseline"]["value"] > 0 and c4["cpu_baseline"]["n_variables_timed"] <= 100000
+    # linear trial mode, reported beside the reference-shaped figure at the sizes where a trial costs two long passes
+    for blk in (d["config"], c4):
+        lin = blk["linear_trial_mode"]
+        assert lin["fit_iterations_per_sec"] > 0 and 1.9 < lin["x_passes_per_iteration"] < 2.6
+        assert lin["roofline"]["bound"] == "mfma"
+    # a convergence measurement that converges: planted data, every annealing stage below tol before the cap
+    cv = d["config"]["fit_to_convergence_planted"]
+    assert cv["stages_converged_before_the_cap"] == 7 and cv["seconds"] > 0
+    assert cv["cluster_purity_vs_planted_groups"] > 0.99
+    assert d["config"]["fit_to_convergence"]["capped"] is True
 
 
 def _two_rank_env():
@@ -98,7 +118,10 @@ def test_two_ranks_full_line_has_the_same_shard_reference_and_the_c2_block():
     p = subprocess.run(cmd, cwd=ROOT, env=_two_rank_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     d = _one_json_line(p.stdout)
-    assert d["n_gpus"] == 2 and d["cpu_baseline"] is None
+    assert d["n_gpus"] == 2
+    # the multi-GPU line carries a CPU baseline too (rank 0, one shard's iteration) and a roofline
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert d["roofline"] is not None and d["roofline"]["frac"] > 0
     ref = d["config"]["single_gpu_same_shard"]
     assert ref["iterations_per_sec_slowest_rank"] > 0 and d["config"]["weak_scaling_vs_same_shard"] > 0
     c2 = d["config"]["c2_weak"]

@@ -117,3 +117,63 @@ print("RCCL_PATH_OK")
 ''' % (ROOT, str(free_port()))
     p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "RCCL_PATH_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
+def _launch_f32(world, out_dir, n, v, m, iters, extra_env=None, timeout=240):
+    import subprocess
+    import sys
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2", LCX_GEMM="ct",
+                   LCX_TEST_DUMP_AFTER=str(timeout - 30), LCX_CHECK_RANKS="1",
+                   LCX_WAIT_TIMEOUT_MS=str(1000 * (timeout - 45)), **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker_f32.py"), str(out_dir),
+                                       str(n), str(v), str(m), str(iters)], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            out, _ = p.communicate()
+        outs.append(out.decode(errors="replace"))
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+
+
+@pytest.mark.parametrize("m", [128, 64])
+def test_sharded_float32_large_kernels_match_single_gpu(m, tmp_path, monkeypatch):
+    """BASELINE configs[3]'s code path at a size the oracle finishes in seconds: float32, n_hidden = 128 (and 64), the
+    column-tiled stream-K kernel (gemm_ct) under world > 1, two ranks holding 4096 variables each.  The sharded run must equal
+    the single-GPU run of the same problem to float32 rounding (shard count only changes the summation order of Y)
+    with the same number of line-search trials, and both must agree with the float32 oracle."""
+    from linearcorex_amd import Corex
+    from tests._dist_worker_f32 import planted_f32, run_loop
+    n, v, iters = 4096, 8192, 3
+    _launch_f32(2, tmp_path, n, v, m, iters)
+    got = np.load(os.path.join(tmp_path, "dist_f32.npz"))
+    assert int(got["world"]) == 2
+    assert ("gemm_ct_kernel<float, %d" % (m // 16)) in str(got["kernel_nt"]) and "gemm_ct_kernel" in str(got["kernel_tn"])
+    monkeypatch.setenv("LCX_GEMM", "ct")
+    xt = planted_f32(n, v, m)
+    single = Corex(n_hidden=m, seed=0, dtype=np.float32, tol=0.0, device=0)
+    be = single._attach_shard(xt, v)
+    h1 = run_loop(single, iters)
+    w1, rho1 = be.get_ws(0), be.get_moment(0, "rho")
+    be.close()
+    h2 = got["history"]
+    assert len(h1) == len(h2) == 7 * iters
+    assert np.max(np.abs(h2 - h1) / np.maximum(1.0, np.abs(h1))) < 5e-5
+    assert int(got["trials"]) == single.stats["trials"]
+    scale = float(np.max(np.abs(w1)))
+    assert np.max(np.abs(got["ws"] - w1)) < 1e-3 * scale
+    assert np.max(np.abs(got["rho"] - rho1)) < 1e-3 * float(np.max(np.abs(rho1)))
+    ref = O.fit_ns_preprocessed(xt, m, seed=0, dtype=np.float32, max_iter=iters, tol=0.0, finish=False)
+    hr = np.asarray(ref.history_tc, np.float64)
+    assert np.max(np.abs(h2 - hr) / np.maximum(1.0, np.abs(hr))) < 2e-3
+    assert abs(int(got["trials"]) - ref.n_trials) <= 2
+    assert np.max(np.abs(got["ws"] - ref.ws)) < 5e-3 * float(np.max(np.abs(ref.ws)))

@@ -103,3 +103,71 @@ def test_config3_merged_pass_matches_separate_passes(monkeypatch):
     assert np.max(np.abs(h1 - h0) / np.maximum(1.0, np.abs(h0))) < 1e-4
     assert abs(runs["1"][1] - runs["0"][1]) <= 1
     assert abs(runs["1"][2] - runs["0"][2]) < 1e-3 * runs["0"][2]
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(1e-300, float(np.max(np.abs(b)))))
+
+
+@pytest.mark.parametrize("shape,kind", [((50000, 100000, 64), 0), ((50000, 125000, 128), 1)], ids=["config3", "config4_shard"])
+def test_full_size_step_vs_oracle(shape, kind):
+    """BASELINE configs[2] and the configs[3] shard at FULL size against the oracle, element by element: the resident matrix is
+    copied back (20 / 25 GB), and one `_calculate_moments_ns` (reference :236-275), one update direction (:292-305) and one
+    whole `_update_ns` with its back-tracking (:306-334) run in NumPy float32 on the host cores - what the reference computes -
+    beside the device path (gemm_ct stream-K slots, 64-bit offsets, the merged pass of config 3, lcx_iterate).
+    Bars: the float32 step bar of tests/test_parity_gpu.py (2e-4 of the array scale; x10 for derived arrays, as there)."""
+    from linearcorex_amd.backend import HipBackend
+    from oracle import corex_oracle as O
+    from bench import _BlasPool                                 # BLAS threads = the cores the cgroup really grants
+    with _BlasPool():
+        _full_size_step(shape, kind, HipBackend, O)
+
+
+def _full_size_step(shape, kind, HipBackend, O):
+    n, v, m = shape
+    tol, eps = 2e-4, 0.36
+    be = HipBackend(n, v, m, np.float32, 0)
+    be.set_linear_mode(False)                                    # what `Corex(line_search="exact")` runs
+    assert "gemm_ct_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)
+    be.generate_x(1, kind, m, 0)
+    x = be.download_x()
+    assert x.dtype == np.float32 and x.shape == (n, v)
+    rng = np.random.RandomState(3)
+    w = rng.randn(m, v).astype(np.float32)
+    w /= (10.0 * O.norm(x, w, 0))[:, np.newaxis]
+    w *= np.float32(3.0)                                         # uj ~ 0.09
+    be.set_ws(w)
+    ref = O.moments_ns(x, w, eps, quick=True)
+    assert ref is not False
+    be.moments_a(0); be.moments_b(0, eps, 1); be.moments_c(0)
+    st = be.read_state(0)
+    assert st[2] == 0
+    tc_ref = float(ref["TC"])
+    assert abs(st[0] - tc_ref) <= tol * 10 * max(1.0, abs(tc_ref)), (st[0], tc_ref)
+    assert abs(st[1] - float(ref["uj"].max())) <= tol
+    errs = {}
+    for key in ("uj", "rho", "ry", "rhoinvrho", "Qij", "Si", "Qi-Si^2"):
+        errs[key] = _rel(be.get_moment(0, key), ref[key])
+        assert errs[key] < tol * 10, (key, errs)
+    d = O.update_direction(x, w, ref, eps)
+    be.update_a()
+    errs["H"] = _rel(be.get_moment(0, "H"), d["H"])
+    assert errs["H"] < tol * 10, errs
+    # the whole iteration in the library (direction, merged pass where it applies, trials, acceptance)
+    out = be.iterate(eps, 1e-5, st[0], False)
+    errs["grad"] = _rel(be.get_moment(0, "grad"), d["grad"])
+    errs["update"] = _rel(be.get_moment(0, "update"), d["update"])
+    assert errs["grad"] < tol * 10 and errs["update"] < tol * 10, errs
+    assert abs(out[2] - float(d["tangent"])) <= tol * 50 * abs(float(d["tangent"])), (out[2], float(d["tangent"]))
+    w_new, m_new, info = O.update_ns(x, w, ref, eps, 1e-5)
+    assert info["status"] == "ok" and out[0] == 0
+    assert int(out[3]) == info["n_trials"] and int(out[4]) == info["n_invalid"], (out, info)
+    tc_new = float(m_new["TC"])
+    assert abs(out[1] - tc_new) <= tol * 10 * max(1.0, abs(tc_new)), (out[1], tc_new)
+    errs["ws"] = _rel(be.get_ws(0), w_new)
+    errs["rho_new"] = _rel(be.get_moment(0, "rho"), m_new["rho"])
+    assert errs["ws"] < tol and errs["rho_new"] < tol * 10, errs
+    print("full-size step vs oracle", shape, {k: "%.2e" % e for k, e in errs.items()},
+          "TC %.6f / %.6f -> %.6f / %.6f, trials %d" % (st[0], tc_ref, out[1], tc_new, int(out[3])))
+    be.close()

@@ -437,6 +437,15 @@ def test_generated_data_is_standardised():
     be2 = HipBackend(2000, 200, 4, np.float32, 0)
     be2.generate_x(1, 1, 4, 100)
     assert np.allclose(be2.download_x(), x[:, 100:], atol=1e-6)
+    # the planted group of a column as bench.py restates it (cluster purity of the convergence run): same group =>
+    # correlation 1/2 (shared factor + unit noise), different groups => none
+    from bench import planted_groups
+    grp = planted_groups(1, 300, 4)
+    c = np.corrcoef(x.astype(np.float64).T)
+    same = grp[:, None] == grp[None, :]
+    off = ~np.eye(300, dtype=bool)
+    assert np.min(c[same & off]) > 0.4 and np.max(np.abs(c[~same])) < 0.12
+    assert np.array_equal(planted_groups(1, 200, 4, col_offset=100), grp[100:])
     be.close()
     be2.close()
 

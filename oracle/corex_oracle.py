@@ -217,6 +217,20 @@ def initial_weights(seed, m, nv, dtype):
     return np.random.RandomState(seed).randn(m, nv).astype(dtype)
 
 
+def invert(x, theta, gaussianize="standard"):
+    """ref :431-438 `invert`: undo the marginal preprocessing."""
+    if gaussianize == "standard":
+        return theta[1] * x + theta[0]
+    if gaussianize == "outliers":
+        return theta[1] * unsquash_tails(x) + theta[0]
+    return x
+
+
+def predict(xz, y, theta, gaussianize="standard"):
+    """ref :440-441 `predict`: invert(X_i Z_j . y^T), xz = moments["X_i Z_j"] (nv, m), y (n, m) -> (n, nv)."""
+    return invert(np.dot(xz, y.T).T, theta, gaussianize)
+
+
 class OracleFit:
     """Result of `fit_ns` (mirrors the reference attributes the parity tests look at)."""
 

@@ -311,3 +311,13 @@ class ShardDouble:
 
     def project(self, x):
         return np.asarray(x, self.dtype).dot(self.w[0].T)
+
+    def predict(self, y, xz=None, syn=False, gaussianize=None, theta=None):
+        from oracle import corex_oracle as O
+        if xz is None:
+            xz = self.get_moment(0, "syn X_i Z_j" if syn else "X_i Z_j")
+        return O.predict(np.asarray(xz, self.dtype), np.asarray(y, self.dtype), theta, gaussianize)
+
+    def invert(self, x, gaussianize, theta):
+        from oracle import corex_oracle as O
+        return O.invert(np.asarray(x, self.dtype), theta, gaussianize)

@@ -204,8 +204,15 @@ def test_synergistic_branch_host_logic():
     assert abs(out.moments["additivity"] - ref.moments["additivity"]) < 1e-9
     cov = out.get_covariance()
     assert np.max(np.abs(cov - ref.get_covariance())) < 1e-10
+    # a restored model has no device handle; get_covariance brings X_i Z_j / X_i Y_j back to a (data-less) backend and
+    # runs the same product there - also after a transform() already created that backend (round-2 advisor finding)
     back = pickle.loads(pickle.dumps(out))
-    assert back._backend is None and np.max(np.abs(back.get_covariance() - cov)) < 1e-12
+    assert back._backend is None
+    back._backend_factory = lambda ns, nv, mm, dt: ShardDouble(ns, nv, mm, dt)
+    assert np.max(np.abs(back.transform(x) - out.transform(x))) < 1e-12
+    assert back._backend is not None and back._backend.n == 1
+    assert np.max(np.abs(back.get_covariance() - cov)) < 1e-12
+    assert np.max(np.abs(back.predict(out.transform(x)[:7]) - out.predict(out.transform(x)[:7]))) < 1e-12
 
 
 def test_bench_gpus_n_spawns_the_ranks_itself():

@@ -247,3 +247,24 @@ def test_oracle_syn_matches_reference(tag):
     assert np.max(np.abs(res.ws - g["planted_%s_ws" % tag])) < 1e-9
     assert np.max(np.abs(res.get_covariance() - g["planted_%s_cov" % tag])) < 1e-9
     assert np.array_equal(res.clusters(), g["planted_%s_clusters" % tag])
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("branch", ["ns", "syn"])
+@pytest.mark.parametrize("gz", ["standard", "outliers"])
+def test_predict_and_invert_match_reference(gz, branch, tag):
+    """`predict` / `invert` (reference :431-441, g_inv :490-494) against tests/golden/g9_predict.npz (the reference's own
+    outputs on big5, tests/golden/make_golden_predict.py): same arithmetic on the same inputs - exact, poles of g_inv
+    (non-finite in float32, where 1 - 1e-10 rounds to 1) included."""
+    g = load_golden("g9_predict")
+    p = "%s_%s_%s_" % (gz, branch, tag)
+    theta = (g[p + "theta_mean"], g[p + "theta_std"])
+    z = g["z"].astype(DT[tag])
+    with np.errstate(all="ignore"):
+        inv = O.invert(z, theta, gz)
+        pred = O.predict(g[p + "xz"], g[p + "y"], theta, gz)
+    assert inv.dtype == g[p + "invert"].dtype
+    assert np.array_equal(np.isfinite(inv), np.isfinite(g[p + "invert"]))
+    ok = np.isfinite(inv)
+    assert np.array_equal(inv[ok], g[p + "invert"][ok])
+    close(pred, g[p + "predict"], tag)

@@ -521,6 +521,8 @@ def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_s
             "iterations_per_sec_incl_stage_changes": float(n_stages * steps / (stage_med.sum() + np.median(chgs, axis=0).sum())),
         },
         "bytes_resident": be.bytes_resident() if hasattr(be, "bytes_resident") else None,
+        "exchange": dict(be.exchange_info(), transport=getattr(model, "_engine_exchange", None),
+                         line_search_in_library=bool(getattr(model, "_iterated_in_library", False))),
     }
     return res, model, be
 
@@ -610,7 +612,11 @@ def config_of(workload, r, world, line_search, force_exchange=False):
             "x_passes_per_iteration": r["x_passes"],
             "x_passes_per_iteration_reference_shaped": 2 + 2 * r["trials"] - r["invalid"],
             "windows": r["windows"], "launch_geometry": r["geo"], "final_TC": r["final_tc"],
-            "bytes_resident": r["bytes_resident"], "force_exchange": bool(force_exchange)}
+            "bytes_resident": r["bytes_resident"], "force_exchange": bool(force_exchange),
+            # who issues the all-reduces of the exchange steps: "rccl" = the library, on a communicator the handle owns
+            # (include/lcx.h lcx_comm_init); "hook" = the library through the caller's transport; None / "caller" = the
+            # host-sequenced path (LCX_EXCHANGE=torch); kind "none" = one rank, no exchange steps
+            "exchange": r.get("exchange")}
 
 
 def linear_mode_block(workload, r3, world):

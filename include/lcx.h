@@ -47,7 +47,8 @@ typedef enum {
     LCX_ERR_ARG = 1,        /* bad argument                                  */
     LCX_ERR_HIP = 2,        /* a HIP runtime call failed (see lcx_last_error) */
     LCX_ERR_NO_DEVICE = 3,  /* no usable gfx950 device                        */
-    LCX_ERR_STATE = 4       /* call sequence violated                         */
+    LCX_ERR_STATE = 4,      /* call sequence violated                         */
+    LCX_ERR_COMM = 5        /* RCCL / the exchange hook failed                */
 } lcx_status;
 
 typedef enum { LCX_F32 = 0, LCX_F64 = 1 } lcx_dtype;
@@ -126,6 +127,27 @@ int lcx_exchange_layout(lcx_ctx* h, int64_t* ybuf_elems, int64_t* sbuf_elems,
                         void** ybuf_dev, void** sbuf_dev);
 int lcx_bind_exchange(lcx_ctx* h, void* ybuf_dev, void* sbuf_dev);
 
+/* ---- exchange inside the library --------------------------------------------------------------------------------------
+ * The sums over all variables (Y = X.W^T with W.W^T, the TC sums with H and the tangent, Y_g with Bj - the
+ * reference's :247, :259, :294, :301-305 seen from one shard) are all-reduces of the two exchange buffers.  Once a
+ * transport is bound, every level below issues the all-reduce of what it produced ITSELF, on the handle's stream, right
+ * behind the kernels that wrote it - the caller calls the same levels and exchanges nothing - and lcx_iterate serves
+ * several ranks: its line-search decisions are taken from all-reduced scalars, which are bit-identical on every rank,
+ * so every rank issues the same sequence of collectives without talking about it.
+ *
+ *   RCCL (one communicator per handle, xGMI inside a node):
+ *       rank 0:     lcx_comm_unique_id(id)         ncclGetUniqueId; ship the LCX_COMM_ID_BYTES to the other ranks
+ *       every rank: lcx_comm_init(h, n, rank, id)  ncclCommInitRank (collective); implies lcx_set_world(h, n)
+ *   any other transport: lcx_set_exchange_hook(h, fn, user): fn sums `count` elements of `dtype` (LCX_F32 / LCX_F64) at the
+ *       device address `dev_buf` over the ranks, in place, ordered with `hip_stream`; returns 0 on success.
+ * lcx_exchange_info: kind -1 = no exchange steps (one rank), 0 = the caller exchanges between the levels, 1 = RCCL, 2 = hook. */
+#define LCX_COMM_ID_BYTES 128
+typedef int (*lcx_allreduce_fn)(void* user, void* dev_buf, int64_t count, int dtype, void* hip_stream);
+int lcx_comm_unique_id(void* id_out /* LCX_COMM_ID_BYTES */);
+int lcx_comm_init(lcx_ctx* h, int nranks, int rank, const void* id /* LCX_COMM_ID_BYTES */);
+int lcx_set_exchange_hook(lcx_ctx* h, lcx_allreduce_fn fn, void* user);
+int lcx_exchange_info(lcx_ctx* h, int* kind, int* world, int64_t* allreduces_issued);
+
 /* ---- data ---------------------------------------------------------------------------------- */
 /* Replaces cm.CUDAMatrix(x) (:427-428): upload the preprocessed shard, row-major, leading
  * dimension ld (elements of the working dtype). */
@@ -199,7 +221,7 @@ int lcx_trial_linear_b(lcx_ctx* h, double eps, double eta);
 /* self.ws, self.moments = w_update, m_update (:139,:334): swap sets                              */
 int lcx_accept_trial(lcx_ctx* h);
 
-/* ---- one whole iteration (:290-334) in one call, one GPU ----------------------------------------------------
+/* ---- one whole iteration (:290-334) in one call -------------------------------------------------------------
  * `_update_ns` with its back-tracking line search, the host side of the decisions included: the levels above
  * (lcx_update_b/_c, lcx_make_trial, lcx_moments_a/_b per trial, lcx_accept_trial) are sequenced inside the library, the
  * scalars of each trial are read from the pinned mirror and the next launches follow immediately - no interpreter between
@@ -212,7 +234,9 @@ int lcx_accept_trial(lcx_ctx* h);
  *       [1] TC of the accepted trial, [2] update_tangent (:305), [3] trials evaluated (:321), [4] trials with max uj >= 1
  *       (:322-326), [5] 1 if the step size fell below min(tol, 1e-10) (:316-319), [6] moment evaluations waited for,
  *       [7] 1 if the next iteration was started.
- * With several ranks the exchange steps sit between the levels, so the caller sequences them itself (LCX_ERR_STATE). */
+ * Several ranks: needs the exchange inside the library (lcx_comm_init / lcx_set_exchange_hook); every rank calls it with the same
+ * arguments and gets the same answer.  While the caller owns the exchange (neither bound) it sequences the levels itself and
+ * this call returns LCX_ERR_STATE. */
 int lcx_iterate(lcx_ctx* h, double eps, double tol, double tc_cur, int more, double* out8);
 
 /* ---- synergistic branch: discourage_overlap=False (:336-384) -------------------------------------

@@ -23,6 +23,9 @@ M_UJ, M_RHO, M_RY, M_INVRHO, M_RHOINVRHO, M_QIJ, M_SI, M_QISI2, M_MI, M_XIZJ, M_
     M_GRAD, M_UPDATE, M_SIG_GRAD, M_H, M_Y, M_SYN_XIZJ, M_SYN_X2Y, M_SYN_XIYJ, M_CY, M_YJ2 = range(21)
 
 _i64, _i32, _dbl, _vp = C.c_int64, C.c_int, C.c_double, C.c_void_p
+COMM_ID_BYTES = 128
+# lcx_allreduce_fn: int (*)(void* user, void* dev_buf, int64_t count, int dtype, void* hip_stream)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _i64, _i32, _vp)
 
 # name -> (argtypes); every function returns int status except the two noted below
 SIGNATURES = {
@@ -38,6 +41,10 @@ SIGNATURES = {
     "lcx_set_exchange": [_vp, _i32],
     "lcx_exchange_layout": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_vp)],
     "lcx_bind_exchange": [_vp, _vp, _vp],
+    "lcx_comm_unique_id": [_vp],
+    "lcx_comm_init": [_vp, _i32, _i32, _vp],
+    "lcx_set_exchange_hook": [_vp, ALLREDUCE_FN, _vp],
+    "lcx_exchange_info": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)],
     "lcx_upload_x": [_vp, _vp, _i64],
     "lcx_upload_preprocess": [_vp, _vp, _i64, _i32, _i32, _dbl, _i32, _vp, _vp, C.POINTER(_i64), C.POINTER(_dbl)],
     "lcx_project_raw": [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp],

@@ -130,6 +130,42 @@ class HipBackend:
     def synchronize(self):
         _abi.check(self.lib.lcx_synchronize(self.h))
 
+    # ---- exchange inside the library (include/lcx.h: lcx_comm_init / lcx_set_exchange_hook) -------
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(_abi.COMM_ID_BYTES)
+        _abi.check(self.lib.lcx_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, world, rank, unique_id):
+        """RCCL communicator owned by the handle (collective: every rank of the group calls it with rank 0's id)."""
+        assert len(unique_id) == _abi.COMM_ID_BYTES
+        _abi.check(self.lib.lcx_comm_init(self.h, int(world), int(rank), C.c_char_p(unique_id)))
+
+    def set_exchange_hook(self, allreduce):
+        """allreduce(dev_ptr, count, dtype_code, hip_stream) -> None sums the buffer over the ranks in place (any transport).
+        The ctypes thunk is kept alive on the backend for as long as the library may call it."""
+        if allreduce is None:
+            _abi.check(self.lib.lcx_set_exchange_hook(self.h, _abi.ALLREDUCE_FN(0), None))
+            self._hook = None
+            return
+
+        def thunk(user, ptr, count, dtype, stream):
+            try:
+                allreduce(int(ptr), int(count), int(dtype), stream)
+                return 0
+            except BaseException:          # must not propagate into C; the library turns the code into LCX_ERR_COMM
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._hook = _abi.ALLREDUCE_FN(thunk)
+        _abi.check(self.lib.lcx_set_exchange_hook(self.h, self._hook, None))
+
+    def exchange_info(self):
+        kind, world, n = C.c_int(), C.c_int(), C.c_int64()
+        _abi.check(self.lib.lcx_exchange_info(self.h, C.byref(kind), C.byref(world), C.byref(n)))
+        return {"kind": {-1: "none", 0: "caller", 1: "rccl", 2: "hook"}[kind.value], "world": world.value,
+                "allreduces_issued": n.value}
+
     # ---- exchange buffers ---------------------------------------------------------------------
     def exchange_tensors(self):
         """(ybuf, sbuf) as torch tensors on this GPU, bound as the handle's exchange buffers and

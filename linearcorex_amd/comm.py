@@ -40,6 +40,39 @@ class Comm:
         if self.world > 1:
             self._dist.barrier(group=self.group)
 
+    def bind_engine(self, backend):
+        """Move the exchange steps into the engine (include/lcx.h, 'exchange inside the library'): afterwards the levels of
+        the C ABI all-reduce what they produce themselves and `lcx_iterate` serves several ranks.  Returns the transport
+        name, or None when the backend has no in-library exchange (the NumPy test double) or LCX_EXCHANGE=torch asks for
+        the host-sequenced path (torch.distributed between the level calls - kept selectable).
+
+        RCCL group ("nccl"): the handle gets an RCCL communicator of its own - rank 0 draws the unique id, which travels
+        through this group's broadcast - and issues ncclAllReduce on its stream.  Any other backend (gloo in the tests, two
+        ranks sharing one GPU): a hook that runs this group's all_reduce on a zero-copy view of the device buffer."""
+        import os
+        mode = os.environ.get("LCX_EXCHANGE", "engine")
+        if mode == "torch" or not self.exchange or not hasattr(backend, "comm_init"):
+            return None
+        import torch
+        if self._dist.get_backend(self.group) == "nccl" and mode != "hook":
+            box = [backend.comm_unique_id() if self.rank == 0 else None]
+            src = self._dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            self._dist.broadcast_object_list(box, src=src, group=self.group, device=torch.device("cuda", backend.device))
+            backend.comm_init(self.world, self.rank, box[0])
+            return "rccl"
+
+        class _View:                        # zero-copy: torch.as_tensor understands __cuda_array_interface__
+            def __init__(self, ptr, count, dtype):
+                self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4" if dtype == 0 else "<f8",
+                                                 "data": (ptr, False), "version": 2}
+
+        def allreduce(ptr, count, dtype, stream):
+            with backend.stream_context():
+                t = torch.as_tensor(_View(ptr, count, dtype), device=torch.device("cuda", backend.device))
+                self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        backend.set_exchange_hook(allreduce)
+        return "hook"
+
     def gather_columns(self, local, nv, like):
         """All-gather per-rank column blocks (last axis) into the full array on every rank.
         `like` is a tensor on the device the group communicates on."""
@@ -74,6 +107,9 @@ class SingleComm:
 
     def barrier(self):
         pass
+
+    def bind_engine(self, backend):
+        return None
 
     def gather_columns(self, local, nv, like=None):
         return local

@@ -185,6 +185,10 @@ class Corex(object):
               every `refresh_every` iterations and at every annealing stage.
     """
 
+    # defaults for models pickled by an earlier build
+    _ex = None
+    _engine_exchange = None
+
     def __init__(self, n_hidden=10, max_iter=10000, tol=1e-5, anneal=True, missing_values=None,
                  discourage_overlap=True, gaussianize='standard', gpu=False,
                  verbose=False, seed=None, *, dtype=np.float32, device=None, comm=None,
@@ -219,6 +223,8 @@ class Corex(object):
         self._comm = comm if comm is not None else SingleComm()
         self._backend_factory = _backend_factory
         self._backend = None
+        self._ex = None
+        self._engine_exchange = None
         self._cols = (0, 0)
         self._tc_cur = np.nan
         if line_search not in ("exact", "linear"):
@@ -275,10 +281,15 @@ class Corex(object):
         if exchange and self._comm.world == 1 and hasattr(be, "set_exchange"):
             be.set_exchange(True)
         self._ex = be.exchange_tensors() if exchange else None
+        # the exchange steps inside the engine (RCCL communicator of the handle, or a hook for other transports): the levels
+        # then all-reduce what they produce themselves and this class issues no collective on the hot path
+        self._engine_exchange = self._comm.bind_engine(be) if exchange else None
         return be
 
     def _allreduce(self, tensor):
-        """Exchange step: all-reduce on the stream the engine's kernels run on."""
+        """Exchange step: all-reduce on the stream the engine's kernels run on - unless the engine does it itself."""
+        if self._engine_exchange:
+            return
         with self._backend.stream_context():
             self._comm.allreduce(tensor)
 
@@ -634,6 +645,7 @@ class Corex(object):
         right where the trial's scalars arrive, and the next iteration's first launches are already queued when this returns."""
         be, m = self._backend, self.moments
         r = be.iterate(self.eps, self.tol, self._tc_cur, more)
+        self._assert_same_on_all_ranks(r[:6], "lcx_iterate (status, TC, tangent, trials, invalid trials, too small)")
         status = int(r[0])
         self.stats["trials"] += int(r[3])
         self.stats["invalid_trials"] += int(r[4])
@@ -653,8 +665,9 @@ class Corex(object):
         new weights stay on the device)."""
         be = self._backend
         m = self.moments
-        if self._in_library and self._ex is None and self.line_search == "exact" and self.verbose <= 1 \
-                and hasattr(be, "iterate"):
+        if self._in_library and (self._ex is None or self._engine_exchange) and self.line_search == "exact" \
+                and self.verbose <= 1 and hasattr(be, "iterate"):
+            self._iterated_in_library = True
             return self._update_ns_in_library(more)
         # H (:294) is already global: it came with the scalar exchange of the evaluation that produced set 0
         be.update_b(self.eps)                # grad (:296-300), Bj partial, Y_g partial
@@ -743,7 +756,7 @@ class Corex(object):
         else:
             x = self.preprocess(x)       # imputation needs the column means of the whole new batch: host side
             y = be.project(np.ascontiguousarray(x[:, c0:c1]))
-        if self._ex is not None:
+        if self._ex is not None and not self._engine_exchange:       # (the engine summed the per-shard partials itself)
             import torch
             with be.stream_context():
                 t = torch.from_numpy(y).to(self._ex[1].device)
@@ -844,7 +857,7 @@ class Corex(object):
         d = dict(self.__dict__)
         if isinstance(d.get("moments"), DeviceMoments):
             d["moments"] = d["moments"].materialize()
-        for k in ("_backend", "_ex", "_backend_factory"):
+        for k in ("_backend", "_ex", "_backend_factory", "_engine_exchange"):
             d[k] = None
         if not isinstance(d.get("_comm"), SingleComm):
             d["_comm"] = SingleComm()

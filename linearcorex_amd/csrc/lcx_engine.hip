@@ -13,6 +13,8 @@
 #include <time.h>
 #include <sys/mman.h>
 #include <unistd.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types and prototypes only: the library is resolved at run time (see RcclApi)
 
 #include <map>
 #include <mutex>
@@ -54,6 +56,60 @@ static int fail(int code, const std::string& msg) {
 
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// -------------------------------------------------------------------------------------------------
+// exchange transport: who sums the exchange buffers over the ranks that share the variables axis
+// -------------------------------------------------------------------------------------------------
+// RCCL is bound at run time (dlopen of librccl.so.1, which is the copy a hosting process - PyTorch - has already loaded, so
+// that both use one HIP runtime): a single-GPU user of liblcx_hip.so never needs it.
+struct RcclApi {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+    bool ok = false;
+};
+static RcclApi& rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void* lib = nullptr;
+        for (const char* n : names) {
+            lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { api.error = std::string("cannot load librccl.so.1: ") + dlerror(); return; }
+        api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))dlsym(lib, "ncclCommInitRank");
+        api.AllReduce = (decltype(api.AllReduce))dlsym(lib, "ncclAllReduce");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(lib, "ncclCommDestroy");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(lib, "ncclGetErrorString");
+        api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy && api.GetErrorString;
+        if (!api.ok) api.error = "librccl.so.1 lacks one of ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy";
+    });
+    return api;
+}
+#define RCCLCHECK(expr)                                                                                         \
+    do {                                                                                                        \
+        ncclResult_t r_ = (expr);                                                                               \
+        if (r_ != ncclSuccess)                                                                                  \
+            return fail(LCX_ERR_COMM, std::string(#expr) + ": " + rccl().GetErrorString(r_) + " (" + __FILE__ + ":" + \
+                                          std::to_string(__LINE__) + ")");                                      \
+    } while (0)
+
+// kind 0: none - the caller all-reduces the exchange buffers between the level calls (lcx_bind_exchange);
+// kind 1: an RCCL communicator owned by the handle (lcx_comm_init): ncclAllReduce on the handle's stream;
+// kind 2: the caller's function (lcx_set_exchange_hook): any other transport (MPI, gloo in the tests).
+struct Transport {
+    int kind = 0;
+    ncclComm_t comm = nullptr;
+    lcx_allreduce_fn hook = nullptr;
+    void* user = nullptr;
+    int rank = 0, nranks = 1;
+};
 
 // -------------------------------------------------------------------------------------------------
 // context
@@ -157,11 +213,29 @@ struct lcx_ctx {
     bool early_grad, grad_ready;
     double spec_eps;
     size_t bytes_resident;      // device bytes owned by the handle (X, its transposed copy, moments, work space)
+    Transport tr;               // in-library exchange (kind != 0): every level sums what it produced over the ranks itself
+    int64_t n_exchanges;        // all-reduces issued by the library (diagnostics)
 };
 
 template <typename T> static inline T* P(void* p) { return reinterpret_cast<T*>(p); }
 static int wait_published(lcx_ctx* h, MomentSet& s);
 static inline void cancel_speculation(lcx_ctx* h);
+
+// Sum `count` elements at `buf` (device memory) over the ranks, in place, stream-ordered with the handle's kernels.
+// Without a bound transport this is the caller's job between the level calls; without exchange steps there is nothing to sum.
+static int exchange(lcx_ctx* h, void* buf, int64_t count, int dtype) {
+    if (!h->exchange || h->tr.kind == 0 || count <= 0) return LCX_OK;
+    h->n_exchanges += 1;
+    if (h->tr.kind == 1) {
+        RCCLCHECK(rccl().AllReduce(buf, buf, (size_t)count, dtype == LCX_F32 ? ncclFloat : ncclDouble, ncclSum, h->tr.comm, h->stream));
+        return LCX_OK;
+    }
+    const int rc = h->tr.hook(h->tr.user, buf, count, dtype, (void*)h->stream);
+    if (rc != 0) return fail(LCX_ERR_COMM, "the exchange hook reported failure " + std::to_string(rc));
+    return LCX_OK;
+}
+// the library can sequence whole iterations when it does not depend on the caller for the sums
+static inline bool self_contained(const lcx_ctx* h) { return !h->exchange || h->tr.kind != 0 || h->world == 1; }
 
 // Temporary device buffers of one call: freed on every return path (an OOM in the middle of a call must not leak the
 // buffers allocated before it - that is exactly when memory matters).
@@ -362,6 +436,7 @@ template <typename T, int CT> struct Geo {
 template <typename T, int CT> struct Impl {
     static constexpr int Mp = 16 * CT;
     static constexpr int VPB = PV_THREADS / Mp;
+    static constexpr int DT = sizeof(T) == 4 ? LCX_F32 : LCX_F64;
 
     // resident blocks per CU of a kernel at a given block size / dynamic LDS
     template <typename F> static int blocks_per_cu(F* f, int threads, size_t lds) {
@@ -616,7 +691,8 @@ template <typename T, int CT> struct Impl {
         // without an exchange the summed Y is final: the set's own copy is written by the same reduction
         LCXCHECK(nt_big(h, w, nullptr, false, (!h->exchange && h->nt_S > 1) ? P<T>(h->set[which].Y) : (T*)nullptr));
         if (!h->exchange) return LCX_OK;         // nothing to exchange: W.W^T is formed with Y^T.Y in lcx_moments_b (one launch)
-        return gram_w(h, w);
+        LCXCHECK(gram_w(h, w));
+        return exchange(h, h->ybuf, h->ybuf_elems, DT);          // L1 of SURVEY 8e: [Y_partial | W.W^T partial]
     }
 
     // per-factor moments; ysrc != null: first form the Y^T.Y partials of that Y
@@ -710,7 +786,7 @@ template <typename T, int CT> struct Impl {
         hipLaunchKernelGGL((reduce_wide_kernel<T, double>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
                            P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, h->sbuf + SB_H, skip);
         KCHECK();
-        return LCX_OK;
+        return exchange(h, h->sbuf, SB_H + Mp * Mp, LCX_F64);    // L2 + L3 + L5: TC sums, pending tangent, H of this set
     }
 
     static int moments_b(lcx_ctx* h, int which, double eps, int quick) {
@@ -732,7 +808,8 @@ template <typename T, int CT> struct Impl {
                            h->stream, P<T>(h->Wt[0]), P<T>(h->update), P<T>(h->Wt[1]), n1,
                            P<T>(h->set[0].Y), P<T>(h->ydir), P<T>(h->set[1].Y), n2, (T)eta);
         KCHECK();
-        return gram_pair(h, P<T>(h->Wt[1]), P<T>(h->set[1].Y));
+        LCXCHECK(gram_pair(h, P<T>(h->Wt[1]), P<T>(h->set[1].Y)));
+        return exchange(h, P<T>(h->ybuf) + h->Npad * Mp, (int64_t)Mp * Mp, DT);      // W'.W'^T partial
     }
     // b: (W.W^T tail global) uj, flag, D' = D + eta*D(update), rho ... TC partial sums
     static int trial_linear_b(lcx_ctx* h, double eps, double eta) {
@@ -756,7 +833,7 @@ template <typename T, int CT> struct Impl {
         hipLaunchKernelGGL((reduce_wide_kernel<T, double>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
                            P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, h->sbuf + SB_H, (const int*)nullptr);
         KCHECK();
-        return LCX_OK;
+        return exchange(h, h->sbuf + SB_H, (int64_t)Mp * Mp, LCX_F64);
     }
 
     // grad (:296-300) and the per-block Bj partials (:302) of set `which`, from its moments and the H its evaluation left in sbuf
@@ -773,7 +850,7 @@ template <typename T, int CT> struct Impl {
     static int update_b(lcx_ctx* h, double eps) {
         (void)eps;
         if (h->spec_dirty) {                            // an abandoned speculation overwrote the H of set 0 in sbuf
-            if (h->exchange) return fail(LCX_ERR_STATE, "abandoned lcx_iterate speculation with several ranks");
+            if (!self_contained(h)) return fail(LCX_ERR_STATE, "abandoned lcx_iterate speculation while the caller owns the exchange");
             LCXCHECK(update_a(h));
             h->spec_dirty = false;
         }
@@ -781,7 +858,10 @@ template <typename T, int CT> struct Impl {
         const bool merged = use_merged(h);
         if (h->grad_ready) h->grad_ready = false;       // lcx_iterate already computed it behind the accepted trial's evaluation
         else LCXCHECK(launch_grad(h, 0));
-        if (!merged) return nt_big(h, P<T>(h->grad), nullptr, true);
+        if (!merged) {
+            LCXCHECK(nt_big(h, P<T>(h->grad), nullptr, true));
+            return exchange(h, h->ybuf, h->ybuf_elems, DT);      // L4: [Y_g partial | Bj partial]
+        }
         if constexpr (sizeof(T) == 4 && CT >= 2 && CT <= 4) {
             // Bj (:302) does not wait for the pass: sum its per-block partials now, form update and ws + update (:303, :320) and
             // put both B operands side by side, then ONE pass over X for [Y_g | Y of the first trial]
@@ -858,6 +938,7 @@ template <typename T, int CT> struct Impl {
     static int evaluate_trial(lcx_ctx* h, double eps) {
         LCXCHECK(moments_a(h, 1));
         LCXCHECK(moments_b(h, 1, eps, 1));
+        LCXCHECK(moments_c(h, 1));                   // several ranks: TC / tangent from the summed scalars, publication
         h->early_grad = false;
         // Worth it while the gradient kernel is shorter than the host's decision latency (~20 us): up to ~1M (variable, factor)
         // pairs (config 2: 5 us).  On large shards a rejected trial would waste more than the gap it hides (config 4 shard: 289 us).
@@ -887,8 +968,9 @@ template <typename T, int CT> struct Impl {
         return rc;
     }
     static int iterate_body(lcx_ctx* h, double eps, double tol, double tc_cur, int more, double* out) {
-        if (h->exchange)
-            return fail(LCX_ERR_STATE, "lcx_iterate drives one GPU; with several ranks the caller exchanges between the levels "
+        if (!self_contained(h))
+            return fail(LCX_ERR_STATE, "lcx_iterate with several ranks needs the exchange inside the library (lcx_comm_init or "
+                                       "lcx_set_exchange_hook); otherwise the caller exchanges between the levels "
                                        "(lcx_update_b ... lcx_moments_c)");
         const bool consumed = h->spec_pending && h->spec_eps == eps;
         if (h->spec_pending && !consumed) cancel_speculation(h);
@@ -1033,7 +1115,7 @@ template <typename T, int CT> struct Impl {
         hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(h->M + 3), dim3(PV_THREADS), 0, h->stream, h->detpart, h->pv_grid,
                            h->M + 3, h->sbuf + sb_det(Mp), (const int*)nullptr);
         KCHECK();
-        return LCX_OK;
+        return exchange(h, h->sbuf + sb_det(Mp), h->M + 3, LCX_F64);
     }
     static int syn_moments_c(lcx_ctx* h, int which) {
         MomentSet& s = h->set[which];
@@ -1051,7 +1133,7 @@ template <typename T, int CT> struct Impl {
         hipLaunchKernelGGL((reduce_wide_kernel<T, double>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
                            P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, h->sbuf + SB_H, (const int*)nullptr);
         KCHECK();
-        return LCX_OK;
+        return exchange(h, h->sbuf + SB_H, (int64_t)Mp * Mp, LCX_F64);
     }
     // ws' = (1-eta) ws + eta (R - H ws) (:380-382) -> set 1
     static int syn_update_b(lcx_ctx* h, double eta) {
@@ -1466,6 +1548,7 @@ template <typename T, int CT> struct Impl {
             HIPCHECK(hipMemcpy2DAsync(xd, h->ldx * sizeof(T), reinterpret_cast<const T*>(x_host) + r0 * ld, ld * sizeof(T),
                                       h->V * sizeof(T), nr, hipMemcpyHostToDevice, h->stream));
             LCXCHECK(project_block(h, tmps, xd, rows_pad, yd, &xt_tmp));
+            LCXCHECK(exchange(h, yd, rows_pad * Mp, DT));        // every rank projects the same rows: sum of the per-shard partials
             HIPCHECK(hipMemcpyAsync(tmp.data(), yd, sizeof(T) * rows_pad * Mp, hipMemcpyDeviceToHost, h->stream));
             HIPCHECK(hipStreamSynchronize(h->stream));
             for (int64_t r = 0; r < nr; ++r)
@@ -1620,6 +1703,7 @@ template <typename T, int CT> struct Impl {
                 KCHECK();
             }
             LCXCHECK(project_block(h, tmps, xd, rows_pad, yd, &xt_tmp));
+            LCXCHECK(exchange(h, yd, rows_pad * Mp, DT));        // every rank projects the same rows: sum of the per-shard partials
             HIPCHECK(hipMemcpyAsync(tmp.data(), yd, sizeof(T) * rows_pad * Mp, hipMemcpyDeviceToHost, h->stream));
             HIPCHECK(hipStreamSynchronize(h->stream));
             for (int64_t r = 0; r < nr; ++r)
@@ -1918,6 +2002,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
         }
     }
     h->world = 1;
+    h->n_exchanges = 0;
     h->seq_next = 0;
     h->spec_pending = h->spec_dirty = false;
     h->early_grad = h->grad_ready = false;
@@ -1931,6 +2016,7 @@ int lcx_destroy(lcx_ctx* h) {
     if (!h) return LCX_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->tr.kind == 1 && h->tr.comm) (void)rccl().CommDestroy(h->tr.comm);
     void* ptrs[] = {h->X, h->XT, h->Wt[0], h->Wt[1], h->grad, h->update, h->sgrad, h->scratch, h->ydir, h->ddir, h->ybuf_own, h->sbuf_own,
                     h->gw, h->y2part, h->ygbuf,
                     h->ypart, h->dpart, h->gpart, h->gpartw, h->tcpart, h->bjpart, h->tanpart, h->detpart, h->ryinv, h->invwork,
@@ -1996,6 +2082,65 @@ int lcx_bind_exchange(lcx_ctx* h, void* y, void* s) {
     if (y) HIPCHECK(hipMemsetAsync(y, 0, (size_t)h->ybuf_elems * h->es, h->stream));
     if (s) HIPCHECK(hipMemsetAsync(s, 0, sizeof(double) * h->sbuf_elems, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
+    return LCX_OK;
+}
+
+// ---- exchange inside the library ---------------------------------------------------------------------
+int lcx_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(LCX_ERR_ARG, "lcx_comm_unique_id: null");
+    if (!rccl().ok) return fail(LCX_ERR_COMM, rccl().error);
+    ncclUniqueId id;
+    RCCLCHECK(rccl().GetUniqueId(&id));
+    static_assert(sizeof(id) == LCX_COMM_ID_BYTES, "LCX_COMM_ID_BYTES must equal NCCL_UNIQUE_ID_BYTES");
+    memcpy(id_out, &id, sizeof(id));
+    return LCX_OK;
+}
+
+static int drop_transport(lcx_ctx* h) {
+    if (h->tr.kind == 1 && h->tr.comm) {
+        (void)hipStreamSynchronize(h->stream);
+        (void)rccl().CommDestroy(h->tr.comm);
+    }
+    h->tr = Transport();
+    return LCX_OK;
+}
+
+int lcx_comm_init(lcx_ctx* h, int nranks, int rank, const void* id_in) {
+    NEED_MUT(h);
+    if (nranks < 1 || rank < 0 || rank >= nranks || !id_in) return fail(LCX_ERR_ARG, "lcx_comm_init: bad rank / size / id");
+    if (!rccl().ok) return fail(LCX_ERR_COMM, rccl().error);
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    LCXCHECK(drop_transport(h));
+    ncclUniqueId id;
+    memcpy(&id, id_in, sizeof(id));
+    ncclComm_t comm = nullptr;
+    RCCLCHECK(rccl().CommInitRank(&comm, nranks, id, rank));
+    h->tr.kind = 1;
+    h->tr.comm = comm;
+    h->tr.rank = rank;
+    h->tr.nranks = nranks;
+    h->world = nranks;
+    h->exchange = true;          // also for a group of one rank: the caller asked for the multi-rank path
+    return LCX_OK;
+}
+
+int lcx_set_exchange_hook(lcx_ctx* h, lcx_allreduce_fn fn, void* user) {
+    NEED_MUT(h);
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    LCXCHECK(drop_transport(h));
+    if (fn) {
+        h->tr.kind = 2;
+        h->tr.hook = fn;
+        h->tr.user = user;
+    }
+    return LCX_OK;
+}
+
+int lcx_exchange_info(lcx_ctx* h, int* kind, int* world, int64_t* allreduces_issued) {
+    NEED(h);
+    if (kind) *kind = h->exchange ? h->tr.kind : -1;
+    if (world) *world = h->world;
+    if (allreduces_issued) *allreduces_issued = h->n_exchanges;
     return LCX_OK;
 }
 
@@ -2088,7 +2233,12 @@ static int detail_entry(lcx_ctx* h, int which) {
     }
     return fail(LCX_ERR_ARG, "bad CT");
 }
-int lcx_moments_detail(lcx_ctx* h, int which) { NEED(h); WHICH_OK(which); return detail_entry(h, which); }
+int lcx_moments_detail(lcx_ctx* h, int which) {
+    NEED(h);
+    WHICH_OK(which);
+    LCXCHECK(detail_entry(h, which));
+    return exchange(h, h->sbuf + sb_det(h->Mp), h->M + 3, LCX_F64);
+}
 
 int lcx_update_a(lcx_ctx* h) { NEED_MUT(h); DISPATCH(h, update_a, h); }
 int lcx_update_b(lcx_ctx* h, double eps) { NEED_MUT(h); DISPATCH(h, update_b, h, eps); }

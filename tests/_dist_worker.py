@@ -85,6 +85,8 @@ def main():
         np.savez(os.path.join(out_dir, "dist_result.npz"), history=np.asarray(model.history["TC"], np.float64),
                  ws=model.ws, clusters=model.clusters(), transform=y, rho=rho, xz=xz, si=si, cov=cov,
                  tcs=model.tcs, world=comm.world, trials=model.stats["trials"],
+                 transport=str(getattr(model, "_engine_exchange", None)),
+                 in_library=np.array(bool(getattr(model, "_iterated_in_library", False))),
                  calls=np.array(len(getattr(model._backend, "calls", []))))
     mark("results gathered")
     dist.barrier()

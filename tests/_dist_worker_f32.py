@@ -46,7 +46,8 @@ def main():
     if comm.rank == 0:
         np.savez(os.path.join(out_dir, "dist_f32.npz"), history=h, ws=ws, rho=rho, trials=model.stats["trials"],
                  world=comm.world, kernel_nt=names[0], kernel_tn=names[1],
-                 in_library=np.array(bool(getattr(model, "_iterated_in_library", False))))
+                 in_library=np.array(bool(getattr(model, "_iterated_in_library", False))),
+                 transport=str(getattr(model, "_engine_exchange", None)))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -16,14 +16,14 @@ pytestmark = pytest.mark.gpu
 MAX_ITER = 25          # per annealing stage: gloo stages every CUDA all-reduce through the host (slow)
 
 
-def _launch_once(world, out_dir, n, v, m, mode, timeout):
+def _launch_once(world, out_dir, n, v, m, mode, timeout, exchange="engine"):
     import subprocess
     import sys
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2", LCX_EXCHANGE=exchange,
                    LCX_TEST_DUMP_AFTER=str(max(10, timeout - 30)), LCX_CHECK_RANKS="1", LCX_TEST_TRACE="1",
                    LCX_WAIT_TIMEOUT_MS=str(1000 * max(10, timeout - 45)))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(out_dir),
@@ -43,13 +43,13 @@ def _launch_once(world, out_dir, n, v, m, mode, timeout):
     return timed_out, procs, outs
 
 
-def launch_hip(world, out_dir, n, v, m, mode):
+def launch_hip(world, out_dir, n, v, m, mode, exchange="engine"):
     """A normal run takes 3-8 s.  No retry: a rank that waits for a state publication longer than LCX_WAIT_TIMEOUT_MS fails
     with the expected / seen sequence numbers (lcx_read_state -> LCX_ERR_STATE), a rank still alive after
     LCX_TEST_DUMP_AFTER seconds prints the Python stack of every thread, and both end up in
     gpurun_out/dist_stall_stacks.log.  (Round 1 saw this launch stall in 2 of ~12 suites and retried it; 60 stress launches
     and 6 suites of round 2 - profiles/r02_dist_stress_*.txt - never reproduced it.)"""
-    timed_out, procs, outs = _launch_once(world, out_dir, n, v, m, mode, 150)
+    timed_out, procs, outs = _launch_once(world, out_dir, n, v, m, mode, 150, exchange)
     if timed_out:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "dist_stall_stacks.log"), "a") as f:
@@ -60,15 +60,20 @@ def launch_hip(world, out_dir, n, v, m, mode):
 
 
 # world 3 runs in the CPU suite; on the GPU box gloo needs ~4 minutes for it
-@pytest.mark.parametrize("world,mode,shape", [(2, "exact", (400, 331, 5)), (2, "linear", (400, 331, 5)),
-                                              (2, "exact", (300, 6001, 8))])
-def test_sharded_fit_on_device_matches_oracle(world, mode, shape, tmp_path):
+@pytest.mark.parametrize("world,mode,shape,exchange", [
+    (2, "exact", (400, 331, 5), "engine"), (2, "exact", (400, 331, 5), "torch"), (2, "linear", (400, 331, 5), "engine"),
+    (2, "linear", (400, 331, 5), "torch"), (2, "exact", (300, 6001, 8), "engine")])
+def test_sharded_fit_on_device_matches_oracle(world, mode, shape, exchange, tmp_path):
     # (400, 331, 5): uneven shards, ragged padding; (300, 6001, 8): few column tiles per shard - the X.W^T pass is split
-    # into dozens of slots and summed by the wide reductions before the exchange
+    # into dozens of slots and summed by the wide reductions before the exchange.
+    # exchange "engine": the all-reduces are issued by the library through its hook (the transport here is gloo) and the exact
+    # line search runs inside lcx_iterate on both ranks; "torch": the host-sequenced path, torch.distributed between the levels
     n, v, m = shape
-    launch_hip(world, tmp_path, n, v, m, mode)
+    launch_hip(world, tmp_path, n, v, m, mode, exchange)
     got = np.load(os.path.join(tmp_path, "dist_result.npz"))
     assert int(got["world"]) == world
+    assert str(got["transport"]) == ("hook" if exchange == "engine" else "None")
+    assert bool(got["in_library"]) == (exchange == "engine" and mode == "exact")
     x, _ = O.gen_planted(n, v, m, seed=2)
     ref = O.fit_ns(x, m, seed=0, dtype=np.float64, keep_x=True, max_iter=MAX_ITER)
     h, h_ref = got["history"], np.asarray(ref.history_tc)
@@ -85,9 +90,11 @@ def test_sharded_fit_on_device_matches_oracle(world, mode, shape, tmp_path):
 
 
 def test_rccl_exchange_path_single_rank(tmp_path):
-    """The multi-rank device path with the REAL backend (torch.distributed 'nccl' = RCCL) in a group of one
-    rank: world>1 engine kernels, bound exchange tensors, RCCL launches interleaved with the engine's kernels on
-    the shared stream.  All-reduces over one rank are identities, so the result must equal the oracle."""
+    """The multi-rank device path with the REAL transport in a group of one rank: world>1 engine kernels and RCCL launches
+    interleaved with them on the handle's stream.  In-engine exchange (lcx_comm_init: a communicator owned by the handle,
+    ncclAllReduce issued by the library, the exact line search inside lcx_iterate) against the host-sequenced path
+    (LCX_EXCHANGE=torch: torch.distributed 'nccl' between the level calls): bit-identical trajectories, both equal to the
+    oracle (all-reduces over one rank are identities)."""
     import subprocess
     import sys
     code = r'''
@@ -104,14 +111,28 @@ from oracle import corex_oracle as O
 x, _ = O.gen_planted(400, 331, 5, seed=2)
 for syn in (False, True):
     ref = (O.fit_syn if syn else O.fit_ns)(x, 5, seed=0, dtype=np.float64, max_iter=40)
-    out = Corex(n_hidden=5, seed=0, dtype=np.float64, device=0, comm=Comm(always_exchange=True), max_iter=40,
-                discourage_overlap=not syn).fit(x)
-    assert out._ex is not None and out._backend.torch_stream is not None
-    h, hr = np.asarray(out.history["TC"], np.float64), np.asarray(ref.history_tc)
-    assert len(h) == len(hr), (len(h), len(hr))
-    assert np.max(np.abs(h - hr) / np.maximum(1, np.abs(hr))) < 1e-8
-    assert np.max(np.abs(out.ws - ref.ws)) < 1e-7
-    assert np.max(np.abs(out.transform(x) - ref.transform(O.preprocess(x)[0]))) < 1e-7
+    runs = {}
+    for mode in ("engine", "torch"):
+        os.environ["LCX_EXCHANGE"] = mode
+        out = Corex(n_hidden=5, seed=0, dtype=np.float64, device=0, comm=Comm(always_exchange=True), max_iter=40,
+                    discourage_overlap=not syn).fit(x)
+        assert out._ex is not None and out._backend.torch_stream is not None
+        info = out._backend.exchange_info()
+        if mode == "engine":
+            assert out._engine_exchange == "rccl" and info["kind"] == "rccl" and info["allreduces_issued"] > 100, info
+            assert syn or out._iterated_in_library
+        else:
+            assert out._engine_exchange is None and info["kind"] == "caller" and info["allreduces_issued"] == 0, info
+        h, hr = np.asarray(out.history["TC"], np.float64), np.asarray(ref.history_tc)
+        assert len(h) == len(hr), (len(h), len(hr))
+        assert np.max(np.abs(h - hr) / np.maximum(1, np.abs(hr))) < 1e-8
+        assert np.max(np.abs(out.ws - ref.ws)) < 1e-7
+        y = out.transform(x)
+        assert np.max(np.abs(y - ref.transform(O.preprocess(x)[0]))) < 1e-7
+        runs[mode] = (h, out.ws.copy(), y, out.stats["trials"])
+        out._backend.close()
+    assert np.array_equal(runs["engine"][0], runs["torch"][0]) and np.array_equal(runs["engine"][1], runs["torch"][1])
+    assert np.array_equal(runs["engine"][2], runs["torch"][2]) and runs["engine"][3] == runs["torch"][3]
 dist.destroy_process_group()
 print("RCCL_PATH_OK")
 ''' % (ROOT, str(free_port()))
@@ -156,7 +177,7 @@ def test_sharded_float32_large_kernels_match_single_gpu(m, tmp_path, monkeypatch
     n, v, iters = 4096, 8192, 3
     _launch_f32(2, tmp_path, n, v, m, iters)
     got = np.load(os.path.join(tmp_path, "dist_f32.npz"))
-    assert int(got["world"]) == 2
+    assert int(got["world"]) == 2 and str(got["transport"]) == "hook" and bool(got["in_library"])
     assert ("gemm_ct_kernel<float, %d" % (m // 16)) in str(got["kernel_nt"]) and "gemm_ct_kernel" in str(got["kernel_tn"])
     monkeypatch.setenv("LCX_GEMM", "ct")
     xt = planted_f32(n, v, m)

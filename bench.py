@@ -437,11 +437,17 @@ def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_s
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(u) for u in t.cpu()]
 
-    # clocks: >= 250 ms of X passes before anything is timed
+    # clocks: about 250 ms of X passes before anything is timed.  The count comes from the workload's size alone - the same on
+    # every rank: with live exchange steps every pass carries a collective
+    n_, v_, m_, tag_ = WORKLOADS[workload]
+    est_ms = max(2.0 * n_ * v_ * m_ / (60e12 if tag_ == "f32" else 30e12), n_ * v_ * (4 if tag_ == "f32" else 8) / 3e12) * 1e3
+    n_warm = int(min(4000, max(4, 250.0 / max(est_ms, 1e-3))))
+    be.synchronize()
     t0 = time.perf_counter()
-    pass_ms = be.bench_gemm(1, 2)
-    while time.perf_counter() - t0 < 0.25:
-        be.bench_gemm(1, max(2, int(20.0 / max(pass_ms, 1e-3))) if pass_ms < 1.0 else 4)
+    for _ in range(n_warm):
+        be.moments_a(1)
+    be.synchronize()
+    pass_ms = (time.perf_counter() - t0) * 1e3 / n_warm
     every = args.timing_sample if args.timing_sample > 0 else (1 if pass_ms >= 1.0 else 16)
     timing = kernel_timing and not args.no_kernel_timing
     if timing:
@@ -730,7 +736,7 @@ def main():
     if ge._stale() and any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")):
         sys.stderr.write("bench.py: liblcx_hip.so is stale and a profiler is attached - run `python __graft_entry__.py` first\n")
         return 3
-    ge.build()
+    ge.build(probe=False)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path is the only product path)")
     # test hooks: LCX_BENCH_DEVICE pins every rank to one device and LCX_BENCH_BACKEND=gloo replaces RCCL, so that the

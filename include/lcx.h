@@ -328,27 +328,12 @@ int lcx_timing_read(lcx_ctx* h, int kind, int64_t* launches, double* total_ms);
 /* every X pass issued since the last reset while timing was enabled (timed or skipped by the sampling) */
 int lcx_timing_passes(lcx_ctx* h, int kind, int64_t* passes);
 int lcx_timing_reset(lcx_ctx* h);
-/* micro-benchmark: `iters` back-to-back launches of one X-streaming GEMM (kind as above, with its
- * partial-sum reduction) on the resident X; returns the average wall time per launch from HIP events */
-int lcx_bench_gemm(lcx_ctx* h, int kind, int iters, double* avg_ms);
-/* experiment: the launches of one moment evaluation (lcx_moments_a + lcx_moments_b of set 1, one GPU) issued directly vs
- * captured into a hipGraph and replayed; average wall time per evaluation of each */
-int lcx_bench_graph(lcx_ctx* h, double eps, int iters, double* direct_ms, double* graph_ms);
 /* geometry actually used (for the roofline arithmetic): padded sizes and launch shapes */
 int lcx_geometry(lcx_ctx* h, int64_t* n_pad, int64_t* ldx, int* m_pad, int64_t* info8);
 
 /* name of the kernel function behind pass `kind` as rocprofv3 prints it (without "void " and the
  * argument list), so that bench.py's roofline line and the committed rocprof summary name the same row */
 int lcx_kernel_name(lcx_ctx* h, int kind, char* buf, int64_t len);
-
-/* ---- kernel unit tests (parity of the two GEMM kernels in isolation) -------------------------- */
-/* out (n_rows x m_pad) = A (n_rows x k, ld=lda) . B^T with B given as (k x m_pad) row-major     */
-int lcx_test_gemm_nt(int dtype, int device, const void* a_host, int64_t n_rows, int64_t k, int64_t lda,
-                     const void* b_host, int m_pad, void* out_host, int force_split, int force_kw);
-/* out (v x m_pad) = A^T . B, A (k x v, ld=lda), B (k x m_pad)                                    */
-int lcx_test_gemm_tn(int dtype, int device, const void* a_host, int64_t k, int64_t v, int64_t lda,
-                     const void* b_host, int m_pad, const void* rowscale_host, void* out_host,
-                     int force_split, int force_kw);
 
 #ifdef __cplusplus
 }

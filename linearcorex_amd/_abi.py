@@ -88,12 +88,8 @@ SIGNATURES = {
     "lcx_timing_read": [_vp, _i32, C.POINTER(_i64), C.POINTER(_dbl)],
     "lcx_timing_passes": [_vp, _i32, C.POINTER(_i64)],
     "lcx_timing_reset": [_vp],
-    "lcx_bench_gemm": [_vp, _i32, _i32, C.POINTER(_dbl)],
-    "lcx_bench_graph": [_vp, _dbl, _i32, C.POINTER(_dbl), C.POINTER(_dbl)],
     "lcx_geometry": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i64)],
     "lcx_kernel_name": [_vp, _i32, C.c_char_p, _i64],
-    "lcx_test_gemm_nt": [_i32, _i32, _vp, _i64, _i64, _i64, _vp, _i32, _vp, _i32, _i32],
-    "lcx_test_gemm_tn": [_i32, _i32, _vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _i32, _i32],
 }
 
 _lib = None

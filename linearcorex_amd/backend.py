@@ -27,8 +27,9 @@ MOMENT_KEYS = {
 
 
 class HipBackend:
-    def __init__(self, n_samples, nv_local, n_hidden, dtype=np.float32, device=0):
-        self.lib = _abi.load()
+    def __init__(self, n_samples, nv_local, n_hidden, dtype=np.float32, device=0, lib=None):
+        # lib: another build of the same ABI (tools/liblcx_probe.so, the lab: the engine plus kernel test hooks)
+        self.lib = lib if lib is not None else _abi.load()
         self.dtype = np.dtype(dtype)
         self.n_samples, self.nv, self.m = int(n_samples), int(nv_local), int(n_hidden)
         self.device = int(device)
@@ -106,17 +107,6 @@ class HipBackend:
         buf = C.create_string_buffer(256)
         _abi.check(self.lib.lcx_kernel_name(self.h, int(kind), buf, 256))
         return buf.value.decode()
-
-    def bench_graph(self, eps=0.1, iters=50):
-        """(direct_ms, graph_ms) per moment evaluation: plain launches vs a replayed hipGraph (experiment)."""
-        d, g = C.c_double(), C.c_double()
-        _abi.check(self.lib.lcx_bench_graph(self.h, float(eps), int(iters), C.byref(d), C.byref(g)))
-        return d.value, g.value
-
-    def bench_gemm(self, kind, iters=20):
-        ms = C.c_double()
-        _abi.check(self.lib.lcx_bench_gemm(self.h, int(kind), int(iters), C.byref(ms)))
-        return ms.value
 
     def set_world(self, world):
         _abi.check(self.lib.lcx_set_world(self.h, int(world)))
@@ -434,27 +424,3 @@ class HipBackend:
         out = np.empty((x.shape[0], self.m), dtype=self.dtype)
         _abi.check(self.lib.lcx_project(self.h, p, x.shape[0], x.shape[1], _abi.np_ptr(out)))
         return out
-
-
-def gemm_nt_check(a, b_km, m_pad, dtype, device=0, split=1, waves=4):
-    """Isolated run of the X.B^T kernel: a (n x k), b_km (k x m_pad) -> (n x m_pad)."""
-    lib = _abi.load()
-    a = np.ascontiguousarray(a, dtype=dtype)
-    b = np.ascontiguousarray(b_km, dtype=dtype)
-    out = np.empty((a.shape[0], m_pad), dtype=dtype)
-    _abi.check(lib.lcx_test_gemm_nt(_abi.dtype_code(dtype), device, _abi.np_ptr(a), a.shape[0], a.shape[1],
-                                    a.shape[1], _abi.np_ptr(b), m_pad, _abi.np_ptr(out), split, waves))
-    return out
-
-
-def gemm_tn_check(a, b_km, m_pad, dtype, device=0, rowscale=None, split=1, waves=4):
-    """Isolated run of the A^T.B kernel: a (k x v), b_km (k x m_pad) -> (v x m_pad)."""
-    lib = _abi.load()
-    a = np.ascontiguousarray(a, dtype=dtype)
-    b = np.ascontiguousarray(b_km, dtype=dtype)
-    rs = None if rowscale is None else np.ascontiguousarray(rowscale, dtype=dtype)
-    out = np.empty((a.shape[1], m_pad), dtype=dtype)
-    _abi.check(lib.lcx_test_gemm_tn(_abi.dtype_code(dtype), device, _abi.np_ptr(a), a.shape[0], a.shape[1],
-                                    a.shape[1], _abi.np_ptr(b), m_pad,
-                                    None if rs is None else _abi.np_ptr(rs), _abi.np_ptr(out), split, waves))
-    return out

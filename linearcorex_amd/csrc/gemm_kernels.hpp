@@ -170,9 +170,7 @@ gemm_nt_kernel(const T* __restrict__ X, int64_t ldx, const T* __restrict__ B, T*
 // A: [K][lda] (or panel-major, see below) with K a multiple of 64 and the tile columns in bounds;
 // optional per-row scale of A (used for H, linearcorex.py:294).
 // ------------------------------------------------------------------------------------------------
-// MODE is for ablation probes only (tools/gemm_probe.hip): 0 = real kernel, 1 = loads without MFMA,
-// 2 = MFMA without loads (registers loaded once).
-template <typename T, int CT, int RT, int KW, bool SCALE, int MODE, int U, bool NTA = false>
+template <typename T, int CT, int RT, int KW, bool SCALE, int U, bool NTA = false>
 __device__ __forceinline__ void
 tn_body(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const T* __restrict__ B,
         const T* __restrict__ rowscale, T* __restrict__ out, int64_t out_rows, int kgroups,
@@ -208,7 +206,7 @@ tn_body(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const T* __re
     T s0[U], s1[U];
 
 #define LCX_TN_LOAD(G, AA, BB, SS)                                                    \
-    if (MODE != 2 || (G) == g0) {                                                     \
+    {                                                                                 \
         const int64_t rb = (int64_t)(G) * (4 * U);                                    \
         _Pragma("unroll") for (int st = 0; st < U; ++st) {                            \
             AA[st] = NTA ? ldg_nt<T, RT>(ap + (rb + 4 * st) * lda) : ldg<T, RT>(ap + (rb + 4 * st) * lda); \
@@ -222,15 +220,13 @@ tn_body(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const T* __re
         _Pragma("unroll") for (int t = 0; t < RT; ++t) {                              \
             const T av = SCALE ? AA[st].v[t] * SS[st] : AA[st].v[t];                  \
             _Pragma("unroll") for (int u = 0; u < CT; ++u) {                          \
-                if (MODE == 1) { asm volatile("" ::"v"(av), "v"(BB[st].v[u])); }      \
-                else acc[t][u] = MF<T>::mma(av, BB[st].v[u], acc[t][u]);              \
+                acc[t][u] = MF<T>::mma(av, BB[st].v[u], acc[t][u]);                   \
             }                                                                         \
         }                                                                             \
     }
 
     if (g0 < g1) {
         LCX_TN_LOAD(g0, a0, b0, s0);
-        if (MODE == 2) { LCX_TN_LOAD(g0, a1, b1, s1); }
         int g = g0;
         while (true) {
             int gn = (g + 1 < g1) ? g + 1 : g1 - 1;
@@ -265,13 +261,13 @@ tn_body(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const T* __re
     }
 }
 
-template <typename T, int CT, int RT, int KW, bool SCALE, int MODE = 0, int U = 4, bool NTA = false>
+template <typename T, int CT, int RT, int KW, bool SCALE, int U = 4, bool NTA = false>
 __global__ void __launch_bounds__(64 * KW)
 gemm_tn_kernel(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const T* __restrict__ B,
                const T* __restrict__ rowscale, T* __restrict__ out, int64_t out_rows, int kgroups,
                int nsplit, const int* __restrict__ skip_flag) {
     if (skip_flag != nullptr && *skip_flag != 0) return;
-    tn_body<T, CT, RT, KW, SCALE, MODE, U, NTA>(A, lda, tile_stride, B, rowscale, out, out_rows, kgroups, nsplit,
+    tn_body<T, CT, RT, KW, SCALE, U, NTA>(A, lda, tile_stride, B, rowscale, out, out_rows, kgroups, nsplit,
                                                  blockIdx.x, blockIdx.y);
 }
 
@@ -287,7 +283,7 @@ __global__ void __launch_bounds__(64 * KW)
 gram_pair_kernel(GramProblem<T> p0, GramProblem<T> p1) {
     const GramProblem<T> p = blockIdx.z ? p1 : p0;
     if ((int)blockIdx.y >= p.nsplit) return;
-    tn_body<T, CT, RT, KW, false, 0, 4>(p.A, 16 * CT, 16 * RT, p.A, nullptr, p.out, 16 * CT, p.kgroups, p.nsplit,
+    tn_body<T, CT, RT, KW, false, 4>(p.A, 16 * CT, 16 * RT, p.A, nullptr, p.out, 16 * CT, p.kgroups, p.nsplit,
                                          blockIdx.x, blockIdx.y);
 }
 
@@ -346,7 +342,7 @@ __device__ __forceinline__ int piece_col(int t, int r) {
     return (t / EPL) * 16 * EPL + r * EPL + (t % EPL);
 }
 
-template <typename T, int CT, int RT, int KW, int U, bool NT = false, int PRIO = 0>
+template <typename T, int CT, int RT, int KW, int U, bool NT = false>
 __global__ void __launch_bounds__(64 * KW)
 gemm_ct_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T* __restrict__ out,
                int64_t out_rows, int64_t vcols, int ng /* groups of 4*U rows */, int nsuper, int maxslots,
@@ -412,15 +408,10 @@ gemm_ct_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T*
             Pk<T, CT> bb[U];                                                              \
             _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
                 bb[st] = *reinterpret_cast<const Pk<T, CT>*>(&Bs[BUF][(4 * st + q) * Mp + i * CT]); \
-            /* PRIO 1, 2: s_setprio around the MFMA burst; 3, 4: scheduler hints (iglp_opt 0 / 1) - probe variants */ \
-            if (PRIO == 1 || PRIO == 2) __builtin_amdgcn_s_setprio(PRIO);                 \
-            if (PRIO == 3) __builtin_amdgcn_iglp_opt(0);                                  \
-            if (PRIO == 4) __builtin_amdgcn_iglp_opt(1);                                  \
             _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
             _Pragma("unroll") for (int t = 0; t < RT; ++t)                                \
             _Pragma("unroll") for (int u = 0; u < CT; ++u)                                \
                 acc[t][u] = MF<T>::mma(AA[st][t], bb[st].v[u], acc[t][u]);                \
-            if (PRIO == 1 || PRIO == 2) __builtin_amdgcn_s_setprio(0);                    \
         }
 
         LCX_CT_LOADA(0, a0);
@@ -472,165 +463,6 @@ gemm_ct_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T*
             }
         }
         __syncthreads();            // Bs is reused by the next segment
-        L0 += cnt;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// gemm_ct32: gemm_ct on v_mfma_f32_32x32x2_f32 (float32 only).
-//
-// Same decomposition, LDS staging of B, stream-K work split and slot contract as gemm_ct.  The 32x32x2 form runs at the
-// same 64 FLOP/clk/SIMD as 16x16x4 but does twice the work per instruction, i.e. half the operand-register reads per
-// flop - the large float32 shards are power-limited (the shader clock sags to ~2.1 GHz under gemm_ct at n_hidden 64),
-// so what is saved there returns as clock.
-//   A operand: lane l feeds X column i = l & 31 of a 32-column block at contraction row kq = l >> 5 of a 2-row step;
-//   a lane loads EPL = min(4, NTB) consecutive floats of a row (16 bytes; 32 lanes = 512 contiguous bytes), element e
-//   going to column block (piece * EPL + e) - the same "interleaved columns" trick as load_row_pieces;
-//   B operand: lane l feeds factor (NU * j + u), j = l & 31, u < NU = Mp / 32, row kq: one ds_read of NU floats;
-//   D layout: register r of lane l is output row 8 (r / 4) + 4 (l >> 5) + r % 4, column l & 31.
-// A wave owns 32 * NTB columns of A; the block's KW waves own KW adjacent such tiles.  A group is 2 * U2 rows.
-// ------------------------------------------------------------------------------------------------
-template <int NTB> struct Epl32 { static constexpr int v = NTB < 4 ? NTB : 4; };
-template <int NTB>
-__device__ __forceinline__ int col32(int t, int i) {
-    constexpr int EPL = Epl32<NTB>::v;
-    return (t / EPL) * 32 * EPL + i * EPL + (t % EPL);
-}
-
-template <int CT, int NTB, int KW, int U2, bool NT = true>
-__global__ void __launch_bounds__(64 * KW)
-gemm_ct32_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, float* __restrict__ out,
-                 int64_t out_rows, int64_t vcols, int ng /* groups of 2*U2 rows */, int nsuper, int maxslots,
-                 const int* __restrict__ skip_flag) {
-    constexpr int Mp = 16 * CT, NU = Mp / 32;
-    constexpr int ROWS = 2 * U2;
-    constexpr int CHUNK = ROWS * Mp;
-    constexpr int PCS = CHUNK * 4 / 16;
-    constexpr int NTH = 64 * KW;
-    constexpr int PPT = (PCS + NTH - 1) / NTH;
-    constexpr int EPL = Epl32<NTB>::v;
-    constexpr int WT = 32 * NTB;                              // columns per wave
-    typedef float acc_t __attribute__((ext_vector_type(16)));
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    typedef typename VecT<float, EPL>::type AV;
-    static_assert(Mp % 32 == 0, "gemm_ct32 needs a multiple of 32 padded factors");
-    __shared__ __attribute__((aligned(16))) float Bs[2][CHUNK];
-    if (skip_flag != nullptr && *skip_flag != 0) return;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 31, kq = lane >> 5;
-    const int64_t total = (int64_t)nsuper * ng;
-    const int nb = gridDim.x;
-    int64_t L0 = total * blockIdx.x / nb;
-    const int64_t L1 = total * (blockIdx.x + 1) / nb;
-
-    while (L0 < L1) {
-        const int st_ = (int)(L0 / ng);
-        const int s0 = (int)(L0 - (int64_t)st_ * ng);
-        const int s1 = (L1 - L0) < (int64_t)(ng - s0) ? s0 + (int)(L1 - L0) : ng;
-        const int cnt = s1 - s0;
-        const int64_t v0 = ((int64_t)st_ * KW + wave) * WT;
-        const bool active = v0 < vcols;
-
-        acc_t acc[NTB][NU];
-#pragma unroll
-        for (int t = 0; t < NTB; ++t)
-#pragma unroll
-            for (int u = 0; u < NU; ++u)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
-        const float* ap = A + (active ? v0 : 0) + (int64_t)kq * lda + i * EPL;
-        float a0[U2][NTB], a1[U2][NTB];
-        f4 bst[PPT];
-
-#define LCX_C32_LOADA(R, AA)                                                              \
-        if (active) {                                                                     \
-            const int64_t rb = (int64_t)(s0 + (R)) * ROWS;                                \
-            _Pragma("unroll") for (int st = 0; st < U2; ++st)                             \
-            _Pragma("unroll") for (int p = 0; p < NTB / EPL; ++p) {                       \
-                const AV* src = reinterpret_cast<const AV*>(ap + (rb + 2 * st) * lda + p * 32 * EPL); \
-                const AV v = NT ? __builtin_nontemporal_load(src) : *src;                 \
-                _Pragma("unroll") for (int e = 0; e < EPL; ++e) {                         \
-                    if constexpr (EPL == 1) AA[st][p] = v; else AA[st][p * EPL + e] = v[e]; \
-                }                                                                         \
-            }                                                                             \
-        }
-#define LCX_C32_LOADB(R)                                                                  \
-        {                                                                                 \
-            const f4* src = reinterpret_cast<const f4*>(B + (int64_t)(s0 + (R)) * CHUNK); \
-            _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                             \
-                const int pc = p * NTH + (int)threadIdx.x;                                \
-                if (PCS % NTH == 0 || pc < PCS) bst[p] = src[pc];                         \
-            }                                                                             \
-        }
-#define LCX_C32_STOREB(BUF)                                                               \
-        {                                                                                 \
-            f4* dstp = reinterpret_cast<f4*>(&Bs[BUF][0]);                                \
-            _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                             \
-                const int pc = p * NTH + (int)threadIdx.x;                                \
-                if (PCS % NTH == 0 || pc < PCS) dstp[pc] = bst[p];                        \
-            }                                                                             \
-        }
-#define LCX_C32_MMA(AA, BUF)                                                              \
-        if (active) {                                                                     \
-            Pk<float, NU> bb[U2];                                                         \
-            _Pragma("unroll") for (int st = 0; st < U2; ++st)                             \
-                bb[st] = *reinterpret_cast<const Pk<float, NU>*>(&Bs[BUF][(2 * st + kq) * Mp + i * NU]); \
-            _Pragma("unroll") for (int st = 0; st < U2; ++st)                             \
-            _Pragma("unroll") for (int t = 0; t < NTB; ++t)                               \
-            _Pragma("unroll") for (int u = 0; u < NU; ++u)                                \
-                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(AA[st][t], bb[st].v[u], acc[t][u], 0, 0, 0); \
-        }
-
-        LCX_C32_LOADA(0, a0);
-        LCX_C32_LOADB(0);
-        int r = 0;
-        while (true) {
-            LCX_C32_STOREB(0);
-            if (r + 1 < cnt) { LCX_C32_LOADA(r + 1, a1); LCX_C32_LOADB(r + 1); }
-            __syncthreads();
-            LCX_C32_MMA(a0, 0);
-            if (++r >= cnt) break;
-            LCX_C32_STOREB(1);
-            if (r + 1 < cnt) { LCX_C32_LOADA(r + 1, a0); LCX_C32_LOADB(r + 1); }
-            __syncthreads();
-            LCX_C32_MMA(a1, 1);
-            if (++r >= cnt) break;
-        }
-#undef LCX_C32_LOADA
-#undef LCX_C32_LOADB
-#undef LCX_C32_STOREB
-#undef LCX_C32_MMA
-
-        const int fb = sk_owner((int64_t)st_ * ng, total, nb);
-        if (active) {
-            float* dst = out + ((int64_t)(blockIdx.x - fb) * out_rows + v0) * Mp;
-#pragma unroll
-            for (int t = 0; t < NTB; ++t)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int row = 8 * (g / 4) + 4 * kq + (g % 4);
-                    Pk<float, NU> o;
-#pragma unroll
-                    for (int u = 0; u < NU; ++u) o.v[u] = acc[t][u][g];
-                    *reinterpret_cast<Pk<float, NU>*>(dst + (int64_t)col32<NTB>(t, row) * Mp + i * NU) = o;
-                }
-            if (s1 == ng) {        // last contributor of this super tile: zero the slots nobody writes
-                const int lb = sk_owner((int64_t)st_ * ng + ng - 1, total, nb);
-                Pk<float, NU> z;
-#pragma unroll
-                for (int u = 0; u < NU; ++u) z.v[u] = 0.f;
-                for (int sl = lb - fb + 1; sl < maxslots; ++sl) {
-                    float* zd = out + ((int64_t)sl * out_rows + v0) * Mp;
-#pragma unroll
-                    for (int t = 0; t < NTB; ++t)
-#pragma unroll
-                        for (int g = 0; g < 16; ++g)
-                            *reinterpret_cast<Pk<float, NU>*>(zd + (int64_t)(32 * t + 2 * g + kq) * Mp + i * NU) = z;
-                }
-            }
-        }
-        __syncthreads();
         L0 += cnt;
     }
 }

@@ -626,7 +626,7 @@ gram_tc_kernel(const T* __restrict__ A, const T* __restrict__ rowscale, T* __res
         return;
     }
     if (skip_flag != nullptr && *skip_flag != 0) return;
-    tn_body<T, CT, RT, KW, true, 0, 4>(A, 16 * CT, 16 * RT, A, rowscale, out, 16 * CT, kgroups, nsplit, blockIdx.x, blockIdx.y);
+    tn_body<T, CT, RT, KW, true, 4>(A, 16 * CT, 16 * RT, A, rowscale, out, 16 * CT, kgroups, nsplit, blockIdx.x, blockIdx.y);
 }
 
 // update_tangent on demand (lcx_read_state of the current solution before any trial was evaluated)
@@ -985,8 +985,8 @@ __global__ void cov_prep_kernel(const T* __restrict__ src_a, const T* __restrict
     }
 }
 
-// MODE 0: get_covariance (rows are variables, symmetric scaling std_r std_c, unit diagonal).
-// MODE 1: predict (:440-441) - rows are the n_rows samples of a staged block of Y (A = Y [rows][Mp], B = X_i Z_j [V][Mp]),
+// PREDICT false: get_covariance (rows are variables, symmetric scaling std_r std_c, unit diagonal).
+// PREDICT true:  predict (:440-441) - rows are the n_rows samples of a staged block of Y (A = Y [rows][Mp], B = X_i Z_j [V][Mp]),
 //         and the epilogue is `invert` (:431-438): out[r][c] = std_c f(y_r . xz_c) + mean_c with f = identity ('standard',
 //         kind 1) or g_inv (:490-494; 'outliers', kind 2); kind 0 writes the product unchanged.  aux = mean.
 template <typename T>
@@ -999,7 +999,7 @@ __device__ __forceinline__ T g_inv_dev(T x) {
     return xp + (T)atanh((double)d);
 }
 
-template <typename T, int Mp, int MODE>
+template <typename T, int Mp, bool PREDICT>
 __global__ void __launch_bounds__(256)
 cov_syrk_kernel(const T* __restrict__ A, const T* __restrict__ B, const T* __restrict__ stdv, int64_t V, int64_t row0,
                 int64_t nrows, T denom, T* __restrict__ out, int64_t ldo, const T* __restrict__ aux, int kind) {
@@ -1019,7 +1019,7 @@ cov_syrk_kernel(const T* __restrict__ A, const T* __restrict__ B, const T* __res
         for (int idx = tid; idx < 64 * KC; idx += 256) {
             const int a = idx / KC, j = idx % KC;
             const int64_t vr = rb + a, vc = cb + a;
-            As[a][j] = ((MODE == 1 || vr < V) && vr < row0 + nrows) ? A[vr * Mp + j0 + j] : (T)0;
+            As[a][j] = ((PREDICT || vr < V) && vr < row0 + nrows) ? A[vr * Mp + j0 + j] : (T)0;
             Bs[(a & 3) * 16 + (a >> 2)][j] = (vc < V) ? B[vc * Mp + j0 + j] : (T)0;      // column 4 j + u -> row 16 u + j
         }
         __syncthreads();
@@ -1034,15 +1034,15 @@ cov_syrk_kernel(const T* __restrict__ A, const T* __restrict__ B, const T* __res
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int64_t c = cb + 4 * i + u;
-        sc.v[u] = (c < V && (MODE == 0 || kind != 0)) ? stdv[c] : (T)(MODE == 0 ? 0 : 1);
-        mu.v[u] = (MODE == 1 && kind != 0 && c < V) ? aux[c] : (T)0;
+        sc.v[u] = (c < V && (!PREDICT || kind != 0)) ? stdv[c] : (T)(PREDICT ? 1 : 0);
+        mu.v[u] = (PREDICT && kind != 0 && c < V) ? aux[c] : (T)0;
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int64_t r = rb + 16 * wave + MF<T>::row(lane, g);
-        if ((MODE == 0 && r >= V) || r >= row0 + nrows) continue;
+        if ((!PREDICT && r >= V) || r >= row0 + nrows) continue;
         Pk<T, 4> o;
-        if (MODE == 0) {
+        if (!PREDICT) {
             const T sr = stdv[r];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1061,7 +1061,7 @@ cov_syrk_kernel(const T* __restrict__ A, const T* __restrict__ B, const T* __res
     }
 }
 
-// invert (:431-438) of a staged block of rows, elementwise: out = std_c f(x) + mean_c (f as in cov_syrk_kernel MODE 1)
+// invert (:431-438) of a staged block of rows, elementwise: out = std_c f(x) + mean_c (f as in the predict epilogue of cov_syrk_kernel)
 template <typename T>
 __global__ void invert_rows_kernel(const T* __restrict__ x, int64_t nrows, int64_t V, int64_t ld, const T* __restrict__ mean,
                                    const T* __restrict__ stdv, int kind, T* __restrict__ out) {

@@ -18,7 +18,7 @@ def _asym(n, k, seed):
 @pytest.mark.parametrize("shape,split,waves", [((70, 45), 1, 1), ((257, 300), 1, 4), ((1000, 1111), 3, 4),
                                                ((64, 2048), 2, 8), ((333, 64), 1, 2)])
 def test_gemm_nt(dtype, m_pad, shape, split, waves):
-    from linearcorex_amd.backend import gemm_nt_check
+    from tests.probe import gemm_nt_check
     n, k = shape
     a = _asym(n, k, 1).astype(dtype)
     b = _asym(k, m_pad, 2).astype(dtype)          # asymmetric: catches row/col swaps
@@ -33,7 +33,7 @@ def test_gemm_nt(dtype, m_pad, shape, split, waves):
 @pytest.mark.parametrize("shape,split,waves", [((70, 45), 1, 1), ((300, 257), 1, 4), ((1111, 1000), 3, 4),
                                                ((2048, 64), 2, 8), ((64, 333), 1, 2)])
 def test_gemm_tn(dtype, m_pad, shape, split, waves):
-    from linearcorex_amd.backend import gemm_tn_check
+    from tests.probe import gemm_tn_check
     k, v = shape
     a = _asym(k, v, 3).astype(dtype)
     b = _asym(k, m_pad, 4).astype(dtype)
@@ -45,7 +45,7 @@ def test_gemm_tn(dtype, m_pad, shape, split, waves):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_gemm_tn_rowscale(dtype):
-    from linearcorex_amd.backend import gemm_tn_check
+    from tests.probe import gemm_tn_check
     k, v, m_pad = 500, 200, 32
     a = _asym(k, v, 5).astype(dtype)
     b = _asym(k, m_pad, 6).astype(dtype)
@@ -59,7 +59,7 @@ def test_gemm_tn_rowscale(dtype):
 def test_gemm_linearity_at_config2_size():
     """Size-independent property at BASELINE.json config-2 shape (10k x 5k, m=32, f64):
     (X.(B1+B2)^T) == X.B1^T + X.B2^T and X^T.(Y1+Y2) == X^T.Y1 + X^T.Y2 up to rounding."""
-    from linearcorex_amd.backend import gemm_nt_check, gemm_tn_check
+    from tests.probe import gemm_nt_check, gemm_tn_check
     rng = np.random.RandomState(0)
     n, v, m_pad = 10000, 5000, 32
     x = rng.randn(n, v)
@@ -88,7 +88,7 @@ def test_gemm_linearity_at_config2_size():
 def test_gemm_ct(dtype, m_pad, shape, blocks):
     """Ragged sizes (inactive trailing waves of a super tile), block counts that cut super tiles at
     arbitrary groups (several partial slots + zero-filled ones), one block, more blocks than units."""
-    from linearcorex_amd.backend import gemm_tn_check
+    from tests.probe import gemm_tn_check
     k, v = shape
     a = _asym(k, v, 8).astype(dtype)
     b = _asym(k, m_pad, 9).astype(dtype)
@@ -99,7 +99,7 @@ def test_gemm_ct(dtype, m_pad, shape, blocks):
 
 
 def test_gemm_ct_is_deterministic_and_matches_tn():
-    from linearcorex_amd.backend import gemm_tn_check
+    from tests.probe import gemm_tn_check
     rng = np.random.RandomState(3)
     k, v, m_pad = 5000, 3000, 64
     a, b = rng.randn(k, v).astype(np.float32), rng.randn(k, m_pad).astype(np.float32)
@@ -115,7 +115,7 @@ def test_gemm_ct_is_deterministic_and_matches_tn():
 @pytest.mark.parametrize("shape,split", [((70, 45), 1), ((300, 257), 1), ((1111, 1000), 3), ((2048, 64), 2), ((64, 333), 1),
                                          ((4096, 640), 7), ((10000, 1300), 6)])
 def test_gemm_tn4(m_pad, shape, split):
-    from linearcorex_amd.backend import gemm_tn_check
+    from tests.probe import gemm_tn_check
     k, v = shape
     a = _asym(k, v, 10).astype(np.float64)
     b = _asym(k, m_pad, 11).astype(np.float64)

@@ -6,7 +6,7 @@
 #include <stdlib.h>
 #include <vector>
 #include <string.h>
-#include "../linearcorex_amd/csrc/gemm_kernels.hpp"
+#include "probe_kernels.hpp"
 using namespace lcx;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
@@ -15,7 +15,7 @@ void run(const char* tag, const T* A, int64_t lda_in, int64_t K, int64_t vcols, 
     const int64_t lda = panel ? 16 * RT : lda_in, tstride = panel ? K * 16 * RT : 16 * RT;
     dim3 grid((unsigned)(vcols / (16 * RT)), (unsigned)S);
     size_t lds = (size_t)KW * 16 * RT * 16 * CT * sizeof(T);
-    auto kern = gemm_tn_kernel<T, CT, RT, KW, false, MODE, U>;
+    auto kern = gemm_tn_probe_kernel<T, CT, RT, KW, false, MODE, U>;
     if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int bpc = 0;
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, lds));

@@ -7,7 +7,7 @@
 #include <stdlib.h>
 #include <vector>
 #include <string.h>
-#include "../linearcorex_amd/csrc/gemm_kernels.hpp"
+#include "probe_kernels.hpp"
 using namespace lcx;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
@@ -280,7 +280,7 @@ void suite(const char* name, int64_t K, int64_t V, std::initializer_list<int> sp
         size_t lds = (size_t)KW * 16 * RT * 16 * CT * sizeof(T);
         const int64_t tiles = V / (16 * RT);
         hipLaunchKernelGGL((k3<T, CT, RT, 4, 4, true, 0>), dim3((unsigned)((tiles + KW - 1) / KW), S), dim3(64 * KW), 0, 0, A, V, B, out, V, (int)K, S, V);
-        hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 4, false, 0, 4>), dim3((unsigned)(V / (16 * RT)), 3), dim3(64 * KW), lds, 0, A, V, (int64_t)(16 * RT), B, (const T*)nullptr, ref, V, (int)(K / 16), 3, (const int*)nullptr);
+        hipLaunchKernelGGL((gemm_tn_probe_kernel<T, CT, RT, 4, false, 0, 4>), dim3((unsigned)(V / (16 * RT)), 3), dim3(64 * KW), lds, 0, A, V, (int64_t)(16 * RT), B, (const T*)nullptr, ref, V, (int)(K / 16), 3, (const int*)nullptr);
         CK(hipDeviceSynchronize());
         const size_t n1 = (size_t)V * 16 * CT;
         std::vector<T> o((size_t)S * n1), r2((size_t)3 * n1);
@@ -300,7 +300,7 @@ void suite(const char* name, int64_t K, int64_t V, std::initializer_list<int> sp
         const int S = 3, KW = 4;
         size_t lds = (size_t)KW * 16 * RT * 16 * CT * sizeof(T);
         hipLaunchKernelGGL((k2<T, CT, RT, 4, 4, true, true, 0, 0>), dim3((unsigned)(V / (16 * RT)), S), dim3(64 * KW), lds, 0, A, V, B, out, V, (int)K, S);
-        hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 4, false, 0, 4>), dim3((unsigned)(V / (16 * RT)), S), dim3(64 * KW), lds, 0, A, V, (int64_t)(16 * RT), B, (const T*)nullptr, ref, V, (int)(K / 16), S, (const int*)nullptr);
+        hipLaunchKernelGGL((gemm_tn_probe_kernel<T, CT, RT, 4, false, 0, 4>), dim3((unsigned)(V / (16 * RT)), S), dim3(64 * KW), lds, 0, A, V, (int64_t)(16 * RT), B, (const T*)nullptr, ref, V, (int)(K / 16), S, (const int*)nullptr);
         CK(hipDeviceSynchronize());
         std::vector<T> o((size_t)S * V * 16 * CT), r2(o.size());
         CK(hipMemcpy(o.data(), out, o.size() * sizeof(T), hipMemcpyDeviceToHost));

@@ -10,7 +10,7 @@
 #include <functional>
 #include <string>
 #include <string.h>
-#include "../linearcorex_amd/csrc/gemm_kernels.hpp"
+#include "probe_kernels.hpp"
 using namespace lcx;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
@@ -225,7 +225,7 @@ Variant mk5(const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* ou
 
 template <typename T, int CT, int RT, int KW>
 Variant mkprod(const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* out, int S) {
-    auto kern = gemm_tn_kernel<T, CT, RT, KW, false, 0, 4>;
+    auto kern = gemm_tn_probe_kernel<T, CT, RT, KW, false, 0, 4>;
     size_t lds = (size_t)KW * 16 * RT * 16 * CT * sizeof(T);
     char buf[200];
     snprintf(buf, 200, "production gemm_tn RT=%d KW=%d S=%d blocks=%d", RT, KW, S, (int)(vcols / (16 * RT)) * S);
@@ -267,7 +267,7 @@ bool check(const T* A, int64_t K, int64_t V, const T* B, T* out, T* ref, Variant
     v.launch();
     const int KW = 4;
     size_t lds = (size_t)KW * 16 * 4 * 16 * CT * sizeof(T);
-    hipLaunchKernelGGL((gemm_tn_kernel<T, CT, 4, 4, false, 0, 4>), dim3((unsigned)(V / 64), 3), dim3(64 * KW), lds, 0, A, V, (int64_t)64, B, (const T*)nullptr, ref, V, (int)(K / 16), 3, (const int*)nullptr);
+    hipLaunchKernelGGL((gemm_tn_probe_kernel<T, CT, 4, 4, false, 0, 4>), dim3((unsigned)(V / 64), 3), dim3(64 * KW), lds, 0, A, V, (int64_t)64, B, (const T*)nullptr, ref, V, (int)(K / 16), 3, (const int*)nullptr);
     CK(hipDeviceSynchronize());
     const size_t n1 = (size_t)V * 16 * CT;
     std::vector<T> o((size_t)maxslots * n1), r2((size_t)3 * n1);

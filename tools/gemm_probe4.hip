@@ -8,7 +8,7 @@
 #include <functional>
 #include <string>
 #include <string.h>
-#include "../linearcorex_amd/csrc/gemm_kernels.hpp"
+#include "probe_kernels.hpp"
 using namespace lcx;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
@@ -25,7 +25,7 @@ struct Variant { std::string name; std::function<void()> launch; std::vector<flo
 
 template <typename T, int CT, int RT, int KW, int U, bool NT = false, int PRIO = 0>
 Variant mkct(const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* out, int bpc_use = 0) {
-    auto kern = gemm_ct_kernel<T, CT, RT, KW, U, NT, PRIO>;
+    auto kern = gemm_ct_probe_kernel<T, CT, RT, KW, U, NT, PRIO>;
     int bpc = 0;
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, 0));
     const int use = bpc_use > 0 ? bpc_use : bpc;
@@ -42,7 +42,7 @@ Variant mkct(const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* o
 
 template <typename T, int CT, int RT, int KW>
 Variant mkprod(const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* out, int S) {
-    auto kern = gemm_tn_kernel<T, CT, RT, KW, false, 0, 4>;
+    auto kern = gemm_tn_probe_kernel<T, CT, RT, KW, false, 0, 4>;
     size_t lds = (size_t)KW * 16 * RT * 16 * CT * sizeof(T);
     if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     char buf[200];

@@ -10,7 +10,7 @@
 #include <functional>
 #include <string>
 #include <string.h>
-#include "../linearcorex_amd/csrc/gemm_kernels.hpp"
+#include "probe_kernels.hpp"
 using namespace lcx;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -91,7 +91,7 @@ Variant mkvf(const double* A, int64_t lda, int64_t K, int64_t vcols, const doubl
 }
 
 Variant mkprod(const double* A, int64_t lda, int64_t K, int64_t vcols, const double* B, double* out, int S) {
-    auto kern = gemm_tn_kernel<double, 2, 4, 4, false, 0, 4>;
+    auto kern = gemm_tn_probe_kernel<double, 2, 4, 4, false, 0, 4>;
     size_t lds = (size_t)4 * 64 * 32 * 8;
     char buf[200];
     snprintf(buf, 200, "production gemm_tn (MFMA) S=%d", S);

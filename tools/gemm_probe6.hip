@@ -6,7 +6,7 @@
 #include <algorithm>
 #include <functional>
 #include <string>
-#include "../linearcorex_amd/csrc/gemm_kernels.hpp"
+#include "probe_kernels.hpp"
 using namespace lcx;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 struct Variant { std::string name; std::function<void()> launch; std::vector<float> ms; int slots; };
@@ -24,7 +24,7 @@ Variant mk4(const double* A, int64_t lda, int64_t K, int64_t vcols, const double
 }
 template <int CT, int RT, int KW>
 Variant mkprod(const double* A, int64_t lda, int64_t K, int64_t vcols, const double* B, double* out, int S) {
-    auto kern = gemm_tn_kernel<double, CT, RT, KW, false, 0, 4>;
+    auto kern = gemm_tn_probe_kernel<double, CT, RT, KW, false, 0, 4>;
     size_t lds = (size_t)KW * 16 * RT * 16 * CT * 8;
     if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     char buf[200];

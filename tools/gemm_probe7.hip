@@ -6,13 +6,13 @@
 #include <algorithm>
 #include <functional>
 #include <string>
-#include "../linearcorex_amd/csrc/gemm_kernels.hpp"
+#include "probe_kernels.hpp"
 using namespace lcx;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 struct Variant { std::string name; std::function<void()> launch; std::vector<float> ms; };
 template <int CT, int RT, int KW, int MODE, int U, bool NTA>
 Variant mk(const float* A, int64_t lda, int64_t K, int64_t vcols, const float* B, float* out, int S) {
-    auto kern = gemm_tn_kernel<float, CT, RT, KW, false, MODE, U, NTA>;
+    auto kern = gemm_tn_probe_kernel<float, CT, RT, KW, false, MODE, U, NTA>;
     size_t lds = (size_t)KW * 16 * RT * 16 * CT * 4;
     if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int bpc = 0;

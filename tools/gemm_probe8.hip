@@ -26,7 +26,7 @@ struct Variant { std::string name; std::function<void()> launch; std::vector<flo
 
 template <typename T, int CT, int RT, int KW, int U, bool NT = true, int PRIO = 0>
 Variant mkct(const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* out, int bpc_use = 0) {
-    auto kern = gemm_ct_kernel<T, CT, RT, KW, U, NT, PRIO>;
+    auto kern = gemm_ct_probe_kernel<T, CT, RT, KW, U, NT, PRIO>;
     int bpc = 0;
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, 0));
     const int use = bpc_use > 0 && bpc_use < bpc ? bpc_use : bpc;

@@ -26,7 +26,7 @@ SHAPES = {"c2": (10000, 5000, 32, np.float64), "c2m64": (10000, 5000, 64, np.flo
 
 def main():
     ge.build()
-    from linearcorex_amd.backend import HipBackend
+    from tests.probe import ProbeBackend as HipBackend      # the lab build of the engine (tools/liblcx_probe.so)
     name = sys.argv[1] if len(sys.argv) > 1 else "c2"
     if name in SHAPES:
         n, v, m, dt = SHAPES[name]

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge  # noqa: E402
 
 ge.build()
-from linearcorex_amd.backend import HipBackend  # noqa: E402
+from tests.probe import ProbeBackend as HipBackend  # noqa: E402  (the lab build of the engine: tools/liblcx_probe.so)
 
 for name, (n, v, m, dt) in {"c2": (10000, 5000, 32, np.float64), "c5": (400, 20000, 30, np.float64),
                             "big5": (2000, 50, 5, np.float64), "c2f32": (10000, 5000, 32, np.float32)}.items():

@@ -12,7 +12,7 @@ import __graft_entry__ as ge  # noqa: E402
 
 def main():
     ge.build()
-    from linearcorex_amd.backend import HipBackend
+    from tests.probe import ProbeBackend as HipBackend      # the lab build of the engine (tools/liblcx_probe.so)
     ns = [256, 1000, 4000, 16000, 60000]
     vs = [64, 500, 3000, 20000, 120000]
     ms = [(5, np.float32), (30, np.float32), (60, np.float32), (120, np.float32), (30, np.float64), (60, np.float64)]

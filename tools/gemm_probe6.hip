@@ -163,7 +163,58 @@ void suite_occ(const char* name, int64_t K, int64_t V, std::initializer_list<int
     CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(out));
 }
 
+// round 3: a merged pass for float64 with <= 32 padded factors - X.[grad | ws + update]^T as ONE 64-column contraction
+// (two 32-column passes read X twice; at config 2 the pass is HBM-bound, so the second read is the cost).  Reference row:
+// the production 32-column kernel; the 64-column candidates must beat TWICE its time.
+void suite_merged(const char* name, int64_t K, int64_t V, std::initializer_list<int> splits) {
+    double *A, *B, *out;
+    CK(hipMalloc(&A, 8 * K * V)); CK(hipMalloc(&B, 8 * K * 64)); CK(hipMalloc(&out, 8 * 40 * V * 64));
+    std::vector<double> h((size_t)K * V);
+    for (size_t x = 0; x < h.size(); ++x) h[x] = (double)rand() / RAND_MAX - 0.5;
+    CK(hipMemcpy(A, h.data(), 8 * K * V, hipMemcpyHostToDevice));
+    CK(hipMemcpy(B, h.data() + 7, 8 * K * 64, hipMemcpyHostToDevice));
+    const double gb = 8 * ((double)K * V + 64.0 * (K + V)) / 1e9, tf = 2.0 * K * V * 64 / 1e12;
+    printf("== %s: K=%ld V=%ld f64; first row = the 32-column production kernel (GB/s, TF/s columns are for 64 columns)\n", name, (long)K, (long)V);
+    std::vector<Variant> vs;
+    vs.push_back(mk4<2, 4, 4, 4, true>(A, V, K, V, B, out, *splits.begin()));
+    for (int S : splits) {
+        vs.push_back(mk4<4, 4, 4, 4, true, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<4, 4, 4, 2, true, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<4, 2, 4, 4, true, false>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<4, 2, 4, 4, true, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<4, 2, 4, 2, true, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4<4, 2, 8, 2, true, true>(A, V, K, V, B, out, S));
+    }
+    // correctness of the 64-column variants against the 16x16x4 kernel
+    std::vector<Variant> ref;
+    ref.push_back(mkprod<4, 2, 4>(A, V, K, V, B, out, 3));
+    const size_t n1 = (size_t)V * 64;
+    ref[0].launch(); CK(hipDeviceSynchronize());
+    std::vector<double> r((size_t)ref[0].slots * n1);
+    CK(hipMemcpy(r.data(), out, r.size() * 8, hipMemcpyDeviceToHost));
+    for (size_t vi = 1; vi < 7; ++vi) {
+        CK(hipMemset(out, 0xff, 8 * (size_t)vs[vi].slots * n1));
+        vs[vi].launch(); CK(hipDeviceSynchronize());
+        std::vector<double> o((size_t)vs[vi].slots * n1);
+        CK(hipMemcpy(o.data(), out, o.size() * 8, hipMemcpyDeviceToHost));
+        double md = 0, mx = 0;
+        for (size_t x = 0; x < n1; ++x) {
+            double so = 0, sr = 0;
+            for (int s2 = 0; s2 < vs[vi].slots; ++s2) so += o[s2 * n1 + x];
+            for (int s2 = 0; s2 < ref[0].slots; ++s2) sr += r[s2 * n1 + x];
+            md = fmax(md, fabs(so - sr)); mx = fmax(mx, fabs(sr));
+        }
+        printf("check %-66s max |diff| %.3e %s\n", vs[vi].name.c_str(), md, md <= 1e-11 * mx ? "ok" : "FAIL");
+    }
+    bench(vs, gb, tf);
+    CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(out));
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "merged") {
+        suite_merged("c2_x_gw (X.[grad | ws+update]^T, contraction over the 5056 variables)", 5056, 10048, {1, 2, 3, 4});
+        return 0;
+    }
     if (argc > 1 && std::string(argv[1]) == "occ") {
         suite_occ<2>("c2_xty", 10048, 5120, {3, 4, 6, 9, 12});
         suite_occ<2>("c2_xw", 5120, 10112, {2, 3, 4, 6});

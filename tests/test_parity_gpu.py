@@ -657,3 +657,39 @@ def test_merged_pass_equals_separate_passes(m, monkeypatch):
     ref = O.fit_ns(x, m, seed=0, dtype=np.float32, max_iter=6)
     h_ref = np.asarray(ref.history_tc, np.float64)
     assert len(h_ref) == len(h1) and np.max(np.abs(h1 - h_ref) / np.maximum(1.0, np.abs(h_ref))) < 2e-3
+
+
+@pytest.mark.parametrize("m", [64, 128])
+def test_linear_mode_float32_large_shards(m, monkeypatch):
+    """The linear trial mode (trials cost no pass over X: Y and X^T.Y of ws + eta*update follow from the direction's passes,
+    re-anchored on an exact evaluation every 16 iterations and at every stage) on the kernels BASELINE configs[2] / [3] run:
+    float32, gemm_ct, n_hidden 64 / 128, 4096 x 8192, 7 stages x 20 iterations.  Same mathematics as the exact mode, different
+    rounding: the TC history must stay within the float32 end-to-end bar of the exact mode (5e-4 relative; measured 1e-5..1e-4),
+    trial counts within 3 %, and the weights must describe the same solution."""
+    from linearcorex_amd import Corex
+    from linearcorex_amd.preprocess import preprocess as pp
+    monkeypatch.setenv("LCX_GEMM", "ct")
+    n, v, iters = 4096, 8192, 20
+    x, _ = O.gen_planted(n, v, m, seed=51)
+    xt = pp(x.astype(np.float32), None, "standard", None)[0]
+    runs = {}
+    for mode in ("exact", "linear"):
+        model = Corex(n_hidden=m, seed=0, dtype=np.float32, tol=0.0, device=0, line_search=mode)
+        be = model._attach_shard(xt, v)
+        for i_eps, eps in enumerate(model._init_weights()):
+            model._begin_stage(i_eps, eps)
+            for k in range(iters):
+                model._iterate(more=k + 1 < iters)
+        runs[mode] = (np.asarray(model.history["TC"], np.float64), be.get_ws(0), dict(model.stats))
+        be.close()
+    (h0, w0, s0), (h1, w1, s1) = runs["exact"], runs["linear"]
+    assert len(h0) == len(h1) == 7 * iters
+    assert s1.get("refreshes", 0) >= 7                     # the 16-iteration re-anchor fired in every stage
+    dev = np.max(np.abs(h1 - h0) / np.maximum(1.0, np.abs(h0)))
+    assert dev < 5e-4, dev
+    assert abs(s1["trials"] - s0["trials"]) <= 0.03 * s0["trials"] + 2, (s0["trials"], s1["trials"])
+    assert relerr(w1, w0) < 2e-2
+    agree = np.mean(np.argmax(np.abs(w1), axis=0) == np.argmax(np.abs(w0), axis=0))
+    assert agree >= 0.995, agree
+    print("linear vs exact float32 m=%d: max rel TC deviation %.2e, trials %d vs %d, ws %.2e, clusters agree %.4f"
+          % (m, dev, s1["trials"], s0["trials"], relerr(w1, w0), agree))

@@ -157,7 +157,9 @@ int lcx_upload_x(lcx_ctx* h, const void* x_host, int64_t ld);
  * it is NaN or equals `missing`, only when has_missing != 0), estimate theta = (mean, std) (fit != 0;
  * 'standard': std over the observed cells :411-413, 'outliers': np.std over all rows :420-421, both clipped
  * at 1e-10) or take the given one (fit == 0), standardise, and for kind 2 squash the tails with g (:483-487).
- * kind: 0 pass-through ('none' and any unknown name, :404-405), 1 'standard', 2 'outliers'.
+ * kind: 0 pass-through ('none' and any unknown name, :404-405), 1 'standard', 2 'outliers', 3 'empirical' (:424-426: every
+ * column becomes norm.ppf((rankdata(column) - 0.5) / n_samples), ties get their average rank; no theta - a per-column
+ * segmented sort of the transposed copy, so a new batch is transformed by uploading it into a handle of its own).
  * mean_io / std_io: nv_local values of the working dtype; n_obs_out: nv_local int64 or NULL;
  * max_abs_out: max |x~| (for the "more than 6 stds" warning, :416-417) or NULL. */
 int lcx_upload_preprocess(lcx_ctx* h, const void* x_raw_host, int64_t ld, int kind, int has_missing, double missing,

@@ -204,7 +204,7 @@ class HipBackend:
         assert x.shape == (self.n_samples, self.nv), x.shape
         _abi.check(self.lib.lcx_upload_x(self.h, p, x.shape[1]))
 
-    PP_KINDS = {"standard": 1, "outliers": 2}     # anything else passes through (reference :404-405)
+    PP_KINDS = {"standard": 1, "outliers": 2, "empirical": 3}     # anything else passes through (reference :404-405)
 
     def upload_preprocess(self, x_raw, gaussianize, missing_values=None, theta=None):
         """preprocess(x, fit=theta is None) of the reference (:397-429) on the device for this shard.
@@ -224,6 +224,11 @@ class HipBackend:
                                                   _abi.np_ptr(mean), _abi.np_ptr(std),
                                                   n_obs.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(mx)))
         return (mean, std), (n_obs if has_missing else self.n_samples), mx.value
+
+    def project_resident(self):
+        """x~ . ws^T of the resident shard itself: (n_samples, m), this shard's partial."""
+        self.moments_a(0)
+        return self.get_moment(0, "Y")
 
     def project_raw(self, x_raw, gaussianize, theta):
         x, p = self._a(x_raw)
@@ -387,7 +392,7 @@ class HipBackend:
         (nv_local, m) of a restored model, None = the resident moments."""
         y, py = self._a(y)
         assert y.ndim == 2 and y.shape[1] == self.m, y.shape
-        kind = self.PP_KINDS.get(gaussianize, 0)
+        kind = self.PP_KINDS.get(gaussianize, 0) % 3               # 'empirical' has no inverse: passes through (:437-438)
         mean = std = None
         if kind:
             mean, std = np.ascontiguousarray(theta[0], self.dtype), np.ascontiguousarray(theta[1], self.dtype)
@@ -408,7 +413,7 @@ class HipBackend:
         """invert (linearcorex.py:431-438) of host rows (n_rows, nv_local)."""
         x, px = self._a(x)
         assert x.ndim == 2 and x.shape[1] == self.nv, x.shape
-        kind = self.PP_KINDS.get(gaussianize, 0)
+        kind = self.PP_KINDS.get(gaussianize, 0) % 3
         mean = std = None
         if kind:
             mean, std = np.ascontiguousarray(theta[0], self.dtype), np.ascontiguousarray(theta[1], self.dtype)

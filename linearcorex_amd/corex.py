@@ -343,26 +343,24 @@ class Corex(object):
         self._cols = (c0, c1)
         be = self._make_backend(self.n_samples, c1 - c0)
         self._x_resident = True
+        # preprocess(x, fit=True) (:109, :397-429) happens on the device, per shard, while uploading - 'empirical'
+        # (:424-426: per-column rank -> normal quantile) included: a segmented sort of the transposed copy
         if self.gaussianize == 'empirical':
-            # rank-based gaussianisation (:424-426) is a per-column sort: host side, then a plain upload
-            x = self.preprocess(x, fit=True)
-            be.upload_x(np.ascontiguousarray(x[:, c0:c1]))
-        else:
-            # preprocess(x, fit=True) (:109, :397-429) happens on the device, per shard, while uploading
-            theta, n_obs, max_abs = be.upload_preprocess(np.ascontiguousarray(x[:, c0:c1]), self.gaussianize,
-                                                         self.missing_values, None)
-            if self.gaussianize in ('standard', 'outliers'):
-                self.theta = (self._gather(theta[0]), self._gather(theta[1]))
-            self.n_obs = self._gather(n_obs) if self.missing_values is not None else len(x)
-            if self.gaussianize == 'standard' and self.verbose:
-                if self._ex is not None:
-                    import torch
-                    with be.stream_context():
-                        t = torch.tensor([max_abs], dtype=torch.float64, device=self._ex[1].device)
-                        self._comm.allreduce_max(t)
-                        max_abs = float(t.item())
-                if max_abs > 6:
-                    print("Warning: outliers more than 6 stds away from mean. Consider using gaussianize='outliers'")
+            print("Warning: correct inversion/transform of empirical gauss transform not implemented.")     # :425
+        theta, n_obs, max_abs = be.upload_preprocess(np.ascontiguousarray(x[:, c0:c1]), self.gaussianize,
+                                                     self.missing_values, None)
+        if self.gaussianize in ('standard', 'outliers'):
+            self.theta = (self._gather(theta[0]), self._gather(theta[1]))
+        self.n_obs = self._gather(n_obs) if self.missing_values is not None else len(x)
+        if self.gaussianize == 'standard' and self.verbose:
+            if self._ex is not None:
+                import torch
+                with be.stream_context():
+                    t = torch.tensor([max_abs], dtype=torch.float64, device=self._ex[1].device)
+                    self._comm.allreduce_max(t)
+                    max_abs = float(t.item())
+            if max_abs > 6:
+                print("Warning: outliers more than 6 stds away from mean. Consider using gaussianize='outliers'")
         del x
         return self._fit_resident()
 
@@ -753,10 +751,13 @@ class Corex(object):
             else:
                 theta = (np.zeros(c1 - c0, self.dtype), np.ones(c1 - c0, self.dtype))
             y = be.project_raw(np.ascontiguousarray(x[:, c0:c1]), self.gaussianize, theta)   # preprocess on the device
+            engine_summed = True
         else:
-            x = self.preprocess(x)       # imputation needs the column means of the whole new batch: host side
-            y = be.project(np.ascontiguousarray(x[:, c0:c1]))
-        if self._ex is not None and not self._engine_exchange:       # (the engine summed the per-shard partials itself)
+            # imputation needs the column means of the whole new batch (:403), the rank transform its whole columns (:424-426):
+            # the batch becomes the resident shard of a handle of its own and goes through the same device preprocess as a fit
+            y = self._project_new_batch(np.ascontiguousarray(x[:, c0:c1]))
+            engine_summed = False
+        if self._ex is not None and not (self._engine_exchange and engine_summed):   # (else the engine summed the partials itself)
             import torch
             with be.stream_context():
                 t = torch.from_numpy(y).to(self._ex[1].device)
@@ -771,8 +772,26 @@ class Corex(object):
             return y, self._calculate_moments(quick=False, details=True)
         return y
 
+    def _project_new_batch(self, x_local):
+        """x~ . ws^T of a new batch whose preprocessing needs whole columns; per-shard partial like `project_raw`."""
+        be = self._backend
+        if self._backend_factory is not None:
+            tmp = self._backend_factory(x_local.shape[0], x_local.shape[1], self.m, self.dtype)
+        else:
+            from .backend import HipBackend
+            tmp = HipBackend(x_local.shape[0], x_local.shape[1], self.m, self.dtype, be.device)
+        try:
+            if self.gaussianize == 'empirical':
+                print("Warning: correct inversion/transform of empirical gauss transform not implemented.")     # :425
+            tmp.upload_preprocess(x_local, self.gaussianize, self.missing_values, self._theta_local())
+            tmp.set_ws(be.get_ws(0))
+            return tmp.project_resident()
+        finally:
+            tmp.close()
+
     def preprocess(self, x, fit=False):
-        """Per-marginal standardisation (:397-429); host side (a one-off O(ns*nv) pass)."""
+        """Per-marginal standardisation (:397-429) of a host array, on the host: the reference's public helper.  `fit` /
+        `transform` do not call it - they preprocess on the device (lcx_upload_preprocess / lcx_project_raw)."""
         from .preprocess import preprocess as _pp
         x, self.theta, self.n_obs = _pp(x, self.theta if not fit else None, self.gaussianize,
                                         self.missing_values, verbose=self.verbose)

@@ -29,6 +29,12 @@
 
 using namespace lcx;
 
+// empirical.hip: gaussianize='empirical' (:424-426) - per-column rank -> normal quantile, from a segmented sort of the
+// transposed copy; rewrites both layouts of the shard
+namespace lcx {
+template <typename T> int empirical_columns(T* X, int64_t ldx, T* XT, int64_t Npad, int64_t N, int64_t V, hipStream_t st, std::string* err);
+}
+
 // -------------------------------------------------------------------------------------------------
 // error plumbing
 // -------------------------------------------------------------------------------------------------
@@ -1600,6 +1606,8 @@ template <typename T, int CT> struct Impl {
         const dim3 grid((unsigned)strips, (unsigned)RS);
         const unsigned fgrid = (unsigned)cdiv(V, 256);
         T* X = P<T>(h->X);
+        const bool empirical = kind == PP_KIND_EMPIRICAL;        // (:424-426) imputation as usual, then ranks: no theta
+        if (empirical) kind = PP_KIND_NONE;
         const bool need_stats = kind != PP_KIND_NONE;
         if (has_missing || (fit && need_stats)) {
             hipLaunchKernelGGL((pp_colsum_kernel<T>), grid, dim3(256), 0, h->stream, X, N, V, h->ldx, has_missing, (T)sentinel,
@@ -1632,6 +1640,11 @@ template <typename T, int CT> struct Impl {
             hipLaunchKernelGGL((pp_apply_kernel<T>), grid, dim3(256), 0, h->stream, X, N, V, h->ldx, has_missing, (T)sentinel, imp, mean, stdv,
                                kind, bmax);
             KCHECK();
+        }
+        if (empirical) {
+            LCXCHECK(make_xt(h));
+            std::string err;
+            if (empirical_columns<T>(X, h->ldx, P<T>(h->XT), h->Npad, N, V, h->stream, &err) != 0) return fail(LCX_ERR_HIP, err);
         }
         HIPCHECK(hipStreamSynchronize(h->stream));
         if (fit && need_stats && mean_io && std_io) {
@@ -2078,7 +2091,7 @@ int lcx_upload_preprocess(lcx_ctx* h, const void* x, int64_t ld, int kind, int h
                           void* std_io, int64_t* n_obs_out, double* max_abs_out) {
     NEED_MUT(h);
     if (!x || ld < h->V) return fail(LCX_ERR_ARG, "lcx_upload_preprocess: bad leading dimension");
-    if (kind < 0 || kind > 2) return fail(LCX_ERR_ARG, "lcx_upload_preprocess: kind must be 0 (none), 1 (standard) or 2 (outliers)");
+    if (kind < 0 || kind > 3) return fail(LCX_ERR_ARG, "lcx_upload_preprocess: kind must be 0 (none), 1 (standard), 2 (outliers) or 3 (empirical)");
     DISPATCH(h, upload_preprocess, h, x, ld, kind, has_missing, missing, fit, mean_io, std_io, n_obs_out, max_abs_out);
 }
 

@@ -1132,7 +1132,7 @@ __global__ void generate_kernel(T* __restrict__ X, int64_t N, int64_t V, int64_t
 // A cell is missing if it is NaN or equals the sentinel (only when missing values are enabled, as in
 // the reference); infinities are neither observed nor imputed (:505-507).
 // ------------------------------------------------------------------------------------------------
-constexpr int PP_KIND_NONE = 0, PP_KIND_STANDARD = 1, PP_KIND_OUTLIERS = 2;
+constexpr int PP_KIND_NONE = 0, PP_KIND_STANDARD = 1, PP_KIND_OUTLIERS = 2, PP_KIND_EMPIRICAL = 3;   // 3: empirical.hip
 
 template <typename T>
 __device__ __forceinline__ bool pp_missing(T x, int has_missing, T sentinel) {

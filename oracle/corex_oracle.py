@@ -75,10 +75,13 @@ def preprocess(x, theta=None, gaussianize="standard", missing_values=None):
         if theta is None:
             theta = (np.mean(x, axis=0), np.std(x, axis=0, ddof=0).clip(1e-10))  # ref :420-421
         x = squash_tails((x - theta[0]) / theta[1])
+    elif gaussianize == "empirical":
+        from scipy.stats import norm, rankdata
+        x = np.array([norm.ppf((rankdata(col) - 0.5) / len(col)) for col in x.T]).T      # ref :424-426
     elif gaussianize == "none":
         pass
     else:
-        raise ValueError("oracle covers gaussianize in {'standard','outliers','none'}")
+        raise ValueError("oracle covers gaussianize in {'standard','outliers','empirical','none'}")
     return x, theta, n_obs
 
 

@@ -321,3 +321,6 @@ class ShardDouble:
     def invert(self, x, gaussianize, theta):
         from oracle import corex_oracle as O
         return O.invert(np.asarray(x, self.dtype), theta, gaussianize)
+
+    def project_resident(self):
+        return self.x.dot(self.w[0].T)

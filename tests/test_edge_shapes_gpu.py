@@ -143,18 +143,24 @@ def test_repeated_fits_release_their_device_memory():
     assert int(free0.value) - int(free1.value) < (64 << 20), (free0.value, free1.value)      # a leak shows as LESS free memory
 
 
-def test_empirical_gaussianize_goes_through_the_host_rank_transform(capsys):
-    """gaussianize='empirical' (reference :424-426: rank transform per column, done on the host like the reference does) must
-    give the fit of the rank-transformed data; 'none' (and any unknown name, :404-405) passes the data through."""
+def test_empirical_gaussianize_end_to_end(capsys):
+    """gaussianize='empirical' (reference :424-426: rank transform per column, here on the device) must give the fit of the
+    rank-transformed data, and `transform` of a new batch ranks that batch (as the reference's preprocess does); 'none' (and
+    any unknown name, :404-405) passes the data through."""
     from linearcorex_amd import Corex
-    from linearcorex_amd.preprocess import preprocess as pp
     x = np.random.RandomState(9).lognormal(size=(300, 40))
+    x[:, 3] = np.round(x[:, 3])                                                          # ties
     out = Corex(n_hidden=3, seed=0, dtype=np.float64, device=0, max_iter=6, gaussianize="empirical").fit(x)
     assert "empirical gauss transform not implemented" in capsys.readouterr().out      # the reference's own warning (:425)
-    xr = pp(x, None, "empirical", None)[0]
+    xr = O.preprocess(x.copy(), None, "empirical")[0]
     ref = Corex(n_hidden=3, seed=0, dtype=np.float64, device=0, max_iter=6, gaussianize="none").fit(xr)
     h, hr = np.asarray(out.history["TC"], np.float64), np.asarray(ref.history["TC"], np.float64)
-    assert len(h) == len(hr) and np.array_equal(h, hr)
+    assert len(h) == len(hr) and np.max(np.abs(h - hr)) < 1e-9
     orc = O.fit_ns(xr, 3, seed=0, dtype=np.float64, max_iter=6, gaussianize="none")
     assert np.max(np.abs(h - np.asarray(orc.history_tc))) < 1e-9
-    assert out.transform(x).shape == (300, 3)
+    assert np.max(np.abs(out.transform(x) - xr.dot(orc.ws.T))) < 1e-8
+    x2 = np.random.RandomState(10).lognormal(size=(77, 40))
+    assert np.max(np.abs(out.transform(x2) - O.preprocess(x2.copy(), None, "empirical")[0].dot(orc.ws.T))) < 1e-8
+    assert out.invert(xr[:5]) is not None and np.array_equal(out.invert(xr[:5]), xr[:5])    # no inverse: passes through (:437-438)
+    out._backend.close()
+    ref._backend.close()

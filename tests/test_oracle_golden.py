@@ -268,3 +268,15 @@ def test_predict_and_invert_match_reference(gz, branch, tag):
     ok = np.isfinite(inv)
     assert np.array_equal(inv[ok], g[p + "invert"][ok])
     close(pred, g[p + "predict"], tag)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("name", ["emp", "emp_missing"])
+def test_empirical_gaussianize_matches_reference(name, tag):
+    """gaussianize='empirical' (reference :424-426, after mean imputation :403) against the reference's own preprocess
+    output (g9_predict.npz): rank transform with average ranks for ties, normal quantiles."""
+    g = load_golden("g9_predict")
+    x = np.array(g["emp_x_missing" if name == "emp_missing" else "emp_x"], dtype=DT[tag])
+    out, theta, n_obs = O.preprocess(x, None, "empirical", -1e6 if name == "emp_missing" else None)
+    assert theta is None
+    assert np.array_equal(out, g["%s_%s" % (name, tag)])

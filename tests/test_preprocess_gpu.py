@@ -90,3 +90,46 @@ def test_project_raw_matches_host_preprocess(dtype, kind):
     scale = np.abs(np.asarray(xt, np.float64)) @ np.abs(w.astype(np.float64)).T
     assert np.max(np.abs(y - ref) / scale) < (2e-5 if dtype == np.float32 else 1e-12)
     be.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("name", ["emp", "emp_missing"])
+def test_preprocess_empirical_against_the_reference(dtype, name):
+    """gaussianize='empirical' on the device (lcx_upload_preprocess kind 3: segmented sort of the transposed copy, average ranks
+    for ties, AS 241 normal quantile) against the reference's own preprocess output (g9_predict.npz; heavy ties, continuous
+    columns, missing cells imputed before ranking).  Ranks are integers / half-integers: an error there would show as >= 1e-3."""
+    from tests.conftest import load_golden
+    g = load_golden("g9_predict")
+    tag = "f32" if dtype == np.float32 else "f64"
+    x = np.array(g["emp_x_missing" if name == "emp_missing" else "emp_x"], dtype=dtype)
+    ref = g["%s_%s" % (name, tag)]
+    n, v = x.shape
+    be = _backend(n, v, dtype)
+    theta, n_obs, _ = be.upload_preprocess(x, "empirical", -1e6 if name == "emp_missing" else None, None)
+    got = be.download_x()
+    assert np.max(np.abs(got.astype(np.float64) - ref)) < (1e-12 if dtype == np.float64 else 5e-7)
+    if name == "emp_missing":
+        assert np.array_equal(n_obs, np.sum(x != -1e6, axis=0))
+    # both layouts of the shard carry the transformed data: X.W^T through the transposed copy
+    w = np.random.RandomState(0).randn(3, v).astype(dtype)
+    be.set_ws(w)
+    y = be.project_resident()
+    assert np.max(np.abs(y - ref.astype(dtype).dot(w.T))) < (1e-10 if dtype == np.float64 else 2e-4)
+    be.close()
+
+
+@pytest.mark.parametrize("shape", [(64, 70), (1000, 257), (5000, 33), (70000, 5)])
+def test_preprocess_empirical_shapes(shape):
+    """ragged sizes, more rows than one sort chunk holds columns for, all-equal and two-valued columns"""
+    n, v = shape
+    rng = np.random.RandomState(n + v)
+    x = rng.randn(n, v)
+    x[:, 0] = 3.0                                  # one tie group of n
+    x[:, 1] = (rng.rand(n) < 0.3) * 1.0            # two values
+    x[:, 2] = np.round(x[:, 2], 1)
+    ref = O.preprocess(x.copy(), None, "empirical")[0]
+    be = _backend(n, v, np.float64)
+    be.upload_preprocess(x, "empirical", None, None)
+    got = be.download_x()
+    assert np.max(np.abs(got - ref)) < 1e-12
+    be.close()

@@ -217,8 +217,7 @@ __device__ __forceinline__ void tc_store(const double* sbuf, SetState* st) {
 // state is published by the tail block that rides in the launch of the H Gram that always follows (gram_tc_kernel).
 // A fused tail here (ticket, last block sums and publishes) cost 11-14 us on top of an 8-16 us body: two dependent
 // atomic round trips plus the publication (tools/epilogue_probe.hip, profiles/r01_epilogue_probe_tail.txt).
-// ABL is for ablation probes only: 1 = no m x m matvec, 2 = no M x V stores, 8 = no logarithms, 16 = first slot only.
-template <typename T, int Mp, int ABL = 0>
+template <typename T, int Mp>
 __global__ void __launch_bounds__(PV_THREADS)
 moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride,
                         const T* __restrict__ d_base, const T* __restrict__ d_dir, T eta,
@@ -255,10 +254,9 @@ moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride
             d = d_base[o] + eta * d_dir[o];
         } else {
             d = dpart[o];
-            if (!(ABL & 16))
-                for (int k = 1; k < nsplit; ++k) d += dpart[k * pstride + o];
+            for (int k = 1; k < nsplit; ++k) d += dpart[k * pstride + o];
         }
-        if (ok && !(ABL & 2)) d_out[o] = d;
+        if (ok) d_out[o] = d;
         const T rho = ok ? (c1 * d / ns + c2 * W[o]) : (T)0;
         const T inv = (T)1 / ((T)1 - rho * rho);
         const T rir = rho * inv;
@@ -266,34 +264,25 @@ moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride
         rir_s[vl * Mp + j] = rir;
         const T si = group_sum<Mp, T>(rho * rir, gs_scratch, tid);
         __syncthreads();
-        T qv = (ABL & 1) ? rir : (T)0;
-        if (!(ABL & 1)) {
-            if (OpInLds<Mp>::v) {
+        T qv = (T)0;
+        if (OpInLds<Mp>::v) {
 #pragma unroll 8
-                for (int k = 0; k < Mp; ++k) qv += ry_s[k * Mp + j] * rir_s[vl * Mp + k];   // ry symmetric
-            } else {
+            for (int k = 0; k < Mp; ++k) qv += ry_s[k * Mp + j] * rir_s[vl * Mp + k];   // ry symmetric
+        } else {
 #pragma unroll 8
-                for (int k = 0; k < Mp; ++k) qv += (T)ry[k * Mp + j] * rir_s[vl * Mp + k];
-            }
+            for (int k = 0; k < Mp; ++k) qv += (T)ry[k * Mp + j] * rir_s[vl * Mp + k];
         }
         const T q2 = group_sum<Mp, T>(rir * (qv - si * rho), gs_scratch, tid);
         if (ok) {
-            if (!(ABL & 2)) {
-                rho_o[o] = rho;
-                rir_o[o] = rir;
-                qij_o[o] = qv;
-            }
+            rho_o[o] = rho;
+            rir_o[o] = rir;
+            qij_o[o] = qv;
             if (j == 0) {
                 si_o[v] = si;
                 q2_o[v] = q2;
                 hscale_o[v] = (T)1 / ((T)1 + q2);
-                if (ABL & 8) {
-                    s1 += (double)si;
-                    s2 += (double)q2;
-                } else {
-                    s1 += (double)log((T)1 + si);
-                    s2 += (double)log((T)1 + q2);
-                }
+                s1 += (double)log((T)1 + si);
+                s2 += (double)log((T)1 + q2);
             }
         }
     }

@@ -55,6 +55,7 @@ def main():
     c0, c1 = comm.shard(v)
     assert model._backend.nv == c1 - c0
     y = model.transform(x)
+    xr = model.predict(y[:50])              # sharded columns of the product, gathered: a collective like transform
     if os.environ.get("LCX_EAGER_GATHER_ELEMS") == "0":
         # sharded moments were NOT put together at the end of fit: touching one must raise (never a hidden collective that
         # the other ranks do not join), pickling must work without them, and the explicit collective brings them in
@@ -83,7 +84,7 @@ def main():
     cov = model.get_covariance() if (syn and comm.world == 1) else np.zeros(1)
     if comm.rank == 0:
         np.savez(os.path.join(out_dir, "dist_result.npz"), history=np.asarray(model.history["TC"], np.float64),
-                 ws=model.ws, clusters=model.clusters(), transform=y, rho=rho, xz=xz, si=si, cov=cov,
+                 ws=model.ws, clusters=model.clusters(), transform=y, predict=xr, rho=rho, xz=xz, si=si, cov=cov,
                  tcs=model.tcs, world=comm.world, trials=model.stats["trials"],
                  transport=str(getattr(model, "_engine_exchange", None)),
                  in_library=np.array(bool(getattr(model, "_iterated_in_library", False))),

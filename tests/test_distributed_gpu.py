@@ -82,6 +82,7 @@ def test_sharded_fit_on_device_matches_oracle(world, mode, shape, exchange, tmp_
     assert np.array_equal(got["clusters"], ref.clusters())
     assert np.max(np.abs(got["ws"] - ref.ws)) < 1e-7
     assert np.max(np.abs(got["transform"] - ref.transform(ref.x_tilde))) < 1e-7
+    assert np.max(np.abs(got["predict"] - O.predict(ref.moments["X_i Z_j"], ref.transform(ref.x_tilde)[:50], ref.theta))) < 1e-6
     assert np.max(np.abs(got["rho"] - ref.moments["rho"])) < 1e-7
     assert np.max(np.abs(got["xz"] - ref.moments["X_i Z_j"])) < 1e-7
     assert np.max(np.abs(got["tcs"] - ref.moments["TCs"])) < 1e-7

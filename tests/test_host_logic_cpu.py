@@ -263,3 +263,54 @@ def test_bench_roofline_accounting_with_the_merged_pass():
     assert 0.9 < it["fraction_of_step_inside_the_x_passes"] < 1.0
     # committed profiles are only quoted for the library they were taken from
     assert rf["traffic"] is None or rf["traffic_profile_matches_library"] is True
+
+
+def test_headers_are_plain_c_and_a_c_program_links_the_library(tmp_path):
+    """include/lcx.h is the boundary a non-Python host binds: it must compile as C (not only as C++), a C program must link
+    against liblcx_hip.so and resolve every call it makes, and the probe library must export the boundary too (its handles are
+    created through it) plus the lab hooks of tools/lcx_probe.h.  No compute: the container has no GPU (lcx_create must say so)."""
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    src = tmp_path / "bind.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "lcx.h"
+#include "lcx_probe.h"
+static int hook(void* user, void* buf, int64_t count, int dtype, void* stream) { (void)user; (void)buf; (void)count; (void)dtype; (void)stream; return 0; }
+int main(void) {
+    int n = -1;
+    lcx_ctx* h = NULL;
+    lcx_allreduce_fn fn = hook;
+    char id[LCX_COMM_ID_BYTES];
+    (void)fn; (void)id;
+    if (lcx_abi_version() != 1) return 2;
+    if (lcx_device_count(&n) != LCX_OK) return 3;
+    if (n == 0) {
+        int rc = lcx_create(&h, 100, 20, 4, LCX_F64, 0);
+        if (rc != LCX_ERR_NO_DEVICE || h != NULL) return 4;
+        printf("no device: %s\n", lcx_last_error());
+    }
+    printf("devices %d, abi %d\n", n, lcx_abi_version());
+    return 0;
+}
+''')
+    inc = ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tools")]
+    for hdr in ("lcx.h", "lcx_probe.h"):
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c"] + inc +
+                              [os.path.join(ROOT, "include" if hdr == "lcx.h" else "tools", hdr)])
+    exe = tmp_path / "bind"
+    libdir = os.path.join(ROOT, "linearcorex_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror"] + inc + ["-o", str(exe), str(src), "-L", libdir, "-l:liblcx_hip.so",
+                           "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"])
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    assert "abi 1" in p.stdout
+    # the lab library: the whole boundary plus its own four hooks
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "tools", "liblcx_probe.so")], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert set(header_functions()) <= exported
+    assert {"lcx_test_gemm_nt", "lcx_test_gemm_tn", "lcx_bench_gemm", "lcx_bench_graph"} <= exported
+    prod = subprocess.run(["nm", "-D", "--defined-only", os.path.join(libdir, "liblcx_hip.so")], capture_output=True, text=True).stdout
+    prod_syms = {ln.split()[-1] for ln in prod.splitlines() if " T lcx_" in ln}
+    assert prod_syms == set(header_functions()), prod_syms ^ set(header_functions())      # nothing beyond the boundary

@@ -9,7 +9,7 @@
 #include <stdlib.h>
 #include <stdint.h>
 #include <vector>
-#include "moment_kernels.hpp"
+#include "probe_kernels.hpp"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 using namespace lcx;
 
@@ -23,7 +23,7 @@ static float run(int grid, int iters, const double* dpart, int nsplit, int64_t p
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     unsigned int seq = 0;
     auto launch = [&]() {
-        hipLaunchKernelGGL((moments_epilogue_kernel<double, Mp, ABL>), dim3(grid), dim3(PV_THREADS), lds, 0, dpart, nsplit, pstride,
+        hipLaunchKernelGGL((moments_epilogue_probe_kernel<double, Mp, ABL>), dim3(grid), dim3(PV_THREADS), lds, 0, dpart, nsplit, pstride,
                            (const double*)nullptr, (const double*)nullptr, 0.0, d_out, W, ry, V, 10000.0, 0.1, rho, rir, qij, si, q2, hs,
                            tcpart, (const int*)nullptr);
     };

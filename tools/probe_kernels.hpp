@@ -1,6 +1,7 @@
 // probe_kernels.hpp - kernel variants that only the probes under tools/ instantiate (not part of the library).
 #pragma once
 #include "../linearcorex_amd/csrc/gemm_kernels.hpp"
+#include "../linearcorex_amd/csrc/moment_kernels.hpp"
 
 namespace lcx {
 
@@ -543,6 +544,95 @@ gemm_ct3_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T
         }
         __syncthreads();
         L0 += cnt;
+    }
+}
+
+// moments_epilogue_kernel with its ablation knob (tools/epilogue_probe.hip; moved out of moment_kernels.hpp in round 3)
+// ABL is for ablation probes only: 1 = no m x m matvec, 2 = no M x V stores, 8 = no logarithms, 16 = first slot only.
+template <typename T, int Mp, int ABL = 0>
+__global__ void __launch_bounds__(PV_THREADS)
+moments_epilogue_probe_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride,
+                        const T* __restrict__ d_base, const T* __restrict__ d_dir, T eta,
+                        T* __restrict__ d_out,
+                        const T* __restrict__ W, const double* __restrict__ ry, int64_t V,
+                        double n_samples, double eps, T* __restrict__ rho_o, T* __restrict__ rir_o,
+                        T* __restrict__ qij_o, T* __restrict__ si_o, T* __restrict__ q2_o,
+                        T* __restrict__ hscale_o, double* __restrict__ tcpart,
+                        const int* __restrict__ skip_flag) {
+    constexpr int VPB = PV_THREADS / Mp;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* ry_s = reinterpret_cast<T*>(smem_raw);
+    T* rir_s = ry_s + (OpInLds<Mp>::v ? Mp * Mp : 0);
+    __shared__ T gs_scratch[PV_THREADS / 64];
+    __shared__ double bs_scratch[PV_THREADS / 64];
+    if (skip_flag != nullptr && *skip_flag != 0) return;       // invalid trial (:250-251): the tail block still publishes
+
+    const int tid = threadIdx.x, vl = tid / Mp, j = tid % Mp;
+    if (OpInLds<Mp>::v)
+        for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) ry_s[idx] = (T)ry[idx];
+    __syncthreads();
+
+    const T c1 = (T)(1.0 - eps * eps), c2 = (T)(eps * eps), ns = (T)n_samples;
+    double s1 = 0.0, s2 = 0.0;
+    const int64_t ngroups = (V + VPB - 1) / VPB;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t v = grp * VPB + vl;
+        const bool ok = v < V;
+        const int64_t o = (ok ? v : 0) * Mp + j;
+        // D = X^T.Y of this weight matrix: either the partial sums of a fresh pass over X, or - X^T.Y
+        // being linear in W - D(W) + eta*D(update) from the current solution
+        T d;
+        if (d_base != nullptr) {
+            d = d_base[o] + eta * d_dir[o];
+        } else {
+            d = dpart[o];
+            if (!(ABL & 16))
+                for (int k = 1; k < nsplit; ++k) d += dpart[k * pstride + o];
+        }
+        if (ok && !(ABL & 2)) d_out[o] = d;
+        const T rho = ok ? (c1 * d / ns + c2 * W[o]) : (T)0;
+        const T inv = (T)1 / ((T)1 - rho * rho);
+        const T rir = rho * inv;
+        __syncthreads();                       // rir_s reuse across iterations
+        rir_s[vl * Mp + j] = rir;
+        const T si = group_sum<Mp, T>(rho * rir, gs_scratch, tid);
+        __syncthreads();
+        T qv = (ABL & 1) ? rir : (T)0;
+        if (!(ABL & 1)) {
+            if (OpInLds<Mp>::v) {
+#pragma unroll 8
+                for (int k = 0; k < Mp; ++k) qv += ry_s[k * Mp + j] * rir_s[vl * Mp + k];   // ry symmetric
+            } else {
+#pragma unroll 8
+                for (int k = 0; k < Mp; ++k) qv += (T)ry[k * Mp + j] * rir_s[vl * Mp + k];
+            }
+        }
+        const T q2 = group_sum<Mp, T>(rir * (qv - si * rho), gs_scratch, tid);
+        if (ok) {
+            if (!(ABL & 2)) {
+                rho_o[o] = rho;
+                rir_o[o] = rir;
+                qij_o[o] = qv;
+            }
+            if (j == 0) {
+                si_o[v] = si;
+                q2_o[v] = q2;
+                hscale_o[v] = (T)1 / ((T)1 + q2);
+                if (ABL & 8) {
+                    s1 += (double)si;
+                    s2 += (double)q2;
+                } else {
+                    s1 += (double)log((T)1 + si);
+                    s2 += (double)log((T)1 + q2);
+                }
+            }
+        }
+    }
+    s1 = block_sum<double>(s1, bs_scratch, tid);
+    s2 = block_sum<double>(s2, bs_scratch, tid);
+    if (tid == 0) {
+        tcpart[2 * blockIdx.x] = s1;
+        tcpart[2 * blockIdx.x + 1] = s2;
     }
 }
 

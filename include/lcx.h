@@ -120,9 +120,13 @@ int lcx_set_linear_mode(lcx_ctx* h, int enable);
  * multi-rank code path of the library on a single GPU.  lcx_set_world(h, n > 1) enables it by itself. */
 int lcx_set_exchange(lcx_ctx* h, int enable);
 
-/* Exchange buffers (device pointers).  ybuf: n_samples_padded*m_padded + m_padded*m_padded
- * elements of the working dtype; sbuf: lcx_sbuf_count doubles.  lcx_exchange_layout reports
- * element counts; lcx_bind_exchange(NULL, NULL) restores the handle's own buffers. */
+/* Exchange buffers (device pointers).  ybuf, elements of the working dtype:
+ *     [ Y: n_samples_padded * m_padded | tail: m_padded^2 | Y_g: n_samples_padded * m_padded, only on shards that can run the
+ *       merged pass (lcx_timing_read kind 2) ]
+ * A caller that owns the exchange all-reduces the first two parts (n_pad * m_pad + m_pad^2 elements, lcx_geometry) between
+ * the levels; the third part is only ever exchanged by the library itself.  sbuf: lcx_sbuf_count doubles (lcx_read_sbuf).
+ * lcx_exchange_layout reports the element counts of the whole buffers; lcx_bind_exchange(NULL, NULL) restores the handle's
+ * own buffers. */
 int lcx_exchange_layout(lcx_ctx* h, int64_t* ybuf_elems, int64_t* sbuf_elems,
                         void** ybuf_dev, void** sbuf_dev);
 int lcx_bind_exchange(lcx_ctx* h, void* ybuf_dev, void* sbuf_dev);

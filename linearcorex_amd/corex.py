@@ -293,9 +293,20 @@ class Corex(object):
         with self._backend.stream_context():
             self._comm.allreduce(tensor)
 
+    def _y_main(self):
+        """elements of the Y exchange buffer a level exchange covers: [Y (n_pad x m_pad) | tail (m_pad^2)]; shards that can run
+        the merged pass keep Y_g behind it (include/lcx.h, lcx_exchange_layout), which only the engine's own exchange touches"""
+        be = self._backend
+        n = getattr(be, "_ybuf_main", None)
+        if n is None:
+            g = be.geometry()
+            n = g["n_pad"] * g["m_pad"] + g["m_pad"] ** 2 if "n_pad" in g else len(self._ex[0])
+            be._ybuf_main = n
+        return n
+
     def _xy(self):
-        if self._ex is not None:
-            self._allreduce(self._ex[0])
+        if self._ex is not None and not self._engine_exchange:
+            self._allreduce(self._ex[0][:self._y_main()])
 
     def _x_scalars(self):
         """Scalar exchange of a moment evaluation: the two TC sums, the tangent partial of the current direction
@@ -316,8 +327,9 @@ class Corex(object):
 
     def _xtail(self):
         """all-reduce only the m_pad^2 tail of the Y exchange buffer (W.W^T partials)."""
-        if self._ex is not None:
-            self._allreduce(self._ex[0][-be_mp2(self._backend):])
+        if self._ex is not None and not self._engine_exchange:
+            n = self._y_main()
+            self._allreduce(self._ex[0][n - be_mp2(self._backend):n])
 
     def _gather(self, local, key=None):
         """Per-variable arrays are sharded on the last (m x nv, nv) or first (nv x m) axis."""

@@ -173,7 +173,9 @@ struct lcx_ctx {
     void *grad, *update, *sgrad, *scratch;
     void *ydir, *ddir;          // Y(update) [Npad][Mp], D(update) [Vp][Mp]
     bool have_linear;
-    void *ybuf_own, *ybuf;
+    void *ybuf_own, *ybuf;      // [Y (Npad Mp) | tail (Mp^2) | Y_g (Npad Mp), only with the merged pass]: ybuf_main = the first two
+    int64_t ybuf_main;
+    void* bjg;                  // [Mp] global Bj of the direction (merged pass under exchange: the tail is reused for W'.W'^T)
     double *sbuf_own, *sbuf;
     int64_t ybuf_elems, sbuf_elems;
     void *ypart, *dpart, *gpart, *gpartw;
@@ -698,7 +700,7 @@ template <typename T, int CT> struct Impl {
         LCXCHECK(nt_big(h, w, nullptr, false, (!h->exchange && h->nt_S > 1) ? P<T>(h->set[which].Y) : (T*)nullptr));
         if (!h->exchange) return LCX_OK;         // nothing to exchange: W.W^T is formed with Y^T.Y in lcx_moments_b (one launch)
         LCXCHECK(gram_w(h, w));
-        return exchange(h, h->ybuf, h->ybuf_elems, DT);          // L1 of SURVEY 8e: [Y_partial | W.W^T partial]
+        return exchange(h, h->ybuf, h->ybuf_main, DT);           // L1 of SURVEY 8e: [Y_partial | W.W^T partial]
     }
 
     // per-factor moments; ysrc != null: first form the Y^T.Y partials of that Y
@@ -866,7 +868,7 @@ template <typename T, int CT> struct Impl {
         else LCXCHECK(launch_grad(h, 0));
         if (!merged) {
             LCXCHECK(nt_big(h, P<T>(h->grad), nullptr, true));
-            return exchange(h, h->ybuf, h->ybuf_elems, DT);      // L4: [Y_g partial | Bj partial]
+            return exchange(h, h->ybuf, h->ybuf_main, DT);       // L4: [Y_g partial | Bj partial]
         }
         if constexpr (sizeof(T) == 4 && CT >= 2 && CT <= 4) {
             // Bj (:302) does not wait for the pass: sum its per-block partials now, form update and ws + update (:303, :320) and
@@ -875,9 +877,17 @@ template <typename T, int CT> struct Impl {
             hipLaunchKernelGGL((reduce_y_bj_kernel<T, false>), dim3(Mp), dim3(PV_THREADS), 0, h->stream, P<T>(h->ypart), 1, n,
                                P<T>(h->ybuf), 0, h->bjpart, h->pv_grid, Mp, P<T>(h->ybuf) + n);
             KCHECK();
+            const T* bj = P<T>(h->ybuf) + n;
+            if (h->exchange) {
+                // several ranks: `update` needs Bj over ALL variables before the pass - one tiny all-reduce in front of it - and
+                // the tail of ybuf is needed again for W'.W'^T of the first trial, so the global Bj moves to a buffer of its own
+                LCXCHECK(exchange(h, P<T>(h->ybuf) + n, Mp, DT));
+                HIPCHECK(hipMemcpyAsync(h->bjg, P<T>(h->ybuf) + n, sizeof(T) * Mp, hipMemcpyDeviceToDevice, h->stream));
+                bj = P<T>(h->bjg);
+            }
             const int grid = update_grid(h);
             hipLaunchKernelGGL((update_kernel<T, Mp>), dim3(grid), dim3(PV_THREADS), 0, h->stream, P<T>(h->dpart), 0, h->ldx * Mp,
-                               P<T>(h->grad), P<T>(h->Wt[0]), s.uj, P<T>(h->ybuf) + n, h->V, (double)h->N, eps, P<T>(h->update),
+                               P<T>(h->grad), P<T>(h->Wt[0]), s.uj, bj, h->V, (double)h->N, eps, P<T>(h->update),
                                P<T>(h->sgrad), h->tanpart, (const T*)nullptr, (T*)nullptr, grid, (const T*)nullptr, (const T*)nullptr,
                                (int64_t)0, (T*)nullptr, P<T>(h->Wt[1]), h->world, P<T>(h->gw), 0);
             KCHECK();
@@ -890,12 +900,21 @@ template <typename T, int CT> struct Impl {
             hipLaunchKernelGGL((reduce_split_kernel<T>), dim3((unsigned)(cdiv(n2, 256) < 2048 ? cdiv(n2, 256) : 2048)), dim3(256), 0,
                                h->stream, P<T>(h->y2part), h->nt2_S, n2, Mp, P<T>(h->ygbuf), P<T>(h->ybuf), P<T>(h->set[1].Y));
             KCHECK();
+            if (h->exchange) {
+                // what lcx_moments_a(1) would have left for the first trial - W'.W'^T partial in the tail - and ONE all-reduce of
+                // [Y' | W'.W'^T | Y_g] (ygbuf sits right behind the tail); lcx_moments_b copies the summed Y' into set 1
+                LCXCHECK(gram_w(h, P<T>(h->Wt[1])));
+                LCXCHECK(exchange(h, h->ybuf, h->ybuf_elems, DT));
+            }
             h->w1_ready = h->y1_ready = true;
         }
         return LCX_OK;
     }
-    // the merged pass needs: its buffers, one GPU (the exchange would have to carry both Y), and the Y-space tangent
-    static bool use_merged(const lcx_ctx* h) { return h->merged_ok && !h->exchange && !h->full_sig && h->gw != nullptr; }
+    // the merged pass needs: its buffers, the Y-space tangent, and - with several ranks - the exchange inside the library (a caller
+    // that all-reduces the buffers itself between the levels does not know about the Bj exchange in front of the pass)
+    static bool use_merged(const lcx_ctx* h) {
+        return h->merged_ok && (!h->exchange || h->tr.kind != 0) && !h->full_sig && h->gw != nullptr;
+    }
     static int update_grid(const lcx_ctx* h) { return (int)(cdiv(h->V * Mp, PV_THREADS) < 1536 ? cdiv(h->V * Mp, PV_THREADS) : 1536); }
 
     static int update_c(lcx_ctx* h, double eps) {
@@ -910,7 +929,8 @@ template <typename T, int CT> struct Impl {
             // merged flow: update / ws + update were formed before the pass (lcx_update_b); what is left is the Y-space part -
             // Y(update) and the Y term of update_tangent - from Y_g, which sits in its own buffer
             hipLaunchKernelGGL((update_kernel<T, Mp>), dim3(gridy), dim3(PV_THREADS), 0, h->stream, P<T>(h->dpart), 0, h->ldx * Mp,
-                               P<T>(h->grad), P<T>(h->Wt[0]), s.uj, P<T>(h->ybuf) + h->Npad * Mp, h->V, (double)h->N, eps, P<T>(h->update),
+                               P<T>(h->grad), P<T>(h->Wt[0]), s.uj, h->exchange ? P<T>(h->bjg) : P<T>(h->ybuf) + h->Npad * Mp, h->V,
+                               (double)h->N, eps, P<T>(h->update),
                                P<T>(h->sgrad), h->tanpart, (const T*)nullptr, (T*)nullptr, 0, P<T>(h->ygbuf), P<T>(s.Y), ny, P<T>(h->ydir),
                                (T*)nullptr, h->world, (T*)nullptr, grid);
             KCHECK();
@@ -1885,21 +1905,24 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     A_(h->ddir, mv);
     h->gw = h->y2part = h->ygbuf = nullptr;
     h->y1_ready = false;
+    h->bjg = nullptr;
     if (h->merged_ok) {
         A_(h->gw, 2 * mv);
-        A_(h->ygbuf, (size_t)h->Npad * Mp * es);
         A_(h->y2part, (size_t)h->nt2_S * h->Npad * 2 * Mp * es);
+        A_(h->bjg, (size_t)Mp * es);
     }
     h->have_linear = false;
     h->full_sig = true;
     h->exchange = false;
     h->w1_ready = h->y1_ready = false;
-    h->ybuf_elems = h->Npad * Mp + (int64_t)Mp * Mp;
+    h->ybuf_main = h->Npad * Mp + (int64_t)Mp * Mp;
+    h->ybuf_elems = h->ybuf_main + (h->merged_ok ? h->Npad * Mp : 0);    // Y_g of the merged pass right behind the tail
     h->sbuf_elems = (int64_t)SB_H + (int64_t)Mp * Mp + Mp + 8;
     A_(h->ybuf_own, (size_t)h->ybuf_elems * es);
     A_(h->sbuf_own, sizeof(double) * h->sbuf_elems);
     h->ybuf = h->ybuf_own;
     h->sbuf = h->sbuf_own;
+    if (h->merged_ok) h->ygbuf = (char*)h->ybuf + (size_t)h->ybuf_main * es;
     A_(h->ypart, h->nt_S > 1 ? (size_t)h->nt_S * h->Npad * Mp * es : 16);
     A_(h->dpart, (size_t)h->tn_S * mv);
     {
@@ -1953,7 +1976,7 @@ int lcx_destroy(lcx_ctx* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->tr.kind == 1 && h->tr.comm) (void)rccl().CommDestroy(h->tr.comm);
     void* ptrs[] = {h->X, h->XT, h->Wt[0], h->Wt[1], h->grad, h->update, h->sgrad, h->scratch, h->ydir, h->ddir, h->ybuf_own, h->sbuf_own,
-                    h->gw, h->y2part, h->ygbuf,
+                    h->gw, h->y2part, h->bjg,
                     h->ypart, h->dpart, h->gpart, h->gpartw, h->tcpart, h->bjpart, h->tanpart, h->detpart, h->ryinv, h->invwork,
                     h->states, h->order_dev, h->ticket};
     for (void* p : ptrs) (void)hipFree(p);
@@ -2013,6 +2036,7 @@ int lcx_bind_exchange(lcx_ctx* h, void* y, void* s) {
     NEED_MUT(h);
     HIPCHECK(hipStreamSynchronize(h->stream));
     h->ybuf = y ? y : h->ybuf_own;
+    if (h->merged_ok) h->ygbuf = (char*)h->ybuf + (size_t)h->ybuf_main * h->es;
     h->sbuf = s ? (double*)s : h->sbuf_own;
     if (y) HIPCHECK(hipMemsetAsync(y, 0, (size_t)h->ybuf_elems * h->es, h->stream));
     if (s) HIPCHECK(hipMemsetAsync(s, 0, sizeof(double) * h->sbuf_elems, h->stream));

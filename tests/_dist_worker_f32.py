@@ -39,13 +39,16 @@ def main():
     c0, c1 = comm.shard(v)
     model = Corex(n_hidden=m, seed=0, dtype=np.float32, tol=0.0, device=0, comm=comm)
     be = model._attach_shard(np.ascontiguousarray(xt[:, c0:c1]), v)
-    names = (be.kernel_name(0), be.kernel_name(1))
+    names = (be.kernel_name(0), be.kernel_name(1), be.kernel_name(2))
+    be.timing_enable(True)
     h = run_loop(model, iters)
+    merged_passes = be.timing_passes_by_kind()["gemm_nt2"]
+    be.timing_enable(False)
     ws = model._gather(be.get_ws(0))
     rho = model._gather(be.get_moment(0, "rho"))
     if comm.rank == 0:
         np.savez(os.path.join(out_dir, "dist_f32.npz"), history=h, ws=ws, rho=rho, trials=model.stats["trials"],
-                 world=comm.world, kernel_nt=names[0], kernel_tn=names[1],
+                 world=comm.world, kernel_nt=names[0], kernel_tn=names[1], kernel_merged=names[2], merged_passes=merged_passes,
                  in_library=np.array(bool(getattr(model, "_iterated_in_library", False))),
                  transport=str(getattr(model, "_engine_exchange", None)))
     dist.barrier()

@@ -199,3 +199,34 @@ def test_sharded_float32_large_kernels_match_single_gpu(m, tmp_path, monkeypatch
     assert np.max(np.abs(h2 - hr) / np.maximum(1.0, np.abs(hr))) < 2e-3
     assert abs(int(got["trials"]) - ref.n_trials) <= 2
     assert np.max(np.abs(got["ws"] - ref.ws)) < 5e-3 * float(np.max(np.abs(ref.ws)))
+
+
+@pytest.mark.parametrize("m", [24, 64])
+def test_sharded_merged_pass_under_exchange(m, tmp_path, monkeypatch):
+    """The merged pass X.[grad | ws + update]^T with several ranks (exchange inside the library): Bj is all-reduced in front of
+    the pass, then ONE all-reduce carries [Y' | W'.W'^T | Y_g].  Two ranks x 640 variables, 19200 samples (75 super tiles: the
+    merged kernel splits into <= 8 slots), float32 on gemm_ct: the trajectory must equal the single-GPU run (merged pass as
+    well) to float32 rounding with the same number of line-search trials, and the float32 oracle within the usual bar."""
+    from linearcorex_amd import Corex
+    from tests._dist_worker_f32 import planted_f32, run_loop
+    n, v, iters = 19200, 1280, 4
+    _launch_f32(2, tmp_path, n, v, m, iters)
+    got = np.load(os.path.join(tmp_path, "dist_f32.npz"))
+    assert int(got["world"]) == 2 and str(got["transport"]) == "hook" and bool(got["in_library"])
+    assert "gemm_ct_kernel<float" in str(got["kernel_merged"]) and int(got["merged_passes"]) > 0
+    monkeypatch.setenv("LCX_GEMM", "ct")
+    xt = planted_f32(n, v, m)
+    single = Corex(n_hidden=m, seed=0, dtype=np.float32, tol=0.0, device=0)
+    be = single._attach_shard(xt, v)
+    h1 = run_loop(single, iters)
+    assert be.kernel_name(2)
+    w1 = be.get_ws(0)
+    be.close()
+    h2 = got["history"]
+    assert len(h1) == len(h2) == 7 * iters
+    assert np.max(np.abs(h2 - h1) / np.maximum(1.0, np.abs(h1))) < 5e-5
+    assert int(got["trials"]) == single.stats["trials"]
+    assert np.max(np.abs(got["ws"] - w1)) < 1e-3 * float(np.max(np.abs(w1)))
+    ref = O.fit_ns_preprocessed(xt, m, seed=0, dtype=np.float32, max_iter=iters, tol=0.0, finish=False)
+    hr = np.asarray(ref.history_tc, np.float64)
+    assert np.max(np.abs(h2 - hr) / np.maximum(1.0, np.abs(hr))) < 2e-3

@@ -48,6 +48,7 @@ WORKLOADS = {
     "c2": (10000, 5000, 32, "f64"),      # BASELINE.json configs[1]
     "c3": (50000, 100000, 64, "f32"),    # configs[2] (MFMA roofline run; X generated on device)
     "c4shard": (50000, 125000, 128, "f32"),  # configs[3], one GPU's shard
+    "c4full": (50000, 1000000, 128, "f32"),  # configs[3] unsharded on ONE GPU: single-copy mode (gemm_cr), 200 GB of X
     "c3f64": (50000, 50000, 64, "f64"),  # large float64 shards (gemm_ct on float64; not BASELINE lines)
     "c3f64m32": (50000, 50000, 32, "f64"),
     "c3f64m128": (50000, 50000, 128, "f64"),
@@ -61,6 +62,7 @@ WORKLOADS = {
 DESCRIPTION = {
     "c2": "BASELINE.json configs[1]", "c3": "BASELINE.json configs[2], the MFMA roofline run",
     "c4shard": "BASELINE.json configs[3], one GPU's shard of the 1M-variable problem",
+    "c4full": "BASELINE.json configs[3] unsharded: the whole 1M-variable problem on one GPU, one resident copy of X",
 }
 
 
@@ -93,6 +95,8 @@ def parse(argv=None):
                          "workload (0 = skip)")
     ap.add_argument("--convergence-planted-max-iter", type=int, default=2000,
                     help="iterations per annealing stage allowed to the whole-fit wall-clock measurement on planted data")
+    ap.add_argument("--c4full-steps", type=int, default=3,
+                    help="iterations per window of the config-4-unsharded-on-one-GPU block of the default N=1 line (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-sample", type=int, default=0,
                     help="HIP-event pairs around every n-th X pass of the timed windows (a pair costs ~5 us of stream time; "
@@ -907,6 +911,22 @@ def main():
             model5._backend = None
             del model5, be5
             out["config"]["c4shard"] = c4
+            # ---- configs[3] as ONE problem on this one GPU: 50 000 x 1 000 000 x 128 float32, 200 GB of X.  Two resident copies
+            # do not fit 288 GB, so the engine keeps the row-major copy only and X.B^T runs on gemm_cr (chosen by itself).  The
+            # matrix is the one the 8-rank run shards: this is that run's single-process counterpart.  Short windows (an
+            # iteration is ~0.45 s); not a headline
+            if args.c4full_steps > 0:
+                r6, model6, be6 = measure(args, comm, world, rank, local_rank, "c4full", args.c4full_steps, 1, "exact", repeats=1)
+                c6 = config_of("c4full", r6, world, "exact")
+                c6["value"] = r6["its_per_s"]
+                c6["ms_per_step"] = r6["per_step_s"] * 1e3
+                c6["dtype"] = "f32"
+                c6["roofline"] = roofline_of("c4full", r6, world)
+                c6["kernels"] = r6["kernel_names"]
+                be6.close()
+                model6._backend = None
+                del model6, be6
+                out["config"]["c4_unsharded_one_gpu"] = c6
 
         # ---- CPU baseline of the headline workload: rank 0, the other ranks wait in the barrier below ----
         if rank == 0 and args.cpu_seconds > 0 and (world == 1 and comm is None or world > 1):

@@ -97,7 +97,12 @@ int         lcx_device_count(int* out_count);
 /* ---- handle -------------------------------------------------------------------------------- */
 /* Replaces cm.cublas_init() (:85-86).  Allocates all device state for an
  * (n_samples x nv_local) shard with n_hidden factors on HIP device `device`.  n_hidden <= 256 (padded to 16 / 32 / 64 /
- * 128 / 256 columns).  A failed allocation releases what was allocated before it. */
+ * 128 / 256 columns).  A failed allocation releases what was allocated before it.
+ * The shard is normally resident twice, row-major and transposed, so that both X-streaming contractions read their big operand
+ * in their preferred layout.  When two copies would not leave room for the rest (or LCX_SINGLE_COPY=1) only the row-major
+ * copy is kept and X.B^T contracts along its rows (gemm_cr: 4-6 % slower per pass): half the resident bytes - a 50 000 x
+ * 1 000 000 float32 problem (BASELINE configs[3], unsharded) then fits one 288 GB MI355X.  lcx_kernel_name(h, 0, ..) names
+ * the kernel in use; lcx_bytes_resident reports the copies. */
 int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
                int dtype, int device);
 int lcx_destroy(lcx_ctx* h);
@@ -330,6 +335,8 @@ int lcx_invert(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, int k
 int lcx_timing_enable(lcx_ctx* h, int enable);
 /* time only every `every`-th X pass (an event pair costs ~5 us of stream time; default 1 = all) */
 int lcx_timing_sample(lcx_ctx* h, int every);
+/* launches / total_ms: the timed passes that did their work.  A pass whose trial went invalid (:250-251) returns at its skip
+ * flag; such launches (shorter than a fifth of the longest of their kind) are not averaged in */
 int lcx_timing_read(lcx_ctx* h, int kind, int64_t* launches, double* total_ms);
 /* every X pass issued since the last reset while timing was enabled (timed or skipped by the sampling) */
 int lcx_timing_passes(lcx_ctx* h, int kind, int64_t* passes);

@@ -468,6 +468,151 @@ gemm_ct_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T*
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_cr: D[r][j] = sum_k A[r][k] B[k][j] with A ROW-major and the contraction along its contiguous axis - X.B^T read from
+// X itself, so that a large shard does not need a transposed copy (half the resident bytes).
+//
+// Same machine as gemm_ct: a block's KW waves own KW adjacent tiles of 16*RT output rows and walk the same contraction
+// range, B is staged once per block through LDS (global -> VGPR -> LDS, double buffered, one barrier per group of 4*U
+// contraction steps), the (super tile, group) units are split stream-K style over one round of resident blocks, partial
+// tiles go to slots with the same contract (fixed slot count, zero-filled by the last contributor).  What differs is the A
+// operand: lane (i, q) loads E = 16 / sizeof(T) CONSECUTIVE contraction elements of row i (one 16-byte load; the 4 lane
+// groups q cover 64 contiguous bytes of the row), i.e. load p of a group holds k = p*4E + q*E + e.  An MFMA step may take its
+// 4 contraction elements in any order as long as both operands agree, so step (p, e) reads the B rows p*4E + q*E + e from LDS.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int CT, int RT, int KW, int U, bool NT = false>
+__global__ void __launch_bounds__(64 * KW)
+gemm_cr_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T* __restrict__ out,
+               int64_t out_rows, int64_t nrows, int ng /* groups of 4*U contraction elements */, int nsuper, int maxslots,
+               const int* __restrict__ skip_flag) {
+    constexpr int Mp = 16 * CT;
+    constexpr int E = 16 / (int)sizeof(T);                   // contraction elements per 16-byte load
+    constexpr int NL = U / E;                                // loads per row tile per group
+    static_assert(U % E == 0, "gemm_cr: a group must be whole 16-byte loads");
+    constexpr int CHUNK = 4 * U * Mp;
+    constexpr int PCS = CHUNK * (int)sizeof(T) / 16;
+    constexpr int NTH = 64 * KW;
+    constexpr int PPT = (PCS + NTH - 1) / NTH;
+    typedef typename MF<T>::acc_t acc_t;
+    typedef typename VecT<T, E>::type AV;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) T Bs[2][CHUNK];
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t total = (int64_t)nsuper * ng;
+    const int nb = gridDim.x;
+    int64_t L0 = total * blockIdx.x / nb;
+    const int64_t L1 = total * (blockIdx.x + 1) / nb;
+
+    while (L0 < L1) {
+        const int st_ = (int)(L0 / ng);
+        const int s0 = (int)(L0 - (int64_t)st_ * ng);
+        const int s1 = (L1 - L0) < (int64_t)(ng - s0) ? s0 + (int)(L1 - L0) : ng;
+        const int cnt = s1 - s0;
+        const int64_t v0 = ((int64_t)st_ * KW + wave) * (16 * RT);
+        const bool active = v0 < nrows;
+
+        acc_t acc[RT][CT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int u = 0; u < CT; ++u) acc[t][u] = (acc_t){0, 0, 0, 0};
+        const T* ap = A + ((active ? v0 : 0) + i) * lda + q * E;
+        AV a0[NL][RT], a1[NL][RT];
+        f4 bst[PPT];
+
+#define LCX_CR_LOADA(R, AA)                                                               \
+        if (active) {                                                                     \
+            const int64_t kb = (int64_t)(s0 + (R)) * (4 * U);                             \
+            _Pragma("unroll") for (int p = 0; p < NL; ++p)                                \
+            _Pragma("unroll") for (int t = 0; t < RT; ++t) {                              \
+                const AV* src = reinterpret_cast<const AV*>(ap + (int64_t)(16 * t) * lda + kb + p * 4 * E); \
+                AA[p][t] = NT ? __builtin_nontemporal_load(src) : *src;                   \
+            }                                                                             \
+        }
+#define LCX_CR_LOADB(R)                                                                   \
+        {                                                                                 \
+            const f4* src = reinterpret_cast<const f4*>(B + (int64_t)(s0 + (R)) * CHUNK); \
+            _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                             \
+                const int pc = p * NTH + (int)threadIdx.x;                                \
+                if (PCS % NTH == 0 || pc < PCS) bst[p] = src[pc];                         \
+            }                                                                             \
+        }
+#define LCX_CR_STOREB(BUF)                                                                \
+        {                                                                                 \
+            f4* dstp = reinterpret_cast<f4*>(&Bs[BUF][0]);                                \
+            _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                             \
+                const int pc = p * NTH + (int)threadIdx.x;                                \
+                if (PCS % NTH == 0 || pc < PCS) dstp[pc] = bst[p];                        \
+            }                                                                             \
+        }
+#define LCX_CR_MMA(AA, BUF)                                                               \
+        if (active) {                                                                     \
+            Pk<T, CT> bb[U];                                                              \
+            _Pragma("unroll") for (int p = 0; p < NL; ++p)                                \
+            _Pragma("unroll") for (int e = 0; e < E; ++e)                                 \
+                bb[p * E + e] = *reinterpret_cast<const Pk<T, CT>*>(&Bs[BUF][(p * 4 * E + q * E + e) * Mp + i * CT]); \
+            _Pragma("unroll") for (int p = 0; p < NL; ++p)                                \
+            _Pragma("unroll") for (int e = 0; e < E; ++e)                                 \
+            _Pragma("unroll") for (int t = 0; t < RT; ++t)                                \
+            _Pragma("unroll") for (int u = 0; u < CT; ++u)                                \
+                acc[t][u] = MF<T>::mma(AA[p][t][e], bb[p * E + e].v[u], acc[t][u]);       \
+        }
+
+        LCX_CR_LOADA(0, a0);
+        LCX_CR_LOADB(0);
+        int r = 0;
+        while (true) {
+            LCX_CR_STOREB(0);
+            if (r + 1 < cnt) { LCX_CR_LOADA(r + 1, a1); LCX_CR_LOADB(r + 1); }
+            __syncthreads();
+            LCX_CR_MMA(a0, 0);
+            if (++r >= cnt) break;
+            LCX_CR_STOREB(1);
+            if (r + 1 < cnt) { LCX_CR_LOADA(r + 1, a0); LCX_CR_LOADB(r + 1); }
+            __syncthreads();
+            LCX_CR_MMA(a1, 1);
+            if (++r >= cnt) break;
+        }
+#undef LCX_CR_LOADA
+#undef LCX_CR_LOADB
+#undef LCX_CR_STOREB
+#undef LCX_CR_MMA
+
+        const int fb = sk_owner((int64_t)st_ * ng, total, nb);
+        if (active) {
+            T* dst = out + ((int64_t)(blockIdx.x - fb) * out_rows + v0) * Mp;
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    Pk<T, CT> o;
+#pragma unroll
+                    for (int u = 0; u < CT; ++u) o.v[u] = acc[t][u][g];
+                    *reinterpret_cast<Pk<T, CT>*>(dst + (16 * t + MF<T>::row(lane, g)) * Mp + i * CT) = o;
+                }
+            if (s1 == ng) {
+                const int lb = sk_owner((int64_t)st_ * ng + ng - 1, total, nb);
+                Pk<T, CT> z;
+#pragma unroll
+                for (int u = 0; u < CT; ++u) z.v[u] = (T)0;
+                for (int sl = lb - fb + 1; sl < maxslots; ++sl) {
+                    T* zd = out + ((int64_t)sl * out_rows + v0) * Mp;
+#pragma unroll
+                    for (int t = 0; t < RT; ++t)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<Pk<T, CT>*>(zd + (16 * t + 4 * g + q) * Mp + i * CT) = z;
+                }
+            }
+        }
+        __syncthreads();
+        L0 += cnt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // gemm_tn4: the float64 small-shard contraction on v_mfma_f64_4x4x4 (4 blocks).
 //
 // Measured on MI355X (tools/mfma_peak.hip): v_mfma_f64_16x16x4 issues every ~104 cycles (47.6 TF/s, 60 % of

@@ -167,7 +167,8 @@ struct lcx_ctx {
     int M, Mp, CT;
     hipStream_t own_stream, stream;
     void* X;                    // [Npad][ldx]
-    void* XT;                   // [ldx][Npad] transposed copy
+    void* XT;                   // [ldx][Npad] transposed copy (absent in single-copy mode)
+    bool single_copy;           // X.B^T is read from X itself (gemm_cr): half the resident bytes, a 4-6 % slower pass
     void* Wt[2];
     MomentSet set[2];
     void *grad, *update, *sgrad, *scratch;
@@ -208,6 +209,8 @@ struct lcx_ctx {
     int64_t t_launch[3];        // kind 0 = X.B^T, 1 = X^T.Y, 2 = the merged X.[grad | ws+update]^T pass (2 Mp columns)
     int64_t t_pass[3];          // every X pass issued while timing is on (sampled or not)
     double t_ms[3];
+    double t_max[3];            // longest timed launch per kind; launches below a fifth of it were skipped by their flag
+    int64_t t_skipped[3];
     bool have_direction;
     int world;                  // ranks sharing the variables axis (1: no exchange between levels)
     unsigned int seq_next;
@@ -289,12 +292,23 @@ static int timing_end(lcx_ctx* h, int kind, TimingPair* tp) {
     return LCX_OK;
 }
 static int timing_collect(lcx_ctx* h) {
-    for (auto& tp : h->pending) {
-        float ms = 0.f;
+    // The X^T.Y pass of an invalid trial (:250-251) returns at its first instruction (skip flag): such a launch is not a pass
+    // and must not pull the average down.  A launch shorter than a fifth of the longest one of its kind is counted apart.
+    std::vector<float> dur(h->pending.size());
+    for (size_t k = 0; k < h->pending.size(); ++k) {
+        TimingPair& tp = h->pending[k];
         HIPCHECK(hipEventSynchronize(tp.b));
-        HIPCHECK(hipEventElapsedTime(&ms, tp.a, tp.b));
-        h->t_launch[tp.kind] += 1;
-        h->t_ms[tp.kind] += ms;
+        HIPCHECK(hipEventElapsedTime(&dur[k], tp.a, tp.b));
+        if (dur[k] > h->t_max[tp.kind]) h->t_max[tp.kind] = dur[k];
+    }
+    for (size_t k = 0; k < h->pending.size(); ++k) {
+        TimingPair& tp = h->pending[k];
+        if (dur[k] < 0.2 * h->t_max[tp.kind]) {
+            h->t_skipped[tp.kind] += 1;
+        } else {
+            h->t_launch[tp.kind] += 1;
+            h->t_ms[tp.kind] += dur[k];
+        }
         h->pool.push_back(tp);
     }
     h->pending.clear();
@@ -394,6 +408,17 @@ static int launch_ct(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t
     const int ng = (int)(K / (4 * S::U));
     hipLaunchKernelGGL((gemm_ct_kernel<T, CT, S::RT, S::KW, S::U, true>), dim3((unsigned)nb), dim3(64 * S::KW), 0, st, A, lda, B, out,
                        vcols, vcols, ng, nsuper, maxslots, skip);
+    KCHECK();
+    return LCX_OK;
+}
+// gemm_cr launch (X.B^T from the row-major shard itself): same unit / slot contract as launch_ct
+template <typename T, int CT>
+static int launch_cr(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t nrows, const T* B, T* out, int nb, int nsuper,
+                     int maxslots, const int* skip) {
+    typedef CtShape<T, CT> S;
+    const int ng = (int)(K / (4 * S::U));
+    hipLaunchKernelGGL((gemm_cr_kernel<T, CT, S::RT, S::KW, S::U, false>), dim3((unsigned)nb), dim3(64 * S::KW), 0, st, A, lda, B, out, nrows,
+                       nrows, ng, nsuper, maxslots, skip);
     KCHECK();
     return LCX_OK;
 }
@@ -571,7 +596,7 @@ template <typename T, int CT> struct Impl {
             };
             int nb, ns, sl;
             ct_geometry<T, CT>(cus, h->ldx, h->Npad, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
-            h->nt_ct = force ? !strcmp(force, "ct") : use_ct(sl, h->ldx);
+            h->nt_ct = h->single_copy || (force ? !strcmp(force, "ct") : use_ct(sl, h->ldx));
             if (h->nt_ct) { h->nt_nb = nb; h->nt_nsuper = ns; h->nt_S = sl; h->nt_KW = CtShape<T, CT>::KW; }
             ct_geometry<T, CT>(cus, h->Npad, h->ldx, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
             h->tn_ct = force ? !strcmp(force, "ct") : use_ct(sl, h->Npad);
@@ -612,7 +637,9 @@ template <typename T, int CT> struct Impl {
         TimingPair tp;
         LCXCHECK(timing_begin(h, 0, &tp));
         T* dst = h->nt_S > 1 ? P<T>(h->ypart) : P<T>(h->ybuf);
-        if (h->nt_ct)
+        if (h->single_copy)
+            LCXCHECK((launch_cr<T, CT>(h->stream, P<T>(h->X), h->ldx, h->ldx, h->Npad, B, dst, h->nt_nb, h->nt_nsuper, h->nt_S, skip)));
+        else if (h->nt_ct)
             LCXCHECK((launch_ct<T, CT>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, B, dst, h->nt_nb, h->nt_nsuper, h->nt_S, skip)));
         else if (h->f64_4x4) {
             if constexpr (sizeof(T) == 8 && CT <= 2)
@@ -647,6 +674,7 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
     static int make_xt(lcx_ctx* h) {
+        if (h->single_copy) { HIPCHECK(hipStreamSynchronize(h->stream)); return LCX_OK; }
         dim3 grid((unsigned)(h->ldx / 64), (unsigned)(h->Npad / 64));
         hipLaunchKernelGGL((transpose_kernel<T>), grid, dim3(256), 0, h->stream, P<T>(h->X), h->ldx, P<T>(h->XT), h->Npad);
         KCHECK();
@@ -893,8 +921,12 @@ template <typename T, int CT> struct Impl {
             KCHECK();
             TimingPair tp;
             LCXCHECK(timing_begin(h, 2, &tp));
-            LCXCHECK((launch_ct<T, 2 * CT>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, P<T>(h->gw), P<T>(h->y2part), h->nt2_nb,
-                                           h->nt2_nsuper, h->nt2_S, nullptr)));
+            if (h->single_copy)
+                LCXCHECK((launch_cr<T, 2 * CT>(h->stream, P<T>(h->X), h->ldx, h->ldx, h->Npad, P<T>(h->gw), P<T>(h->y2part), h->nt2_nb,
+                                               h->nt2_nsuper, h->nt2_S, nullptr)));
+            else
+                LCXCHECK((launch_ct<T, 2 * CT>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, P<T>(h->gw), P<T>(h->y2part), h->nt2_nb,
+                                               h->nt2_nsuper, h->nt2_S, nullptr)));
             LCXCHECK(timing_end(h, 2, &tp));
             const int64_t n2 = 2 * n;
             hipLaunchKernelGGL((reduce_split_kernel<T>), dim3((unsigned)(cdiv(n2, 256) < 2048 ? cdiv(n2, 256) : 2048)), dim3(256), 0,
@@ -1589,8 +1621,13 @@ template <typename T, int CT> struct Impl {
         if (kind == 2) {
             if (!h->merged_ok) { buf[0] = 0; return LCX_OK; }
             if constexpr (CT <= 4)
-                snprintf(buf, (size_t)len, "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true>", sizeof(T) == 8 ? "double" : "float", 2 * CT,
-                         CtShape<T, 2 * CT>::RT, CtShape<T, 2 * CT>::KW, CtShape<T, 2 * CT>::U);
+                snprintf(buf, (size_t)len, h->single_copy ? "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, false>" : "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true>",
+                         sizeof(T) == 8 ? "double" : "float", 2 * CT, CtShape<T, 2 * CT>::RT, CtShape<T, 2 * CT>::KW, CtShape<T, 2 * CT>::U);
+            return LCX_OK;
+        }
+        if (kind == 0 && h->single_copy) {
+            snprintf(buf, (size_t)len, "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, false>", sizeof(T) == 8 ? "double" : "float", CT, CtShape<T, CT>::RT,
+                     CtShape<T, CT>::KW, CtShape<T, CT>::U);
             return LCX_OK;
         }
         if (kind == 0 ? h->nt_ct : h->tn_ct)
@@ -1662,9 +1699,17 @@ template <typename T, int CT> struct Impl {
             KCHECK();
         }
         if (empirical) {
-            LCXCHECK(make_xt(h));
+            T* xt = P<T>(h->XT);
+            if (h->single_copy) {                   // the sort works on contiguous columns: a transposed copy for its duration
+                LCXCHECK(tmps.get(&xt, sizeof(T) * (size_t)h->Npad * h->ldx));
+                dim3 tg((unsigned)(h->ldx / 64), (unsigned)(h->Npad / 64));
+                hipLaunchKernelGGL((transpose_kernel<T>), tg, dim3(256), 0, h->stream, X, h->ldx, xt, h->Npad);
+                KCHECK();
+            } else {
+                LCXCHECK(make_xt(h));
+            }
             std::string err;
-            if (empirical_columns<T>(X, h->ldx, P<T>(h->XT), h->Npad, N, V, h->stream, &err) != 0) return fail(LCX_ERR_HIP, err);
+            if (empirical_columns<T>(X, h->ldx, xt, h->Npad, N, V, h->stream, &err) != 0) return fail(LCX_ERR_HIP, err);
         }
         HIPCHECK(hipStreamSynchronize(h->stream));
         if (fit && need_stats && mean_io && std_io) {
@@ -1855,7 +1900,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     h->timing = false;
     h->t_every = 1;
     h->t_count = 0;
-    for (int k = 0; k < 3; ++k) { h->t_launch[k] = 0; h->t_pass[k] = 0; h->t_ms[k] = 0.0; }
+    for (int k = 0; k < 3; ++k) { h->t_launch[k] = 0; h->t_pass[k] = 0; h->t_ms[k] = 0.0; h->t_max[k] = 0.0; h->t_skipped[k] = 0; }
     h->have_direction = false;
     h->target_waves = prop.multiProcessorCount * 12;
     h->n_cus = prop.multiProcessorCount;
@@ -1865,6 +1910,20 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     }
     h->stream = h->own_stream;
     hipStream_t st = h->stream;
+    {
+        // One resident copy of the shard instead of two: X.B^T then reads X itself (gemm_cr: 4-6 % slower than gemm_ct on the
+        // transposed copy, tools/gemm_probe4 cr).  LCX_SINGLE_COPY=1 / 0 forces; by default only when two copies would not
+        // leave room for the rest (moments and work space are ~ 20 M x V arrays).
+        const char* e = getenv("LCX_SINGLE_COPY");
+        const double xb = (double)h->Npad * (double)h->ldx * (double)h->es;
+        size_t free_b = 0, total_b = 0;
+        bool want = false;
+        if (e && *e) want = atoi(e) != 0;
+        else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            want = 2.0 * xb + 24.0 * (double)h->ldx * h->Mp * h->es > 0.94 * (double)free_b && xb < 0.9 * (double)free_b;
+        h->single_copy = want;
+        (void)hipGetLastError();
+    }
 
     int rc = LCX_OK;
     {
@@ -1880,7 +1939,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     // a failed allocation releases everything allocated so far (lcx_destroy copes with a half-built handle)
 #define A_(ptr, bytes) do { const size_t b_ = (bytes); int r_ = dev_alloc((void**)&(ptr), b_, st); if (r_ != LCX_OK) { (void)lcx_destroy(h); return r_; } h->bytes_resident += b_ ? b_ : 16; } while (0)
     A_(h->X, (size_t)h->Npad * h->ldx * es);
-    A_(h->XT, (size_t)h->Npad * h->ldx * es);
+    if (!h->single_copy) A_(h->XT, (size_t)h->Npad * h->ldx * es);
     for (int k = 0; k < 2; ++k) {
         A_(h->Wt[k], mv);
         A_(h->set[k].Y, (size_t)h->Npad * Mp * es);
@@ -2402,7 +2461,7 @@ int lcx_invert(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, int k
 int lcx_bytes_resident(lcx_ctx* h, int64_t* total, int64_t* x_bytes) {
     NEED(h);
     if (total) *total = (int64_t)h->bytes_resident;
-    if (x_bytes) *x_bytes = (int64_t)(2 * (size_t)h->Npad * h->ldx * h->es);
+    if (x_bytes) *x_bytes = (int64_t)((h->single_copy ? 1 : 2) * (size_t)h->Npad * h->ldx * h->es);
     return LCX_OK;
 }
 
@@ -2446,7 +2505,7 @@ int lcx_timing_reset(lcx_ctx* h) {
     NEED(h);
     HIPCHECK(hipStreamSynchronize(h->stream));
     LCXCHECK(timing_collect(h));
-    for (int k = 0; k < 3; ++k) { h->t_launch[k] = 0; h->t_pass[k] = 0; h->t_ms[k] = 0.0; }
+    for (int k = 0; k < 3; ++k) { h->t_launch[k] = 0; h->t_pass[k] = 0; h->t_ms[k] = 0.0; h->t_max[k] = 0.0; h->t_skipped[k] = 0; }
     return LCX_OK;
 }
 int lcx_timing_passes(lcx_ctx* h, int kind, int64_t* passes) {

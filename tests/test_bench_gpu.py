@@ -65,6 +65,10 @@ def test_default_line_is_the_c3_line_with_the_c2_block():
     assert c4["value"] > 0 and c4["n_hidden"] == 128 and c4["n_variables_per_gpu"] == 125000
     assert c4["roofline"]["bound"] == "mfma" and 0.3 < c4["roofline"]["frac"] < 1.0
     assert c4["cpu_baseline"]["value"] > 0 and c4["cpu_baseline"]["n_variables_timed"] <= 100000
+    # configs[3] unsharded on this one GPU (single resident copy, gemm_cr)
+    c6 = d["config"]["c4_unsharded_one_gpu"]
+    assert c6["value"] > 1.0 and c6["n_variables_total"] == 1000000 and "gemm_cr_kernel" in c6["kernels"]["gemm_nt"]
+    assert c6["bytes_resident"]["total"] < 250e9
     # linear trial mode, reported beside the reference-shaped figure at the sizes where a trial costs two long passes
     for blk in (d["config"], c4):
         lin = blk["linear_trial_mode"]

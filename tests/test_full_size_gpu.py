@@ -171,3 +171,40 @@ def _full_size_step(shape, kind, HipBackend, O):
     print("full-size step vs oracle", shape, {k: "%.2e" % e for k, e in errs.items()},
           "TC %.6f / %.6f -> %.6f / %.6f, trials %d" % (st[0], tc_ref, out[1], tc_new, int(out[3])))
     be.close()
+
+
+def test_config4_unsharded_on_one_gpu():
+    """BASELINE configs[3] as ONE problem - 50 000 x 1 000 000, n_hidden 128, float32, 200 GB of X - on one MI355X: two resident
+    copies do not fit 288 GB, so the handle keeps the row-major copy only and X.B^T runs on gemm_cr (chosen by itself).  The
+    matrix is the one the 8-rank run shards (counter-based generator keyed by the global column), so this fit is that run's
+    single-process reference.  Checked here: the size-independent properties of test_full_size_properties and a short fit."""
+    from linearcorex_amd import Corex
+    from linearcorex_amd.backend import HipBackend
+    n, v, m = 50000, 1000000, 128
+    be = HipBackend(n, v, m, np.float32, 0)
+    assert "gemm_cr_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)
+    br = be.bytes_resident()
+    assert br["x_and_transposed_copy"] < 1.01 * 4 * 50048 * 1000000 and br["total"] < 250e9
+    be.generate_x(1, 1, m, 0)
+    cols = np.unique(np.concatenate([[0, 1, v - 1, v - 2, 124999, 125000, 500000], np.linspace(0, v - 1, m).astype(int)]))[:m]
+    c = 0.5
+    w = np.zeros((m, v), np.float32)
+    w[np.arange(m), cols] = c
+    be.set_ws(w)
+    st = _moments(be, 0.0)
+    uj = be.get_moment(0, "uj")
+    assert np.max(np.abs(uj - c * c)) < 2e-5
+    rho = be.get_moment(0, "rho")
+    assert np.max(np.abs(rho[np.arange(m), cols] - c)) < 2e-5 and np.max(np.abs(rho)) <= c + 2e-5
+    assert np.isfinite(st[0])
+    del rho, w
+    be.close()
+    mdl = Corex(n_hidden=m, seed=0, dtype=np.float32, device=0, max_iter=1)
+    mdl.fit_generated(n, v, seed=1, kind=1, n_groups=m)
+    h = np.asarray(mdl.history["TC"], np.float64)
+    assert len(h) == 7 and np.all(np.isfinite(h)) and float(np.max(mdl.moments["uj"])) < 1.0
+    assert mdl.ws.shape == (m, v) and np.all(np.isfinite(mdl.ws))
+    from bench import planted_groups, cluster_purity
+    print("config 4 unsharded on one GPU: TC per stage", ["%.1f" % t for t in h], "cluster purity after 7 iterations %.3f"
+          % cluster_purity(mdl.clusters(), planted_groups(1, v, m), m), "resident GB %.1f" % (mdl._backend.bytes_resident()["total"] / 1e9))
+    mdl._backend.close()

@@ -693,3 +693,58 @@ def test_linear_mode_float32_large_shards(m, monkeypatch):
     assert agree >= 0.995, agree
     print("linear vs exact float32 m=%d: max rel TC deviation %.2e, trials %d vs %d, ws %.2e, clusters agree %.4f"
           % (m, dev, s1["trials"], s0["trials"], relerr(w1, w0), agree))
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_single_copy_mode_end_to_end(tag, monkeypatch):
+    """One resident copy of the shard (LCX_SINGLE_COPY=1; automatic when two would not fit): X.B^T is read from the row-major X
+    itself by gemm_cr instead of from the transposed copy.  Same fit as the two-copy path to rounding, and vs the oracle at
+    the usual bars; the handle owns half the X bytes."""
+    from linearcorex_amd import Corex
+    dt = DT[tag]
+    x = O.gen_planted(500, 2000, 8, seed=1)[0]
+    runs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LCX_SINGLE_COPY", flag)
+        out = Corex(n_hidden=8, seed=0, dtype=dt, device=0, max_iter=12, tol=0.0).fit(x)      # tol 0: the same 7 x 12 iterations everywhere
+        be = out._backend
+        assert ("gemm_cr_kernel" in be.kernel_name(0)) == (flag == "1")
+        br = be.bytes_resident()
+        runs[flag] = (np.asarray(out.history["TC"], np.float64), out.ws.copy(), out.clusters(), br["x_and_transposed_copy"],
+                      out.get_covariance(), out.transform(x))
+        be.close()
+    (h1, w1, c1, b1, cov1, y1), (h0, w0, c0, b0, cov0, y0) = runs["1"], runs["0"]
+    assert b1 * 2 == b0
+    assert len(h1) == len(h0)
+    tol = 1e-9 if tag == "f64" else 5e-4
+    assert np.max(np.abs(h1 - h0) / np.maximum(1.0, np.abs(h0))) < tol
+    assert relerr(w1, w0) < tol * 10 and relerr(cov1, cov0) < tol * 10 and relerr(y1, y0) < tol * 10
+    ref = O.fit_ns(x, 8, seed=0, dtype=dt, max_iter=12, tol=0.0)
+    hr = np.asarray(ref.history_tc, np.float64)
+    assert len(hr) == len(h1) == 84
+    assert np.max(np.abs(h1 - hr) / np.maximum(1.0, np.abs(hr))) < (1e-8 if tag == "f64" else 2e-3)
+    if tag == "f64":
+        assert np.array_equal(c1, ref.clusters())
+
+
+def test_single_copy_merged_pass_and_empirical(monkeypatch):
+    """single-copy mode on the paths that used the transposed copy for something else: the merged pass (gemm_cr with 2 m_pad
+    columns) and gaussianize='empirical' (a transposed copy only for the duration of the sort)"""
+    from linearcorex_amd import Corex
+    x, _ = O.gen_planted(19200, 1280, 8, seed=81)
+    runs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LCX_SINGLE_COPY", flag)
+        out = Corex(n_hidden=24, seed=0, max_iter=4, dtype=np.float32, device=0).fit(x)
+        assert ("gemm_cr_kernel" in out._backend.kernel_name(2)) == (flag == "1")
+        runs[flag] = (np.asarray(out.history["TC"], np.float64), out.stats["trials"])
+        out._backend.close()
+    assert len(runs["1"][0]) == len(runs["0"][0]) == 28 and runs["1"][1] == runs["0"][1]
+    assert np.max(np.abs(runs["1"][0] - runs["0"][0]) / np.maximum(1.0, np.abs(runs["0"][0]))) < 5e-5
+    monkeypatch.setenv("LCX_SINGLE_COPY", "1")
+    xe = np.random.RandomState(3).lognormal(size=(700, 90))
+    out = Corex(n_hidden=3, seed=0, dtype=np.float64, device=0, max_iter=5, gaussianize="empirical").fit(xe)
+    xr = O.preprocess(xe.copy(), None, "empirical")[0]
+    orc = O.fit_ns(xr, 3, seed=0, dtype=np.float64, max_iter=5, gaussianize="none")
+    assert np.max(np.abs(np.asarray(out.history["TC"], np.float64) - np.asarray(orc.history_tc))) < 1e-9
+    out._backend.close()

@@ -40,6 +40,29 @@ Variant mkct(const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* o
     return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, A, lda, B, out, vcols, vcols, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
 }
 
+// round 3: gemm_cr (A row-major, contraction along its contiguous axis: X.B^T from X itself, no transposed copy)
+template <typename T, int CT, int RT, int KW, int U, bool NT = false>
+Variant mkcr(const T* A, int64_t lda, int64_t K, int64_t nrows, const T* B, T* out, int bpc_use = 0) {
+    auto kern = gemm_cr_kernel<T, CT, RT, KW, U, NT>;
+    int bpc = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, 0));
+    const int use = bpc_use > 0 ? bpc_use : bpc;
+    const int ng = (int)(K / (4 * U));
+    const int nsuper = (int)((nrows + KW * 16 * RT - 1) / (KW * 16 * RT));
+    int64_t total = (int64_t)nsuper * ng;
+    int nb = 256 * use;
+    if (nb > total) nb = (int)total;
+    const int maxslots = (nb + nsuper - 1) / nsuper + 1;
+    char buf[200];
+    snprintf(buf, 200, "cr (row-major A) RT=%d KW=%d U=%d NT=%d bpc=%d(use %d) nb=%d nsuper=%d slots=%d", RT, KW, U, (int)NT, bpc, use, nb, nsuper, maxslots);
+    return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, A, lda, B, out, nrows, nrows, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
+}
+
+template <typename T> __global__ void transpose_probe_kernel_t(const T* X, int64_t ldx, T* XT, int64_t ldt, int64_t rows, int64_t cols) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < rows * cols; k += (int64_t)gridDim.x * blockDim.x)
+        XT[(k % cols) * ldt + k / cols] = X[(k / cols) * ldx + k % cols];
+}
+
 template <typename T, int CT, int RT, int KW>
 Variant mkprod(const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* out, int S) {
     auto kern = gemm_tn_probe_kernel<T, CT, RT, KW, false, 0, 4>;
@@ -107,6 +130,40 @@ void check(const char* what, Variant& v, Variant& ref, T* out, T* refout, int64_
     printf("check %-10s %-52s max |diff| = %.3e (max |ref| = %.3e) %s\n", what, v.name.c_str(), md, mx, md <= tol * mx ? "ok" : "FAIL");
 }
 
+// Y[N][Mp] = X[N][V] . B[V][Mp]: gemm_ct on XT ([V][N], contraction over its rows) vs gemm_cr on X ([N][V], contraction along rows)
+template <typename T, int CT>
+void suite_cr(const char* name, int64_t N, int64_t V) {
+    T *X, *XT, *B, *out;
+    CK(hipMalloc(&X, sizeof(T) * N * V));
+    CK(hipMalloc(&XT, sizeof(T) * N * V));
+    CK(hipMalloc(&B, sizeof(T) * V * 16 * CT));
+    CK(hipMalloc(&out, sizeof(T) * 40 * N * 16 * CT));
+    {
+        std::vector<T> h((size_t)4096 * 4096);
+        for (size_t x = 0; x < h.size(); ++x) h[x] = (T)((double)rand() / RAND_MAX - 0.5);
+        for (size_t off = 0; off < (size_t)N * V; off += h.size())
+            CK(hipMemcpy(X + off, h.data(), sizeof(T) * std::min(h.size(), (size_t)N * V - off), hipMemcpyHostToDevice));
+        CK(hipMemcpy(B, h.data() + 11, sizeof(T) * V * 16 * CT, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL((transpose_probe_kernel_t<T>), dim3(4096), dim3(256), 0, 0, X, V, XT, N, N, V);
+    CK(hipDeviceSynchronize());
+    const double gb = sizeof(T) * ((double)N * V + 16.0 * CT * (N + V)) / 1e9, tf = 2.0 * N * V * 16 * CT / 1e12;
+    printf("== %s: X %ld x %ld, Mp=%d elt=%zu: X.B^T through the transposed copy (ct) vs from X itself (cr)\n", name, (long)N, (long)V, 16 * CT, sizeof(T));
+    constexpr int R = CtShape<T, CT>::RT;
+    std::vector<Variant> vs;
+    vs.push_back(mkct<T, CT, R, 4, 4, true>(XT, N, V, N, B, out, 2));
+    vs.push_back(mkcr<T, CT, R, 4, 4, false>(X, V, V, N, B, out, 2));
+    vs.push_back(mkcr<T, CT, R, 4, 8, false>(X, V, V, N, B, out, 2));
+    vs.push_back(mkcr<T, CT, R, 4, 4, false>(X, V, V, N, B, out, 3));
+    vs.push_back(mkcr<T, CT, R, 8, 4, false>(X, V, V, N, B, out, 1));
+    if constexpr (CT <= 4 && sizeof(T) == 4) vs.push_back(mkcr<T, CT, R, 4, 16, false>(X, V, V, N, B, out, 2));
+    if constexpr (CT <= 4) vs.push_back(mkcr<T, CT, 2 * R, 4, 4, false>(X, V, V, N, B, out, 2));
+    const double tol = sizeof(T) == 8 ? 1e-12 : 2e-5;
+    for (size_t k = 1; k < vs.size(); ++k) check<T>(name, vs[k], vs[0], out, out, N, 16 * CT, tol);
+    bench(vs, gb, tf);
+    CK(hipFree(X)); CK(hipFree(XT)); CK(hipFree(B)); CK(hipFree(out));
+}
+
 template <typename T, int CT, int TNRT>
 void suite(const char* name, int64_t K, int64_t V, int tnS) {
     T *A, *B, *out;
@@ -137,6 +194,13 @@ void suite(const char* name, int64_t K, int64_t V, int tnS) {
 int main(int argc, char** argv) {
     const char* which = argc > 1 ? argv[1] : "all";
     const bool all = !strcmp(which, "all");
+    if (!strcmp(which, "cr")) {
+        suite_cr<float, 4>("c3", 50048, 100032);
+        suite_cr<float, 8>("c4shard", 50048, 125056);
+        suite_cr<double, 4>("c3f64", 50048, 50048);
+        suite_cr<float, 2>("mid32f32", 20032, 20032);
+        return 0;
+    }
     if (all || !strcmp(which, "c3")) {
         suite<float, 4, 4>("c3l_xty", 50048, 20032, 3);
         suite<float, 4, 4>("c3l_xw", 20032, 50048, 2);

@@ -446,6 +446,8 @@ def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_s
     n_, v_, m_, tag_ = WORKLOADS[workload]
     est_ms = max(2.0 * n_ * v_ * m_ / (60e12 if tag_ == "f32" else 30e12), n_ * v_ * (4 if tag_ == "f32" else 8) / 3e12) * 1e3
     n_warm = int(min(4000, max(4, 250.0 / max(est_ms, 1e-3))))
+    if comm is not None:
+        n_warm = min(n_warm, 300)              # every pass carries a collective (milliseconds each over gloo in the tests)
     be.synchronize()
     t0 = time.perf_counter()
     for _ in range(n_warm):

@@ -96,8 +96,10 @@ int         lcx_device_count(int* out_count);
 
 /* ---- handle -------------------------------------------------------------------------------- */
 /* Replaces cm.cublas_init() (:85-86).  Allocates all device state for an
- * (n_samples x nv_local) shard with n_hidden factors on HIP device `device`.  n_hidden <= 256 (padded to 16 / 32 / 64 /
- * 128 / 256 columns).  A failed allocation releases what was allocated before it.
+ * (n_samples x nv_local) shard with n_hidden factors on HIP device `device`.  n_hidden <= 1024: padded to 16 / 32 / 64 / 128 /
+ * 256 columns on the tuned kernels, to 512 / 1024 on the wide path (257+ factors: every contraction on one generic LDS-staged MFMA
+ * GEMM with the factor axis tiled like any other, one thread per factor in the per-variable kernels - correct, untuned).
+ * A failed allocation releases what was allocated before it.
  * The shard is normally resident twice, row-major and transposed, so that both X-streaming contractions read their big operand
  * in their preferred layout.  When two copies would not leave room for the rest (or LCX_SINGLE_COPY=1) only the row-major
  * copy is kept and X.B^T contracts along its rows (gemm_cr: 4-6 % slower per pass): half the resident bytes - a 50 000 x

@@ -761,6 +761,65 @@ template <int CT, int RT, int KW, int U, bool SERIAL = false> struct Tn4Lds {
     static constexpr size_t bytes = strips > tiles ? strips : tiles;
 };
 
+// ------------------------------------------------------------------------------------------------
+// gemm_wide: every contraction of a model with MORE than 256 factors (n_hidden 257..1024; reference linearcorex.py:72 takes any).
+//
+// The tuned kernels above keep a whole row of m_pad accumulators in registers, which ends at 256 columns.  Beyond that the
+// factor axis is tiled like any other: a plain LDS-staged MFMA GEMM with run-time sizes and strides, one kernel for all the
+// contractions of the path - untuned by intent (no BASELINE config has more than 128 factors), correct and deterministic.
+//   C[z][m][n] = sum_{k in split z} opA(m, k) * B[k][n] (* rowscale[k]),   opA = A[m][k] (TRANS_A false) or A[k][m] (true)
+// Block = 4 waves, tile 64 (m) x 64 (n): wave w owns rows 16 w .. 16 w + 15 and four 16-column MFMA tiles; the contraction
+// advances 16 elements per step through LDS.  M, N multiples of 64, K multiple of 16 per split; grid = (N / 64, M / 64, splits).
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool TRANS_A, bool SCALE>
+__global__ void __launch_bounds__(256)
+gemm_wide_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, const T* __restrict__ rowscale,
+                 T* __restrict__ C, int64_t ldc, int64_t M, int64_t K, int nsplit, const int* __restrict__ skip_flag) {
+    typedef typename MF<T>::acc_t acc_t;
+    __shared__ T As[64][17];          // [m][k], padded: the 16 rows x 4 lane groups of an operand read hit distinct banks
+    __shared__ T Bs[16][68];          // [k][n]
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.y * 64, n0 = (int64_t)blockIdx.x * 64;
+    const int64_t ksteps = K / 16;
+    const int64_t s0 = ksteps * blockIdx.z / nsplit, s1 = ksteps * (blockIdx.z + 1) / nsplit;
+    acc_t acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = (acc_t){0, 0, 0, 0};
+    for (int64_t st = s0; st < s1; ++st) {
+        const int64_t k0 = st * 16;
+        __syncthreads();
+        if (TRANS_A) {                // A[k][m]: thread -> (k = tid / 16, 4 consecutive m)
+            const int k = tid >> 4, mm = (tid & 15) * 4;
+            const T sc = SCALE ? rowscale[k0 + k] : (T)1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) As[mm + e][k] = A[(k0 + k) * lda + m0 + mm + e] * sc;
+        } else {                      // A[m][k]: thread -> (m = tid / 4, 4 consecutive k)
+            const int mm = tid >> 2, k = (tid & 3) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) As[mm][k + e] = A[(m0 + mm) * lda + k0 + k + e] * (SCALE ? rowscale[k0 + k + e] : (T)1);
+        }
+        {
+            const int k = tid >> 4, nn = (tid & 15) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Bs[k][nn + e] = B[(k0 + k) * ldb + n0 + nn + e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const T av = As[16 * wave + i][4 * s + q];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = MF<T>::mma(av, Bs[4 * s + q][16 * u + i], acc[u]);
+        }
+    }
+    T* dst = C + ((int64_t)blockIdx.z * M + m0 + 16 * wave) * ldc + n0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[(int64_t)MF<T>::row(lane, g) * ldc + 16 * u + i] = acc[u][g];
+}
+
 // tile shapes of gemm_ct: 16-byte A loads wherever the accumulators fit (RT*CT*4 registers of T)
 template <typename T, int CT> struct CtShape {
     // 256 padded factors (CT = 16): half the column tile, so that the accumulators stay at 128 registers

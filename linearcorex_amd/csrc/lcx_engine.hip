@@ -468,8 +468,22 @@ template <typename T, int CT> struct Geo {
 // -------------------------------------------------------------------------------------------------
 template <typename T, int CT> struct Impl {
     static constexpr int Mp = 16 * CT;
-    static constexpr int VPB = PV_THREADS / Mp;
+    // more than 256 padded factors: the untuned wide path - every contraction on gemm_wide (run-time strides, the factor axis
+    // tiled like any other), the per-variable kernels with one thread per factor
+    static constexpr bool WIDE = CT > 16;
+    static constexpr int NTV = Pvt<Mp>::v;          // threads per block of the per-variable kernels
+    static constexpr int VPB = NTV / Mp;
     static constexpr int DT = sizeof(T) == 4 ? LCX_F32 : LCX_F64;
+
+    // C[z][M][ldc] = sum over split z of opA . B (. rowscale) on gemm_wide; M, N multiples of 64, K of 16
+    template <bool TRANS_A, bool SCALE>
+    static int wide_gemm(lcx_ctx* h, const T* A, int64_t lda, const T* B, int64_t ldb, const T* scale, T* C, int64_t ldc, int64_t M,
+                         int64_t N, int64_t K, int S, const int* skip) {
+        dim3 grid((unsigned)(N / 64), (unsigned)(M / 64), (unsigned)S);
+        hipLaunchKernelGGL((gemm_wide_kernel<T, TRANS_A, SCALE>), grid, dim3(256), 0, h->stream, A, lda, B, ldb, scale, C, ldc, M, K, S, skip);
+        KCHECK();
+        return LCX_OK;
+    }
 
     // resident blocks per CU of a kernel at a given block size / dynamic LDS
     template <typename F> static int blocks_per_cu(F* f, int threads, size_t lds) {
@@ -521,6 +535,29 @@ template <typename T, int CT> struct Impl {
     }
 
     static int geometry(lcx_ctx* h) {
+        if constexpr (WIDE) {
+            h->nt_S = h->tn_S = h->tn_slots = 1;
+            h->nt_KW = h->tn_KW = 4;
+            h->nt_bpc = h->tn_bpc = 1;
+            h->nt_ct = h->tn_ct = h->f64_4x4 = h->merged_ok = false;
+            h->nt_nb = h->nt_nsuper = h->tn_nb = h->tn_nsuper = h->nt2_nb = h->nt2_nsuper = h->nt2_S = 0;
+            // Gram matrices: (Mp / 64)^2 tiles; split the contraction until the chip is about twice covered
+            auto gsplit = [&](int64_t K) {
+                const int64_t tiles = (int64_t)(Mp / 64) * (Mp / 64);
+                int64_t sp = cdiv(2 * (int64_t)h->n_cus, tiles);
+                if (sp > K / 64) sp = K / 64;
+                if (sp > 64) sp = 64;
+                return (int)(sp < 1 ? 1 : sp);
+            };
+            h->gn_S = gsplit(h->Npad);
+            h->gv_S = gsplit(h->ldx);
+            h->pv_grid = (int)(h->V < 1024 ? h->V : 1024);
+            return LCX_OK;
+        } else {
+            return geometry_tuned(h);
+        }
+    }
+    static int geometry_tuned(lcx_ctx* h) {
         constexpr int NT_RT = Geo<T, CT>::NT_RT, TN_RT = Geo<T, CT>::TN_RT;
         const int64_t nchunks = h->ldx / Geo<T, CT>::CH;
         const int64_t kgn = h->Npad / 16, kgv = h->ldx / 16;
@@ -624,11 +661,16 @@ template <typename T, int CT> struct Impl {
 
     // ---- Gram matrix of a [K][Mp] array (K multiple of 16): partials -> gpart[S][Mp][Mp] ------
     static int gram(lcx_ctx* h, const T* A, int64_t K, const T* scale, int S, const int* skip, T* dst) {
-        const int kw = pick_kw(K / 16);
-        constexpr int RT = Geo<T, CT>::G_RT;
-        if (scale)
-            return launch_tn<T, CT, RT, true>(h->stream, A, Mp, K, Mp, A, scale, dst, S, kw, skip);
-        return launch_tn<T, CT, RT, false>(h->stream, A, Mp, K, Mp, A, nullptr, dst, S, kw, skip);
+        if constexpr (WIDE) {
+            if (scale) return wide_gemm<true, true>(h, A, Mp, A, Mp, scale, dst, Mp, Mp, Mp, K, S, skip);
+            return wide_gemm<true, false>(h, A, Mp, A, Mp, nullptr, dst, Mp, Mp, Mp, K, S, skip);
+        } else {
+            const int kw = pick_kw(K / 16);
+            constexpr int RT = Geo<T, CT>::G_RT;
+            if (scale)
+                return launch_tn<T, CT, RT, true>(h->stream, A, Mp, K, Mp, A, scale, dst, S, kw, skip);
+            return launch_tn<T, CT, RT, false>(h->stream, A, Mp, K, Mp, A, nullptr, dst, S, kw, skip);
+        }
     }
 
     // Y(_partial) = X . B^T (linearcorex.py:247 / :210) as a contraction over the rows of XT
@@ -637,16 +679,20 @@ template <typename T, int CT> struct Impl {
         TimingPair tp;
         LCXCHECK(timing_begin(h, 0, &tp));
         T* dst = h->nt_S > 1 ? P<T>(h->ypart) : P<T>(h->ybuf);
-        if (h->single_copy)
-            LCXCHECK((launch_cr<T, CT>(h->stream, P<T>(h->X), h->ldx, h->ldx, h->Npad, B, dst, h->nt_nb, h->nt_nsuper, h->nt_S, skip)));
-        else if (h->nt_ct)
-            LCXCHECK((launch_ct<T, CT>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, B, dst, h->nt_nb, h->nt_nsuper, h->nt_S, skip)));
-        else if (h->f64_4x4) {
-            if constexpr (sizeof(T) == 8 && CT <= 2)
-                LCXCHECK((launch_tn4<CT>(h->stream, P<double>(h->XT), h->Npad, h->ldx, h->Npad, (const double*)B, (double*)dst, h->nt_S, h->nt_KW, skip)));
-        } else
-            LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false, false>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, B, nullptr,
-                                                                         dst, h->nt_S, h->nt_KW, skip)));
+        if constexpr (WIDE) {
+            LCXCHECK((wide_gemm<false, false>(h, P<T>(h->X), h->ldx, B, Mp, nullptr, dst, Mp, h->Npad, Mp, h->ldx, 1, skip)));
+        } else {
+            if (h->single_copy)
+                LCXCHECK((launch_cr<T, CT>(h->stream, P<T>(h->X), h->ldx, h->ldx, h->Npad, B, dst, h->nt_nb, h->nt_nsuper, h->nt_S, skip)));
+            else if (h->nt_ct)
+                LCXCHECK((launch_ct<T, CT>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, B, dst, h->nt_nb, h->nt_nsuper, h->nt_S, skip)));
+            else if (h->f64_4x4) {
+                if constexpr (sizeof(T) == 8 && CT <= 2)
+                    LCXCHECK((launch_tn4<CT>(h->stream, P<double>(h->XT), h->Npad, h->ldx, h->Npad, (const double*)B, (double*)dst, h->nt_S, h->nt_KW, skip)));
+            } else
+                LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false, false>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, B, nullptr,
+                                                                             dst, h->nt_S, h->nt_KW, skip)));
+        }
         LCXCHECK(timing_end(h, 0, &tp));
         const int64_t n = h->Npad * Mp;
         const bool wide = h->nt_S >= WIDE_SPLITS && cdiv(n, 32) < (1 << 20);
@@ -684,16 +730,20 @@ template <typename T, int CT> struct Impl {
     static int tn_big(lcx_ctx* h, const int* skip) {
         TimingPair tp;
         LCXCHECK(timing_begin(h, 1, &tp));
-        if (h->tn_ct)
-            LCXCHECK((launch_ct<T, CT>(h->stream, P<T>(h->X), h->ldx, h->Npad, h->ldx, P<T>(h->ybuf), P<T>(h->dpart), h->tn_nb, h->tn_nsuper,
-                                       h->tn_S, skip)));
-        else if (h->f64_4x4) {
-            if constexpr (sizeof(T) == 8 && CT <= 2)
-                LCXCHECK((launch_tn4<CT>(h->stream, P<double>(h->X), h->ldx, h->Npad, h->ldx, P<double>(h->ybuf), P<double>(h->dpart), h->tn_S,
-                                         h->tn_KW, skip)));
-        } else
-            LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false, false>(h->stream, P<T>(h->X), h->ldx, h->Npad, h->ldx, P<T>(h->ybuf), nullptr,
-                                                                         P<T>(h->dpart), h->tn_S, h->tn_KW, skip)));
+        if constexpr (WIDE) {
+            LCXCHECK((wide_gemm<true, false>(h, P<T>(h->X), h->ldx, P<T>(h->ybuf), Mp, nullptr, P<T>(h->dpart), Mp, h->ldx, Mp, h->Npad, 1, skip)));
+        } else {
+            if (h->tn_ct)
+                LCXCHECK((launch_ct<T, CT>(h->stream, P<T>(h->X), h->ldx, h->Npad, h->ldx, P<T>(h->ybuf), P<T>(h->dpart), h->tn_nb, h->tn_nsuper,
+                                           h->tn_S, skip)));
+            else if (h->f64_4x4) {
+                if constexpr (sizeof(T) == 8 && CT <= 2)
+                    LCXCHECK((launch_tn4<CT>(h->stream, P<double>(h->X), h->ldx, h->Npad, h->ldx, P<double>(h->ybuf), P<double>(h->dpart), h->tn_S,
+                                             h->tn_KW, skip)));
+            } else
+                LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false, false>(h->stream, P<T>(h->X), h->ldx, h->Npad, h->ldx, P<T>(h->ybuf), nullptr,
+                                                                             P<T>(h->dpart), h->tn_S, h->tn_KW, skip)));
+        }
         LCXCHECK(timing_end(h, 1, &tp));
         if (h->tn_slots != h->tn_S) {
             const int64_t n = h->ldx * Mp;
@@ -749,6 +799,21 @@ template <typename T, int CT> struct Impl {
 
     // W'^T-Gram and Y'^T-Gram of a trial in one launch
     static int gram_pair(lcx_ctx* h, const T* w, const T* y) {
+        if constexpr (WIDE) {
+            LCXCHECK(gram(h, w, h->ldx, nullptr, h->gv_S, nullptr, P<T>(h->gpartw)));
+            LCXCHECK(gram(h, y, h->Npad, nullptr, h->gn_S, nullptr, P<T>(h->gpart)));
+        } else {
+            LCXCHECK(gram_pair_tuned(h, w, y));
+        }
+        if (h->exchange) {
+            hipLaunchKernelGGL((reduce_wide_kernel<T, T>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
+                               P<T>(h->gpartw), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp,
+                               P<T>(h->ybuf) + h->Npad * Mp, (const int*)nullptr);
+            KCHECK();
+        }
+        return LCX_OK;
+    }
+    static int gram_pair_tuned(lcx_ctx* h, const T* w, const T* y) {
         constexpr int RT = Geo<T, CT>::G_RT;
         const int kgv = (int)(h->ldx / 16), kgn = (int)(h->Npad / 16);
         // With several ranks the Y^T.Y Gram feeds uj / TC, which every rank must form bit-identically (the line-search
@@ -771,12 +836,6 @@ template <typename T, int CT> struct Impl {
             default: hipLaunchKernelGGL((gram_pair_kernel<T, CT, RT, 4>), grid, dim3(256), lds, h->stream, p0, p1); break;
         }
         KCHECK();
-        if (h->exchange) {
-            hipLaunchKernelGGL((reduce_wide_kernel<T, T>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
-                               P<T>(h->gpartw), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp,
-                               P<T>(h->ybuf) + h->Npad * Mp, (const int*)nullptr);
-            KCHECK();
-        }
         return LCX_OK;
     }
 
@@ -785,7 +844,7 @@ template <typename T, int CT> struct Impl {
         const int* skip = &s.st->invalid;
         const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * Mp : 0) + (size_t)VPB * Mp) * sizeof(T);
         LCXCHECK(allow_lds(moments_epilogue_kernel<T, Mp>, lds));
-        hipLaunchKernelGGL((moments_epilogue_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream,
+        hipLaunchKernelGGL((moments_epilogue_kernel<T, Mp>), dim3(h->pv_grid), dim3(NTV), lds, h->stream,
                            P<T>(h->dpart), h->tn_slots, h->ldx * Mp,
                            linear ? P<T>(h->set[0].D) : (const T*)nullptr, P<T>(h->ddir), (T)eta, P<T>(s.D),
                            P<T>(h->Wt[which]), s.ry, h->V, (double)h->N, eps,
@@ -799,7 +858,12 @@ template <typename T, int CT> struct Impl {
         const unsigned int seq = single ? ++h->seq_next : 0u;
         TcTail tail{h->tcpart, h->pv_grid, h->tanpart, h->tan_blocks, h->sbuf, s.st, h->set[0].st, s.hst_dev, seq, single, skip};
         h->tan_blocks = 0;
-        {
+        if constexpr (WIDE) {
+            // the tail of the evaluation first (the host sees TC as early as possible), then the H Gram on gemm_wide
+            hipLaunchKernelGGL((tc_tail_kernel<T>), dim3(1), dim3(256), 0, h->stream, tail);
+            KCHECK();
+            LCXCHECK(gram(h, P<T>(s.rir), h->ldx, P<T>(s.hscale), h->gv_S, skip, P<T>(h->gpart)));
+        } else {
             constexpr int RT = Geo<T, CT>::G_RT;
             const int kgroups = (int)(h->ldx / 16), kw = pick_kw(kgroups);
             dim3 grid((unsigned)(Mp / (16 * RT)), (unsigned)h->gv_S, 2);
@@ -877,7 +941,7 @@ template <typename T, int CT> struct Impl {
         MomentSet& s = h->set[which];
         const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * (Mp + 1) : 0) + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
         LCXCHECK(allow_lds(grad_kernel<T, Mp>, lds));
-        hipLaunchKernelGGL((grad_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(h->Wt[which]),
+        hipLaunchKernelGGL((grad_kernel<T, Mp>), dim3(h->pv_grid), dim3(NTV), lds, h->stream, P<T>(h->Wt[which]),
                            P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), s.uj, h->sbuf + SB_H, h->V,
                            P<T>(h->grad), h->bjpart, use_merged(h) ? P<T>(h->gw) : (T*)nullptr);
         KCHECK();
@@ -1124,7 +1188,7 @@ template <typename T, int CT> struct Impl {
         KCHECK();
         const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * Mp : 0) + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
         LCXCHECK(allow_lds(detail_kernel<T, Mp>, lds));
-        hipLaunchKernelGGL((detail_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(s.rho),
+        hipLaunchKernelGGL((detail_kernel<T, Mp>), dim3(h->pv_grid), dim3(NTV), lds, h->stream, P<T>(s.rho),
                            h->ryinv, h->V, h->M, mi_o, xz_o, x2y_o, h->detpart);
         KCHECK();
         hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(h->M + 3), dim3(PV_THREADS), 0, h->stream, h->detpart, h->pv_grid,
@@ -1167,7 +1231,7 @@ template <typename T, int CT> struct Impl {
         const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * Mp : 0) + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
         LCXCHECK(allow_lds(detail_kernel<T, Mp>, lds));
         // X_i Z_j = solve(cy, X_i Y_j^T)^T = (ry^-1 rho)_j / sd_j ; X_i^2|Y = 1 - rho^T ry^-1 rho ; hscale <- 1 / X_i^2|Y
-        hipLaunchKernelGGL((detail_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(s.rho), h->ryinv, h->V, h->M,
+        hipLaunchKernelGGL((detail_kernel<T, Mp>), dim3(h->pv_grid), dim3(NTV), lds, h->stream, P<T>(s.rho), h->ryinv, h->V, h->M,
                            (T*)nullptr, P<T>(s.xz), P<T>(s.x2y), h->detpart, (const double*)s.inv_sd, P<T>(s.hscale));
         KCHECK();
         hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(h->M + 3), dim3(PV_THREADS), 0, h->stream, h->detpart, h->pv_grid,
@@ -1198,7 +1262,7 @@ template <typename T, int CT> struct Impl {
         MomentSet& s = h->set[0];
         const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * (Mp + 1) : 0) + (size_t)VPB * Mp) * sizeof(T);
         LCXCHECK(allow_lds(syn_update_kernel<T, Mp>, lds));
-        hipLaunchKernelGGL((syn_update_kernel<T, Mp>), dim3(h->pv_grid), dim3(PV_THREADS), lds, h->stream, P<T>(h->Wt[0]), P<T>(s.xz),
+        hipLaunchKernelGGL((syn_update_kernel<T, Mp>), dim3(h->pv_grid), dim3(NTV), lds, h->stream, P<T>(h->Wt[0]), P<T>(s.xz),
                            P<T>(s.hscale), h->sbuf + SB_H, h->V, (T)eta, P<T>(h->Wt[1]));
         KCHECK();
         return LCX_OK;
@@ -1578,7 +1642,10 @@ template <typename T, int CT> struct Impl {
     // factors: the row-streaming kernel gemm_nt.  256: its register tile does not fit, so the block is transposed and runs
     // through the column-streaming kernel like the resident passes do.
     static int project_block(lcx_ctx* h, DevTemps& tmps, T* xd, int64_t rows_pad, T* yd, T** xt_io) {
-        if constexpr (CT <= 8) {
+        if constexpr (WIDE) {
+            (void)tmps; (void)xt_io;
+            return wide_gemm<false, false>(h, xd, h->ldx, P<T>(h->Wt[0]), Mp, nullptr, yd, Mp, rows_pad, Mp, h->ldx, 1, nullptr);
+        } else if constexpr (CT <= 8) {
             (void)tmps; (void)xt_io;
             return launch_nt<T, CT>(h->stream, xd, h->ldx, rows_pad, P<T>(h->Wt[0]), yd, 1, 4, nullptr);
         } else {
@@ -1618,6 +1685,15 @@ template <typename T, int CT> struct Impl {
     // Name of the kernel instantiation behind the two X-streaming passes, as rocprofv3 prints it (both
     // passes run the same function: X.B^T contracts over the rows of the transposed copy).
     static int kernel_name(lcx_ctx* h, int kind, char* buf, int64_t len) {
+        if constexpr (WIDE) {
+            if (kind == 2) buf[0] = 0;
+            else snprintf(buf, (size_t)len, "lcx::gemm_wide_kernel<%s, %s, false>", sizeof(T) == 8 ? "double" : "float", kind == 0 ? "false" : "true");
+            return LCX_OK;
+        } else {
+            return kernel_name_tuned(h, kind, buf, len);
+        }
+    }
+    static int kernel_name_tuned(lcx_ctx* h, int kind, char* buf, int64_t len) {
         if (kind == 2) {
             if (!h->merged_ok) { buf[0] = 0; return LCX_OK; }
             if constexpr (CT <= 4)
@@ -1810,6 +1886,8 @@ template <typename T, int CT> struct Impl {
                 case 4: return Impl<float, 4>::fn(__VA_ARGS__);                     \
                 case 8: return Impl<float, 8>::fn(__VA_ARGS__);                     \
                 case 16: return Impl<float, 16>::fn(__VA_ARGS__);                   \
+                case 32: return Impl<float, 32>::fn(__VA_ARGS__);                   \
+                case 64: return Impl<float, 64>::fn(__VA_ARGS__);                   \
             }                                                                       \
         } else {                                                                    \
             switch ((h)->CT) {                                                      \
@@ -1818,6 +1896,8 @@ template <typename T, int CT> struct Impl {
                 case 4: return Impl<double, 4>::fn(__VA_ARGS__);                    \
                 case 8: return Impl<double, 8>::fn(__VA_ARGS__);                    \
                 case 16: return Impl<double, 16>::fn(__VA_ARGS__);                  \
+                case 32: return Impl<double, 32>::fn(__VA_ARGS__);                  \
+                case 64: return Impl<double, 64>::fn(__VA_ARGS__);                  \
             }                                                                       \
         }                                                                           \
         return fail(LCX_ERR_ARG, "unsupported n_hidden padding");                   \
@@ -1829,6 +1909,8 @@ static int ct_for(int m) {
     if (m <= 64) return 4;
     if (m <= 128) return 8;
     if (m <= 256) return 16;
+    if (m <= 512) return 32;           // the wide path (gemm_wide): 512 / 1024 padded factors
+    if (m <= 1024) return 64;
     return 0;
 }
 
@@ -1878,7 +1960,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     if (!out || n_samples < 1 || nv_local < 1 || n_hidden < 1) return fail(LCX_ERR_ARG, "lcx_create: bad sizes");
     if (dtype != LCX_F32 && dtype != LCX_F64) return fail(LCX_ERR_ARG, "lcx_create: dtype must be LCX_F32 or LCX_F64");
     const int ct = ct_for(n_hidden);
-    if (!ct) return fail(LCX_ERR_ARG, "lcx_create: n_hidden > 256 is not supported by this build");
+    if (!ct) return fail(LCX_ERR_ARG, "lcx_create: n_hidden > 1024 is not supported by this build");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(LCX_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= ndev) return fail(LCX_ERR_ARG, "lcx_create: device index out of range");
@@ -1921,7 +2003,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
         if (e && *e) want = atoi(e) != 0;
         else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
             want = 2.0 * xb + 24.0 * (double)h->ldx * h->Mp * h->es > 0.94 * (double)free_b && xb < 0.9 * (double)free_b;
-        h->single_copy = want;
+        h->single_copy = want || ct > 16;     // the wide path reads X.B^T from the row-major copy anyway (gemm_wide)
         (void)hipGetLastError();
     }
 
@@ -2204,13 +2286,17 @@ static int get_ws_impl(lcx_ctx* h, int which, void* w) {
                          case 2: return Impl<float,2>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
                          case 4: return Impl<float,4>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
                          case 8: return Impl<float,8>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
-                         case 16: return Impl<float,16>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true); }
+                         case 16: return Impl<float,16>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
+                         case 32: return Impl<float,32>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
+                         case 64: return Impl<float,64>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true); }
     } else {
         switch (h->CT) { case 1: return Impl<double,1>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
                          case 2: return Impl<double,2>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
                          case 4: return Impl<double,4>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
                          case 8: return Impl<double,8>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
-                         case 16: return Impl<double,16>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true); }
+                         case 16: return Impl<double,16>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
+                         case 32: return Impl<double,32>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
+                         case 64: return Impl<double,64>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true); }
     }
     return fail(LCX_ERR_ARG, "bad CT");
 }
@@ -2241,13 +2327,17 @@ static int detail_entry(lcx_ctx* h, int which) {
                          case 2: return Impl<float,2>::detail(h, which, nullptr, nullptr, nullptr);
                          case 4: return Impl<float,4>::detail(h, which, nullptr, nullptr, nullptr);
                          case 8: return Impl<float,8>::detail(h, which, nullptr, nullptr, nullptr);
-                         case 16: return Impl<float,16>::detail(h, which, nullptr, nullptr, nullptr); }
+                         case 16: return Impl<float,16>::detail(h, which, nullptr, nullptr, nullptr);
+                         case 32: return Impl<float,32>::detail(h, which, nullptr, nullptr, nullptr);
+                         case 64: return Impl<float,64>::detail(h, which, nullptr, nullptr, nullptr); }
     } else {
         switch (h->CT) { case 1: return Impl<double,1>::detail(h, which, nullptr, nullptr, nullptr);
                          case 2: return Impl<double,2>::detail(h, which, nullptr, nullptr, nullptr);
                          case 4: return Impl<double,4>::detail(h, which, nullptr, nullptr, nullptr);
                          case 8: return Impl<double,8>::detail(h, which, nullptr, nullptr, nullptr);
-                         case 16: return Impl<double,16>::detail(h, which, nullptr, nullptr, nullptr); }
+                         case 16: return Impl<double,16>::detail(h, which, nullptr, nullptr, nullptr);
+                         case 32: return Impl<double,32>::detail(h, which, nullptr, nullptr, nullptr);
+                         case 64: return Impl<double,64>::detail(h, which, nullptr, nullptr, nullptr); }
     }
     return fail(LCX_ERR_ARG, "bad CT");
 }

@@ -23,6 +23,9 @@ constexpr int PV_THREADS = 256;
 // (n_hidden 129..256) Mp^2 elements no longer fit next to the per-variable strips and every thread reads its column of
 // the operator from global memory instead (coalesced over the factor index, served by L2).
 template <int Mp> struct OpInLds { static constexpr bool v = Mp <= 128; };
+// Threads per block of the per-variable kernels: 256 (PV_THREADS / Mp variables per block) up to 256 padded factors; beyond
+// (n_hidden 257..1024, the untuned wide path) one variable per block and one thread per factor.
+template <int Mp> struct Pvt { static constexpr int v = Mp > 256 ? Mp : 256; };
 
 // state scalars per moment set (mirrors LCX_S_* in include/lcx.h)
 struct SetState {
@@ -94,15 +97,15 @@ __device__ __forceinline__ R group_sum(R v, R* scratch /* [PV_THREADS/64] per us
     return v;
 }
 
-template <typename R>
-__device__ __forceinline__ R block_sum(R v, R* scratch /* [PV_THREADS/64] */, int tid) {
+template <typename R, int NT = PV_THREADS>
+__device__ __forceinline__ R block_sum(R v, R* scratch /* [NT/64] */, int tid) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     __syncthreads();
     if ((tid & 63) == 0) scratch[tid >> 6] = v;
     __syncthreads();
     R s = scratch[0];
-    for (int w = 1; w < PV_THREADS / 64; ++w) s += scratch[w];
+    for (int w = 1; w < NT / 64; ++w) s += scratch[w];
     return s;
 }
 
@@ -179,11 +182,13 @@ small_moments_kernel(const T* __restrict__ gy, int nsplit, const T* __restrict__
     }
     __syncthreads();
     if (!last_s) return;
-    if (tid < 256) {
+    {
+        // thread t takes the factors t, t + 256, ... (one each up to 256 factors): max uj and sum of log(1 - uj)
         double u = -1e300, l = 0.0;
-        if (tid < m) {
-            u = __hip_atomic_load(&sm.uj[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            l = (double)log((T)1 - (T)u);          // log(1-uj) in working precision (:274)
+        for (int j = tid; j < m; j += 256) {
+            const double uv = __hip_atomic_load(&sm.uj[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u = fmax(u, uv);
+            l += (double)log((T)1 - (T)uv);        // log(1-uj) in working precision (:274)
         }
         uu[tid] = u;
         lg[tid] = l;
@@ -191,7 +196,8 @@ small_moments_kernel(const T* __restrict__ gy, int nsplit, const T* __restrict__
     __syncthreads();
     if (tid == 0) {
         double mx = -1e300, slog = 0.0;
-        for (int j = 0; j < m; ++j) { mx = fmax(mx, uu[j]); slog += lg[j]; }
+        const int nact = m < 256 ? m : 256;
+        for (int j = 0; j < nact; ++j) { mx = fmax(mx, uu[j]); slog += lg[j]; }
         st->max_uj = mx;
         st->sum_log_rj = slog;
         const int inv = (quick && mx >= 1.0) ? 1 : 0;
@@ -218,7 +224,7 @@ __device__ __forceinline__ void tc_store(const double* sbuf, SetState* st) {
 // A fused tail here (ticket, last block sums and publishes) cost 11-14 us on top of an 8-16 us body: two dependent
 // atomic round trips plus the publication (tools/epilogue_probe.hip, profiles/r01_epilogue_probe_tail.txt).
 template <typename T, int Mp>
-__global__ void __launch_bounds__(PV_THREADS)
+__global__ void __launch_bounds__(Pvt<Mp>::v)
 moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride,
                         const T* __restrict__ d_base, const T* __restrict__ d_dir, T eta,
                         T* __restrict__ d_out,
@@ -227,17 +233,18 @@ moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride
                         T* __restrict__ qij_o, T* __restrict__ si_o, T* __restrict__ q2_o,
                         T* __restrict__ hscale_o, double* __restrict__ tcpart,
                         const int* __restrict__ skip_flag) {
-    constexpr int VPB = PV_THREADS / Mp;
+    constexpr int NT = Pvt<Mp>::v;
+    constexpr int VPB = NT / Mp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* ry_s = reinterpret_cast<T*>(smem_raw);
     T* rir_s = ry_s + (OpInLds<Mp>::v ? Mp * Mp : 0);
-    __shared__ T gs_scratch[PV_THREADS / 64];
-    __shared__ double bs_scratch[PV_THREADS / 64];
+    __shared__ T gs_scratch[NT / 64];
+    __shared__ double bs_scratch[NT / 64];
     if (skip_flag != nullptr && *skip_flag != 0) return;       // invalid trial (:250-251): the tail block still publishes
 
     const int tid = threadIdx.x, vl = tid / Mp, j = tid % Mp;
     if (OpInLds<Mp>::v)
-        for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) ry_s[idx] = (T)ry[idx];
+        for (int idx = tid; idx < Mp * Mp; idx += NT) ry_s[idx] = (T)ry[idx];
     __syncthreads();
 
     const T c1 = (T)(1.0 - eps * eps), c2 = (T)(eps * eps), ns = (T)n_samples;
@@ -286,8 +293,8 @@ moments_epilogue_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride
             }
         }
     }
-    s1 = block_sum<double>(s1, bs_scratch, tid);
-    s2 = block_sum<double>(s2, bs_scratch, tid);
+    s1 = block_sum<double, NT>(s1, bs_scratch, tid);
+    s2 = block_sum<double, NT>(s2, bs_scratch, tid);
     if (tid == 0) {
         tcpart[2 * blockIdx.x] = s1;
         tcpart[2 * blockIdx.x + 1] = s2;
@@ -404,19 +411,20 @@ __global__ void tc_final_kernel(const double* __restrict__ sbuf, SetState* st, S
 // dynamic LDS: h_s[Mp*(Mp+1)] (T) + w_s[VPB*Mp] (T) + bj_s[VPB*Mp] (double)
 // ------------------------------------------------------------------------------------------------
 template <typename T, int Mp>
-__global__ void __launch_bounds__(PV_THREADS)
+__global__ void __launch_bounds__(Pvt<Mp>::v)
 grad_kernel(const T* __restrict__ W, const T* __restrict__ rho_i, const T* __restrict__ rir_i,
             const T* __restrict__ qij_i, const T* __restrict__ si_i, const T* __restrict__ q2_i,
             const double* __restrict__ uj, const double* __restrict__ H /* sbuf, diag ignored */,
             int64_t V, T* __restrict__ grad_o, double* __restrict__ bjpart, T* __restrict__ grad2_o = nullptr) {
-    constexpr int VPB = PV_THREADS / Mp;
+    constexpr int NT = Pvt<Mp>::v;
+    constexpr int VPB = NT / Mp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* h_s = reinterpret_cast<T*>(smem_raw);        // [Mp][Mp+1]
     T* w_s = h_s + (OpInLds<Mp>::v ? Mp * (Mp + 1) : 0);           // [VPB][Mp]
     double* bj_s = reinterpret_cast<double*>(w_s + VPB * Mp + (((VPB * Mp) & 1) ? 1 : 0));
     const int tid = threadIdx.x, vl = tid / Mp, j = tid % Mp;
     if (OpInLds<Mp>::v)
-        for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) {
+        for (int idx = tid; idx < Mp * Mp; idx += NT) {
             const int a = idx / Mp, b = idx % Mp;
             h_s[a * (Mp + 1) + b] = (a == b) ? (T)0 : (T)H[idx];       // fill_diagonal(H, 0), :295
         }
@@ -618,6 +626,10 @@ gram_tc_kernel(const T* __restrict__ A, const T* __restrict__ rowscale, T* __res
     tn_body<T, CT, RT, KW, true, 4>(A, 16 * CT, 16 * RT, A, rowscale, out, 16 * CT, kgroups, nsplit, blockIdx.x, blockIdx.y);
 }
 
+// the tail as a launch of its own (the wide path, whose H Gram runs on gemm_wide)
+template <typename T>
+__global__ void __launch_bounds__(256) tc_tail_kernel(TcTail tail) { tc_tail_block<T>(tail); }
+
 // update_tangent on demand (lcx_read_state of the current solution before any trial was evaluated)
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -755,21 +767,22 @@ __global__ void invert_kernel(const double* __restrict__ a, int Mp, double* __re
 // optional outputs (may be null): mi_o, xz_o [Vp][Mp], x2y_o [Vp]
 // dynamic LDS: ri_s[Mp*Mp] (T) + rho_s[VPB*Mp] (T) + acc_s[VPB*Mp] (double)
 template <typename T, int Mp>
-__global__ void __launch_bounds__(PV_THREADS)
+__global__ void __launch_bounds__(Pvt<Mp>::v)
 detail_kernel(const T* __restrict__ rho_i, const double* __restrict__ ryinv, int64_t V, int m,
               T* __restrict__ mi_o, T* __restrict__ xz_o, T* __restrict__ x2y_o,
               double* __restrict__ dpart_sums, const double* __restrict__ xz_fscale = nullptr,
               T* __restrict__ inv_x2y_o = nullptr) {
-    constexpr int VPB = PV_THREADS / Mp;
+    constexpr int NT = Pvt<Mp>::v;
+    constexpr int VPB = NT / Mp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* ri_s = reinterpret_cast<T*>(smem_raw);
     T* rho_s = ri_s + (OpInLds<Mp>::v ? Mp * Mp : 0);
     double* acc_s = reinterpret_cast<double*>(rho_s + VPB * Mp + (((VPB * Mp) & 1) ? 1 : 0));
-    __shared__ T gs_scratch[PV_THREADS / 64];
-    __shared__ double bs_scratch[PV_THREADS / 64];
+    __shared__ T gs_scratch[NT / 64];
+    __shared__ double bs_scratch[NT / 64];
     const int tid = threadIdx.x, vl = tid / Mp, j = tid % Mp;
     if (OpInLds<Mp>::v)
-        for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) ri_s[idx] = (T)ryinv[idx];
+        for (int idx = tid; idx < Mp * Mp; idx += NT) ri_s[idx] = (T)ryinv[idx];
     __syncthreads();
     double col_mi = 0.0, s_max = 0.0, s_ixy = 0.0;
     const int64_t ngroups = (V + VPB - 1) / VPB;
@@ -831,9 +844,9 @@ detail_kernel(const T* __restrict__ rho_i, const double* __restrict__ ryinv, int
         for (int k = 0; k < VPB; ++k) colsum += acc_s[k * Mp + tid];
         outp[tid] = colsum;
     }
-    const double tot = block_sum<double>(tid < m ? colsum : 0.0, bs_scratch, tid);
-    s_max = block_sum<double>(s_max, bs_scratch, tid);
-    s_ixy = block_sum<double>(s_ixy, bs_scratch, tid);
+    const double tot = block_sum<double, NT>(tid < m ? colsum : 0.0, bs_scratch, tid);
+    s_max = block_sum<double, NT>(s_max, bs_scratch, tid);
+    s_ixy = block_sum<double, NT>(s_ixy, bs_scratch, tid);
     if (tid == 0) { outp[m] = s_max; outp[m + 1] = s_ixy; outp[m + 2] = tot; }
 }
 
@@ -849,8 +862,6 @@ __global__ void __launch_bounds__(256)
 syn_small_kernel(const T* __restrict__ gy, int nsplit, int Mp, int m, double n_samples, double yscale,
                  double* __restrict__ cy, double* __restrict__ yj2, double* __restrict__ ry,
                  double* __restrict__ inv_sd, SetState* st) {
-    __shared__ double sd_s[256];
-    __shared__ double lg_s[256];
     const int tid = threadIdx.x;
     const int mm = Mp * Mp;
     for (int idx = tid; idx < mm; idx += blockDim.x) {
@@ -862,22 +873,20 @@ syn_small_kernel(const T* __restrict__ gy, int nsplit, int Mp, int m, double n_s
         cy[idx] = (double)c;
     }
     __syncthreads();
-    if (tid < Mp) {
-        const double d = cy[tid * Mp + tid];
-        yj2[tid] = d;
-        sd_s[tid] = sqrt((double)(T)d);
-        inv_sd[tid] = 1.0 / sd_s[tid];
-        // the reference keeps W and every moment of this branch in float64 (:121), also when x is float32
-        lg_s[tid] = tid < m ? 0.5 * log(d) - 0.5 * log(yscale * yscale) : 0.0;
+    for (int j = tid; j < Mp; j += blockDim.x) {            // (any number of factors: the wide path has more than one per thread)
+        const double d = cy[j * Mp + j];
+        yj2[j] = d;
+        inv_sd[j] = 1.0 / sqrt((double)(T)d);
     }
     __syncthreads();
     for (int idx = tid; idx < mm; idx += blockDim.x) {
         const int a = idx / Mp, b = idx % Mp;
-        ry[idx] = (double)((T)cy[idx] / ((T)sd_s[a] * (T)sd_s[b]));
+        ry[idx] = (double)((T)cy[idx] / ((T)sqrt((double)(T)yj2[a]) * (T)sqrt((double)(T)yj2[b])));
     }
     if (tid == 0) {
+        // the reference keeps W and every moment of this branch in float64 (:121), also when x is float32
         double s = 0.0;
-        for (int j = 0; j < m; ++j) s += lg_s[j];
+        for (int j = 0; j < m; ++j) s += 0.5 * log(yj2[j]) - 0.5 * log(yscale * yscale);
         st->sum_log_rj = s;           // here: sum_j I(Y_j ; X)
         st->max_uj = 0.0;
         st->invalid = 0;
@@ -908,16 +917,17 @@ __global__ void syn_tc_kernel(const double* __restrict__ sbuf, int m, SetState* 
 // _update_syn (:375-383): ws' = (1-eta) ws + eta (X_i Z_j^T / X_i^2|Y - H ws), H diagonal zeroed
 // dynamic LDS: h_s[Mp*(Mp+1)] (T) + w_s[VPB*Mp] (T)
 template <typename T, int Mp>
-__global__ void __launch_bounds__(PV_THREADS)
+__global__ void __launch_bounds__(Pvt<Mp>::v)
 syn_update_kernel(const T* __restrict__ W, const T* __restrict__ xz, const T* __restrict__ inv_x2y,
                   const double* __restrict__ H, int64_t V, T eta, T* __restrict__ w_out) {
-    constexpr int VPB = PV_THREADS / Mp;
+    constexpr int NT = Pvt<Mp>::v;
+    constexpr int VPB = NT / Mp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* h_s = reinterpret_cast<T*>(smem_raw);
     T* w_s = h_s + (OpInLds<Mp>::v ? Mp * (Mp + 1) : 0);
     const int tid = threadIdx.x, vl = tid / Mp, j = tid % Mp;
     if (OpInLds<Mp>::v)
-        for (int idx = tid; idx < Mp * Mp; idx += PV_THREADS) {
+        for (int idx = tid; idx < Mp * Mp; idx += NT) {
             const int a = idx / Mp, b = idx % Mp;
             h_s[a * (Mp + 1) + b] = (a == b) ? (T)0 : (T)H[idx];
         }

@@ -62,10 +62,11 @@ def launch_hip(world, out_dir, n, v, m, mode, exchange="engine"):
 # world 3 runs in the CPU suite; on the GPU box gloo needs ~4 minutes for it
 @pytest.mark.parametrize("world,mode,shape,exchange", [
     (2, "exact", (400, 331, 5), "engine"), (2, "exact", (400, 331, 5), "torch"), (2, "linear", (400, 331, 5), "engine"),
-    (2, "linear", (400, 331, 5), "torch"), (2, "exact", (300, 6001, 8), "engine")])
+    (2, "linear", (400, 331, 5), "torch"), (2, "exact", (300, 6001, 8), "engine"), (2, "exact", (260, 391, 300), "engine")])
 def test_sharded_fit_on_device_matches_oracle(world, mode, shape, exchange, tmp_path):
     # (400, 331, 5): uneven shards, ragged padding; (300, 6001, 8): few column tiles per shard - the X.W^T pass is split
-    # into dozens of slots and summed by the wide reductions before the exchange.
+    # into dozens of slots and summed by the wide reductions before the exchange; (260, 391, 300): 300 factors - the wide path
+    # (gemm_wide, one thread per factor) under the exchange.
     # exchange "engine": the all-reduces are issued by the library through its hook (the transport here is gloo) and the exact
     # line search runs inside lcx_iterate on both ranks; "torch": the host-sequenced path, torch.distributed between the levels
     n, v, m = shape

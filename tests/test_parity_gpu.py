@@ -69,6 +69,12 @@ CASES = [
     (300, 400, 200, 0.36, 23),
     (200, 333, 256, 0.0, 24),
     (520, 1100, 129, 0.6, 25),
+    # 257..1024 factors: the wide path - every contraction on gemm_wide (the factor axis tiled like any other), one thread per
+    # factor in the per-variable kernels
+    (220, 300, 300, 0.36, 26),
+    (200, 333, 512, 0.0, 27),
+    (150, 260, 600, 0.6, 28),
+    (130, 1024, 1024, 0.216, 29),
 ]
 
 
@@ -628,11 +634,46 @@ def test_more_than_128_factors_end_to_end(tag):
         assert len(hs) == len(hs_ref) and np.max(np.abs(hs - hs_ref) / np.maximum(1.0, np.abs(hs_ref))) < 1e-8
 
 
-def test_more_than_256_factors_is_refused():
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("m", [300, 520])
+def test_more_than_256_factors_end_to_end(tag, m):
+    """n_hidden above 256 (the reference takes any n_hidden, :72) on the wide path (m_pad 512 / 1024): a short fit follows the
+    oracle, clusters bit-exact on planted data in float64; transform, predict, get_covariance, the linear trial mode and the
+    synergistic branch work as well."""
+    from linearcorex_amd import Corex
+    n, v = 500, 900
+    x, grp = O.gen_planted(n, v, 12, seed=72)
+    ref = O.fit_ns(x, m, seed=0, dtype=DT[tag], max_iter=3, keep_x=True)
+    out = Corex(n_hidden=m, seed=0, max_iter=3, dtype=DT[tag], device=0).fit(x)
+    assert out._backend.geometry()["m_pad"] == (512 if m <= 512 else 1024)
+    assert "gemm_wide_kernel" in out._backend.kernel_name(0)
+    h_ref, h = np.asarray(ref.history_tc, np.float64), np.asarray(out.history["TC"], np.float64)
+    assert len(h) == len(h_ref)
+    tol = 1e-8 if tag == "f64" else 2e-3
+    assert np.max(np.abs(h - h_ref) / np.maximum(1.0, np.abs(h_ref))) < tol
+    assert relerr(out.transform(x), ref.transform(ref.x_tilde)) < (1e-7 if tag == "f64" else 2e-3)
+    if tag == "f64":
+        assert np.array_equal(out.clusters(), ref.clusters())
+        assert relerr(out.ws, ref.ws) < 1e-6
+        assert relerr(out.get_covariance(), ref.get_covariance()) < 1e-6
+        assert relerr(out.moments["X_i Z_j"], ref.moments["X_i Z_j"]) < 1e-6
+        y = ref.transform(ref.x_tilde)[:40]
+        assert relerr(out.predict(y), O.predict(ref.moments["X_i Z_j"], y, ref.theta)) < 1e-6
+        if m == 300:
+            lin = Corex(n_hidden=m, seed=0, max_iter=3, dtype=np.float64, device=0, line_search="linear").fit(x)
+            hl = np.asarray(lin.history["TC"], np.float64)
+            assert len(hl) == len(h_ref) and np.max(np.abs(hl - h_ref) / np.maximum(1.0, np.abs(h_ref))) < 1e-6
+            syn_ref = O.fit_syn(x, m, seed=0, dtype=np.float64, max_iter=4)
+            syn = Corex(n_hidden=m, seed=0, max_iter=4, dtype=np.float64, device=0, discourage_overlap=False).fit(x)
+            hs, hs_ref = np.asarray(syn.history["TC"], np.float64), np.asarray(syn_ref.history_tc)
+            assert len(hs) == len(hs_ref) and np.max(np.abs(hs - hs_ref) / np.maximum(1.0, np.abs(hs_ref))) < 1e-8
+
+
+def test_more_than_1024_factors_is_refused():
     from linearcorex_amd import Corex
     from linearcorex_amd._abi import LcxError
-    with pytest.raises(LcxError, match="n_hidden > 256"):
-        Corex(n_hidden=257, seed=0, device=0).fit(np.random.RandomState(0).randn(50, 300))
+    with pytest.raises(LcxError, match="n_hidden > 1024"):
+        Corex(n_hidden=1025, seed=0, device=0).fit(np.random.RandomState(0).randn(50, 300))
 
 
 @pytest.mark.parametrize("m", [24, 64])

@@ -1184,7 +1184,7 @@ template <typename T, int CT> struct Impl {
     // detail sums; optionally materialise MI / XiZj / Xi2|Y into scratch arrays
     static int detail(lcx_ctx* h, int which, T* mi_o, T* xz_o, T* x2y_o) {
         MomentSet& s = h->set[which];
-        hipLaunchKernelGGL(invert_kernel, dim3(1), dim3(256), 0, h->stream, s.ry, Mp, h->invwork, h->ryinv);
+        hipLaunchKernelGGL(invert_kernel, dim3(1), dim3(WIDE ? 1024 : 256), 0, h->stream, s.ry, Mp, h->invwork, h->ryinv);
         KCHECK();
         const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * Mp : 0) + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
         LCXCHECK(allow_lds(detail_kernel<T, Mp>, lds));
@@ -1226,7 +1226,7 @@ template <typename T, int CT> struct Impl {
         hipLaunchKernelGGL((syn_rho_kernel<T>), dim3((unsigned)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048)), dim3(256), 0, h->stream,
                            P<T>(h->dpart), h->tn_slots, h->ldx * Mp, total, Mp, (double)h->N, s.inv_sd, P<T>(s.D), P<T>(s.rho));
         KCHECK();
-        hipLaunchKernelGGL(invert_kernel, dim3(1), dim3(256), 0, h->stream, s.ry, Mp, h->invwork, h->ryinv);
+        hipLaunchKernelGGL(invert_kernel, dim3(1), dim3(WIDE ? 1024 : 256), 0, h->stream, s.ry, Mp, h->invwork, h->ryinv);
         KCHECK();
         const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * Mp : 0) + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
         LCXCHECK(allow_lds(detail_kernel<T, Mp>, lds));

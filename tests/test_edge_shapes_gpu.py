@@ -89,7 +89,7 @@ def test_abi_misuse_returns_status_codes():
     assert lib.lcx_create(C.byref(h), 0, 10, 2, 0, 0) == ARG                 # no samples
     assert lib.lcx_create(C.byref(h), 10, 10, 2, 7, 0) == ARG                # unknown dtype
     assert lib.lcx_create(C.byref(h), 10, 10, 2, 0, 99) == ARG               # no such device
-    assert lib.lcx_create(C.byref(h), 10, 10, 300, 0, 0) == ARG              # more than 256 factors
+    assert lib.lcx_create(C.byref(h), 10, 10, 1025, 0, 0) == ARG             # more than 1024 factors
     be = HipBackend(64, 40, 3, np.float64, 0)
     assert lib.lcx_moments_a(be.h, 2) == ARG                                  # which must be 0 or 1
     assert lib.lcx_make_trial(be.h, C.c_double(1.0)) == STATE                 # no direction yet

@@ -1,0 +1,67 @@
+"""Randomised end-to-end parity of the round-3 device paths (float64, seeded): every gaussianize option with and without missing
+cells, one or two resident copies of the shard, up to 600 factors (the wide path) - fit, transform of the training data and of
+a NEW batch (whose imputation / rank transform needs whole columns of that batch), predict and invert against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import corex_oracle as O
+from tests.test_parity_gpu import relerr
+
+pytestmark = pytest.mark.gpu
+
+rng = np.random.RandomState(303)
+CASES = []
+for k in range(12):
+    n = int(rng.choice([65, 200, 513, 900]))
+    v = int(rng.choice([17, 64, 130, 300, 700]))
+    m = int(rng.choice([2, 5, 16, 33, 100, 300, 600]))
+    if m > 256:                       # the wide path: keep the problem small (its inverse is a one-block Gauss-Jordan)
+        n, v = min(n, 200), max(v, 300)
+    elif m > v:
+        m = max(1, v // 2)
+    gz = ["standard", "outliers", "empirical", "none"][k % 4]
+    missing = k % 3 == 1
+    single = k % 2 == 0
+    CASES.append((n, v, m, gz, missing, single, int(rng.randint(1, 1000))))
+
+
+@pytest.mark.parametrize("n,v,m,gz,missing,single,seed", CASES)
+def test_random_features(n, v, m, gz, missing, single, seed, monkeypatch, capsys):
+    from linearcorex_amd import Corex
+    monkeypatch.setenv("LCX_SINGLE_COPY", "1" if single else "0")
+    r = np.random.RandomState(seed)
+    x, _ = O.gen_planted(n, v, max(1, min(m, 5)), seed=seed)
+    x = x * (0.5 + 2 * r.rand(v)) + 3 * r.randn(v)                 # marginals with their own location and scale
+    x[:, ::7] = np.sign(x[:, ::7]) * np.abs(x[:, ::7]) ** 1.6      # some heavy tails
+    x[:, 1::9] = np.round(x[:, 1::9])                              # some ties (ranks of the empirical transform)
+    if gz == "none":                                               # passes the data through: the fit then needs standard marginals
+        x = (x - x.mean(axis=0)) / x.std(axis=0)
+    x2 = x[r.permutation(n)[: max(3, n // 3)]] + 0.1 * r.randn(max(3, n // 3), v)
+    mv = None
+    if missing:
+        mv = -1e6
+        x = x.copy(); x[r.rand(n, v) < 0.04] = mv
+        x2 = x2.copy(); x2[r.rand(*x2.shape) < 0.04] = mv
+    iters = 3 if m > 256 else 8
+    ref = O.fit_ns(x, m, seed=0, dtype=np.float64, max_iter=iters, gaussianize=gz, missing_values=mv, keep_x=True)
+    out = Corex(n_hidden=m, seed=0, dtype=np.float64, device=0, max_iter=iters, gaussianize=gz, missing_values=mv).fit(x)
+    capsys.readouterr()
+    be = out._backend
+    assert ("gemm_cr_kernel" in be.kernel_name(0) or "gemm_wide_kernel" in be.kernel_name(0)) == (single or m > 256)
+    h, hr = np.asarray(out.history["TC"], np.float64), np.asarray(ref.history_tc)
+    assert len(h) == len(hr), (len(h), len(hr))
+    assert relerr(h, hr) < 1e-6
+    assert relerr(out.ws, ref.ws) < 1e-5
+    assert np.array_equal(out.clusters(), ref.clusters())
+    if mv is not None:
+        assert np.array_equal(out.n_obs, np.sum(x != mv, axis=0))
+    y_ref = ref.transform(ref.x_tilde)
+    assert relerr(out.transform(x), y_ref) < 1e-6
+    x2t = O.preprocess(x2.copy(), ref.theta, gz, mv)[0]
+    assert relerr(out.transform(x2), x2t.dot(ref.ws.T)) < 1e-6     # a new batch: imputed / ranked by itself (:403, :424-426)
+    pred_ref = O.predict(ref.moments["X_i Z_j"], y_ref[:11], ref.theta, gz)
+    assert relerr(out.predict(y_ref[:11]), pred_ref) < 1e-6
+    z = r.randn(5, v) * 2
+    assert relerr(out.invert(z), O.invert(z, ref.theta, gz)) < 1e-12
+    assert relerr(out.get_covariance(), ref.get_covariance()) < 1e-6 if gz in ("standard", "outliers") else True
+    be.close()

@@ -918,17 +918,22 @@ def main():
             # matrix is the one the 8-rank run shards: this is that run's single-process counterpart.  Short windows (an
             # iteration is ~0.45 s); not a headline
             if args.c4full_steps > 0:
-                r6, model6, be6 = measure(args, comm, world, rank, local_rank, "c4full", args.c4full_steps, 1, "exact", repeats=1)
-                c6 = config_of("c4full", r6, world, "exact")
-                c6["value"] = r6["its_per_s"]
-                c6["ms_per_step"] = r6["per_step_s"] * 1e3
-                c6["dtype"] = "f32"
-                c6["roofline"] = roofline_of("c4full", r6, world)
-                c6["kernels"] = r6["kernel_names"]
-                be6.close()
-                model6._backend = None
-                del model6, be6
-                out["config"]["c4_unsharded_one_gpu"] = c6
+                # 209 GB on one GPU: if the device cannot give that (another tenant, fragmentation) the block reports the error
+                # and the line goes out without it - the headline does not depend on it
+                try:
+                    r6, model6, be6 = measure(args, comm, world, rank, local_rank, "c4full", args.c4full_steps, 1, "exact", repeats=1)
+                    c6 = config_of("c4full", r6, world, "exact")
+                    c6["value"] = r6["its_per_s"]
+                    c6["ms_per_step"] = r6["per_step_s"] * 1e3
+                    c6["dtype"] = "f32"
+                    c6["roofline"] = roofline_of("c4full", r6, world)
+                    c6["kernels"] = r6["kernel_names"]
+                    be6.close()
+                    model6._backend = None
+                    del model6, be6
+                    out["config"]["c4_unsharded_one_gpu"] = c6
+                except Exception as e:          # noqa: BLE001
+                    out["config"]["c4_unsharded_one_gpu"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
         # ---- CPU baseline of the headline workload: rank 0, the other ranks wait in the barrier below ----
         if rank == 0 and args.cpu_seconds > 0 and (world == 1 and comm is None or world > 1):

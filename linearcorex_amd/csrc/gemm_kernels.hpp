@@ -787,25 +787,35 @@ gemm_wide_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, 
     acc_t acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = (acc_t){0, 0, 0, 0};
+    // staging: thread -> one 4-element vector of A (TRANS_A: row k = tid / 16, 4 consecutive m; else row m = tid / 4, 4 consecutive k)
+    // and one of B (row k = tid / 16, 4 consecutive n); the vectors of step st + 1 are in flight while step st multiplies
+    const int ak = TRANS_A ? (tid >> 4) : (tid & 3) * 4, am = TRANS_A ? (tid & 15) * 4 : (tid >> 2);
+    const int bk = tid >> 4, bn = (tid & 15) * 4;
+    const T* asrc = TRANS_A ? A + (int64_t)ak * lda + m0 + am : A + (m0 + am) * lda + ak;
+    const T* bsrc = B + (int64_t)bk * ldb + n0 + bn;
+    Pk<T, 4> a4, b4;
+    if (s0 < s1) {
+        a4 = ldg<T, 4>(TRANS_A ? asrc + s0 * 16 * lda : asrc + s0 * 16);
+        b4 = ldg<T, 4>(bsrc + s0 * 16 * ldb);
+    }
     for (int64_t st = s0; st < s1; ++st) {
         const int64_t k0 = st * 16;
         __syncthreads();
-        if (TRANS_A) {                // A[k][m]: thread -> (k = tid / 16, 4 consecutive m)
-            const int k = tid >> 4, mm = (tid & 15) * 4;
-            const T sc = SCALE ? rowscale[k0 + k] : (T)1;
+        if (TRANS_A) {
+            const T sc = SCALE ? rowscale[k0 + ak] : (T)1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) As[mm + e][k] = A[(k0 + k) * lda + m0 + mm + e] * sc;
-        } else {                      // A[m][k]: thread -> (m = tid / 4, 4 consecutive k)
-            const int mm = tid >> 2, k = (tid & 3) * 4;
+            for (int e = 0; e < 4; ++e) As[am + e][ak] = a4.v[e] * sc;
+        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) As[mm][k + e] = A[(m0 + mm) * lda + k0 + k + e] * (SCALE ? rowscale[k0 + k + e] : (T)1);
+            for (int e = 0; e < 4; ++e) As[am][ak + e] = a4.v[e] * (SCALE ? rowscale[k0 + ak + e] : (T)1);
         }
-        {
-            const int k = tid >> 4, nn = (tid & 15) * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) Bs[k][nn + e] = B[(k0 + k) * ldb + n0 + nn + e];
-        }
+        for (int e = 0; e < 4; ++e) Bs[bk][bn + e] = b4.v[e];
         __syncthreads();
+        if (st + 1 < s1) {
+            a4 = ldg<T, 4>(TRANS_A ? asrc + (k0 + 16) * lda : asrc + k0 + 16);
+            b4 = ldg<T, 4>(bsrc + (k0 + 16) * ldb);
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const T av = As[16 * wave + i][4 * s + q];

@@ -235,7 +235,7 @@ class Corex(object):
         self.stats = {"iterations": 0, "moment_evals": 0, "trials": 0, "invalid_trials": 0}
         import os
         self._check_ranks = os.environ.get("LCX_CHECK_RANKS", "0") not in ("", "0")
-        # LCX_HOST_LOOP=1: sequence the levels of `_update_ns` from this class (what several ranks always do) instead of
+        # LCX_HOST_LOOP=1: sequence the levels of `_update_ns` from this class (what a caller-owned exchange needs) instead of
         # handing the whole iteration to the engine (lcx_iterate) - same results, kept selectable for tests
         self._in_library = os.environ.get("LCX_HOST_LOOP", "0") in ("", "0")
 

@@ -1,7 +1,9 @@
-"""Host-side marginal preprocessing (reference: linearcorex.py:397-429, :483-524).
+"""The reference's module-level helpers (`g`, `g_inv`, `mean_impute`, `random_impute`; linearcorex.py:483-524) and the host
+form of `Corex.preprocess(x)` (:397-429), which returns a host array by contract.
 
-A one-off O(n_samples * n_variables) pass either side of the accelerated path;
-kept on the host in NumPy for now, with the reference's exact conventions:
+`fit`, `transform`, `predict` and `invert` do NOT come through here: they preprocess on the device (lcx_upload_preprocess /
+lcx_project_raw / lcx_predict / lcx_invert, include/lcx.h).  What is kept are the reference's exact conventions for callers that use
+these functions directly:
   * 'standard'  : mean / sqrt(sum((x-mean)^2)/n_obs) with per-column n_obs when values are missing,
                   std clipped at 1e-10 (:411-415);
   * 'outliers'  : np.std(ddof=0) scaling followed by the tanh tail squash `g` (:418-423);

@@ -104,7 +104,7 @@ def parse(argv=None):
     ap.add_argument("--force-exchange", action="store_true",
                     help="1 GPU only: run the multi-rank device path (world>1 kernels + RCCL all-reduces in a group of "
                          "one rank) to measure the fixed cost of the exchange steps")
-    ap.add_argument("--line-search", default="exact", choices=["linear", "exact"],
+    ap.add_argument("--line-search", default="exact", choices=["linear", "exact", "exact-y"],
                     help="exact (default, the headline): reference-shaped, every trial makes 2 passes over X "
                          "(linearcorex.py:321); linear: trials cost no pass over X")
     ap.add_argument("--repeats", type=int, default=0, help="walks of the schedule (0 = as many as MIN_TIMED_SECONDS needs)")
@@ -823,6 +823,14 @@ def main():
         be3.close()
         model3._backend = None
         del model3, be3
+        # in between: only the trials AFTER the first one of an iteration reuse products, and only on the Y side (lcx_set_trial_reuse)
+        r3, model3, be3 = measure(args, comm, world, rank, local_rank, head, args.steps, args.warmup, "exact-y")
+        cfg["later_trials_by_linearity"] = dict(linear_mode_block(head, r3, world), refresh_every=None,
+                                                what="line_search='exact-y': trials after the first take X.w_update^T by linearity "
+                                                     "from the iteration's own exact products; one X pass per such trial instead of two")
+        be3.close()
+        model3._backend = None
+        del model3, be3
     if args.extras and world == 1 and comm is None and generated and args.convergence_max_iter > 0:
         # BASELINE.json's second figure for the headline workload.  On the iid matrix of the throughput run there is nothing to
         # converge to (every stage runs into the cap): that run is labelled as capped, and the convergence measurement proper is
@@ -909,6 +917,11 @@ def main():
             del model4, be4
             r5, model5, be5 = measure(args, comm, world, rank, local_rank, "c4shard", 10, 3, "linear")
             c4["linear_trial_mode"] = linear_mode_block("c4shard", r5, world)
+            be5.close()
+            model5._backend = None
+            del model5, be5
+            r5, model5, be5 = measure(args, comm, world, rank, local_rank, "c4shard", 10, 3, "exact-y")
+            c4["later_trials_by_linearity"] = dict(linear_mode_block("c4shard", r5, world), refresh_every=None)
             be5.close()
             model5._backend = None
             del model5, be5

@@ -251,6 +251,13 @@ int lcx_accept_trial(lcx_ctx* h);
  * arguments and gets the same answer.  While the caller owns the exchange (neither bound) it sequences the levels itself and
  * this call returns LCX_ERR_STATE. */
 int lcx_iterate(lcx_ctx* h, double eps, double tol, double tc_cur, int more, double* out8);
+/* enable != 0: inside lcx_iterate the back-tracking trials AFTER the first one of an iteration (:320-321 at eta = 1/2, 1/4, ...)
+ * take X.w_update^T by linearity - Y + eta X.update^T, both already computed exactly by this iteration (:247 of the accepted
+ * solution, :210 through lcx_update_c) - and make ONE pass over X (X^T.Y', :259) instead of two.  Same mathematics as :321, other
+ * rounding (an exact re-association like the Y-space update_tangent of lcx_set_linear_mode(0)); nothing is carried across
+ * iterations but the Y of an accepted solution, which each step mixes convexly with fresh products (no drift, no re-anchoring).
+ * Off by default: the default iteration re-evaluates every trial with two passes, as the reference does. */
+int lcx_set_trial_reuse(lcx_ctx* h, int enable);
 
 /* ---- synergistic branch: discourage_overlap=False (:336-384) -------------------------------------
  * One evaluation of _calculate_moments_syn on set `which`:

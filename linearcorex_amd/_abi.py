@@ -38,6 +38,7 @@ SIGNATURES = {
     "lcx_synchronize": [_vp],
     "lcx_set_world": [_vp, _i32],
     "lcx_set_linear_mode": [_vp, _i32],
+    "lcx_set_trial_reuse": [_vp, _i32],
     "lcx_set_exchange": [_vp, _i32],
     "lcx_exchange_layout": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_vp)],
     "lcx_bind_exchange": [_vp, _vp, _vp],

@@ -117,6 +117,9 @@ class HipBackend:
     def set_linear_mode(self, enable):
         _abi.check(self.lib.lcx_set_linear_mode(self.h, 1 if enable else 0))
 
+    def set_trial_reuse(self, enable):
+        _abi.check(self.lib.lcx_set_trial_reuse(self.h, 1 if enable else 0))
+
     def synchronize(self):
         _abi.check(self.lib.lcx_synchronize(self.h))
 

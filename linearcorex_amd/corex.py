@@ -183,6 +183,9 @@ class Corex(object):
               moments follow from the direction already computed for `_sig` (:301) and cost no pass
               over X - same mathematics, different rounding; the solution is re-evaluated exactly
               every `refresh_every` iterations and at every annealing stage.
+              "exact-y": as "exact", except that the trials AFTER the first one of an iteration take X.w_update^T by
+              linearity from this iteration's own exact products (one pass over X per such trial instead of two; no drift,
+              no re-anchoring - include/lcx.h, lcx_set_trial_reuse).  Needs the line search inside the library.
     """
 
     # defaults for models pickled by an earlier build
@@ -227,8 +230,8 @@ class Corex(object):
         self._engine_exchange = None
         self._cols = (0, 0)
         self._tc_cur = np.nan
-        if line_search not in ("exact", "linear"):
-            raise ValueError("line_search must be 'exact' or 'linear'")
+        if line_search not in ("exact", "linear", "exact-y"):
+            raise ValueError("line_search must be 'exact', 'linear' or 'exact-y'")
         self.line_search = line_search
         self.refresh_every = int(refresh_every)
         self._since_exact = 0
@@ -276,6 +279,8 @@ class Corex(object):
         self._backend = be
         if hasattr(be, "set_linear_mode"):
             be.set_linear_mode(self.line_search == "linear")
+        if self.line_search == "exact-y":
+            be.set_trial_reuse(True)
         exchange = getattr(self._comm, "exchange", self._comm.world > 1)
         be.set_world(self._comm.world)
         if exchange and self._comm.world == 1 and hasattr(be, "set_exchange"):
@@ -675,10 +680,13 @@ class Corex(object):
         new weights stay on the device)."""
         be = self._backend
         m = self.moments
-        if self._in_library and (self._ex is None or self._engine_exchange) and self.line_search == "exact" \
+        if self._in_library and (self._ex is None or self._engine_exchange) and self.line_search in ("exact", "exact-y") \
                 and self.verbose <= 1 and hasattr(be, "iterate"):
             self._iterated_in_library = True
             return self._update_ns_in_library(more)
+        if self.line_search == "exact-y":
+            raise RuntimeError("line_search='exact-y' runs inside lcx_iterate only (not with LCX_HOST_LOOP=1, verbose > 1 or a "
+                               "caller-owned exchange)")
         # H (:294) is already global: it came with the scalar exchange of the evaluation that produced set 0
         be.update_b(self.eps)                # grad (:296-300), Bj partial, Y_g partial
         self._xy()

@@ -191,6 +191,10 @@ struct lcx_ctx {
     // merged pass (float32 large shards with <= 64 padded factors): X.grad^T and the first trial's X.(ws+update)^T as ONE
     // pass over X with 2 Mp columns - half the X traffic of the two and the more efficient wide kernel
     bool merged_ok, y1_ready;   // y1_ready: ybuf / set[1].Y already hold Y of the eta = 1 trial
+    // lcx_set_trial_reuse: the trials AFTER the first one of an iteration take X.w_update^T by linearity from what the iteration has
+    // already computed exactly (Y of the current solution and X.update^T of lcx_update_c) instead of one more pass over X;
+    // yk_ready: ybuf holds the Y of such a trial
+    bool reuse_y, yk_ready;
     void *gw, *y2part, *ygbuf;  // [Vp][2 Mp] operand [grad | ws + update]; partial slots [S][Npad][2 Mp]; Y_g [Npad][Mp]
     int nt2_nb, nt2_nsuper, nt2_S;
     // launch geometry
@@ -772,7 +776,11 @@ template <typename T, int CT> struct Impl {
             h->y1_ready = false;
             return LCX_OK;
         }
-        h->y1_ready = false;
+        if (which == 1 && h->yk_ready) {                        // trial_by_linearity left it in ybuf (and the W'.W'^T tail, if exchanged)
+            h->yk_ready = false;
+            return LCX_OK;
+        }
+        h->y1_ready = h->yk_ready = false;
         T* w = P<T>(h->Wt[which]);
         // without an exchange the summed Y is final: the set's own copy is written by the same reduction
         LCXCHECK(nt_big(h, w, nullptr, false, (!h->exchange && h->nt_S > 1) ? P<T>(h->set[which].Y) : (T*)nullptr));
@@ -1054,6 +1062,29 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
 
+    // A back-tracking trial after the first one (:320-321 at eta = 1/2, 1/4, ...): w_update = ws + eta update, and - X.u^T being
+    // linear in u - X.w_update^T = Y + eta X.update^T, where Y belongs to the current solution and X.update^T = -rj (Y_g - c Y)
+    // is what lcx_update_c formed from this iteration's exact pass X.grad^T.  The trial then needs ONE pass over X (X^T.Y') instead of
+    // two.  Nothing is carried across iterations except the Y of an accepted solution, which every such step mixes with fresh
+    // products in a convex combination: no drift, no re-anchoring (unlike the linear trial mode, which also reuses X^T.Y).
+    static int trial_by_linearity(lcx_ctx* h, double eta) {
+        const int64_t n1 = h->V * Mp, n2 = h->Npad * Mp;
+        hipLaunchKernelGGL((axpy2_kernel<T>), dim3((unsigned)(cdiv(n1 + n2, 256) < 2048 ? cdiv(n1 + n2, 256) : 2048)), dim3(256), 0,
+                           h->stream, P<T>(h->Wt[0]), P<T>(h->update), P<T>(h->Wt[1]), n1,
+                           P<T>(h->set[0].Y), P<T>(h->ydir), P<T>(h->ybuf), n2, (T)eta);
+        KCHECK();
+        if (h->exchange) {
+            // Y and X.update^T are already sums over all ranks; only W'.W'^T of the trial is still per shard
+            LCXCHECK(gram_w(h, P<T>(h->Wt[1])));
+            LCXCHECK(exchange(h, P<T>(h->ybuf) + h->Npad * Mp, (int64_t)Mp * Mp, DT));
+        } else if (h->nt_S > 1) {
+            HIPCHECK(hipMemcpyAsync(h->set[1].Y, h->ybuf, (size_t)n2 * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+        }
+        h->w1_ready = h->y1_ready = false;
+        h->yk_ready = true;
+        return LCX_OK;
+    }
+
     // ---- one whole fixed-point iteration with its back-tracking line search (:290-334), one GPU -------------------
     // :321 for the weights in set 1, and right behind it the gradient those weights would need next (:296-300): if the trial
     // is accepted that gradient is already there when the host has decided, if not it is overwritten by the next trial's
@@ -1085,7 +1116,7 @@ template <typename T, int CT> struct Impl {
             // direction / trial flags half set: make the level API start over (lcx_update_b then restores the H of set 0)
             h->spec_pending = false;
             h->spec_dirty = true;
-            h->early_grad = h->grad_ready = h->have_direction = h->w1_ready = h->y1_ready = false;
+            h->early_grad = h->grad_ready = h->have_direction = h->w1_ready = h->y1_ready = h->yk_ready = false;
         }
         return rc;
     }
@@ -1105,7 +1136,8 @@ template <typename T, int CT> struct Impl {
         while (true) {
             if (!first) {
                 if (eta < eta_min) { too_small = 1; break; }                     // :316-319
-                LCXCHECK(make_trial(h, eta));                                    // :320
+                if (h->reuse_y && !h->full_sig) LCXCHECK(trial_by_linearity(h, eta));
+                else LCXCHECK(make_trial(h, eta));                               // :320
                 LCXCHECK(evaluate_trial(h, eps));                                // :321
             }
             ++trials;
@@ -1929,10 +1961,10 @@ static inline void cancel_speculation(lcx_ctx* h) {
         h->early_grad = h->grad_ready = false;
         h->spec_dirty = true;
         h->have_direction = false;
-        h->w1_ready = h->y1_ready = false;
+        h->w1_ready = h->y1_ready = h->yk_ready = false;
     }
 }
-#define NEED_MUT(h) NEED(h); cancel_speculation(h); (h)->early_grad = (h)->grad_ready = false
+#define NEED_MUT(h) NEED(h); cancel_speculation(h); (h)->early_grad = (h)->grad_ready = (h)->yk_ready = false
 
 // -------------------------------------------------------------------------------------------------
 // C ABI
@@ -2472,6 +2504,13 @@ int lcx_read_state(lcx_ctx* h, int which, double* out) {
     out[LCX_S_TANGENT] = s.tangent;
     out[LCX_S_SUM_LOG_RJ] = s.sum_log_rj;
     out[5] = out[6] = out[7] = 0.0;
+    return LCX_OK;
+}
+
+int lcx_set_trial_reuse(lcx_ctx* h, int enable) {
+    NEED_MUT(h);
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    h->reuse_y = enable != 0;
     return LCX_OK;
 }
 

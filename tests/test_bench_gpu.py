@@ -71,6 +71,9 @@ def test_default_line_is_the_c3_line_with_the_c2_block():
     assert c6["bytes_resident"]["total"] < 250e9
     # linear trial mode, reported beside the reference-shaped figure at the sizes where a trial costs two long passes
     for blk in (d["config"], c4):
+        mid = blk["later_trials_by_linearity"]               # line_search="exact-y": between the reference-shaped and the linear mode
+        assert mid["fit_iterations_per_sec"] > blk["fit_iterations_per_sec"] if "fit_iterations_per_sec" in blk else True
+        assert blk["linear_trial_mode"]["x_passes_per_iteration"] < mid["x_passes_per_iteration"] < blk["x_passes_per_iteration"]
         lin = blk["linear_trial_mode"]
         assert lin["fit_iterations_per_sec"] > 0 and 1.9 < lin["x_passes_per_iteration"] < 2.6
         assert lin["roofline"]["bound"] == "mfma"

@@ -110,25 +110,30 @@ def _rel(a, b):
     return float(np.max(np.abs(a - b)) / max(1e-300, float(np.max(np.abs(b)))))
 
 
-@pytest.mark.parametrize("shape,kind", [((50000, 100000, 64), 0), ((50000, 125000, 128), 1)], ids=["config3", "config4_shard"])
-def test_full_size_step_vs_oracle(shape, kind):
+@pytest.mark.parametrize("shape,kind,reuse", [((50000, 100000, 64), 0, False), ((50000, 125000, 128), 1, False),
+                                              ((50000, 125000, 128), 1, True)],
+                         ids=["config3", "config4_shard", "config4_shard_later_trials_by_linearity"])
+def test_full_size_step_vs_oracle(shape, kind, reuse):
     """BASELINE configs[2] and the configs[3] shard at FULL size against the oracle, element by element: the resident matrix is
     copied back (20 / 25 GB), and one `_calculate_moments_ns` (reference :236-275), one update direction (:292-305) and one
     whole `_update_ns` with its back-tracking (:306-334) run in NumPy float32 on the host cores - what the reference computes -
     beside the device path (gemm_ct stream-K slots, 64-bit offsets, the merged pass of config 3, lcx_iterate).
-    Bars: the float32 step bar of tests/test_parity_gpu.py (2e-4 of the array scale; x10 for derived arrays, as there)."""
+    Bars: the float32 step bar of tests/test_parity_gpu.py (2e-4 of the array scale; x10 for derived arrays, as there).
+    Third case: the same with lcx_set_trial_reuse (the iteration of the configs[3] shard back-tracks 7 times: trials 2..8 take
+    X.w_update^T by linearity) - same accepted step, same trial count, same bars against the oracle's two-pass trials."""
     from linearcorex_amd.backend import HipBackend
     from oracle import corex_oracle as O
     from bench import _BlasPool                                 # BLAS threads = the cores the cgroup really grants
     with _BlasPool():
-        _full_size_step(shape, kind, HipBackend, O)
+        _full_size_step(shape, kind, HipBackend, O, reuse)
 
 
-def _full_size_step(shape, kind, HipBackend, O):
+def _full_size_step(shape, kind, HipBackend, O, reuse=False):
     n, v, m = shape
     tol, eps = 2e-4, 0.36
     be = HipBackend(n, v, m, np.float32, 0)
     be.set_linear_mode(False)                                    # what `Corex(line_search="exact")` runs
+    be.set_trial_reuse(reuse)                                    # True: line_search="exact-y" (trials 2..8 of the shard's iteration by linearity)
     assert "gemm_ct_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)
     be.generate_x(1, kind, m, 0)
     x = be.download_x()

@@ -789,3 +789,54 @@ def test_single_copy_merged_pass_and_empirical(monkeypatch):
     orc = O.fit_ns(xr, 3, seed=0, dtype=np.float64, max_iter=5, gaussianize="none")
     assert np.max(np.abs(np.asarray(out.history["TC"], np.float64) - np.asarray(orc.history_tc))) < 1e-9
     out._backend.close()
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_later_trials_by_linearity(tag, monkeypatch):
+    """line_search='exact-y' (lcx_set_trial_reuse): the back-tracking trials after the first one of an iteration take
+    X.w_update^T = Y + eta X.update^T from the iteration's own exact products and make one pass over X instead of two.  An exact
+    re-association: the trajectory must equal the reference-shaped one to rounding - float64 1e-10 on the TC history, float32 on
+    the large-shard kernels (gemm_ct, 4096 x 8192, 128 factors) within 5e-5 - with the same number of trials in every iteration
+    that still moves TC (on a converged plateau the Wolfe test compares rounding noise and either run may halve eta a few more
+    times), and it must really save passes: every trial after the first skips its X.B^T launch."""
+    from linearcorex_amd import Corex
+    from linearcorex_amd.preprocess import preprocess as pp
+    if tag == "f64":
+        x, _ = O.gen_planted(700, 900, 6, seed=91)
+        m, iters, dt = 6, 25, np.float64
+    else:
+        monkeypatch.setenv("LCX_GEMM", "ct")
+        x, _ = O.gen_planted(4096, 8192, 128, seed=51)
+        m, iters, dt = 128, 12, np.float32
+    xt = pp(x.astype(dt), None, "standard", None)[0]
+    runs = {}
+    for mode in ("exact", "exact-y"):
+        model = Corex(n_hidden=m, seed=0, dtype=dt, tol=0.0, device=0, line_search=mode)
+        be = model._attach_shard(xt, x.shape[1])
+        be.timing_enable(True)
+        per = []
+        for i_eps, eps in enumerate(model._init_weights()):
+            model._begin_stage(i_eps, eps)
+            for k in range(iters):
+                t0 = model.stats["trials"]
+                model._iterate(more=k + 1 < iters)
+                per.append(model.stats["trials"] - t0)
+        passes = be.timing_passes_by_kind()
+        runs[mode] = (np.asarray(model.history["TC"], np.float64), be.get_ws(0), np.asarray(per), passes)
+        be.close()
+    (h0, w0, t0, p0), (h1, w1, t1, p1) = runs["exact"], runs["exact-y"]
+    assert len(h0) == len(h1) == 7 * iters
+    tol = 1e-10 if tag == "f64" else 5e-5
+    assert np.max(np.abs(h1 - h0) / np.maximum(1.0, np.abs(h0))) < tol
+    assert relerr(w1, w0) < (1e-8 if tag == "f64" else 5e-3)
+    prev = np.concatenate([[h0[0] - 1.0], h0[:-1]])
+    moving = np.abs(h0 - prev) > (1e-9 if tag == "f64" else 1e-5) * np.abs(h0)         # iterations that still move TC
+    assert moving.sum() > 3 * iters and t0[moving].sum() > moving.sum() + 5             # ... and back-track now and then
+    assert np.array_equal(t0[moving], t1[moving])
+    # every trial after the first one of its iteration skipped its X.B^T pass; the X^T.Y passes are all there
+    nt1 = p1["gemm_nt"] + p1["gemm_nt2"]
+    assert nt1 <= 7 * iters * 2 + 20, (nt1, p1)
+    assert p0["gemm_nt"] + p0["gemm_nt2"] - nt1 >= (t1 - 1).sum() - 14
+    if tag == "f64":
+        ref = O.fit_ns_preprocessed(xt, m, seed=0, dtype=dt, max_iter=iters, tol=0.0, finish=False)
+        assert np.max(np.abs(h1 - np.asarray(ref.history_tc)) / np.maximum(1.0, np.abs(h1))) < 1e-8

@@ -37,7 +37,8 @@ def main():
     comm = Comm()
     xt = planted_f32(n, v, m)
     c0, c1 = comm.shard(v)
-    model = Corex(n_hidden=m, seed=0, dtype=np.float32, tol=0.0, device=0, comm=comm)
+    model = Corex(n_hidden=m, seed=0, dtype=np.float32, tol=0.0, device=0, comm=comm,
+                  line_search=os.environ.get("LCX_TEST_LINE_SEARCH", "exact"))
     be = model._attach_shard(np.ascontiguousarray(xt[:, c0:c1]), v)
     names = (be.kernel_name(0), be.kernel_name(1), be.kernel_name(2))
     be.timing_enable(True)

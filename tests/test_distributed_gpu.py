@@ -231,3 +231,27 @@ def test_sharded_merged_pass_under_exchange(m, tmp_path, monkeypatch):
     ref = O.fit_ns_preprocessed(xt, m, seed=0, dtype=np.float32, max_iter=iters, tol=0.0, finish=False)
     hr = np.asarray(ref.history_tc, np.float64)
     assert np.max(np.abs(h2 - hr) / np.maximum(1.0, np.abs(hr))) < 2e-3
+
+
+def test_sharded_later_trials_by_linearity(tmp_path, monkeypatch):
+    """line_search='exact-y' with two ranks: the trials after the first one of an iteration take X.w_update^T by linearity from
+    global Y and X.update^T, so they exchange only W'.W'^T (no N x m all-reduce) and make one pass over their shard.  Must walk the
+    trajectory of the reference-shaped single-GPU run to float32 rounding, with the same number of trials."""
+    from linearcorex_amd import Corex
+    from tests._dist_worker_f32 import planted_f32, run_loop
+    n, v, m, iters = 4096, 8192, 128, 6
+    _launch_f32(2, tmp_path, n, v, m, iters, extra_env={"LCX_TEST_LINE_SEARCH": "exact-y"})
+    got = np.load(os.path.join(tmp_path, "dist_f32.npz"))
+    assert int(got["world"]) == 2 and str(got["transport"]) == "hook" and bool(got["in_library"])
+    monkeypatch.setenv("LCX_GEMM", "ct")
+    xt = planted_f32(n, v, m)
+    single = Corex(n_hidden=m, seed=0, dtype=np.float32, tol=0.0, device=0)
+    be = single._attach_shard(xt, v)
+    h1 = run_loop(single, iters)
+    w1 = be.get_ws(0)
+    be.close()
+    h2 = got["history"]
+    assert len(h1) == len(h2) == 7 * iters
+    assert np.max(np.abs(h2 - h1) / np.maximum(1.0, np.abs(h1))) < 5e-5
+    assert int(got["trials"]) == single.stats["trials"] and single.stats["trials"] > 7 * iters + 3
+    assert np.max(np.abs(got["ws"] - w1)) < 1e-3 * float(np.max(np.abs(w1)))

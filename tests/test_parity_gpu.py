@@ -791,7 +791,7 @@ def test_single_copy_merged_pass_and_empirical(monkeypatch):
     out._backend.close()
 
 
-@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("tag", ["f32", "f64", "f32_merged"])
 def test_later_trials_by_linearity(tag, monkeypatch):
     """line_search='exact-y' (lcx_set_trial_reuse): the back-tracking trials after the first one of an iteration take
     X.w_update^T = Y + eta X.update^T from the iteration's own exact products and make one pass over X instead of two.  An exact
@@ -804,15 +804,20 @@ def test_later_trials_by_linearity(tag, monkeypatch):
     if tag == "f64":
         x, _ = O.gen_planted(700, 900, 6, seed=91)
         m, iters, dt = 6, 25, np.float64
-    else:
+    elif tag == "f32":
         monkeypatch.setenv("LCX_GEMM", "ct")
         x, _ = O.gen_planted(4096, 8192, 128, seed=51)
         m, iters, dt = 128, 12, np.float32
+    else:                                   # the merged pass X.[grad | ws + update]^T in front of the trials
+        monkeypatch.setenv("LCX_GEMM", "ct")
+        x, _ = O.gen_planted(19200, 1280, 8, seed=81)
+        m, iters, dt = 24, 8, np.float32
     xt = pp(x.astype(dt), None, "standard", None)[0]
     runs = {}
     for mode in ("exact", "exact-y"):
         model = Corex(n_hidden=m, seed=0, dtype=dt, tol=0.0, device=0, line_search=mode)
         be = model._attach_shard(xt, x.shape[1])
+        assert bool(be.kernel_name(2)) == (tag == "f32_merged")
         be.timing_enable(True)
         per = []
         for i_eps, eps in enumerate(model._init_weights()):
@@ -831,7 +836,7 @@ def test_later_trials_by_linearity(tag, monkeypatch):
     assert relerr(w1, w0) < (1e-8 if tag == "f64" else 5e-3)
     prev = np.concatenate([[h0[0] - 1.0], h0[:-1]])
     moving = np.abs(h0 - prev) > (1e-9 if tag == "f64" else 1e-5) * np.abs(h0)         # iterations that still move TC
-    assert moving.sum() > 3 * iters and t0[moving].sum() > moving.sum() + 5             # ... and back-track now and then
+    assert moving.sum() > 3 * iters and t0[moving].sum() > moving.sum() + 3             # ... and back-track now and then
     assert np.array_equal(t0[moving], t1[moving])
     # every trial after the first one of its iteration skipped its X.B^T pass; the X^T.Y passes are all there
     nt1 = p1["gemm_nt"] + p1["gemm_nt2"]
@@ -840,3 +845,26 @@ def test_later_trials_by_linearity(tag, monkeypatch):
     if tag == "f64":
         ref = O.fit_ns_preprocessed(xt, m, seed=0, dtype=dt, max_iter=iters, tol=0.0, finish=False)
         assert np.max(np.abs(h1 - np.asarray(ref.history_tc)) / np.maximum(1.0, np.abs(h1))) < 1e-8
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_later_trials_by_linearity_whole_fit(tag, g1):
+    """line_search='exact-y' through `fit()` itself (stage changes, convergence test, final detail moments and factor sort) on
+    big5: the result of the reference-shaped fit, to rounding."""
+    from linearcorex_amd import Corex
+    dt = DT[tag]
+    a = Corex(n_hidden=5, seed=0, dtype=dt, device=0).fit(g1["x_raw"])
+    b = Corex(n_hidden=5, seed=0, dtype=dt, device=0, line_search="exact-y").fit(g1["x_raw"])
+    ha, hb = np.asarray(a.history["TC"], np.float64), np.asarray(b.history["TC"], np.float64)
+    if tag == "f64":
+        assert len(ha) == len(hb) == len(g1["f64_history_tc"])
+        assert np.max(np.abs(hb - ha) / np.maximum(1.0, np.abs(ha))) < 1e-9
+        assert np.array_equal(a.clusters(), b.clusters()) and relerr(b.get_covariance(), a.get_covariance()) < 1e-8
+        assert relerr(b.get_covariance(), g1["f64_cov"]) < 1e-6
+    else:
+        assert abs(len(ha) - len(hb)) <= 0.06 * len(ha)
+        assert abs(float(b.tc) - float(a.tc)) < 5e-5 * abs(float(a.tc))
+        assert np.array_equal(a.clusters(), b.clusters())
+    assert b.stats["trials"] > len(hb)
+    a._backend.close()
+    b._backend.close()

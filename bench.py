@@ -12,10 +12,15 @@ with --steps / --warmup:
     ms_per_step = sum_over_stages( median_over_repeats( window ) ) / (7 * steps)
 
 Workloads (BASELINE.json `configs`):
-  N=1  headline  c3       50k x 100k, n_hidden 64, float32, X generated on the device  (MFMA roofline run)
+  N=1  headline  c3       50k x 100k, n_hidden 64, float32, X generated on the device  (MFMA roofline run; >= 3 walks)
        nested    config.c2: 10k x 5k, n_hidden 32, float64                            (HBM-bound; own protocol)
-  N>1  headline  c4shard  50k x 125k per GPU, n_hidden 128, float32, n_variables sharded (weak scaling)
-       nested    config.c2_weak: 10k x 5k per GPU, float64
+                 config.c4shard: 50k x 125k, n_hidden 128, float32                    (the one-GPU point of the --gpus N series)
+                 config.c4_unsharded_one_gpu: 50k x 1M, n_hidden 128, float32         (configs[3] whole, one resident copy of X)
+                 config.linear_trial_mode / later_trials_by_linearity                 (opt-in line searches, reported beside)
+                 config.fit_to_convergence[_planted]                                  (wall clock of whole fits)
+  N>1  headline  c4shard  50k x 125k per GPU, n_hidden 128, float32, n_variables sharded (weak scaling), all-reduces issued by
+                          the library (RCCL communicator per handle), CPU baseline on rank 0
+       nested    config.single_gpu_same_shard, config.c2_weak: 10k x 5k per GPU, float64
 
     python bench.py                                   # N=1, c3 headline + c2 block + CPU baselines
     python bench.py --gpus 8 --steps 20 --warmup 5    # spawns 8 ranks itself (torch.distributed.run as a child)

@@ -348,8 +348,25 @@ class Corex(object):
     # public API
     # ------------------------------------------------------------------------------------------
     def fit_transform(self, x):
+        """`fit(x)` then `transform(x)` (:103-105).  The preprocessed x is still resident after the fit, so the latent factors are
+        one pass X~ . ws^T over it - the same numbers `transform(x)` produces from a second upload of x (same theta; imputation and
+        the rank transform are functions of this very batch) without moving the matrix over PCIe again."""
         self.fit(x)
-        return self.transform(x)
+        be = self._backend
+        if not getattr(self, "_x_resident", False) or be is None or not hasattr(be, "project_resident"):
+            return self.transform(x)
+        if self.gaussianize == 'empirical':       # the reference's second preprocess of x says these again (:416-417, :425)
+            print("Warning: correct inversion/transform of empirical gauss transform not implemented.")
+        elif self.gaussianize == 'standard' and self.verbose and getattr(self, "_fit_max_abs", 0.0) > 6:
+            print("Warning: outliers more than 6 stds away from mean. Consider using gaussianize='outliers'")
+        y = be.project_resident()                 # lcx_moments_a(0): with the exchange in the engine already summed over the ranks
+        if self._ex is not None and not self._engine_exchange:
+            import torch
+            with be.stream_context():
+                t = torch.from_numpy(y).to(self._ex[1].device)
+                self._comm.allreduce(t)
+                y = t.cpu().numpy()
+        return y
 
     def fit(self, x):
         if self.m is None:
@@ -376,6 +393,7 @@ class Corex(object):
                     t = torch.tensor([max_abs], dtype=torch.float64, device=self._ex[1].device)
                     self._comm.allreduce_max(t)
                     max_abs = float(t.item())
+            self._fit_max_abs = max_abs
             if max_abs > 6:
                 print("Warning: outliers more than 6 stds away from mean. Consider using gaussianize='outliers'")
         del x

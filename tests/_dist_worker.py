@@ -50,11 +50,12 @@ def main():
                       discourage_overlap=not syn,
                       _backend_factory=lambda ns, nv, mm, dt: ShardDouble(ns, nv, mm, dt))
     mark("model constructed")
-    model.fit(x)
+    y_resident = model.fit_transform(x)     # one pass over the resident shard + the same all-reduce as transform
     mark("fit done: %d iterations" % len(model.history["TC"]))
     c0, c1 = comm.shard(v)
     assert model._backend.nv == c1 - c0
     y = model.transform(x)
+    assert y_resident.shape == y.shape and np.max(np.abs(y_resident - y)) < 1e-11 * max(1.0, float(np.max(np.abs(y))))
     xr = model.predict(y[:50])              # sharded columns of the product, gathered: a collective like transform
     if os.environ.get("LCX_EAGER_GATHER_ELEMS") == "0":
         # sharded moments were NOT put together at the end of fit: touching one must raise (never a hidden collective that

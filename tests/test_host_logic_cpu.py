@@ -314,3 +314,30 @@ int main(void) {
     prod = subprocess.run(["nm", "-D", "--defined-only", os.path.join(libdir, "liblcx_hip.so")], capture_output=True, text=True).stdout
     prod_syms = {ln.split()[-1] for ln in prod.splitlines() if " T lcx_" in ln}
     assert prod_syms == set(header_functions()), prod_syms ^ set(header_functions())      # nothing beyond the boundary
+
+
+@pytest.mark.parametrize("gaussianize,missing", [("standard", None), ("outliers", None), ("none", None), ("standard", -999.0)])
+def test_fit_transform_reads_the_resident_data(gaussianize, missing):
+    """`fit_transform(x)` (:103-105) = `fit(x)` + `transform(x)`: here the second half is one pass over the shard that is
+    still resident, not a second upload - same numbers, and `transform(x)` afterwards still gives them."""
+    x = np.random.RandomState(12).randn(120, 30)
+    x[:, :10] += x[:, [0]]
+    if missing is not None:
+        x[np.random.RandomState(13).rand(*x.shape) < 0.05] = missing
+    calls = []
+
+    class Counting(ShardDouble):
+        def project_resident(self):
+            calls.append("resident")
+            return ShardDouble.project_resident(self)
+
+        def project_raw(self, *a, **k):
+            calls.append("raw")
+            return ShardDouble.project_raw(self, *a, **k)
+
+    mdl = Corex(n_hidden=3, seed=0, dtype=np.float64, max_iter=5, gaussianize=gaussianize, missing_values=missing,
+                _backend_factory=lambda ns, nv, m, dt: Counting(ns, nv, m, dt))
+    y = mdl.fit_transform(x)
+    assert calls == ["resident"], calls
+    y2 = mdl.transform(x)
+    assert y.shape == (120, 3) and np.max(np.abs(y - y2)) < 1e-12

@@ -133,3 +133,38 @@ def test_preprocess_empirical_shapes(shape):
     got = be.download_x()
     assert np.max(np.abs(got - ref)) < 1e-12
     be.close()
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("gz,missing,branch", [("standard", None, "ns"), ("outliers", None, "ns"), ("none", None, "ns"),
+                                               ("empirical", None, "ns"), ("standard", -999.0, "ns"), ("standard", None, "syn")])
+def test_fit_transform_reads_the_resident_data(gz, missing, branch, tag, monkeypatch):
+    """`fit_transform(x)` (reference :103-105: fit, then transform of the same x) takes the latent factors from the shard
+    that is still resident - one `lcx_moments_a` instead of a second upload and preprocess of x - and must give what
+    `transform(x)` gives; against the oracle's x~ . ws^T as well."""
+    import numpy as np
+    from linearcorex_amd import Corex
+    from linearcorex_amd.backend import HipBackend
+    from oracle import corex_oracle as O
+    dt = {"f32": np.float32, "f64": np.float64}[tag]
+    x = np.random.RandomState(21).randn(333, 70)
+    x[:, :20] += 1.5 * x[:, [0]]
+    x = x * np.linspace(0.5, 3.0, 70) + 2.0
+    if gz == "none":
+        x = (x - x.mean(0)) / x.std(0)
+    if missing is not None:
+        x[np.random.RandomState(22).rand(*x.shape) < 0.04] = missing
+    uploads = []
+    real = HipBackend.project_raw
+    monkeypatch.setattr(HipBackend, "project_raw", lambda self, *a, **k: (uploads.append(1), real(self, *a, **k))[1])
+    mdl = Corex(n_hidden=4, seed=0, dtype=dt, device=0, max_iter=6, gaussianize=gz, missing_values=missing,
+                discourage_overlap=(branch == "ns"))
+    y = mdl.fit_transform(x)
+    assert not uploads and y.shape == (333, 4) and y.dtype == dt
+    y2 = mdl.transform(x)
+    tol = 1e-12 if tag == "f64" else 2e-5
+    scale = max(1.0, float(np.max(np.abs(y2))))
+    assert np.max(np.abs(y.astype(np.float64) - y2)) < tol * scale
+    xt = O.preprocess(x.astype(dt).astype(np.float64), None, gz, missing)[0]
+    assert np.max(np.abs(y - xt.dot(np.asarray(mdl.ws, np.float64).T))) < (1e-10 if tag == "f64" else 1e-3) * scale
+    mdl._backend.close()

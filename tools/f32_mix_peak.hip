@@ -63,9 +63,10 @@ int main() {
         snprintf(tag, 128, "same wave: %2d mfma f32 16x16x4 + %2d %s per trip, %d blocks", NM, NV, PK ? "v_pk_fma_f32" : "v_fma_f32", blocks); \
         run(tag, [&] { hipLaunchKernelGGL((k_same<NM, NV, PK>), dim3(blocks), dim3(256), 0, 0, o, iters, 0.73f, -1.21f, bs, clk); }, \
             waves * iters * (NM * MF + NV * (PK ? 256.0 : 128.0)), clk);
-        SAME(16, 0, false) SAME(0, 32, false) SAME(0, 32, true)
+        SAME(16, 0, false) SAME(16, 8, false) SAME(16, 0, false) SAME(16, 4, false) SAME(16, 2, false) SAME(16, 0, false)
+        SAME(0, 32, false) SAME(0, 32, true)
         SAME(16, 8, false) SAME(16, 16, false) SAME(16, 32, false) SAME(16, 64, false)
-        SAME(16, 8, true) SAME(16, 16, true) SAME(16, 32, true)
+        SAME(16, 8, true) SAME(16, 16, true) SAME(16, 32, true) SAME(16, 0, false)
     }
     return 0;
 }

@@ -55,11 +55,41 @@ class Comm:
             return None
         import torch
         if self._dist.get_backend(self.group) == "nccl" and mode != "hook":
-            box = [backend.comm_unique_id() if self.rank == 0 else None]
+            # The group agrees on the outcome: an id that could not be drawn (no librccl for dlopen) reaches every rank as
+            # None, and after ncclCommInitRank the ranks all-reduce a failure flag.  If the library's own communicator is
+            # not to be had, every rank says so loudly and takes the hook transport below (this group's RCCL all_reduce on
+            # the same device buffers, lcx_iterate still inside the library) - never a silent or a one-sided change.
+            dev = torch.device("cuda", backend.device)
+            err, box = None, [None]
+            if self.rank == 0:
+                try:
+                    if os.environ.get("LCX_TEST_FAIL_COMM_INIT") == "id":
+                        raise RuntimeError("LCX_TEST_FAIL_COMM_INIT=id")
+                    box = [backend.comm_unique_id()]
+                except Exception as e:       # noqa: BLE001 - reported below, on every rank
+                    err = "lcx_comm_unique_id: %s" % e
             src = self._dist.get_global_rank(self.group, 0) if self.group is not None else 0
-            self._dist.broadcast_object_list(box, src=src, group=self.group, device=torch.device("cuda", backend.device))
-            backend.comm_init(self.world, self.rank, box[0])
-            return "rccl"
+            self._dist.broadcast_object_list(box, src=src, group=self.group, device=dev)
+            if box[0] is not None:
+                try:
+                    if os.environ.get("LCX_TEST_FAIL_COMM_INIT") == "init":
+                        raise RuntimeError("LCX_TEST_FAIL_COMM_INIT=init")
+                    backend.comm_init(self.world, self.rank, box[0])
+                except Exception as e:       # noqa: BLE001
+                    err = "lcx_comm_init: %s" % e
+            elif err is None:
+                err = "rank 0 could not draw an RCCL unique id"
+            with backend.stream_context():
+                bad = torch.tensor([0.0 if err is None else 1.0], device=dev)
+                self._dist.all_reduce(bad, op=self._dist.ReduceOp.MAX, group=self.group)
+                failed = float(bad.item()) > 0
+            if not failed:
+                return "rccl"
+            import sys
+            print("linearcorex_amd: rank %d: the engine's own RCCL communicator is not available (%s); every rank exchanges "
+                  "through this process group's all_reduce instead (LCX_EXCHANGE=hook)"
+                  % (self.rank, err or "another rank failed"), file=sys.stderr, flush=True)
+            backend.set_exchange_hook(None)                  # drops a communicator this rank may have got
 
         class _View:                        # zero-copy: torch.as_tensor understands __cuda_array_interface__
             def __init__(self, ptr, count, dtype):

@@ -96,7 +96,8 @@ def test_rccl_exchange_path_single_rank(tmp_path):
     interleaved with them on the handle's stream.  In-engine exchange (lcx_comm_init: a communicator owned by the handle,
     ncclAllReduce issued by the library, the exact line search inside lcx_iterate) against the host-sequenced path
     (LCX_EXCHANGE=torch: torch.distributed 'nccl' between the level calls): bit-identical trajectories, both equal to the
-    oracle (all-reduces over one rank are identities)."""
+    oracle (all-reduces over one rank are identities).  Also the hook transport on the RCCL group (LCX_EXCHANGE=hook) and the
+    agreed fall-back to it when the library's own communicator cannot be set up (id not drawn / ncclCommInitRank failed)."""
     import subprocess
     import sys
     code = r'''
@@ -114,8 +115,9 @@ x, _ = O.gen_planted(400, 331, 5, seed=2)
 for syn in (False, True):
     ref = (O.fit_syn if syn else O.fit_ns)(x, 5, seed=0, dtype=np.float64, max_iter=40)
     runs = {}
-    for mode in ("engine", "torch"):
-        os.environ["LCX_EXCHANGE"] = mode
+    for mode in ("engine", "torch", "hook", "fallback-id", "fallback-init"):
+        os.environ["LCX_EXCHANGE"] = "engine" if mode.startswith("fallback") else mode
+        os.environ["LCX_TEST_FAIL_COMM_INIT"] = mode.split("-")[1] if mode.startswith("fallback") else ""
         out = Corex(n_hidden=5, seed=0, dtype=np.float64, device=0, comm=Comm(always_exchange=True), max_iter=40,
                     discourage_overlap=not syn).fit(x)
         assert out._ex is not None and out._backend.torch_stream is not None
@@ -123,8 +125,11 @@ for syn in (False, True):
         if mode == "engine":
             assert out._engine_exchange == "rccl" and info["kind"] == "rccl" and info["allreduces_issued"] > 100, info
             assert syn or out._iterated_in_library
-        else:
+        elif mode == "torch":
             assert out._engine_exchange is None and info["kind"] == "caller" and info["allreduces_issued"] == 0, info
+        else:       # the group's own all_reduce behind the library's hook: asked for, or agreed on after a failed communicator
+            assert out._engine_exchange == "hook" and info["kind"] == "hook" and info["allreduces_issued"] > 100, info
+            assert syn or out._iterated_in_library
         h, hr = np.asarray(out.history["TC"], np.float64), np.asarray(ref.history_tc)
         assert len(h) == len(hr), (len(h), len(hr))
         assert np.max(np.abs(h - hr) / np.maximum(1, np.abs(hr))) < 1e-8
@@ -133,8 +138,9 @@ for syn in (False, True):
         assert np.max(np.abs(y - ref.transform(O.preprocess(x)[0]))) < 1e-7
         runs[mode] = (h, out.ws.copy(), y, out.stats["trials"])
         out._backend.close()
-    assert np.array_equal(runs["engine"][0], runs["torch"][0]) and np.array_equal(runs["engine"][1], runs["torch"][1])
-    assert np.array_equal(runs["engine"][2], runs["torch"][2]) and runs["engine"][3] == runs["torch"][3]
+    for other in ("torch", "hook", "fallback-id", "fallback-init"):
+        assert np.array_equal(runs["engine"][0], runs[other][0]) and np.array_equal(runs["engine"][1], runs[other][1]), other
+        assert np.array_equal(runs["engine"][2], runs[other][2]) and runs["engine"][3] == runs[other][3], other
 dist.destroy_process_group()
 print("RCCL_PATH_OK")
 ''' % (ROOT, str(free_port()))

@@ -92,7 +92,9 @@ def fit_layers(x, layers, corex_factory, missing=-1e6, verbose=0):
             models.append(corex_factory(n_hidden, l, missing_values=missing).fit(x))
             print('Time for first layer: %0.2f' % (time() - t0))
         else:
-            x_prev = models[-1].transform(x_prev)
+            # the layer below was fitted on x_prev, which is still resident on its device: no second upload (:542)
+            resident = getattr(models[-1], "transform_fitted", lambda: None)()
+            x_prev = models[-1].transform(x_prev) if resident is None else resident
             models.append(corex_factory(n_hidden, l).fit(x_prev))
     return models
 

@@ -352,9 +352,16 @@ class Corex(object):
         one pass X~ . ws^T over it - the same numbers `transform(x)` produces from a second upload of x (same theta; imputation and
         the rank transform are functions of this very batch) without moving the matrix over PCIe again."""
         self.fit(x)
+        y = self.transform_fitted()
+        return self.transform(x) if y is None else y
+
+    def transform_fitted(self):
+        """Latent factors of the data this model was fitted on, taken from the shard that is still resident on the device
+        (what `transform(x_fit)` returns; the stacking recipe vis_corex.py:542 asks for exactly this).  None when the data
+        are not resident any more (a model restored from a pickle): call `transform(x)` then."""
         be = self._backend
-        if not getattr(self, "_x_resident", False) or be is None or not hasattr(be, "project_resident"):
-            return self.transform(x)
+        if not getattr(self, "_x_resident", False) or be is None or not hasattr(be, "project_resident") or self.ws.size == 0:
+            return None
         if self.gaussianize == 'empirical':       # the reference's second preprocess of x says these again (:416-417, :425)
             print("Warning: correct inversion/transform of empirical gauss transform not implemented.")
         elif self.gaussianize == 'standard' and self.verbose and getattr(self, "_fit_max_abs", 0.0) > 6:

@@ -26,7 +26,10 @@ Workloads (BASELINE.json `configs`):
     python bench.py --gpus 8 --steps 20 --warmup 5    # spawns 8 ranks itself (torch.distributed.run as a child)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # or launched as ranks
 
-Prints ONE JSON line on rank 0.
+Prints ONE compact JSON line (a few KB: the contract keys, `roofline`, `cpu_baseline`, scalar riders of the nested
+measurements) on rank 0's stdout.  Every nested block (c2, c4shard, the opt-in line searches, convergence runs, use-site
+split, launch geometry ...) goes to the side file named in `config.detail` (default gpurun_out/bench_detail.json) and as one
+`BENCH_DETAIL {...}` line to stderr - the driver keeps only a few KB of stdout, and a 21 KB line could not be parsed.
 """
 import argparse
 import json
@@ -100,8 +103,12 @@ def parse(argv=None):
                          "workload (0 = skip)")
     ap.add_argument("--convergence-planted-max-iter", type=int, default=2000,
                     help="iterations per annealing stage allowed to the whole-fit wall-clock measurement on planted data")
-    ap.add_argument("--c4full-steps", type=int, default=3,
-                    help="iterations per window of the config-4-unsharded-on-one-GPU block of the default N=1 line (0 = skip)")
+    ap.add_argument("--c4full-steps", type=int, default=0,
+                    help="iterations per window of a config-4-unsharded-on-one-GPU block (209 GB resident) added to the N=1 "
+                         "detail record (0 = skip, the default: `--workload c4full` measures it on its own)")
+    ap.add_argument("--detail-out", default=None,
+                    help="where the full record goes (default gpurun_out/bench_detail.json, bench_detail_gpusN.json for N > 1)")
+    ap.add_argument("--max-line-bytes", type=int, default=4096, help="budget of the stdout line")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-sample", type=int, default=0,
                     help="HIP-event pairs around every n-th X pass of the timed windows (a pair costs ~5 us of stream time; "
@@ -533,6 +540,7 @@ def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_s
             "ms_per_step_walk_min_median_max": [float(np.min(walk_totals) / (n_stages * steps) * 1e3),
                                                 float(np.median(walk_totals) / (n_stages * steps) * 1e3),
                                                 float(np.max(walk_totals) / (n_stages * steps) * 1e3)],
+            "ms_per_step_by_walk": [float(t / (n_stages * steps) * 1e3) for t in walk_totals],
             "stage_change_ms_median": float(np.median(chgs[:, 1:]) * 1e3) if n_stages > 1 else None,
             "first_stage_start_ms_median": float(np.median(chgs[:, 0]) * 1e3),
             "iterations_per_sec_incl_stage_changes": float(n_stages * steps / (stage_med.sum() + np.median(chgs, axis=0).sum())),
@@ -599,6 +607,12 @@ def roofline_of(workload, r, world):
                     algorithmic_bytes_per_launch=alg_bytes, algorithmic_flops_per_launch=alg_flops,
                     arithmetic_intensity_flop_per_byte=intensity, use_sites=kernels)
     roofline.update(tinfo)
+    roofline["by_kernel"] = by_fn
+    if "gemm_nt2" in kernels and not dom_wide:
+        # the merged 2 x n_hidden-column pass (one read of X, twice the flops): its own fraction of the same peak
+        k2 = kernels["gemm_nt2"]
+        roofline["merged_pass"] = {"kernel": r["kernel_names"]["gemm_nt2"], "avg_launch_us": k2["avg_us"], "launches": k2["launches"],
+                                   "achieved_TFLOPs": k2["TFLOPs"], "frac": k2["TFLOPs"] / mfma_peak}
     rp_us, rp_src = load_rocprof_avg(workload, dom)
     roofline.update(rocprofv3_avg_kernel_us=rp_us, rocprofv3_source=rp_src)
     # whole-iteration view: algorithmic bytes / flops of the X passes an iteration makes over the iteration time
@@ -720,6 +734,121 @@ def covariance_block(model, be, label):
     return out
 
 
+# ------------------------------------------------------------------------------------------------------
+# the stdout line: compact by construction.  The driver keeps a few KB of stdout; round 3's 21 KB line could not be parsed.
+# ------------------------------------------------------------------------------------------------------
+def _r(x, digits=6):
+    """floats to `digits` significant digits (bytes on the line, not precision anybody reads)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        if not math.isfinite(x):
+            return None
+        return float("%.*g" % (digits, x))
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items()}
+    return x
+
+
+def _pick(d, *path, default=None):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+ROOFLINE_LINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "launches",
+                      "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "rocprofv3_avg_kernel_us",
+                      "rocprofv3_source", "traffic_source", "traffic_profile_matches_library", "mfma_util_pmc")
+
+
+def compact_line(out, detail_path):
+    """The record the driver parses: contract keys + full `roofline` (scalars) + `cpu_baseline` (one-sentence sample) +
+    scalar riders of the nested measurements.  Everything else lives in the detail record."""
+    cfg = out["config"]
+    c = {k: cfg.get(k) for k in ("workload", "n_samples", "n_variables_total", "n_variables_per_gpu", "n_hidden", "line_search",
+                                 "x_passes_per_iteration", "x_passes_per_iteration_reference_shaped",
+                                 "line_search_trials_per_iteration")}
+    w = cfg.get("windows") or {}
+    c["windows"] = {k: w.get(k) for k in ("walks_timed", "timed_iterations", "timed_seconds", "ms_per_step_walk_min_median_max")}
+    c["exchange"] = _pick(cfg, "exchange", "transport") or _pick(cfg, "exchange", "kind")
+    c["bytes_resident_total"] = _pick(cfg, "bytes_resident", "total")
+    c["bytes_resident_x"] = _pick(cfg, "bytes_resident", "x_and_transposed_copy")
+    if cfg.get("force_exchange"):
+        c["force_exchange"] = True
+    riders = {
+        # the other line searches of the same workload, reported beside `value`
+        "reference_shaped_value": _pick(cfg, "reference_shaped", "fit_iterations_per_sec"),
+        "exact_y_value": _pick(cfg, "later_trials_by_linearity", "fit_iterations_per_sec"),
+        "linear_value": _pick(cfg, "linear_trial_mode", "fit_iterations_per_sec"),
+        "merged_pass_roofline_frac": _pick(out, "roofline", "merged_pass", "frac"),
+        "fit_to_convergence_planted_seconds": _pick(cfg, "fit_to_convergence_planted", "seconds"),
+        "fit_to_convergence_planted_iterations": _pick(cfg, "fit_to_convergence_planted", "iterations"),
+        "weak_scaling_vs_same_shard": cfg.get("weak_scaling_vs_same_shard"),
+        "single_gpu_same_shard_value": _pick(cfg, "single_gpu_same_shard", "iterations_per_sec_slowest_rank"),
+    }
+    for name in ("c2", "c2_weak", "c4shard", "c4_unsharded_one_gpu"):
+        b = cfg.get(name)
+        if isinstance(b, dict) and "value" in b:
+            riders[name + "_value"] = b.get("value")
+            riders[name + "_line_search"] = b.get("line_search")
+            riders[name + "_ms_per_step"] = b.get("ms_per_step")
+            riders[name + "_roofline_frac"] = _pick(b, "roofline", "frac")
+            riders[name + "_roofline_bound"] = _pick(b, "roofline", "bound")
+            riders[name + "_reference_shaped_value"] = _pick(b, "reference_shaped", "fit_iterations_per_sec")
+            riders[name + "_cpu_baseline_value"] = _pick(b, "cpu_baseline", "value")
+            riders[name + "_fit_to_convergence_seconds"] = _pick(b, "fit_to_convergence", "seconds")
+    c.update({k: v for k, v in riders.items() if v is not None})
+    c["detail"] = detail_path
+    rl = out.get("roofline")
+    if rl:
+        it = rl.get("iteration") or {}
+        rl = dict({k: rl.get(k) for k in ROOFLINE_LINE_KEYS},
+                  iteration={k: it.get(k) for k in ("x_passes", "achieved_TFLOPs", "achieved_GBps",
+                                                    "fraction_of_step_inside_the_x_passes")})
+    cb = out.get("cpu_baseline")
+    if cb:
+        cb = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "trials_per_iteration", "x_passes_per_iteration",
+                                     "n_variables_timed", "scaled_linearly_in_n_variables_by") if cb.get(k) is not None}
+        cb["sample"] = cb["sample"].split(";")[0][:300]          # the first sentence; the rest is in the detail record
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data")}
+    line.update(config=c, roofline=rl, cpu_baseline=cb)
+    return _r(line)
+
+
+def emit(out, args, real_stdout):
+    """Full record -> side file + one BENCH_DETAIL line on stderr; compact record -> the one stdout line."""
+    rel = args.detail_out or os.path.join("gpurun_out", "bench_detail.json" if out["n_gpus"] == 1
+                                          else "bench_detail_gpus%d.json" % out["n_gpus"])
+    path = rel if os.path.isabs(rel) else os.path.join(ROOT, rel)
+    full = json.dumps(out)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(full + "\n")
+    except OSError as e:
+        sys.stderr.write("bench.py: could not write %s: %s\n" % (path, e))
+        rel = None
+    sys.stderr.write("BENCH_DETAIL " + full + "\n")
+    sys.stderr.flush()
+    line = compact_line(out, rel)
+    text = json.dumps(line, separators=(",", ":"))
+    # a budget, not a hope: shed riders, then the sample sentence, until the line fits
+    droppable = [k for k in list(line["config"]) if k.endswith(("_cpu_baseline_value", "_fit_to_convergence_seconds", "_line_search",
+                                                                "_roofline_bound", "_ms_per_step"))]
+    while len(text) > args.max_line_bytes and droppable:
+        line["config"].pop(droppable.pop())
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text) > args.max_line_bytes and line.get("cpu_baseline"):
+        line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:120]
+        text = json.dumps(line, separators=(",", ":"))
+    os.write(real_stdout, (text + "\n").encode())
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -793,7 +922,9 @@ def main():
     # of bench.py headlines another workload, configs[2], so value(N) / (N x value(1)) across lines is not an efficiency.)
     same_shard_single = None
     if world > 1 and args.extras:
-        r1, m1, b1 = measure(args, None, 1, rank, local_rank, head, args.steps, args.warmup, args.line_search, repeats=args.repeats)
+        # bounded: at most 10 iterations per window, one timed walk (the --gpus 8 job has to stay within minutes)
+        r1, m1, b1 = measure(args, None, 1, rank, local_rank, head, min(args.steps, 10), min(args.warmup, 3), args.line_search,
+                             repeats=max(1, args.repeats))
         b1.close()
         m1._backend = None
         del m1, b1
@@ -821,21 +952,20 @@ def main():
     model._backend = None
     del model, be
     generated = x_head is None
-    if args.extras and generated and args.line_search == "exact":
-        # the linear trial mode where a trial costs two 5-11 ms passes: reported beside the headline, never as `value`
-        r3, model3, be3 = measure(args, comm, world, rank, local_rank, head, args.steps, args.warmup, "linear")
-        cfg["linear_trial_mode"] = linear_mode_block(head, r3, world)
-        be3.close()
-        model3._backend = None
-        del model3, be3
-        # in between: only the trials AFTER the first one of an iteration reuse products, and only on the Y side (lcx_set_trial_reuse)
-        r3, model3, be3 = measure(args, comm, world, rank, local_rank, head, args.steps, args.warmup, "exact-y")
-        cfg["later_trials_by_linearity"] = dict(linear_mode_block(head, r3, world), refresh_every=None,
-                                                what="line_search='exact-y': trials after the first take X.w_update^T by linearity "
-                                                     "from the iteration's own exact products; one X pass per such trial instead of two")
-        be3.close()
-        model3._backend = None
-        del model3, be3
+    if args.extras and generated:
+        # the other line searches of the same workload, reported beside the headline, never as `value`: "exact" = the
+        # reference-shaped iteration (every trial two passes over X, :321), "exact-y" = trials after the first one of an
+        # iteration take X.w_update^T by linearity (lcx_set_trial_reuse), "linear" = trials cost no pass over X
+        names = {"exact": "reference_shaped", "exact-y": "later_trials_by_linearity", "linear": "linear_trial_mode"}
+        for ls in ("exact", "exact-y", "linear"):
+            if ls == args.line_search:
+                continue
+            r3, model3, be3 = measure(args, comm, world, rank, local_rank, head, args.steps, args.warmup, ls)
+            cfg[names[ls]] = dict(linear_mode_block(head, r3, world), line_search=ls,
+                                  refresh_every=16 if ls == "linear" else None)
+            be3.close()
+            model3._backend = None
+            del model3, be3
     if args.extras and world == 1 and comm is None and generated and args.convergence_max_iter > 0:
         # BASELINE.json's second figure for the headline workload.  On the iid matrix of the throughput run there is nothing to
         # converge to (every stage runs into the cap): that run is labelled as capped, and the convergence measurement proper is
@@ -861,9 +991,10 @@ def main():
     if args.extras:
         # ---- nested block: BASELINE.json configs[1] (HBM-bound), 5k variables per GPU, its own fixed protocol ----
         c2_steps, c2_warm = 30, 5
-        r2, model2, be2 = measure(args, comm, world, rank, local_rank, "c2", c2_steps, c2_warm, "exact", keep_x=True)
+        c2_ls = args.line_search if args.line_search != "linear" else "exact"
+        r2, model2, be2 = measure(args, comm, world, rank, local_rank, "c2", c2_steps, c2_warm, c2_ls, keep_x=True)
         x2 = r2.pop("x_host")
-        blk = config_of("c2", r2, world, "exact")
+        blk = config_of("c2", r2, world, c2_ls)
         blk["value"] = r2["its_per_s"] * world
         blk["ms_per_step"] = r2["per_step_s"] * 1e3
         blk["dtype"] = "f64"
@@ -873,14 +1004,19 @@ def main():
         be2.close()
         model2._backend = None
         del model2, be2
-        # the same iterations with the linear trial mode: reported beside, never as a headline
-        r3, model3, be3 = measure(args, comm, world, rank, local_rank, "c2", c2_steps, c2_warm, "linear", kernel_timing=True)
-        blk["linear_trial_mode"] = {"fit_iterations_per_sec": r3["its_per_s"], "ms_per_step": r3["per_step_s"] * 1e3,
-                                    "x_passes_per_iteration": r3["x_passes"],
-                                    "line_search_trials_per_iteration": r3["trials"], "final_TC": r3["final_tc"]}
-        be3.close()
-        model3._backend = None
-        del model3, be3
+        if world == 1:
+            # the other line searches on the same X (several ranks: skipped, the --gpus N job stays within minutes)
+            names = {"exact": "reference_shaped", "exact-y": "later_trials_by_linearity", "linear": "linear_trial_mode"}
+            for ls in ("exact", "exact-y", "linear"):
+                if ls == c2_ls:
+                    continue
+                r3, model3, be3 = measure(args, comm, world, rank, local_rank, "c2", c2_steps, c2_warm, ls, kernel_timing=True)
+                blk[names[ls]] = {"fit_iterations_per_sec": r3["its_per_s"], "ms_per_step": r3["per_step_s"] * 1e3,
+                                  "x_passes_per_iteration": r3["x_passes"], "line_search": ls,
+                                  "line_search_trials_per_iteration": r3["trials"], "final_TC": r3["final_tc"]}
+                be3.close()
+                model3._backend = None
+                del model3, be3
         if world == 1 and comm is None and x2 is not None:
             # BASELINE.json's second figure: wall-clock of a whole fit() to |dTC| < 1e-5 per annealing stage (reference
             # defaults :72-74), including the upload + on-device preprocess and the final detail moments
@@ -909,8 +1045,9 @@ def main():
         # shard), so that the series 1 -> 8 is self-contained in the driver's records ----
         c4 = None
         if auto and world == 1 and comm is None and head == "c3":
-            r4, model4, be4 = measure(args, comm, world, rank, local_rank, "c4shard", 10, 3, "exact")
-            c4 = config_of("c4shard", r4, world, "exact")
+            c4_ls = args.line_search
+            r4, model4, be4 = measure(args, comm, world, rank, local_rank, "c4shard", 10, 3, c4_ls)
+            c4 = config_of("c4shard", r4, world, c4_ls)
             c4["value"] = r4["its_per_s"]
             c4["ms_per_step"] = r4["per_step_s"] * 1e3
             c4["dtype"] = "f32"
@@ -920,16 +1057,16 @@ def main():
             be4.close()
             model4._backend = None
             del model4, be4
-            r5, model5, be5 = measure(args, comm, world, rank, local_rank, "c4shard", 10, 3, "linear")
-            c4["linear_trial_mode"] = linear_mode_block("c4shard", r5, world)
-            be5.close()
-            model5._backend = None
-            del model5, be5
-            r5, model5, be5 = measure(args, comm, world, rank, local_rank, "c4shard", 10, 3, "exact-y")
-            c4["later_trials_by_linearity"] = dict(linear_mode_block("c4shard", r5, world), refresh_every=None)
-            be5.close()
-            model5._backend = None
-            del model5, be5
+            names = {"exact": "reference_shaped", "exact-y": "later_trials_by_linearity", "linear": "linear_trial_mode"}
+            for ls in ("exact", "exact-y", "linear"):
+                if ls == c4_ls:
+                    continue
+                r5, model5, be5 = measure(args, comm, world, rank, local_rank, "c4shard", 10, 3, ls)
+                c4[names[ls]] = dict(linear_mode_block("c4shard", r5, world), line_search=ls,
+                                     refresh_every=16 if ls == "linear" else None)
+                be5.close()
+                model5._backend = None
+                del model5, be5
             out["config"]["c4shard"] = c4
             # ---- configs[3] as ONE problem on this one GPU: 50 000 x 1 000 000 x 128 float32, 200 GB of X.  Two resident copies
             # do not fit 288 GB, so the engine keeps the row-major copy only and X.B^T runs on gemm_cr (chosen by itself).  The
@@ -980,7 +1117,7 @@ def main():
     sys.stdout.flush()
     sys.stderr.flush()
     if rank == 0:
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        emit(out, args, real_stdout)
     return 0
 
 

@@ -16,6 +16,10 @@ import numpy as np
 from .comm import SingleComm
 from .preprocess import g, g_inv, mean_impute   # noqa: F401  (re-exported like the reference module)
 
+# The line search a model runs when the caller does not name one (LCX_LINE_SEARCH overrides it: what the parity matrix of
+# tests/ uses to run every end-to-end fixture under both re-associations).
+DEFAULT_LINE_SEARCH = "exact"
+
 _DETAIL_KEYS = ("MI", "X_i Y_j", "X_i Z_j", "X_i^2 | Y", "I(Y_j ; X)", "I(X_i ; Y)", "TCs",
                 "TC_no_overlap", "TC_direct", "additivity")
 _DEVICE_KEYS = ("uj", "rho", "ry", "invrho", "rhoinvrho", "Qij", "Si", "Qi-Si^2", "MI", "X_i Z_j",
@@ -195,7 +199,7 @@ class Corex(object):
     def __init__(self, n_hidden=10, max_iter=10000, tol=1e-5, anneal=True, missing_values=None,
                  discourage_overlap=True, gaussianize='standard', gpu=False,
                  verbose=False, seed=None, *, dtype=np.float32, device=None, comm=None,
-                 eliminate_synergy=None, line_search="exact", refresh_every=16, _backend_factory=None):
+                 eliminate_synergy=None, line_search=None, refresh_every=16, _backend_factory=None):
         if eliminate_synergy is not None:
             discourage_overlap = bool(eliminate_synergy)
         self.m = n_hidden
@@ -230,13 +234,18 @@ class Corex(object):
         self._engine_exchange = None
         self._cols = (0, 0)
         self._tc_cur = np.nan
+        import os
+        # None = the package default (DEFAULT_LINE_SEARCH / LCX_LINE_SEARCH): where "exact-y" cannot run (see _make_backend)
+        # a defaulted model takes "exact" instead, a model that was ASKED for "exact-y" refuses
+        self._line_search_asked = line_search
+        if line_search is None:
+            line_search = os.environ.get("LCX_LINE_SEARCH") or DEFAULT_LINE_SEARCH
         if line_search not in ("exact", "linear", "exact-y"):
             raise ValueError("line_search must be 'exact', 'linear' or 'exact-y'")
-        self.line_search = line_search
+        self.line_search = self._line_search_wanted = line_search
         self.refresh_every = int(refresh_every)
         self._since_exact = 0
         self.stats = {"iterations": 0, "moment_evals": 0, "trials": 0, "invalid_trials": 0}
-        import os
         self._check_ranks = os.environ.get("LCX_CHECK_RANKS", "0") not in ("", "0")
         # LCX_HOST_LOOP=1: sequence the levels of `_update_ns` from this class (what a caller-owned exchange needs) instead of
         # handing the whole iteration to the engine (lcx_iterate) - same results, kept selectable for tests
@@ -277,10 +286,6 @@ class Corex(object):
                 dev = int(os.environ.get("LOCAL_RANK", "0"))
             be = HipBackend(n_samples, nv_local, self.m, self.dtype, dev)
         self._backend = be
-        if hasattr(be, "set_linear_mode"):
-            be.set_linear_mode(self.line_search == "linear")
-        if self.line_search == "exact-y":
-            be.set_trial_reuse(True)
         exchange = getattr(self._comm, "exchange", self._comm.world > 1)
         be.set_world(self._comm.world)
         if exchange and self._comm.world == 1 and hasattr(be, "set_exchange"):
@@ -289,6 +294,25 @@ class Corex(object):
         # the exchange steps inside the engine (RCCL communicator of the handle, or a hook for other transports): the levels
         # then all-reduce what they produce themselves and this class issues no collective on the hot path
         self._engine_exchange = self._comm.bind_engine(be) if exchange else None
+        # which line search runs - decided here, before any data moves.  "exact-y" lives inside lcx_iterate: it needs the
+        # line search in the library (not LCX_HOST_LOOP=1, not the per-trial prints of verbose > 1) and, with several ranks,
+        # the exchange inside the engine
+        ls = getattr(self, "_line_search_wanted", self.line_search)
+        if ls == "exact-y":
+            able = (self._in_library and self.verbose <= 1 and hasattr(be, "iterate") and hasattr(be, "set_trial_reuse")
+                    and (self._ex is None or bool(self._engine_exchange)))
+            if not able:
+                if getattr(self, "_line_search_asked", ls) == "exact-y":
+                    be.close()
+                    self._backend = None
+                    raise RuntimeError("line_search='exact-y' runs inside lcx_iterate only (not with LCX_HOST_LOOP=1, verbose > 1, "
+                                       "a backend without lcx_iterate or a caller-owned exchange)")
+                ls = "exact"
+        self.line_search = ls
+        if hasattr(be, "set_linear_mode"):
+            be.set_linear_mode(ls == "linear")
+        if hasattr(be, "set_trial_reuse"):
+            be.set_trial_reuse(ls == "exact-y")
         return be
 
     def _allreduce(self, tensor):
@@ -709,9 +733,7 @@ class Corex(object):
                 and self.verbose <= 1 and hasattr(be, "iterate"):
             self._iterated_in_library = True
             return self._update_ns_in_library(more)
-        if self.line_search == "exact-y":
-            raise RuntimeError("line_search='exact-y' runs inside lcx_iterate only (not with LCX_HOST_LOOP=1, verbose > 1 or a "
-                               "caller-owned exchange)")
+        assert self.line_search != "exact-y"         # (refused or replaced in _make_backend, before any data moved)
         # H (:294) is already global: it came with the scalar exchange of the evaluation that produced set 0
         be.update_b(self.eps)                # grad (:296-300), Bj partial, Y_g partial
         self._xy()

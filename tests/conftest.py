@@ -53,3 +53,13 @@ def g5():
 @pytest.fixture(scope="session")
 def g6():
     return load_golden("g6_adni_missing")
+
+
+@pytest.fixture(params=["exact", "exact-y"])
+def ls(request, monkeypatch):
+    """The parity matrix of the end-to-end fixtures: every one of them runs under the reference-shaped line search ("exact":
+    each back-tracking trial makes two passes over X, linearcorex.py:321) and under "exact-y" (the trials after the first one
+    of an iteration take X.w_update^T by linearity, lcx_set_trial_reuse) at the SAME bars.  Set through the environment, so
+    that models built by the CLI and by child processes follow it too."""
+    monkeypatch.setenv("LCX_LINE_SEARCH", request.param)
+    return request.param

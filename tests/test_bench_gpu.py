@@ -6,6 +6,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -17,10 +18,29 @@ FAST = ["--steps", "3", "--warmup", "2", "--no-extras", "--repeats", "1"]
 SMALL = {"LCX_BENCH_HEAD": "tiny"}          # a small headline workload instead of BASELINE configs[2] / [3]
 
 
+LINE_BUDGET = 4096          # bytes of the stdout line (the driver keeps a few KB of stdout; round 3's 21 KB line was not parsed)
+
+
 def _one_json_line(stdout):
     lines = [ln for ln in stdout.decode(errors="replace").splitlines() if ln.strip()]
     assert len(lines) == 1, lines
-    return json.loads(lines[0])
+    assert len(lines[0]) <= LINE_BUDGET, len(lines[0])
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert isinstance(d["config"]["workload"], str)
+    return d
+
+
+def _detail(path, stderr=None):
+    """the full record: the side file, and the same record as the BENCH_DETAIL line on stderr"""
+    with open(path) as f:
+        full = json.load(f)
+    if stderr is not None:
+        marked = [ln for ln in stderr.decode(errors="replace").splitlines() if ln.startswith("BENCH_DETAIL ")]
+        assert len(marked) == 1 and json.loads(marked[0][len("BENCH_DETAIL "):]) == full
+    return full
 
 
 def test_single_rank_rccl_stdout_is_one_json_line():
@@ -32,51 +52,68 @@ def test_single_rank_rccl_stdout_is_one_json_line():
     assert d["roofline"]["kernel"].startswith("lcx::gemm_") and 0.0 < d["roofline"]["frac"] < 1.0
     assert d["roofline"]["bound"] == "hbm" and d["dtype"] == "f64"
     assert d["value"] > 0 and d["steps"] == 3
-    w = d["config"]["windows"]
+    assert d["config"]["windows"]["timed_iterations"] == 21
+    w = _detail(os.path.join(ROOT, d["config"]["detail"]), p.stderr)["config"]["windows"]
     assert w["stages"] == 7 and w["steps_per_window"] == 3 and w["timed_iterations"] == 21
 
 
-def test_default_line_is_the_c3_line_with_the_c2_block():
-    """The driver's command: the headline must be BASELINE configs[2] (MFMA-bound), c2 rides along as a nested block, the
-    CPU baselines are real, and the figure must not depend on the driver's --steps 20 --warmup 5."""
+def test_default_line_is_the_c3_line_with_the_c2_block(tmp_path):
+    """The driver's command: the headline must be BASELINE configs[2] (MFMA-bound), the line must fit the driver's stdout
+    budget, c2 and the config-4 shard ride along as scalars on the line and as nested blocks in the detail record, the CPU
+    baselines are real, and the figure must not depend on the driver's --steps 20 --warmup 5."""
+    detail = str(tmp_path / "detail.json")
+    t0 = time.time()
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
-                        "--cpu-seconds", "5"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+                        "--cpu-seconds", "5", "--detail-out", detail], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=1500)
+    wall = time.time() - t0
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
-    d = _one_json_line(p.stdout)
-    assert d["config"]["workload"].startswith("c3:") and d["dtype"] == "f32" and d["n_gpus"] == 1
-    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["unit"] == "TFLOP/s" and 0.3 < d["roofline"]["frac"] < 1.0
-    assert d["roofline"]["kernel"].startswith("lcx::gemm_ct")
+    line = _one_json_line(p.stdout)
+    assert line["config"]["workload"].startswith("c3:") and line["dtype"] == "f32" and line["n_gpus"] == 1
+    rl = line["roofline"]
+    assert rl["bound"] == "mfma" and rl["unit"] == "TFLOP/s" and 0.3 < rl["frac"] < 1.0
+    assert rl["kernel"].startswith("lcx::gemm_c") and rl["avg_launch_us"] > 0 and rl["launches"] > 0
+    assert abs(rl["achieved"] / rl["peak"] - rl["frac"]) < 1e-4
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
+    assert len(line["cpu_baseline"]["sample"]) <= 300
+    c = line["config"]
+    assert c["detail"] == detail and c["windows"]["walks_timed"] >= 3 and c["windows"]["timed_seconds"] >= 0.5
+    lo, med, hi = c["windows"]["ms_per_step_walk_min_median_max"]
+    assert lo <= med <= hi and med / lo < 1.05 and hi / lo < 1.3, (lo, med, hi)
+    # the value is consistent with what was timed, and the whole job fits the driver's patience
+    assert abs(line["value"] * line["ms_per_step"] / 1e3 - 1.0) < 1e-3
+    assert wall < 400, wall
+    for k in ("c2_value", "c2_roofline_frac", "c2_cpu_baseline_value", "c4shard_value", "c4shard_roofline_frac", "linear_value",
+              "fit_to_convergence_planted_seconds"):
+        assert c[k] > 0, k
+    assert ("exact_y_value" in c) != (c["line_search"] == "exact-y") and ("reference_shaped_value" in c) != (c["line_search"] == "exact")
+
+    # ---- the detail record: everything the line used to carry
+    d = _detail(detail, p.stderr)
+    assert d["value"] == pytest.approx(line["value"], rel=1e-5) and d["roofline"]["frac"] == pytest.approx(rl["frac"], rel=1e-5)
     assert d["config"]["windows"]["timed_seconds"] >= 0.5
-    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     c2 = d["config"]["c2"]
     assert c2["roofline"]["bound"] == "hbm" and c2["windows"]["timed_seconds"] >= 0.5
-    assert c2["cpu_baseline"]["value"] > 0
-    lo, med, hi = c2["windows"]["ms_per_step_walk_min_median_max"]
-    assert med / lo < 1.1 and hi / lo < 2.0, (lo, med, hi)      # (one of ~10 walks may catch a host hiccup: the figure is the per-stage median)
+    assert c2["cpu_baseline"]["value"] > 0 and c2["value"] == pytest.approx(c["c2_value"], rel=1e-5)
+    ratios = sorted(w / c2["windows"]["ms_per_step_walk_min_median_max"][0] for w in c2["windows"]["ms_per_step_by_walk"])
+    # (one of ~10 walks may catch a host hiccup: the figure is the per-stage median; 9 of 10 walks must agree)
+    assert ratios[len(ratios) // 2] < 1.1 and ratios[int(0.9 * (len(ratios) - 1))] < 1.25, ratios
     assert c2["get_covariance"]["n_variables"] == 5000 and c2["get_covariance"]["seconds"] > 0
     assert d["config"]["get_covariance_c5_standin"]["n_variables"] == 20000
-    # the headline is timed over >= 3 walks of the schedule and says how far they are apart
-    w = d["config"]["windows"]
-    assert w["walks_timed"] >= 3
-    lo, med, hi = w["ms_per_step_walk_min_median_max"]
-    assert lo <= med <= hi and med / lo < 1.05 and hi / lo < 1.3, (lo, med, hi)
     # the one-GPU point of the weak-scaling series that --gpus N headlines
     c4 = d["config"]["c4shard"]
     assert c4["value"] > 0 and c4["n_hidden"] == 128 and c4["n_variables_per_gpu"] == 125000
     assert c4["roofline"]["bound"] == "mfma" and 0.3 < c4["roofline"]["frac"] < 1.0
     assert c4["cpu_baseline"]["value"] > 0 and c4["cpu_baseline"]["n_variables_timed"] <= 100000
-    # configs[3] unsharded on this one GPU (single resident copy, gemm_cr)
-    c6 = d["config"]["c4_unsharded_one_gpu"]
-    assert c6["value"] > 1.0 and c6["n_variables_total"] == 1000000 and "gemm_cr_kernel" in c6["kernels"]["gemm_nt"]
-    assert c6["bytes_resident"]["total"] < 250e9
-    # linear trial mode, reported beside the reference-shaped figure at the sizes where a trial costs two long passes
-    for blk in (d["config"], c4):
-        mid = blk["later_trials_by_linearity"]               # line_search="exact-y": between the reference-shaped and the linear mode
-        assert mid["fit_iterations_per_sec"] > blk["fit_iterations_per_sec"] if "fit_iterations_per_sec" in blk else True
-        assert blk["linear_trial_mode"]["x_passes_per_iteration"] < mid["x_passes_per_iteration"] < blk["x_passes_per_iteration"]
-        lin = blk["linear_trial_mode"]
-        assert lin["fit_iterations_per_sec"] > 0 and 1.9 < lin["x_passes_per_iteration"] < 2.6
-        assert lin["roofline"]["bound"] == "mfma"
+    # the 209 GB block is opt-in now (--c4full-steps / --workload c4full)
+    assert "c4_unsharded_one_gpu" not in d["config"]
+    # the other line searches, reported beside the headline at the sizes where a trial costs two long passes
+    names = {"exact": "reference_shaped", "exact-y": "later_trials_by_linearity", "linear": "linear_trial_mode"}
+    for blk, own in ((d["config"], d["value"]), (c4, c4["value"])):
+        its = {ls: own if ls == blk["line_search"] else blk[names[ls]]["fit_iterations_per_sec"] for ls in names}
+        xp = {ls: blk["x_passes_per_iteration"] if ls == blk["line_search"] else blk[names[ls]]["x_passes_per_iteration"] for ls in names}
+        assert xp["linear"] < xp["exact-y"] < xp["exact"] and its["linear"] > its["exact-y"] > its["exact"] > 0, (its, xp)
+        assert 1.9 < xp["linear"] < 2.6 and blk["linear_trial_mode"]["roofline"]["bound"] == "mfma"
     # a convergence measurement that converges: planted data, every annealing stage below tol before the cap
     cv = d["config"]["fit_to_convergence_planted"]
     assert cv["stages_converged_before_the_cap"] == 7 and cv["seconds"] > 0
@@ -117,14 +154,20 @@ def test_world_size_mismatch_is_an_error():
     assert p.returncode != 0 and not p.stdout.strip()
 
 
-def test_two_ranks_full_line_has_the_same_shard_reference_and_the_c2_block():
+def test_two_ranks_full_line_has_the_same_shard_reference_and_the_c2_block(tmp_path):
     """The line the driver's multi-GPU run produces (extras on): the headline shard measured on every GPU alone first
     (`config.single_gpu_same_shard`: the one-GPU point of this workload's weak-scaling series), then sharded; the nested
     config-2 block with 5 000 variables per GPU."""
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--repeats", "1"]
+    detail = str(tmp_path / "detail2.json")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--repeats", "1",
+           "--detail-out", detail]
     p = subprocess.run(cmd, cwd=ROOT, env=_two_rank_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
-    d = _one_json_line(p.stdout)
+    line = _one_json_line(p.stdout)
+    assert line["n_gpus"] == 2 and line["cpu_baseline"]["value"] > 0 and line["roofline"]["frac"] > 0
+    assert line["config"]["single_gpu_same_shard_value"] > 0 and line["config"]["weak_scaling_vs_same_shard"] > 0
+    assert line["config"]["c2_weak_value"] > 0
+    d = _detail(detail)
     assert d["n_gpus"] == 2
     # the multi-GPU line carries a CPU baseline too (rank 0, one shard's iteration) and a roofline
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
@@ -133,4 +176,4 @@ def test_two_ranks_full_line_has_the_same_shard_reference_and_the_c2_block():
     assert ref["iterations_per_sec_slowest_rank"] > 0 and d["config"]["weak_scaling_vs_same_shard"] > 0
     c2 = d["config"]["c2_weak"]
     assert c2["n_variables_total"] == 10000 and c2["n_variables_per_gpu"] == 5000 and c2["roofline"]["bound"] == "hbm"
-    assert c2["linear_trial_mode"]["fit_iterations_per_sec"] > 0
+    assert "linear_trial_mode" not in c2          # (several ranks: the other line searches of c2 are skipped)

@@ -63,7 +63,10 @@ def test_full_size_properties(shape):
     mdl._backend.close()
 
 
-def test_config2_full_fit_vs_oracle():
+_C2_CACHE = {}
+
+
+def test_config2_full_fit_vs_oracle(ls):
     """BASELINE.json configs[1] end to end: synthetic Gaussian X 10k x 5k, n_hidden = 32, float64, the whole fit to
     tol = 1e-5 on the device against the NumPy oracle on the host cores (about half a minute of CPU on the GPU box):
     same number of iterations and line-search trials, TC history / weights / covariance within the north-star 1e-6,
@@ -73,8 +76,11 @@ def test_config2_full_fit_vs_oracle():
     from oracle import corex_oracle as O
     n, v, m = 10000, 5000, 32
     x = O.gen_iid(n, v, seed=1, dtype=np.float64)
-    ref = O.fit_ns(x, m, seed=0, dtype=np.float64)
+    if "ref" not in _C2_CACHE:
+        _C2_CACHE["ref"] = O.fit_ns(x, m, seed=0, dtype=np.float64)
+    ref = _C2_CACHE["ref"]
     out = Corex(n_hidden=m, seed=0, dtype=np.float64, device=0).fit(x)
+    assert out.line_search == ls
     h_ref, h = np.asarray(ref.history_tc, np.float64), np.asarray(out.history["TC"], np.float64)
     assert len(h) == len(h_ref), (len(h), len(h_ref))
     assert np.max(np.abs(h - h_ref) / np.maximum(1.0, np.abs(h_ref))) < 1e-6

@@ -46,6 +46,30 @@ def test_driver_reproduces_reference_on_big5(g1, tag, dt):
         assert abs(float(out.tc) - float(g1["f32_tc"])) < 1e-3 * float(g1["f32_tc"])
 
 
+def test_line_search_is_settled_before_any_data_moves(g1, monkeypatch):
+    """'exact-y' lives inside lcx_iterate.  A model that was ASKED for it on a backend that cannot run it (here: the NumPy
+    double has no lcx_iterate; likewise LCX_HOST_LOOP=1, verbose > 1, a caller-owned exchange) refuses when the backend is
+    made - before a shard is uploaded - and leaves no handle behind; a model that merely DEFAULTS to it (LCX_LINE_SEARCH /
+    DEFAULT_LINE_SEARCH) runs the reference-shaped line search instead."""
+    x = g1["x_raw"].astype(np.float64)
+    made = []
+
+    def factory(ns, nv, m, dt):
+        made.append(ShardDouble(ns, nv, m, dt))
+        return made[-1]
+    mdl = Corex(n_hidden=5, seed=0, dtype=np.float64, line_search="exact-y", _backend_factory=factory)
+    with pytest.raises(RuntimeError, match="exact-y"):
+        mdl.fit(x)
+    assert mdl._backend is None and len(made) == 1 and getattr(made[0], "x", None) is None
+    monkeypatch.setenv("LCX_LINE_SEARCH", "exact-y")
+    out = Corex(n_hidden=5, seed=0, dtype=np.float64, max_iter=3, _backend_factory=FACTORY)
+    assert out._line_search_wanted == "exact-y"
+    out.fit(x)
+    assert out.line_search == "exact" and len(out.history["TC"]) == 21
+    with pytest.raises(ValueError):
+        Corex(line_search="armijo")
+
+
 @pytest.mark.parametrize("refresh", [1, 8, 10 ** 9])
 def test_linear_line_search_matches_exact(g1, refresh):
     """line_search='linear' evaluates trials without passes over X (linearity of X^T.(X.u^T));
@@ -263,6 +287,48 @@ def test_bench_roofline_accounting_with_the_merged_pass():
     assert 0.9 < it["fraction_of_step_inside_the_x_passes"] < 1.0
     # committed profiles are only quoted for the library they were taken from
     assert rf["traffic"] is None or rf["traffic_profile_matches_library"] is True
+
+
+def test_bench_stdout_line_stays_within_the_drivers_budget(tmp_path):
+    """bench.emit: the stdout line is the compact record (contract keys, roofline, cpu_baseline, scalar riders) and fits
+    4 KB whatever the nested blocks weigh - fed with round 3's 21 KB record, the one the driver could not parse; the full
+    record goes to the side file and to one BENCH_DETAIL line on stderr."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r03_bench_default.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000
+    args = bench.parse(["--detail-out", str(tmp_path / "d.json")])
+    rd, wr = os.pipe()
+    bench.emit(full, args, wr)
+    os.close(wr)
+    text = os.read(rd, 1 << 20).decode()
+    os.close(rd)
+    assert text.endswith("\n") and text.count("\n") == 1 and len(text) <= 4096, len(text)
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data"):
+        assert line[k] == full[k] or abs(line[k] - full[k]) <= 1e-5 * abs(full[k]), k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "rocprofv3_avg_kernel_us"):
+        assert k in line["roofline"], k
+    assert abs(line["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-5
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"]) and len(line["cpu_baseline"]["sample"]) <= 300
+    c = line["config"]
+    assert c["workload"].startswith("c3:") and c["detail"] == str(tmp_path / "d.json")
+    assert c["c2_value"] > 0 and c["c4shard_value"] > 0 and c["c2_roofline_frac"] > 0 and c["linear_value"] > 0
+    assert not any(isinstance(v, dict) for k, v in c.items() if k != "windows")
+    with open(tmp_path / "d.json") as f:
+        assert json.load(f) == full
+    # a tighter budget sheds riders, never the contract keys
+    args = bench.parse(["--detail-out", str(tmp_path / "d.json"), "--max-line-bytes", "2600"])
+    rd, wr = os.pipe()
+    bench.emit(full, args, wr)
+    os.close(wr)
+    text = os.read(rd, 1 << 20).decode()
+    os.close(rd)
+    assert len(text) <= 2601 and json.loads(text)["roofline"]["frac"] > 0 and "c2_value" in json.loads(text)["config"]
 
 
 def test_headers_are_plain_c_and_a_c_program_links_the_library(tmp_path):

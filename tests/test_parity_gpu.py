@@ -161,12 +161,16 @@ def test_invalid_flag_and_rescale(tag, g4):
 
 
 def _fit(x, m, tag, **kw):
+    import os
     from linearcorex_amd import Corex
-    return Corex(n_hidden=m, seed=0, dtype=DT[tag], device=0, **kw).fit(x)
+    mdl = Corex(n_hidden=m, seed=0, dtype=DT[tag], device=0, **kw).fit(x)
+    # (the `ls` fixture chooses the line search through LCX_LINE_SEARCH: make sure that is the one that ran)
+    assert mdl.line_search == kw.get("line_search", os.environ.get("LCX_LINE_SEARCH", "exact"))
+    return mdl
 
 
 @pytest.mark.parametrize("tag", ["f32", "f64"])
-def test_big5_end_to_end(tag, g1):
+def test_big5_end_to_end(tag, g1, ls):
     out = _fit(g1["x_raw"].astype(np.float64), 5, tag)
     h_ref = g1[tag + "_history_tc"]
     h = np.asarray(out.history["TC"], dtype=np.float64)
@@ -191,7 +195,7 @@ def test_big5_end_to_end(tag, g1):
 
 
 @pytest.mark.parametrize("tag", ["f32", "f64"])
-def test_planted_small_end_to_end(tag, g2_small):
+def test_planted_small_end_to_end(tag, g2_small, ls):
     g = g2_small
     n, v, m = (int(t) for t in g["shape"])
     x, grp = O.gen_planted(n, v, m)
@@ -307,7 +311,7 @@ def test_linear_trial_step_level():
     be.close()
 
 
-def test_planted_mid_f64(g2_mid):
+def test_planted_mid_f64(g2_mid, ls):
     g = g2_mid
     n, v, m = (int(t) for t in g["shape"])
     x, grp = O.gen_planted(n, v, m)
@@ -337,7 +341,7 @@ def test_config2_steps(tag, g3):
 
 
 @pytest.mark.parametrize("tag", ["f32", "f64"])
-def test_outliers_and_missing(tag, g5, g6):
+def test_outliers_and_missing(tag, g5, g6, ls):
     n, v, m = (int(t) for t in g5["shape"])
     x, grp = O.gen_planted(n, v, m, seed=3)
     heavy = np.arange(v) % 20 == 0
@@ -363,7 +367,10 @@ def test_outliers_and_missing(tag, g5, g6):
         assert relerr(out.get_covariance(), g6["f64_cov"]) < 1e-6
 
 
-def test_config5_standin_covariance():
+_C5_CACHE = {}
+
+
+def test_config5_standin_covariance(ls):
     """BASELINE.json config 5 at full size (TCGA-OV stand-in, SURVEY.md 8d: the RPKM matrix is absent from the
     reference checkout): N=400 samples x V=20000 genes, 30 planted groups, heavy tails on 5 % of the columns,
     gaussianize='outliers', discourage_overlap (alias eliminate_synergy) on, float64.
@@ -373,10 +380,13 @@ def test_config5_standin_covariance():
     x, grp = O.gen_planted(n, v, m, seed=1)
     heavy = np.arange(v) % 20 == 0
     x[:, heavy] = np.sign(x[:, heavy]) * np.abs(x[:, heavy]) ** 1.5
-    ref = O.fit_ns(x, m, seed=0, dtype=np.float64, gaussianize="outliers", max_iter=60)
+    if "ref" not in _C5_CACHE:
+        _C5_CACHE["ref"] = O.fit_ns(x, m, seed=0, dtype=np.float64, gaussianize="outliers", max_iter=60)
+    ref = _C5_CACHE["ref"]
     from linearcorex_amd import Corex
     out = Corex(n_hidden=m, seed=0, dtype=np.float64, device=0, gaussianize="outliers", eliminate_synergy=True,
                 max_iter=60).fit(x)
+    assert out.line_search == ls and out.stats["trials"] == ref.n_trials
     h, h_ref = np.asarray(out.history["TC"], np.float64), np.asarray(ref.history_tc)
     assert len(h) == len(h_ref)
     assert relerr(h, h_ref) < 1e-6

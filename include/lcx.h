@@ -154,10 +154,21 @@ int lcx_bind_exchange(lcx_ctx* h, void* ybuf_dev, void* sbuf_dev);
  * lcx_exchange_info: kind -1 = no exchange steps (one rank), 0 = the caller exchanges between the levels, 1 = RCCL, 2 = hook. */
 #define LCX_COMM_ID_BYTES 128
 typedef int (*lcx_allreduce_fn)(void* user, void* dev_buf, int64_t count, int dtype, void* hip_stream);
+/* local, no collective: LCX_OK iff this process can bind librccl (dlopen).  ncclCommInitRank is collective - the ranks compare
+ * this answer BEFORE any of them enters lcx_comm_init, so that a rank without the library cannot leave the others blocked in it */
+int lcx_comm_probe(void);
 int lcx_comm_unique_id(void* id_out /* LCX_COMM_ID_BYTES */);
 int lcx_comm_init(lcx_ctx* h, int nranks, int rank, const void* id /* LCX_COMM_ID_BYTES */);
 int lcx_set_exchange_hook(lcx_ctx* h, lcx_allreduce_fn fn, void* user);
 int lcx_exchange_info(lcx_ctx* h, int* kind, int* world, int64_t* allreduces_issued);
+/* First contact with a bound transport (collective: every rank calls it with its own rank in [0, world), right after lcx_comm_init / lcx_set_exchange_hook and
+ * lcx_bind_exchange, before any level): all-reduces the Y exchange buffer at its real size on the handle's stream, once with a
+ * rank-dependent integer pattern whose sum is known in closed form and once with rank-dependent values over 12 binades, then
+ * shares the verdicts through the scalar buffer.  LCX_OK and *ok = 1 iff every rank got the right sums AND all ranks hold the same
+ * bits (lcx_iterate's decisions rely on that); LCX_ERR_COMM with the diagnosis otherwise, on every rank alike.
+ * seconds_per_allreduce (may be NULL): host wall time of one Y-buffer all-reduce.  The sums the reference
+ * forms in one address space (:247, :259) are only as good as this exchange. */
+int lcx_comm_selftest(lcx_ctx* h, int rank, int* ok, double* seconds_per_allreduce);
 
 /* ---- data ---------------------------------------------------------------------------------- */
 /* Replaces cm.CUDAMatrix(x) (:427-428): upload the preprocessed shard, row-major, leading
@@ -258,6 +269,11 @@ int lcx_iterate(lcx_ctx* h, double eps, double tol, double tc_cur, int more, dou
  * iterations but the Y of an accepted solution, which each step mixes convexly with fresh products (no drift, no re-anchoring).
  * Off by default: the default iteration re-evaluates every trial with two passes, as the reference does. */
 int lcx_set_trial_reuse(lcx_ctx* h, int enable);
+/* The reference divides every sample moment by `self.n_samples`, the sample count of the FIT (linearcorex.py:249, :260, :228, :211,
+ * :355) - also when `transform(x_new, details=True)` (:392-394) hands `_calculate_moments` a batch of another row count.  A handle
+ * that holds such a batch (x_new preprocessed with the fitted theta, the fitted W) is told the fit's count here; every level then
+ * divides by it instead of the handle's own n_samples (the default). */
+int lcx_set_sample_divisor(lcx_ctx* h, double n_samples);
 
 /* ---- synergistic branch: discourage_overlap=False (:336-384) -------------------------------------
  * One evaluation of _calculate_moments_syn on set `which`:

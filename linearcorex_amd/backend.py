@@ -120,6 +120,10 @@ class HipBackend:
     def set_trial_reuse(self, enable):
         _abi.check(self.lib.lcx_set_trial_reuse(self.h, 1 if enable else 0))
 
+    def set_sample_divisor(self, n_samples):
+        """the reference's `self.n_samples` when this handle holds another batch than the fitted one (transform(details=True))"""
+        _abi.check(self.lib.lcx_set_sample_divisor(self.h, float(n_samples)))
+
     def synchronize(self):
         _abi.check(self.lib.lcx_synchronize(self.h))
 
@@ -129,10 +133,24 @@ class HipBackend:
         _abi.check(self.lib.lcx_comm_unique_id(buf))
         return buf.raw
 
+    def comm_probe(self):
+        """Can THIS process load librccl (lcx_comm_probe)?  Local, no collective: the ranks compare notes before any of them
+        enters ncclCommInitRank."""
+        _abi.check(self.lib.lcx_comm_probe())
+
     def comm_init(self, world, rank, unique_id):
         """RCCL communicator owned by the handle (collective: every rank of the group calls it with rank 0's id)."""
         assert len(unique_id) == _abi.COMM_ID_BYTES
         _abi.check(self.lib.lcx_comm_init(self.h, int(world), int(rank), C.c_char_p(unique_id)))
+
+    def comm_selftest(self, rank=0):
+        """First contact with the bound transport (collective): the Y exchange buffer is all-reduced at its real size with
+        patterns whose outcome is known / must be rank-identical (include/lcx.h, lcx_comm_selftest).  Raises LcxError with the
+        diagnosis on EVERY rank if any rank saw a wrong sum or other bits; returns the seconds one such all-reduce took."""
+        ok, sec = C.c_int(0), C.c_double(0.0)
+        _abi.check(self.lib.lcx_comm_selftest(self.h, int(rank), C.byref(ok), C.byref(sec)))
+        assert ok.value == 1
+        return sec.value
 
     def set_exchange_hook(self, allreduce):
         """allreduce(dev_ptr, count, dtype_code, hip_stream) -> None sums the buffer over the ranks in place (any transport).
@@ -379,6 +397,16 @@ class HipBackend:
         ksec = C.c_double()
         _abi.check(self.lib.lcx_covariance(self.h, int(syn), float(eps), ps, _abi.np_ptr(out), self.nv, C.byref(ksec)))
         self._cov_kernel_seconds = ksec.value
+        return out
+
+    def covariance_rows(self, eps, std, row0, nrows, syn=False):
+        """rows [row0, row0 + nrows) of get_covariance (linearcorex.py:443-455) for this shard, (nrows, nv)."""
+        std, ps = self._a(std)
+        out = np.empty((int(nrows), self.nv), dtype=self.dtype)
+        if syn:
+            _abi.check(self.lib.lcx_covariance_rows_syn(self.h, ps, int(row0), int(nrows), _abi.np_ptr(out)))
+        else:
+            _abi.check(self.lib.lcx_covariance_rows(self.h, float(eps), ps, int(row0), int(nrows), _abi.np_ptr(out)))
         return out
 
     def last_covariance_device_seconds(self):

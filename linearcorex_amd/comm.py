@@ -50,45 +50,86 @@ class Comm:
         through this group's broadcast - and issues ncclAllReduce on its stream.  Any other backend (gloo in the tests, two
         ranks sharing one GPU): a hook that runs this group's all_reduce on a zero-copy view of the device buffer."""
         import os
+        import sys
         mode = os.environ.get("LCX_EXCHANGE", "engine")
         if mode == "torch" or not self.exchange or not hasattr(backend, "comm_init"):
             return None
         import torch
+        self.selftest_seconds = None
+
+        def agreed(flag, dev):
+            """MAX over the ranks of a local failure flag, on this group (every rank calls it at the same point)"""
+            with backend.stream_context():
+                bad = torch.tensor([1.0 if flag else 0.0], device=dev)
+                self._dist.all_reduce(bad, op=self._dist.ReduceOp.MAX, group=self.group)
+                return float(bad.item()) > 0
+
+        def selftest(dev, what):
+            """lcx_comm_selftest on every rank; its verdict is shared inside the test itself (rank-identical), the MAX over the
+            ranks on top covers a rank that could not even run it"""
+            err = None
+            if os.environ.get("LCX_COMM_SELFTEST", "1") not in ("", "0"):
+                try:
+                    if os.environ.get("LCX_TEST_FAIL_COMM_INIT") == "selftest" and what == "rccl":
+                        raise RuntimeError("LCX_TEST_FAIL_COMM_INIT=selftest")
+                    self.selftest_seconds = backend.comm_selftest(self.rank)
+                except Exception as e:       # noqa: BLE001 - reported by the caller, on every rank
+                    err = "lcx_comm_selftest (%s): %s" % (what, e)
+            return err
+
         if self._dist.get_backend(self.group) == "nccl" and mode != "hook":
-            # The group agrees on the outcome: an id that could not be drawn (no librccl for dlopen) reaches every rank as
-            # None, and after ncclCommInitRank the ranks all-reduce a failure flag.  If the library's own communicator is
-            # not to be had, every rank says so loudly and takes the hook transport below (this group's RCCL all_reduce on
-            # the same device buffers, lcx_iterate still inside the library) - never a silent or a one-sided change.
+            # The group agrees on every step BEFORE a rank commits to a collective the others might not enter:
+            #   1. every rank probes librccl locally (dlopen) and the flags are MAX-reduced on this group - ncclCommInitRank is
+            #      collective, a rank that raised before entering it would leave the others blocked inside it;
+            #   2. rank 0 draws the id, which reaches every rank (or None) through the group's broadcast;
+            #   3. after ncclCommInitRank the ranks MAX-reduce a failure flag (a failure INSIDE CommInitRank on some ranks only
+            #      is fatal by RCCL's own contract - bounded by its timeout, not by this code);
+            #   4. lcx_comm_selftest: the communicator must SUM at the real buffer size and give every rank the same bits.
+            # If the library's own communicator is not to be had, every rank says so loudly and takes the hook transport below
+            # (this group's RCCL all_reduce on the same device buffers, lcx_iterate still inside the library) - never a silent
+            # or a one-sided change.
             dev = torch.device("cuda", backend.device)
             err, box = None, [None]
-            if self.rank == 0:
-                try:
-                    if os.environ.get("LCX_TEST_FAIL_COMM_INIT") == "id":
-                        raise RuntimeError("LCX_TEST_FAIL_COMM_INIT=id")
-                    box = [backend.comm_unique_id()]
-                except Exception as e:       # noqa: BLE001 - reported below, on every rank
-                    err = "lcx_comm_unique_id: %s" % e
-            src = self._dist.get_global_rank(self.group, 0) if self.group is not None else 0
-            self._dist.broadcast_object_list(box, src=src, group=self.group, device=dev)
-            if box[0] is not None:
-                try:
-                    if os.environ.get("LCX_TEST_FAIL_COMM_INIT") == "init":
-                        raise RuntimeError("LCX_TEST_FAIL_COMM_INIT=init")
-                    backend.comm_init(self.world, self.rank, box[0])
-                except Exception as e:       # noqa: BLE001
-                    err = "lcx_comm_init: %s" % e
-            elif err is None:
-                err = "rank 0 could not draw an RCCL unique id"
-            with backend.stream_context():
-                bad = torch.tensor([0.0 if err is None else 1.0], device=dev)
-                self._dist.all_reduce(bad, op=self._dist.ReduceOp.MAX, group=self.group)
-                failed = float(bad.item()) > 0
-            if not failed:
+            forced = os.environ.get("LCX_TEST_FAIL_COMM_INIT", "")
+            can = True
+            try:
+                if forced == "probe" or forced == "probe:%d" % self.rank:
+                    raise RuntimeError("LCX_TEST_FAIL_COMM_INIT=%s" % forced)
+                backend.comm_probe()
+            except Exception as e:           # noqa: BLE001
+                can, err = False, "librccl probe: %s" % e
+            if agreed(not can, dev):
+                err = err or "another rank cannot load librccl"
+            else:
+                if self.rank == 0:
+                    try:
+                        if forced == "id":
+                            raise RuntimeError("LCX_TEST_FAIL_COMM_INIT=id")
+                        box = [backend.comm_unique_id()]
+                    except Exception as e:       # noqa: BLE001 - reported below, on every rank
+                        err = "lcx_comm_unique_id: %s" % e
+                src = self._dist.get_global_rank(self.group, 0) if self.group is not None else 0
+                self._dist.broadcast_object_list(box, src=src, group=self.group, device=dev)
+                if box[0] is not None:
+                    try:
+                        if forced == "init":
+                            raise RuntimeError("LCX_TEST_FAIL_COMM_INIT=init")
+                        backend.comm_init(self.world, self.rank, box[0])
+                    except Exception as e:       # noqa: BLE001
+                        err = "lcx_comm_init: %s" % e
+                elif err is None:
+                    err = "rank 0 could not draw an RCCL unique id"
+                if agreed(err is not None, dev):
+                    err = err or "another rank failed"
+                else:
+                    err = selftest(dev, "rccl")
+                    if agreed(err is not None, dev):
+                        err = err or "another rank failed the self-test"
+            if err is None:
                 return "rccl"
-            import sys
             print("linearcorex_amd: rank %d: the engine's own RCCL communicator is not available (%s); every rank exchanges "
-                  "through this process group's all_reduce instead (LCX_EXCHANGE=hook)"
-                  % (self.rank, err or "another rank failed"), file=sys.stderr, flush=True)
+                  "through this process group's all_reduce instead (LCX_EXCHANGE=hook)" % (self.rank, err),
+                  file=sys.stderr, flush=True)
             backend.set_exchange_hook(None)                  # drops a communicator this rank may have got
 
         class _View:                        # zero-copy: torch.as_tensor understands __cuda_array_interface__
@@ -101,6 +142,12 @@ class Comm:
                 t = torch.as_tensor(_View(ptr, count, dtype), device=torch.device("cuda", backend.device))
                 self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
         backend.set_exchange_hook(allreduce)
+        # the hook transport gets the same first-contact test; here a failure has no fall-back left: raise on every rank
+        dev = torch.device("cuda", backend.device)
+        err = selftest(dev, "hook")
+        if agreed(err is not None, dev):
+            raise RuntimeError("linearcorex_amd: rank %d: the exchange transport failed its self-test (%s)"
+                               % (self.rank, err or "on another rank"))
         return "hook"
 
     def gather_columns(self, local, nv, like):

@@ -26,6 +26,12 @@ _DEVICE_KEYS = ("uj", "rho", "ry", "invrho", "rhoinvrho", "Qij", "Si", "Qi-Si^2"
                 "X_i^2 | Y")
 
 
+class ShardedMomentError(RuntimeError):
+    """A per-variable moment of a fit over several ranks was touched before `gather_moments` put it together (dict access never
+    issues a collective).  The only error `DeviceMoments.get` / `materialize` treat as "absent": a failing readback (LcxError,
+    also a RuntimeError) propagates."""
+
+
 class DeviceMoments(dict):
     """`self.moments`: same keys as the reference dict (linearcorex.py:249-287).  Scalars and
     per-factor vectors are stored eagerly; the m x nv arrays stay on the GPU and are copied out on
@@ -66,7 +72,7 @@ class DeviceMoments(dict):
         return val
 
     def _sharded_error(self, key):
-        return RuntimeError("moments[%r] is sharded over %d ranks: call model.gather_moments([%r]) on every rank first "
+        return ShardedMomentError("moments[%r] is sharded over %d ranks: call model.gather_moments([%r]) on every rank first "
                             "(dict access never issues a collective)" % (key, self._owner._comm.world, key))
 
     _DERIVED = {"X_i Y_j": "rho", "I(X_i ; Y)": "X_i^2 | Y"}       # derived key -> the device array it is computed from
@@ -106,7 +112,7 @@ class DeviceMoments(dict):
     def get(self, key, default=None):
         try:
             return self[key]
-        except (KeyError, RuntimeError):       # RuntimeError: sharded and not gathered - absent as far as dict.get goes
+        except (KeyError, ShardedMomentError):       # sharded and not gathered: absent as far as dict.get goes
             return default
 
     def materialize(self, keys=None):
@@ -116,7 +122,7 @@ class DeviceMoments(dict):
             if k in self:
                 try:
                     self[k]
-                except (KeyError, RuntimeError):
+                except (KeyError, ShardedMomentError):
                     pass
         return dict(self)
 
@@ -831,13 +837,41 @@ class Corex(object):
                 self._comm.allreduce(t)
                 y = t.cpu().numpy()
         if details:
-            if ns != self.n_samples or not getattr(self, "_x_resident", True):
-                raise NotImplementedError("transform(details=True) evaluates the moments on the resident (fitted) data: "
-                                          "not available for other data or on a model restored from a pickle")
-            if not self.discourage_overlap:
-                return y, self._calculate_moments_syn()
-            return y, self._calculate_moments(quick=False, details=True)
+            # :392-394: the FULL moments of the batch that was handed in (not of the fitted data), with the fitted weights
+            return y, self._moments_of_batch(np.ascontiguousarray(x[:, c0:c1]))
         return y
+
+    def _moments_of_batch(self, x_local):
+        """`self._calculate_moments(x, self.ws)` of `transform(x, details=True)` (:392-394): x is preprocessed with the fitted
+        theta (:389), becomes the resident shard of a handle of its own, and the levels of a full evaluation run on it with the
+        fitted W - divided, as the reference divides, by the sample count of the FIT (`self.n_samples`, :249 / :260 / :355:
+        lcx_set_sample_divisor), whatever the batch's own row count is.  Returns a plain dict (the handle is gone afterwards);
+        several ranks: a collective, the per-variable arrays come back gathered."""
+        w_local = self._backend.get_ws(0)
+        sh = Corex.__new__(Corex)                  # same hyper-parameters, theta, eps, comm; its own handle, stats and moments
+        sh.__dict__.update(self.__dict__)          # (not copy.copy: that goes through __getstate__ and drops comm / factory)
+        sh._backend, sh._ex, sh._engine_exchange = None, None, None
+        sh.moments, sh.history = {}, {}
+        sh.stats = dict.fromkeys(self.stats, 0)
+        be = sh._make_backend(x_local.shape[0], x_local.shape[1])
+        try:
+            if self.gaussianize == 'empirical':
+                print("Warning: correct inversion/transform of empirical gauss transform not implemented.")     # :425
+            be.upload_preprocess(x_local, self.gaussianize, self.missing_values, self._theta_local())
+            be.set_ws(w_local)
+            be.set_sample_divisor(self.n_samples)
+            mo = sh._calculate_moments_syn() if not self.discourage_overlap else sh._calculate_moments(quick=False, details=True)
+            if self._comm.world > 1:
+                mo.gather()
+            out = mo.materialize()
+            # derived keys the reference's dict holds as well
+            for k in ("Y_j^2", "X_i Y_j", "I(X_i ; Y)", "invrho", "Qi"):
+                if k not in out and k in mo:
+                    out[k] = mo[k]
+            return out
+        finally:
+            be.close()
+            sh._backend = None
 
     def _project_new_batch(self, x_local):
         """x~ . ws^T of a new batch whose preprocessing needs whole columns; per-shard partial like `project_raw`."""
@@ -904,15 +938,65 @@ class Corex(object):
                            "model.gather_moments([%r]) was called on every rank (sharded moments are not gathered "
                            "implicitly above LCX_EAGER_GATHER_ELEMS elements)" % (key, key))
 
-    def get_covariance(self):
-        """Covariance estimate (:443-455), nv x nv: a rank-n_hidden product on the device for both branches."""
-        if self._comm.world > 1:
-            raise NotImplementedError("get_covariance() needs all variables on one GPU (nv x nv output)")
+    def get_covariance(self, rows=None):
+        """Covariance estimate (:443-455), nv x nv: a rank-n_hidden product on the device for both branches.
+
+        rows (not in the reference): None = the whole matrix; (start, stop) / slice / range = that block of rows,
+        (stop - start, nv) - what a model of 10^5 variables can still hand out.  Several ranks: every rank holds the columns of
+        its own variables; the call is a collective and every rank gets the same (rows, nv) array."""
         be = self._resident_backend(need_moments=True)
         std = np.asarray(self.theta[1], dtype=self.dtype)
-        if not self.discourage_overlap:                                        # :452-455
-            return be.covariance_syn(std)
-        return be.covariance(self.eps, std)
+        syn = not self.discourage_overlap
+        if rows is None and self._comm.world == 1:
+            return be.covariance_syn(std) if syn else be.covariance(self.eps, std)     # :452-455 / :446-451
+        if rows is None:
+            r0, r1 = 0, self.nv
+        elif isinstance(rows, (slice, range)):
+            r0, r1, step = rows.indices(self.nv) if isinstance(rows, slice) else (rows.start, rows.stop, rows.step)
+            if step != 1:
+                raise ValueError("get_covariance(rows=...): a contiguous block of rows")
+        else:
+            r0, r1 = (int(t) for t in rows)
+        if not 0 <= r0 <= r1 <= self.nv:
+            raise ValueError("get_covariance(rows=(%d, %d)): outside [0, %d]" % (r0, r1, self.nv))
+        if self._comm.world == 1:
+            return be.covariance_rows(self.eps, std, r0, r1 - r0, syn)
+        return self._covariance_rows_sharded(r0, r1, std, syn)
+
+    def _covariance_rows_sharded(self, r0, r1, std, syn):
+        """Rows [r0, r1) of the covariance over several ranks.  cov_ik = sum_j a_ij b_kj (a = b = z = rhoinvrho / (1 + Si),
+        divided by 1 - eps^2, :447-448; or a = X_i Z_j, b = X_i Y_j, :453), diagonal 1, times std_i std_k.  The row operand of
+        the requested variables is put together from its owners by one all-reduce of (rows x n_hidden) numbers per block;
+        every rank multiplies it with the operand of its own columns on the device (the rank-n_hidden product of lcx_predict,
+        kind 0) and the column blocks are gathered."""
+        import torch
+        be, (c0, c1) = self._backend, self._cols
+        if syn:                                                                # :453
+            a_loc = np.asarray(be.get_moment(0, "syn X_i Z_j"), self.dtype)
+            b_loc = np.asarray(be.get_moment(0, "syn X_i Y_j"), self.dtype)
+            denom = 1.0
+        else:                                                                  # :447-448
+            z = be.get_moment(0, "rhoinvrho") / (1 + be.get_moment(0, "Si"))
+            a_loc = b_loc = np.ascontiguousarray(z.T, self.dtype)
+            denom = 1.0 - self.eps ** 2
+        b_scaled = np.ascontiguousarray(b_loc * std[c0:c1, np.newaxis], self.dtype)
+        out = np.empty((r1 - r0, self.nv), dtype=self.dtype)
+        block = 4096
+        for s in range(r0, r1, block):
+            e = min(r1, s + block)
+            a = np.zeros((e - s, self.m), dtype=self.dtype)
+            lo, hi = max(s, c0), min(e, c1)
+            if lo < hi:                                                        # the rows this rank owns
+                a[lo - s:hi - s] = a_loc[lo - c0:hi - c0] * (std[lo:hi, np.newaxis] / self.dtype.type(denom))
+            with be.stream_context():
+                t = torch.from_numpy(a).to(self._ex[1].device)
+                self._comm.allreduce(t)
+                a = t.cpu().numpy()
+            blk = be.predict(a, xz=b_scaled)                                   # (e - s, nv_local) = a . b_scaled^T
+            if lo < hi:
+                blk[np.arange(lo - s, hi - s), np.arange(lo - c0, hi - c0)] = std[lo:hi] ** 2      # fill_diagonal (:449 / :454)
+            out[s - r0:e - r0] = self._gather(blk)
+        return out
 
     # ------------------------------------------------------------------------------------------
     # persistence (vis_corex.py:549 pickles the model)

@@ -5,6 +5,7 @@
 // _calculate_moments_ns / _update_ns (linearcorex.py:236-334) on one HIP stream.  No torch types,
 // no callbacks; multi-GPU exchange happens between the *_a/_b/_c entry points, outside.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -164,6 +165,8 @@ struct lcx_ctx {
     int device, dtype;
     size_t es;
     int64_t N, V, Npad, ldx;    // ldx == Vp
+    double Ndiv;                // the divisor of every sample moment (reference: self.n_samples, :249 / :260 / :355): N, unless the
+                                // handle holds a batch that is evaluated with another fit's sample count (lcx_set_sample_divisor)
     int M, Mp, CT;
     hipStream_t own_stream, stream;
     void* X;                    // [Npad][ldx]
@@ -251,6 +254,48 @@ static int exchange(lcx_ctx* h, void* buf, int64_t count, int dtype) {
 }
 // the library can sequence whole iterations when it does not depend on the caller for the sums
 static inline bool self_contained(const lcx_ctx* h) { return !h->exchange || h->tr.kind != 0 || h->world == 1; }
+
+// ---- first contact with a transport: does it sum, and does every rank get the same bits? --------------------------
+// pattern 0: small integers (exact in both precisions, the sum over the ranks is known in closed form);
+// pattern 1: rank-dependent pseudo-random values over 12 binades (the sum depends on the order of the reduction: what is
+//            checked is that every rank ends up with the SAME bits, which the rank-identical line-search decisions need)
+namespace lcx {
+__device__ __forceinline__ uint64_t st_mix(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+template <typename T>
+__global__ void selftest_fill_kernel(T* __restrict__ buf, int64_t n, int pattern, int rank) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (pattern == 0) {
+            buf[i] = (T)((double)((i % 251) + 1) * (double)(rank + 1));
+        } else {
+            const uint64_t hsh = st_mix((uint64_t)i * 0xD1342543DE82EF95ull + (uint64_t)rank);
+            const double mant = (double)(hsh >> 11) * (1.0 / 9007199254740992.0) - 0.5;       // [-0.5, 0.5)
+            buf[i] = (T)ldexp(mant, (int)((hsh & 1023) % 12) - 6);
+        }
+    }
+}
+// out[0] = number of elements that differ from the closed-form sum (pattern 0 only), out[1] = order-independent hash of the bits
+template <typename T>
+__global__ void selftest_check_kernel(const T* __restrict__ buf, int64_t n, int pattern, int nranks, unsigned long long* __restrict__ out) {
+    unsigned long long bad = 0, hsh = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T v = buf[i];
+        if (pattern == 0) {
+            const T want = (T)((double)((i % 251) + 1) * (double)(nranks * (nranks + 1) / 2));
+            bad += (v != want) ? 1ull : 0ull;
+        }
+        uint64_t bits = 0;
+        if constexpr (sizeof(T) == 4) bits = (uint64_t)__float_as_uint((float)v); else bits = (uint64_t)__double_as_longlong((double)v);
+        hsh += st_mix(bits ^ st_mix((uint64_t)i));
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    atomicAdd(&out[1], hsh);
+}
+}  // namespace lcx
 
 // Temporary device buffers of one call: freed on every return path (an OOM in the middle of a call must not leak the
 // buffers allocated before it - that is exactly when memory matters).
@@ -799,7 +844,7 @@ template <typename T, int CT> struct Impl {
         SmallDesc sd{s.uj, s.ry, s.wmag};
         const T* gw = h->exchange ? P<T>(h->ybuf) + h->Npad * Mp : P<T>(h->gpartw);
         hipLaunchKernelGGL((small_moments_kernel<T>), dim3(Mp * Mp / 32), dim3(256), 0, h->stream, P<T>(h->gpart),
-                           h->gn_S, gw, h->exchange ? 1 : h->gv_S, Mp, h->M, (double)h->N, eps, quick, sd, s.st,
+                           h->gn_S, gw, h->exchange ? 1 : h->gv_S, Mp, h->M, h->Ndiv, eps, quick, sd, s.st,
                            h->ticket);
         KCHECK();
         return LCX_OK;
@@ -855,7 +900,7 @@ template <typename T, int CT> struct Impl {
         hipLaunchKernelGGL((moments_epilogue_kernel<T, Mp>), dim3(h->pv_grid), dim3(NTV), lds, h->stream,
                            P<T>(h->dpart), h->tn_slots, h->ldx * Mp,
                            linear ? P<T>(h->set[0].D) : (const T*)nullptr, P<T>(h->ddir), (T)eta, P<T>(s.D),
-                           P<T>(h->Wt[which]), s.ry, h->V, (double)h->N, eps,
+                           P<T>(h->Wt[which]), s.ry, h->V, h->Ndiv, eps,
                            P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), P<T>(s.hscale),
                            h->tcpart, skip);
         KCHECK();
@@ -987,7 +1032,7 @@ template <typename T, int CT> struct Impl {
             }
             const int grid = update_grid(h);
             hipLaunchKernelGGL((update_kernel<T, Mp>), dim3(grid), dim3(PV_THREADS), 0, h->stream, P<T>(h->dpart), 0, h->ldx * Mp,
-                               P<T>(h->grad), P<T>(h->Wt[0]), s.uj, bj, h->V, (double)h->N, eps, P<T>(h->update),
+                               P<T>(h->grad), P<T>(h->Wt[0]), s.uj, bj, h->V, h->Ndiv, eps, P<T>(h->update),
                                P<T>(h->sgrad), h->tanpart, (const T*)nullptr, (T*)nullptr, grid, (const T*)nullptr, (const T*)nullptr,
                                (int64_t)0, (T*)nullptr, P<T>(h->Wt[1]), h->world, P<T>(h->gw), 0);
             KCHECK();
@@ -1034,7 +1079,7 @@ template <typename T, int CT> struct Impl {
             // Y(update) and the Y term of update_tangent - from Y_g, which sits in its own buffer
             hipLaunchKernelGGL((update_kernel<T, Mp>), dim3(gridy), dim3(PV_THREADS), 0, h->stream, P<T>(h->dpart), 0, h->ldx * Mp,
                                P<T>(h->grad), P<T>(h->Wt[0]), s.uj, h->exchange ? P<T>(h->bjg) : P<T>(h->ybuf) + h->Npad * Mp, h->V,
-                               (double)h->N, eps, P<T>(h->update),
+                               h->Ndiv, eps, P<T>(h->update),
                                P<T>(h->sgrad), h->tanpart, (const T*)nullptr, (T*)nullptr, 0, P<T>(h->ygbuf), P<T>(s.Y), ny, P<T>(h->ydir),
                                (T*)nullptr, h->world, (T*)nullptr, grid);
             KCHECK();
@@ -1043,7 +1088,7 @@ template <typename T, int CT> struct Impl {
         }
         hipLaunchKernelGGL((update_kernel<T, Mp>), dim3(grid + gridy), dim3(PV_THREADS), 0, h->stream, P<T>(h->dpart),
                            h->full_sig ? h->tn_slots : 0, h->ldx * Mp, P<T>(h->grad), P<T>(h->Wt[0]), s.uj, P<T>(h->ybuf) + h->Npad * Mp, h->V,
-                           (double)h->N, eps, P<T>(h->update), P<T>(h->sgrad), h->tanpart,
+                           h->Ndiv, eps, P<T>(h->update), P<T>(h->sgrad), h->tanpart,
                            h->full_sig ? P<T>(s.D) : (const T*)nullptr, h->full_sig ? P<T>(h->ddir) : (T*)nullptr, grid, P<T>(h->ybuf),
                            P<T>(s.Y), ny, P<T>(h->ydir), P<T>(h->Wt[1]), h->world);
         KCHECK();
@@ -1250,13 +1295,13 @@ template <typename T, int CT> struct Impl {
         LCXCHECK(syn_alloc(h));
         MomentSet& s = h->set[which];
         LCXCHECK(gram(h, P<T>(h->ybuf), h->Npad, nullptr, h->gn_S, nullptr, P<T>(h->gpart)));
-        hipLaunchKernelGGL((syn_small_kernel<T>), dim3(1), dim3(256), 0, h->stream, P<T>(h->gpart), h->gn_S, Mp, h->M, (double)h->N,
+        hipLaunchKernelGGL((syn_small_kernel<T>), dim3(1), dim3(256), 0, h->stream, P<T>(h->gpart), h->gn_S, Mp, h->M, h->Ndiv,
                            yscale, s.cy, s.yj2, s.ry, s.inv_sd, s.st);
         KCHECK();
         LCXCHECK(tn_big(h, nullptr));
         const int64_t total = h->V * Mp;
         hipLaunchKernelGGL((syn_rho_kernel<T>), dim3((unsigned)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048)), dim3(256), 0, h->stream,
-                           P<T>(h->dpart), h->tn_slots, h->ldx * Mp, total, Mp, (double)h->N, s.inv_sd, P<T>(s.D), P<T>(s.rho));
+                           P<T>(h->dpart), h->tn_slots, h->ldx * Mp, total, Mp, h->Ndiv, s.inv_sd, P<T>(s.D), P<T>(s.rho));
         KCHECK();
         hipLaunchKernelGGL(invert_kernel, dim3(1), dim3(WIDE ? 1024 : 256), 0, h->stream, s.ry, Mp, h->invwork, h->ryinv);
         KCHECK();
@@ -1371,7 +1416,7 @@ template <typename T, int CT> struct Impl {
         const unsigned pg = (unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
         if (syn)
             hipLaunchKernelGGL((cov_prep_kernel<T>), dim3(pg), dim3(256), 0, h->stream, (const T*)nullptr, (const T*)nullptr, P<T>(s.D), n, Mp,
-                               (T)(1.0 / (double)h->N), (T*)nullptr, P<T>(c.op_b));
+                               (T)(1.0 / h->Ndiv), (T*)nullptr, P<T>(c.op_b));
         else
             hipLaunchKernelGGL((cov_prep_kernel<T>), dim3(pg), dim3(256), 0, h->stream, P<T>(s.rir), P<T>(s.si), (const T*)nullptr, n, Mp, (T)0,
                                P<T>(c.op_a), (T*)nullptr);
@@ -1499,7 +1544,7 @@ template <typename T, int CT> struct Impl {
             case LCX_M_SYN_X2Y: if (!s.xz) return fail(LCX_ERR_STATE, "no synergistic moments"); return fetch_v(h, P<T>(s.x2y), o);
             case LCX_M_SYN_XIYJ: {
                 LCXCHECK(fetch_mv(h, P<T>(s.D), o, false));
-                for (int64_t i = 0; i < h->V * h->M; ++i) o[i] = o[i] / (T)h->N;
+                for (int64_t i = 0; i < h->V * h->M; ++i) o[i] = o[i] / (T)h->Ndiv;
                 return LCX_OK;
             }
             case LCX_M_CY: if (!s.xz) return fail(LCX_ERR_STATE, "no synergistic moments"); return fetch_small(h, s.cy, h->M, h->M, o);
@@ -1519,7 +1564,7 @@ template <typename T, int CT> struct Impl {
         if (key == LCX_M_SYN_XIZJ || key == LCX_M_SYN_XIYJ) {       // (nv, m) host arrays of the synergistic branch (:453)
             LCXCHECK(syn_alloc(h));
             std::vector<T> tmp((size_t)h->ldx * Mp, (T)0);
-            const T scale = key == LCX_M_SYN_XIYJ ? (T)h->N : (T)1;  // kept as X^T.Y = N * X_i Y_j (:355)
+            const T scale = key == LCX_M_SYN_XIYJ ? (T)h->Ndiv : (T)1;  // kept as X^T.Y = N * X_i Y_j (:355)
             for (int64_t v = 0; v < h->V; ++v)
                 for (int j = 0; j < h->M; ++j) tmp[v * Mp + j] = src[v * h->M + j] * scale;
             HIPCHECK(hipMemcpyAsync(key == LCX_M_SYN_XIZJ ? s.xz : s.D, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
@@ -2005,6 +2050,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     h->dtype = dtype;
     h->es = dtype == LCX_F32 ? 4 : 8;
     h->N = n_samples;
+    h->Ndiv = (double)n_samples;
     h->V = nv_local;
     h->M = n_hidden;
     h->CT = ct;
@@ -2218,6 +2264,11 @@ int lcx_bind_exchange(lcx_ctx* h, void* y, void* s) {
 }
 
 // ---- exchange inside the library ---------------------------------------------------------------------
+int lcx_comm_probe(void) {
+    if (!rccl().ok) return fail(LCX_ERR_COMM, rccl().error);
+    return LCX_OK;
+}
+
 int lcx_comm_unique_id(void* id_out) {
     if (!id_out) return fail(LCX_ERR_ARG, "lcx_comm_unique_id: null");
     if (!rccl().ok) return fail(LCX_ERR_COMM, rccl().error);
@@ -2265,6 +2316,72 @@ int lcx_set_exchange_hook(lcx_ctx* h, lcx_allreduce_fn fn, void* user) {
         h->tr.hook = fn;
         h->tr.user = user;
     }
+    return LCX_OK;
+}
+
+int lcx_comm_selftest(lcx_ctx* h, int rank, int* ok_out, double* seconds_per_allreduce) {
+    NEED_MUT(h);
+    if (ok_out) *ok_out = 0;
+    if (!h->exchange || h->tr.kind == 0)
+        return fail(LCX_ERR_STATE, "lcx_comm_selftest: no transport bound (lcx_comm_init / lcx_set_exchange_hook first)");
+    if (rank < 0 || rank >= h->world || (h->tr.kind == 1 && rank != h->tr.rank))
+        return fail(LCX_ERR_ARG, "lcx_comm_selftest: rank " + std::to_string(rank) + " is not this handle's rank in a world of " +
+                                     std::to_string(h->world));
+    const int64_t n = h->ybuf_main;                       // what every level all-reduces: [Y | tail]
+    const int nr = h->world;
+    DevTemps tmp;
+    unsigned long long* res = nullptr;
+    LCXCHECK(tmp.get(&res, 4 * sizeof(unsigned long long)));
+    unsigned long long host[4] = {0, 0, 0, 0};
+    const unsigned grid = (unsigned)std::min<int64_t>(2048, cdiv(n, 256));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipMemsetAsync(res, 0, 4 * sizeof(unsigned long long), h->stream));
+    double secs = 0.0;
+    for (int pattern = 0; pattern < 2; ++pattern) {
+        if (h->dtype == LCX_F32) hipLaunchKernelGGL((lcx::selftest_fill_kernel<float>), dim3(grid), dim3(256), 0, h->stream, (float*)h->ybuf, n, pattern, rank);
+        else hipLaunchKernelGGL((lcx::selftest_fill_kernel<double>), dim3(grid), dim3(256), 0, h->stream, (double*)h->ybuf, n, pattern, rank);
+        KCHECK();
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        const auto t0 = std::chrono::steady_clock::now();
+        LCXCHECK(exchange(h, h->ybuf, n, h->dtype));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (h->dtype == LCX_F32) hipLaunchKernelGGL((lcx::selftest_check_kernel<float>), dim3(grid), dim3(256), 0, h->stream, (const float*)h->ybuf, n, pattern, nr, res + 2 * pattern);
+        else hipLaunchKernelGGL((lcx::selftest_check_kernel<double>), dim3(grid), dim3(256), 0, h->stream, (const double*)h->ybuf, n, pattern, nr, res + 2 * pattern);
+        KCHECK();
+    }
+    HIPCHECK(hipMemcpyAsync(host, res, sizeof(host), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    // every rank learns every rank's verdict through the scalar exchange buffer (doubles): the number of wrong sums, and the
+    // two halves a, b of each result hash with their squares - all ranks hold the same bits iff n * sum(a^2) == (sum a)^2
+    double sv[16] = {0};
+    sv[0] = (double)host[0];
+    for (int pattern = 0; pattern < 2; ++pattern) {
+        const uint64_t hs = host[2 * pattern + 1];
+        for (int k = 0; k < 3; ++k) {
+            const double part = (double)((hs >> (21 * k)) & 0x1FFFFFull);       // 21-bit pieces: squares and 8-rank sums stay exact
+            sv[1 + pattern * 6 + 2 * k] = part;
+            sv[2 + pattern * 6 + 2 * k] = part * part;
+        }
+    }
+    HIPCHECK(hipMemcpyAsync(h->sbuf, sv, 13 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    LCXCHECK(exchange(h, h->sbuf, 13, LCX_F64));
+    HIPCHECK(hipMemcpyAsync(sv, h->sbuf, 13 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    // leave the exchange buffers as lcx_bind_exchange leaves them
+    HIPCHECK(hipMemsetAsync(h->ybuf, 0, (size_t)n * h->es, h->stream));
+    HIPCHECK(hipMemsetAsync(h->sbuf, 0, 13 * sizeof(double), h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (seconds_per_allreduce) *seconds_per_allreduce = secs / 2.0;
+    bool same = true;
+    for (int k = 0; k < 6; ++k) same = same && ((double)nr * sv[2 + 2 * k] == sv[1 + 2 * k] * sv[1 + 2 * k]);
+    if (sv[0] != 0.0)
+        return fail(LCX_ERR_COMM, "lcx_comm_selftest: the all-reduce of " + std::to_string(n) + " elements over " + std::to_string(nr) +
+                                      " ranks returned " + std::to_string((long long)sv[0]) + " wrong sums (all ranks together; this rank: " +
+                                      std::to_string((long long)host[0]) + ")");
+    if (!same)
+        return fail(LCX_ERR_COMM, "lcx_comm_selftest: the ranks hold different bits after the same all-reduce (the line-search "
+                                  "decisions of lcx_iterate need rank-identical sums)");
+    if (ok_out) *ok_out = 1;
     return LCX_OK;
 }
 
@@ -2511,6 +2628,14 @@ int lcx_set_trial_reuse(lcx_ctx* h, int enable) {
     NEED_MUT(h);
     HIPCHECK(hipStreamSynchronize(h->stream));
     h->reuse_y = enable != 0;
+    return LCX_OK;
+}
+
+int lcx_set_sample_divisor(lcx_ctx* h, double n_samples) {
+    NEED_MUT(h);
+    if (!(n_samples >= 1.0)) return fail(LCX_ERR_ARG, "lcx_set_sample_divisor: n_samples must be >= 1");
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    h->Ndiv = n_samples;
     return LCX_OK;
 }
 

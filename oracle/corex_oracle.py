@@ -88,11 +88,14 @@ def preprocess(x, theta=None, gaussianize="standard", missing_values=None):
 # --------------------------------------------------------------------------------------------------
 # moment engine (ref :196-288)
 # --------------------------------------------------------------------------------------------------
-def latent_second_moment(x, w, eps):
-    """u_j = (1-eps^2) * mean_l (x w^T)_lj^2 + eps^2 * sum_i w_ji^2   (ref :247-249, :226-228)."""
+def latent_second_moment(x, w, eps, n_samples=None):
+    """u_j = (1-eps^2) * sum_l (x w^T)_lj^2 / n_samples + eps^2 * sum_i w_ji^2   (ref :247-249, :226-228).
+    n_samples: the reference divides by `self.n_samples`, the sample count of the FIT (ref :249) - for every x it is handed,
+    so `transform(x_new, details=True)` (ref :392-394) evaluates a batch of another size with the fit's divisor.
+    None = len(x), which is the same thing inside `fit`."""
     y = x.dot(w.T)
     ssq = np.einsum("lj,lj->j", y, y)
-    uj = (1 - eps ** 2) * ssq / x.shape[0] + eps ** 2 * np.sum(w ** 2, axis=1)
+    uj = (1 - eps ** 2) * ssq / (x.shape[0] if n_samples is None else n_samples) + eps ** 2 * np.sum(w ** 2, axis=1)
     return y, uj
 
 
@@ -107,10 +110,11 @@ def sig(x, u, eps):
     return (1 - eps ** 2) * proj.T / x.shape[0] + eps ** 2 * u
 
 
-def moments_ns(x, w, eps, quick=False, yscale=1.0):
-    """ref :236-288 `_calculate_moments_ns`.  Returns False when quick and max(u_j) >= 1 (ref :250)."""
-    ns = x.shape[0]
-    y, uj = latent_second_moment(x, w, eps)
+def moments_ns(x, w, eps, quick=False, yscale=1.0, n_samples=None):
+    """ref :236-288 `_calculate_moments_ns`.  Returns False when quick and max(u_j) >= 1 (ref :250).
+    n_samples: `self.n_samples` of the reference (ref :249, :260), see latent_second_moment."""
+    ns = x.shape[0] if n_samples is None else n_samples
+    y, uj = latent_second_moment(x, w, eps, ns)
     mo = {"uj": uj}
     if quick and np.max(uj) >= 1.0:
         return False
@@ -353,9 +357,10 @@ def gen_iid(n, v, seed=1, dtype=np.float64):
 SYN_ETA = 0.1              # ref :141
 
 
-def moments_syn(x, w, yscale=1.0):
-    """ref :336-373 `_calculate_moments_syn` (the `quick` flag is ignored there)."""
-    n = x.shape[0]
+def moments_syn(x, w, yscale=1.0, n_samples=None):
+    """ref :336-373 `_calculate_moments_syn` (the `quick` flag is ignored there).  n_samples: `self.n_samples` of the
+    reference (ref :352, :355), the fit's sample count whatever x is (see latent_second_moment)."""
+    n = x.shape[0] if n_samples is None else n_samples
     m = w.shape[0]
     mo = {}
     y = x.dot(w.T)                                                          # ref :347

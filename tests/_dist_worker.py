@@ -82,10 +82,15 @@ def main():
     rho = model.moments["rho"]
     xz = model.moments["X_i Z_j"]
     si = model.moments["Si"]
-    cov = model.get_covariance() if (syn and comm.world == 1) else np.zeros(1)
+    # get_covariance over the ranks (a collective): the whole matrix while it is small, and a block of rows that straddles a
+    # shard boundary - every rank gets the same (rows, n_variables) array
+    cov = model.get_covariance() if v <= 1000 else np.zeros(1)
+    b = comm.shard(v, 0)[1]
+    cov_rows = model.get_covariance(rows=(max(0, b - 100), min(v, b + 156)))
+    assert cov_rows.shape == (min(v, b + 156) - max(0, b - 100), v)
     if comm.rank == 0:
         np.savez(os.path.join(out_dir, "dist_result.npz"), history=np.asarray(model.history["TC"], np.float64),
-                 ws=model.ws, clusters=model.clusters(), transform=y, predict=xr, rho=rho, xz=xz, si=si, cov=cov,
+                 ws=model.ws, clusters=model.clusters(), transform=y, predict=xr, rho=rho, xz=xz, si=si, cov=cov, cov_rows=cov_rows, cov_row0=max(0, b - 100),
                  tcs=model.tcs, world=comm.world, trials=model.stats["trials"],
                  transport=str(getattr(model, "_engine_exchange", None)),
                  in_library=np.array(bool(getattr(model, "_iterated_in_library", False))),

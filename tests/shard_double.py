@@ -16,6 +16,7 @@ class ShardDouble:
         self.n, self.nv, self.m = int(n_samples), int(nv_local), int(n_hidden)
         self.dtype = np.dtype(dtype)
         self.m_pad = self.m
+        self.ndiv = self.n           # the reference's self.n_samples (set_sample_divisor: another fit's count)
         self.generation = 0
         self.x = None
         self.w = [np.zeros((self.m, self.nv), self.dtype), np.zeros((self.m, self.nv), self.dtype)]
@@ -31,6 +32,9 @@ class ShardDouble:
     # ---- plumbing ----------------------------------------------------------------------------
     def close(self):
         pass
+
+    def set_sample_divisor(self, n_samples):
+        self.ndiv = float(n_samples)
 
     def geometry(self):
         return {"m_pad": self.m}
@@ -102,7 +106,7 @@ class ShardDouble:
 
     def _finish_moments(self, which, eps, quick, y, d):
         """d = X^T.Y of the shard (nv x m); None -> one pass over X."""
-        w, n = self.w[which], self.n
+        w, n = self.w[which], self.ndiv
         gw = self._tail().reshape(self.m, self.m).copy()
         dt = self.dtype.type
         c1, c2 = dt(1 - eps ** 2), dt(eps ** 2)
@@ -200,7 +204,7 @@ class ShardDouble:
         dt = self.dtype.type
         yg = self._y().copy()
         bj = self._tail()[:self.m].copy()[:, np.newaxis]
-        sg = dt(1 - eps ** 2) * self.x.T.dot(yg).T / dt(self.n) + dt(eps ** 2) * self.grad
+        sg = dt(1 - eps ** 2) * self.x.T.dot(yg).T / dt(self.ndiv) + dt(eps ** 2) * self.grad
         rj = 1.0 - mo["uj"][:, np.newaxis]
         self.update = -rj * (self.grad - 2.0 * w / (2 - rj) * bj)
         self.sig_grad = sg
@@ -215,7 +219,7 @@ class ShardDouble:
 
     # ---- synergistic branch (ref :336-384), cut at the same exchange points as include/lcx.h --------------
     def syn_moments_b(self, which, yscale):
-        w, n, m = self.w[which], self.n, self.m
+        w, n, m = self.w[which], self.ndiv, self.m
         y = self._y().copy()
         xy = self.x.T.dot(y) / n                                     # nv x m   (:355)
         cy = y.T.dot(y) / n + yscale ** 2 * np.eye(m)                # == ws.dot(X_i Y_j) + yscale^2 I (:356)
@@ -282,7 +286,7 @@ class ShardDouble:
 
     def init_scale_ws(self):
         y = self._y()
-        uj = np.einsum("lj,lj->j", y, y) / self.n
+        uj = np.einsum("lj,lj->j", y, y) / self.ndiv
         self.w[0] = self.w[0] / (10.0 * np.sqrt(uj))[:, np.newaxis].astype(self.dtype)
         self.generation += 1
 
@@ -308,6 +312,10 @@ class ShardDouble:
         cov = np.dot(z.T, z) / (1.0 - eps ** 2)
         np.fill_diagonal(cov, 1)
         return std[:, np.newaxis] * std * cov
+
+    def covariance_rows(self, eps, std, row0, nrows, syn=False):
+        cov = self.covariance_syn(std) if syn else self.covariance(eps, std)
+        return cov[row0:row0 + nrows]
 
     def project(self, x):
         return np.asarray(x, self.dtype).dot(self.w[0].T)

@@ -23,6 +23,18 @@ def free_port():
     return p
 
 
+def check_covariance(got, ref, tol=1e-8):
+    """get_covariance over the ranks (reference :443-455): the whole matrix (small models) and a block of rows that straddles a
+    shard boundary against the single-process oracle."""
+    cov_ref = ref.get_covariance()
+    scale = float(np.max(np.abs(cov_ref)))
+    r0, rows = int(got["cov_row0"]), got["cov_rows"]
+    assert rows.shape[1] == cov_ref.shape[1] and np.max(np.abs(rows - cov_ref[r0:r0 + rows.shape[0]])) < tol * scale
+    if got["cov"].ndim == 2:
+        assert np.max(np.abs(got["cov"] - cov_ref)) < tol * scale
+        assert np.array_equal(np.diag(got["cov"]), np.asarray(ref.theta[1]) ** 2)
+
+
 def launch(world, out_dir, n, v, m, mode="exact", extra_env=None):
     port = free_port()
     procs = []
@@ -65,6 +77,7 @@ def test_sharded_fit_matches_oracle(world, mode, tmp_path):
     assert np.max(np.abs(got["si"] - ref.moments["Si"])) < 1e-8
     assert np.max(np.abs(got["tcs"] - ref.moments["TCs"])) < 1e-8
     assert int(got["trials"]) == ref.n_trials
+    check_covariance(got, ref)
 
 
 def test_sharded_synergistic_fit_matches_oracle(tmp_path):
@@ -83,6 +96,7 @@ def test_sharded_synergistic_fit_matches_oracle(tmp_path):
     assert np.max(np.abs(got["xz"] - ref.moments["X_i Z_j"])) < 1e-8
     assert np.max(np.abs(got["si"] - ref.moments["Si"])) < 1e-8
     assert np.max(np.abs(got["tcs"] - ref.moments["TCs"])) < 1e-8
+    check_covariance(got, ref)
 
 
 @pytest.mark.parametrize("mode", ["exact", "syn"])

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import corex_oracle as O
-from tests.test_distributed_cpu import ROOT, free_port  # noqa: F401
+from tests.test_distributed_cpu import ROOT, check_covariance, free_port  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -90,6 +90,7 @@ def test_sharded_fit_on_device_matches_oracle(world, mode, shape, exchange, tmp_
     assert np.max(np.abs(got["tcs"] - ref.moments["TCs"])) < 1e-7
     if mode in ("exact", "exact-y"):
         assert int(got["trials"]) == ref.n_trials
+    check_covariance(got, ref, 1e-6)           # sharded get_covariance (the north-star tolerance)
 
 
 def test_rccl_exchange_path_single_rank(tmp_path):
@@ -98,7 +99,9 @@ def test_rccl_exchange_path_single_rank(tmp_path):
     ncclAllReduce issued by the library, the exact line search inside lcx_iterate) against the host-sequenced path
     (LCX_EXCHANGE=torch: torch.distributed 'nccl' between the level calls): bit-identical trajectories, both equal to the
     oracle (all-reduces over one rank are identities).  Also the hook transport on the RCCL group (LCX_EXCHANGE=hook) and the
-    agreed fall-back to it when the library's own communicator cannot be set up (id not drawn / ncclCommInitRank failed)."""
+    agreed fall-back to it when the library's own communicator cannot be set up (librccl not loadable on a rank / id not drawn /
+    ncclCommInitRank failed / the communicator failed lcx_comm_selftest).  Every transport that comes up passes the first-contact
+    self-test (the Y exchange buffer all-reduced at its real size: right sums, rank-identical bits)."""
     import subprocess
     import sys
     code = r'''
@@ -116,12 +119,14 @@ x, _ = O.gen_planted(400, 331, 5, seed=2)
 for syn in (False, True):
     ref = (O.fit_syn if syn else O.fit_ns)(x, 5, seed=0, dtype=np.float64, max_iter=40)
     runs = {}
-    for mode in ("engine", "torch", "hook", "fallback-id", "fallback-init"):
+    for mode in ("engine", "torch", "hook", "fallback-probe", "fallback-id", "fallback-init", "fallback-selftest"):
         os.environ["LCX_EXCHANGE"] = "engine" if mode.startswith("fallback") else mode
         os.environ["LCX_TEST_FAIL_COMM_INIT"] = mode.split("-")[1] if mode.startswith("fallback") else ""
-        out = Corex(n_hidden=5, seed=0, dtype=np.float64, device=0, comm=Comm(always_exchange=True), max_iter=40,
+        comm = Comm(always_exchange=True)
+        out = Corex(n_hidden=5, seed=0, dtype=np.float64, device=0, comm=comm, max_iter=40,
                     discourage_overlap=not syn).fit(x)
         assert out._ex is not None and out._backend.torch_stream is not None
+        assert (comm.selftest_seconds is not None and comm.selftest_seconds > 0) == (mode != "torch"), (mode, comm.selftest_seconds)
         info = out._backend.exchange_info()
         if mode == "engine":
             assert out._engine_exchange == "rccl" and info["kind"] == "rccl" and info["allreduces_issued"] > 100, info
@@ -139,9 +144,40 @@ for syn in (False, True):
         assert np.max(np.abs(y - ref.transform(O.preprocess(x)[0]))) < 1e-7
         runs[mode] = (h, out.ws.copy(), y, out.stats["trials"])
         out._backend.close()
-    for other in ("torch", "hook", "fallback-id", "fallback-init"):
+    for other in ("torch", "hook", "fallback-probe", "fallback-id", "fallback-init", "fallback-selftest"):
         assert np.array_equal(runs["engine"][0], runs[other][0]) and np.array_equal(runs["engine"][1], runs[other][1]), other
         assert np.array_equal(runs["engine"][2], runs[other][2]) and runs["engine"][3] == runs[other][3], other
+# the self-test itself, driven directly: it refuses a handle without a transport, and a transport that does not SUM is caught
+from linearcorex_amd.backend import HipBackend
+from linearcorex_amd import _abi
+be = HipBackend(400, 331, 5, np.float32, 0)
+be.set_world(1)
+be.set_exchange(True)
+be.exchange_tensors()
+try:
+    be.comm_selftest()
+    raise SystemExit("lcx_comm_selftest without a transport did not fail")
+except _abi.LcxError as e:
+    assert "no transport" in str(e), e
+calls = []
+def doubling(ptr, count, dtype, stream):          # a broken transport: "sums" to twice the right answer
+    import torch
+    class V:
+        __cuda_array_interface__ = {"shape": (count,), "typestr": "<f4" if dtype == 0 else "<f8", "data": (ptr, False), "version": 2}
+    with be.stream_context():
+        t = torch.as_tensor(V(), device="cuda:0")
+        t *= 2
+    calls.append(count)
+be.set_exchange_hook(doubling)
+try:
+    be.comm_selftest()
+    raise SystemExit("a transport that does not sum passed lcx_comm_selftest")
+except _abi.LcxError as e:
+    assert "wrong sums" in str(e), e
+assert calls and calls[0] == be.geometry()["n_pad"] * be.geometry()["m_pad"] + be.geometry()["m_pad"] ** 2, calls
+be.set_exchange_hook(lambda ptr, count, dtype, stream: calls.append(-count))      # identity = the right sum over one rank
+assert be.comm_selftest() > 0
+be.close()
 dist.destroy_process_group()
 print("RCCL_PATH_OK")
 ''' % (ROOT, str(free_port()))

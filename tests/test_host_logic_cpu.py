@@ -289,6 +289,47 @@ def test_bench_roofline_accounting_with_the_merged_pass():
     assert rf["traffic"] is None or rf["traffic_profile_matches_library"] is True
 
 
+def check_transform_details(make_model, g1, gz, branch, tag, tol):
+    """`transform(x_new, details=True)` (reference :386-395) against the reference's own output (g10_transform_details.npz): the
+    model is fitted on rows [0, 1400) of big5, the full moments are evaluated on rows [1400, 2000) - another row count - with the
+    fit's n_samples as the divisor, as the reference does (:249, :260, :355)."""
+    from tests.conftest import load_golden
+    from tests.test_oracle_golden import key_name
+    g = load_golden("g10_transform_details")
+    p = "%s_%s_%s_" % (gz, branch, tag)
+    n_fit = int(g["n_fit"])
+    x = g1["x_raw"].astype(np.float64)
+    mdl = make_model(gz, branch == "ns").fit(x[:n_fit])
+    assert mdl.n_samples == n_fit
+    tc_before, moments_before = float(mdl.tc), mdl.moments
+    y, mo = mdl.transform(x[n_fit:], details=True)
+    assert relerr(y, g[p + "y_new"]) < tol
+    keys = [k[len(p + "mom_"):] for k in g.files if k.startswith(p + "mom_")]
+    have = {key_name(k): v for k, v in mo.items()}
+    assert set(keys) <= set(have), sorted(set(keys) - set(have))
+    for k in keys:
+        ref = np.asarray(g[p + "mom_" + k], np.float64)
+        assert np.max(np.abs(np.asarray(have[k], np.float64) - ref)) < tol * max(1.0, float(np.max(np.abs(ref)))), k
+    # the batch's moments, not the fitted data's: TC differs from the model's, and the model is left as it was
+    assert abs(float(mo["TC"]) - float(g[p + "mom_TC"])) < tol * 10 and abs(float(mo["TC"]) - tc_before) > 1.0
+    assert mdl.moments is moments_before and float(mdl.tc) == tc_before
+    # the fitted rows themselves give the model's own TC back
+    y_fit, mo_fit = mdl.transform(x[:n_fit], details=True)
+    assert abs(float(mo_fit["TC"]) - float(g[p + "fit_TC"])) < tol * 10 and relerr(y_fit, g[p + "y_fit"]) < tol
+    # a batch with as many rows as the fit is not mistaken for the fitted data
+    rolled = np.roll(x, 300, axis=0)[:n_fit]
+    _, mo_r = mdl.transform(rolled, details=True)
+    assert abs(float(mo_r["TC"]) - tc_before) > 1e-3
+    return mdl
+
+
+@pytest.mark.parametrize("branch", ["ns", "syn"])
+@pytest.mark.parametrize("gz", ["standard", "outliers"])
+def test_transform_details_evaluates_the_new_batch(g1, gz, branch):
+    check_transform_details(lambda gz_, ov: Corex(n_hidden=5, seed=0, dtype=np.float64, gaussianize=gz_, discourage_overlap=ov,
+                                                  _backend_factory=FACTORY), g1, gz, branch, "f64", 1e-6)
+
+
 def test_bench_stdout_line_stays_within_the_drivers_budget(tmp_path):
     """bench.emit: the stdout line is the compact record (contract keys, roofline, cpu_baseline, scalar riders) and fits
     4 KB whatever the nested blocks weigh - fed with round 3's 21 KB record, the one the driver could not parse; the full

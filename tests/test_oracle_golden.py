@@ -280,3 +280,32 @@ def test_empirical_gaussianize_matches_reference(name, tag):
     out, theta, n_obs = O.preprocess(x, None, "empirical", -1e6 if name == "emp_missing" else None)
     assert theta is None
     assert np.array_equal(out, g["%s_%s" % (name, tag)])
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("branch", ["ns", "syn"])
+@pytest.mark.parametrize("gz", ["standard", "outliers"])
+def test_transform_details_matches_reference(g1, gz, branch, tag):
+    """`transform(x_new, details=True)` (reference :386-395) against tests/golden/g10_transform_details.npz (the reference's own
+    output, tests/golden/make_golden_transform.py): the full moments of a batch of ANOTHER row count than the fit's, preprocessed
+    with the fitted theta and - as the reference does, :249 / :260 / :355 - divided by the fit's `n_samples`."""
+    g = load_golden("g10_transform_details")
+    p = "%s_%s_%s_" % (gz, branch, tag)
+    n_fit, n_new = int(g["n_fit"]), int(g["n_new"])
+    x_new = np.asarray(g1["x_raw"][n_fit:], dtype=DT[tag])
+    assert len(x_new) == n_new != n_fit
+    theta = (g[p + "theta_mean"], g[p + "theta_std"])
+    xt, _, _ = O.preprocess(x_new, theta, gz, None)
+    ws = g[p + "ws"]
+    close(xt.dot(ws.T), g[p + "y_new"], tag)
+    with np.errstate(all="ignore"):
+        mo = O.moments_ns(xt, ws, float(g[p + "eps"]), quick=False, n_samples=n_fit) if branch == "ns" else \
+            O.moments_syn(xt, ws, n_samples=n_fit)
+    keys = [k[len(p + "mom_"):] for k in g.files if k.startswith(p + "mom_")]
+    assert len(keys) >= 16
+    have = {key_name(k): v for k, v in mo.items()}
+    for k in keys:
+        close(have[k], g[p + "mom_" + k], tag, scale=max(1.0, float(np.max(np.abs(g[p + "mom_" + k])))))
+    # the divisor is the fit's: the batch's own row count gives another TC
+    own = O.moments_ns(xt, ws, float(g[p + "eps"]), quick=False) if branch == "ns" else O.moments_syn(xt, ws)
+    assert abs(float(own["TC"]) - float(g[p + "mom_TC"])) > 0.1

@@ -113,3 +113,19 @@ def test_predict_wide_output_blocks():
     ref = O.predict(mdl.moments["X_i Z_j"].astype(np.float64), y.astype(np.float64), mdl.theta, "standard")
     assert pred.shape == (n, v) and _rel(pred, ref) < 2e-5
     mdl._backend.close()
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("branch", ["ns", "syn"])
+@pytest.mark.parametrize("gz", ["standard", "outliers"])
+def test_transform_details_evaluates_the_new_batch(g1, gz, branch, tag):
+    """`transform(x_new, details=True)` (reference :386-395) on the device: the batch goes through lcx_upload_preprocess with the
+    fitted theta on a handle of its own, the levels of a full evaluation run with the fitted W and the FIT's sample count as the
+    divisor (lcx_set_sample_divisor) - against the reference's own output, g10_transform_details.npz.  float64: 1e-6; float32: the
+    end-to-end bar of the float32 fit it starts from."""
+    from linearcorex_amd import Corex
+    from tests.test_host_logic_cpu import check_transform_details
+    dt = np.float64 if tag == "f64" else np.float32
+    mdl = check_transform_details(lambda gz_, ov: Corex(n_hidden=5, seed=0, dtype=dt, device=0, gaussianize=gz_, discourage_overlap=ov),
+                                  g1, gz, branch, tag, 1e-6 if tag == "f64" else 3e-3)
+    mdl._backend.close()

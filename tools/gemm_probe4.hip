@@ -58,6 +58,25 @@ Variant mkcr(const T* A, int64_t lda, int64_t K, int64_t nrows, const T* B, T* o
     return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, A, lda, B, out, nrows, nrows, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
 }
 
+// round 4: gemm_cr with other A-load shapes (probe_kernels.hpp, gemm_cr2_kernel)
+template <typename T, int CT, int RT, int KW, int U, int LOAD>
+Variant mkcr2(const T* A, int64_t lda, int64_t K, int64_t nrows, const T* B, T* out, int bpc_use = 0) {
+    auto kern = gemm_cr2_kernel<T, CT, RT, KW, U, LOAD>;
+    int bpc = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, 0));
+    const int use = bpc_use > 0 ? bpc_use : bpc;
+    const int ng = (int)(K / (4 * U));
+    const int nsuper = (int)((nrows + KW * 16 * RT - 1) / (KW * 16 * RT));
+    int64_t total = (int64_t)nsuper * ng;
+    int nb = 256 * use;
+    if (nb > total) nb = (int)total;
+    const int maxslots = (nb + nsuper - 1) / nsuper + 1;
+    static const char* what[] = {"production mapping", "quad loads + ds_bpermute", "quad loads, NO permute (timing only)", "quad loads + LDS strip"};
+    char buf[200];
+    snprintf(buf, 200, "cr2 %-36s U=%d bpc=%d(use %d) slots=%d", what[LOAD], U, bpc, use, maxslots);
+    return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, A, lda, B, out, nrows, nrows, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
+}
+
 template <typename T> __global__ void transpose_probe_kernel_t(const T* X, int64_t ldx, T* XT, int64_t ldt, int64_t rows, int64_t cols) {
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < rows * cols; k += (int64_t)gridDim.x * blockDim.x)
         XT[(k % cols) * ldt + k / cols] = X[(k / cols) * ldx + k % cols];
@@ -164,6 +183,43 @@ void suite_cr(const char* name, int64_t N, int64_t V) {
     CK(hipFree(X)); CK(hipFree(XT)); CK(hipFree(B)); CK(hipFree(out));
 }
 
+template <typename T, int CT>
+void suite_cr2(const char* name, int64_t N, int64_t V) {
+    T *X, *XT, *B, *out;
+    CK(hipMalloc(&X, sizeof(T) * N * V));
+    CK(hipMalloc(&XT, sizeof(T) * N * V));
+    CK(hipMalloc(&B, sizeof(T) * V * 16 * CT));
+    CK(hipMalloc(&out, sizeof(T) * 40 * N * 16 * CT));
+    {
+        std::vector<T> h((size_t)4096 * 4096);
+        for (size_t x = 0; x < h.size(); ++x) h[x] = (T)((double)rand() / RAND_MAX - 0.5);
+        for (size_t off = 0; off < (size_t)N * V; off += h.size())
+            CK(hipMemcpy(X + off, h.data(), sizeof(T) * std::min(h.size(), (size_t)N * V - off), hipMemcpyHostToDevice));
+        CK(hipMemcpy(B, h.data() + 11, sizeof(T) * V * 16 * CT, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL((transpose_probe_kernel_t<T>), dim3(4096), dim3(256), 0, 0, X, V, XT, N, N, V);
+    CK(hipDeviceSynchronize());
+    const double gb = sizeof(T) * ((double)N * V + 16.0 * CT * (N + V)) / 1e9, tf = 2.0 * N * V * 16 * CT / 1e12;
+    printf("== %s: X %ld x %ld, Mp=%d elt=%zu: X.B^T from the row-major X with other A-load shapes (cr2) vs the transposed copy (ct)\n", name, (long)N,
+           (long)V, 16 * CT, sizeof(T));
+    constexpr int R = CtShape<T, CT>::RT;
+    std::vector<Variant> vs;
+    vs.push_back(mkct<T, CT, R, 4, 4, true>(XT, N, V, N, B, out, 2));
+    vs.push_back(mkcr<T, CT, R, 4, 4, false>(X, V, V, N, B, out, 2));
+    vs.push_back(mkcr2<T, CT, R, 4, 4, 0>(X, V, V, N, B, out, 2));
+    vs.push_back(mkcr2<T, CT, R, 4, 4, 1>(X, V, V, N, B, out, 2));
+    vs.push_back(mkcr2<T, CT, R, 4, 4, 3>(X, V, V, N, B, out, 2));
+    vs.push_back(mkcr2<T, CT, R, 4, 8, 1>(X, V, V, N, B, out, 2));
+    vs.push_back(mkcr2<T, CT, R, 4, 8, 3>(X, V, V, N, B, out, 2));
+    const size_t checked = vs.size();
+    vs.push_back(mkcr2<T, CT, R, 4, 4, 2>(X, V, V, N, B, out, 2));
+    vs.push_back(mkcr2<T, CT, R, 4, 8, 2>(X, V, V, N, B, out, 2));
+    const double tol = sizeof(T) == 8 ? 1e-12 : 2e-5;
+    for (size_t k = 1; k < checked; ++k) check<T>(name, vs[k], vs[0], out, out, N, 16 * CT, tol);
+    bench(vs, gb, tf);
+    CK(hipFree(X)); CK(hipFree(XT)); CK(hipFree(B)); CK(hipFree(out));
+}
+
 template <typename T, int CT, int TNRT>
 void suite(const char* name, int64_t K, int64_t V, int tnS) {
     T *A, *B, *out;
@@ -199,6 +255,12 @@ int main(int argc, char** argv) {
         suite_cr<float, 8>("c4shard", 50048, 125056);
         suite_cr<double, 4>("c3f64", 50048, 50048);
         suite_cr<float, 2>("mid32f32", 20032, 20032);
+        return 0;
+    }
+    if (!strcmp(which, "cr2")) {
+        suite_cr2<float, 4>("c3", 50048, 100032);
+        suite_cr2<float, 8>("c4shard", 50048, 125056);
+        suite_cr2<double, 4>("c3f64", 50048, 50048);
         return 0;
     }
     if (all || !strcmp(which, "c3")) {

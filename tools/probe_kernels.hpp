@@ -549,6 +549,171 @@ gemm_ct3_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T
 
 // moments_epilogue_kernel with its ablation knob (tools/epilogue_probe.hip; moved out of moment_kernels.hpp in round 3)
 // ABL is for ablation probes only: 1 = no m x m matvec, 2 = no M x V stores, 8 = no logarithms, 16 = first slot only.
+
+// ------------------------------------------------------------------------------------------------
+// round 4: gemm_cr with other A-load shapes (X.B^T from the ROW-MAJOR shard, single resident copy).
+//
+// gemm_cr's lane (i, q) loads 16 bytes of row i at chunk q: the MFMA operand layout (lane & 15 = output row, lane >> 4 = contraction
+// sub-index), so 4 CONSECUTIVE lanes touch 4 different rows = 4 cache lines.  LOAD picks what is loaded and how it reaches that layout:
+//   0  production mapping (baseline replica)
+//   1  lane l loads row l >> 2, chunk l & 3 (a lane quad = 64 contiguous bytes; 16 rows x 64 B per instruction as before), then
+//      4 ds_bpermute_b32 per 16 bytes move it into the MFMA layout (destination lane 16 q + i reads from lane 4 i + q)
+//   2  the loads of 1 without the permutation (timing only, wrong results): what the load shape alone is worth
+//   3  loads of 1, the permutation through the wave's own LDS strip (ds_write_b128 lane-linear, ds_read_b128 transposed)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int CT, int RT, int KW, int U, int LOAD>
+__global__ void __launch_bounds__(64 * KW)
+gemm_cr2_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T* __restrict__ out,
+                int64_t out_rows, int64_t nrows, int ng, int nsuper, int maxslots, const int* __restrict__ skip_flag) {
+    constexpr int Mp = 16 * CT;
+    constexpr int E = 16 / (int)sizeof(T);
+    constexpr int NL = U / E;
+    static_assert(U % E == 0, "a group must be whole 16-byte loads");
+    constexpr int CHUNK = 4 * U * Mp;
+    constexpr int PCS = CHUNK * (int)sizeof(T) / 16;
+    constexpr int NTH = 64 * KW;
+    constexpr int PPT = (PCS + NTH - 1) / NTH;
+    typedef typename MF<T>::acc_t acc_t;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) T Bs[2][CHUNK];
+    __shared__ __attribute__((aligned(16))) f4 Tr[LOAD == 3 ? KW * 64 * 2 : 1];     // per wave: two 1 KB strips
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int lr = LOAD == 0 ? i : (lane >> 2), lc = LOAD == 0 ? q : (lane & 3);     // row / 16-byte chunk this lane LOADS
+    const int perm_addr = 4 * (4 * i + q);                                            // ds_bpermute: byte address of the source lane
+    const int64_t total = (int64_t)nsuper * ng;
+    const int nb = gridDim.x;
+    int64_t L0 = total * blockIdx.x / nb;
+    const int64_t L1 = total * (blockIdx.x + 1) / nb;
+
+    while (L0 < L1) {
+        const int st_ = (int)(L0 / ng);
+        const int s0 = (int)(L0 - (int64_t)st_ * ng);
+        const int s1 = (L1 - L0) < (int64_t)(ng - s0) ? s0 + (int)(L1 - L0) : ng;
+        const int cnt = s1 - s0;
+        const int64_t v0 = ((int64_t)st_ * KW + wave) * (16 * RT);
+        const bool active = v0 < nrows;
+
+        acc_t acc[RT][CT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int u = 0; u < CT; ++u) acc[t][u] = (acc_t){0, 0, 0, 0};
+        const T* ap = A + ((active ? v0 : 0) + lr) * lda + lc * E;
+        f4 a0[NL][RT], a1[NL][RT];
+        f4 bst[PPT];
+
+#define LCX_CR2_LOADA(R, AA)                                                              \
+        if (active) {                                                                     \
+            const int64_t kb = (int64_t)(s0 + (R)) * (4 * U);                             \
+            _Pragma("unroll") for (int p = 0; p < NL; ++p)                                \
+            _Pragma("unroll") for (int t = 0; t < RT; ++t)                                \
+                AA[p][t] = *reinterpret_cast<const f4*>(ap + (int64_t)(16 * t) * lda + kb + p * 4 * E); \
+        }
+#define LCX_CR2_LOADB(R)                                                                  \
+        {                                                                                 \
+            const f4* src = reinterpret_cast<const f4*>(B + (int64_t)(s0 + (R)) * CHUNK); \
+            _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                             \
+                const int pc = p * NTH + (int)threadIdx.x;                                \
+                if (PCS % NTH == 0 || pc < PCS) bst[p] = src[pc];                         \
+            }                                                                             \
+        }
+#define LCX_CR2_STOREB(BUF)                                                               \
+        {                                                                                 \
+            f4* dstp = reinterpret_cast<f4*>(&Bs[BUF][0]);                                \
+            _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                             \
+                const int pc = p * NTH + (int)threadIdx.x;                                \
+                if (PCS % NTH == 0 || pc < PCS) dstp[pc] = bst[p];                        \
+            }                                                                             \
+        }
+        // bring a loaded 16-byte piece into the MFMA layout
+#define LCX_CR2_FIX(V, SLOT)                                                              \
+        if (LOAD == 1) {                                                                  \
+            i4 w = __builtin_bit_cast(i4, V);                                             \
+            _Pragma("unroll") for (int d = 0; d < 4; ++d) w[d] = __builtin_amdgcn_ds_bpermute(perm_addr, w[d]); \
+            V = __builtin_bit_cast(f4, w);                                                \
+        } else if (LOAD == 3) {                                                           \
+            f4* strip = &Tr[(wave * 2 + ((SLOT) & 1)) * 64];                              \
+            strip[lane] = V;                                                              \
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                        \
+            __builtin_amdgcn_wave_barrier();                                              \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                        \
+            V = strip[4 * i + q];                                                         \
+        }
+#define LCX_CR2_MMA(AA, BUF)                                                              \
+        if (active) {                                                                     \
+            Pk<T, CT> bb[U];                                                              \
+            _Pragma("unroll") for (int p = 0; p < NL; ++p)                                \
+            _Pragma("unroll") for (int e = 0; e < E; ++e)                                 \
+                bb[p * E + e] = *reinterpret_cast<const Pk<T, CT>*>(&Bs[BUF][(p * 4 * E + q * E + e) * Mp + i * CT]); \
+            _Pragma("unroll") for (int p = 0; p < NL; ++p)                                \
+            _Pragma("unroll") for (int t = 0; t < RT; ++t) { LCX_CR2_FIX(AA[p][t], p * RT + t) } \
+            _Pragma("unroll") for (int p = 0; p < NL; ++p)                                \
+            _Pragma("unroll") for (int e = 0; e < E; ++e)                                 \
+            _Pragma("unroll") for (int t = 0; t < RT; ++t) {                              \
+                typedef typename VecT<T, E>::type AV;                                     \
+                const AV av = __builtin_bit_cast(AV, AA[p][t]);                           \
+                _Pragma("unroll") for (int u = 0; u < CT; ++u)                            \
+                    acc[t][u] = MF<T>::mma(av[e], bb[p * E + e].v[u], acc[t][u]);         \
+            }                                                                             \
+        }
+
+        LCX_CR2_LOADA(0, a0);
+        LCX_CR2_LOADB(0);
+        int r = 0;
+        while (true) {
+            LCX_CR2_STOREB(0);
+            if (r + 1 < cnt) { LCX_CR2_LOADA(r + 1, a1); LCX_CR2_LOADB(r + 1); }
+            __syncthreads();
+            LCX_CR2_MMA(a0, 0);
+            if (++r >= cnt) break;
+            LCX_CR2_STOREB(1);
+            if (r + 1 < cnt) { LCX_CR2_LOADA(r + 1, a0); LCX_CR2_LOADB(r + 1); }
+            __syncthreads();
+            LCX_CR2_MMA(a1, 1);
+            if (++r >= cnt) break;
+        }
+#undef LCX_CR2_LOADA
+#undef LCX_CR2_LOADB
+#undef LCX_CR2_STOREB
+#undef LCX_CR2_FIX
+#undef LCX_CR2_MMA
+
+        const int fb = sk_owner((int64_t)st_ * ng, total, nb);
+        if (active) {
+            T* dst = out + ((int64_t)(blockIdx.x - fb) * out_rows + v0) * Mp;
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    Pk<T, CT> o;
+#pragma unroll
+                    for (int u = 0; u < CT; ++u) o.v[u] = acc[t][u][g];
+                    *reinterpret_cast<Pk<T, CT>*>(dst + (16 * t + MF<T>::row(lane, g)) * Mp + i * CT) = o;
+                }
+            if (s1 == ng) {
+                const int lb = sk_owner((int64_t)st_ * ng + ng - 1, total, nb);
+                Pk<T, CT> z;
+#pragma unroll
+                for (int u = 0; u < CT; ++u) z.v[u] = (T)0;
+                for (int sl = lb - fb + 1; sl < maxslots; ++sl) {
+                    T* zd = out + ((int64_t)sl * out_rows + v0) * Mp;
+#pragma unroll
+                    for (int t = 0; t < RT; ++t)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<Pk<T, CT>*>(zd + (16 * t + 4 * g + q) * Mp + i * CT) = z;
+                }
+            }
+        }
+        __syncthreads();
+        L0 += cnt;
+    }
+}
+
 template <typename T, int Mp, int ABL = 0>
 __global__ void __launch_bounds__(PV_THREADS)
 moments_epilogue_probe_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride,

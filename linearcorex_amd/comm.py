@@ -22,6 +22,7 @@ class Comm:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.exchange = self.world > 1 or bool(always_exchange)
+        self.selftest_seconds = None       # seconds one Y-buffer all-reduce took in the transport's first-contact test (bind_engine)
 
     # contiguous, balanced column ranges
     def shard(self, nv, rank=None):

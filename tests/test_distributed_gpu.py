@@ -182,7 +182,10 @@ dist.destroy_process_group()
 print("RCCL_PATH_OK")
 ''' % (ROOT, str(free_port()))
     p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0 and "RCCL_PATH_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+    err = p.stderr
+    if "Traceback" in err:
+        err = err[err.rindex("Traceback"):]
+    assert p.returncode == 0 and "RCCL_PATH_OK" in p.stdout, (p.stdout[-1000:], err[:4000])
 
 
 def _launch_f32(world, out_dir, n, v, m, iters, extra_env=None, timeout=240):

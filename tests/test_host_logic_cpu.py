@@ -289,17 +289,26 @@ def test_bench_roofline_accounting_with_the_merged_pass():
     assert rf["traffic"] is None or rf["traffic_profile_matches_library"] is True
 
 
-def check_transform_details(make_model, g1, gz, branch, tag, tol):
+def check_transform_details(make_model, g1, gz, branch, tag, tol, from_fixture=False):
     """`transform(x_new, details=True)` (reference :386-395) against the reference's own output (g10_transform_details.npz): the
     model is fitted on rows [0, 1400) of big5, the full moments are evaluated on rows [1400, 2000) - another row count - with the
-    fit's n_samples as the divisor, as the reference does (:249, :260, :355)."""
+    fit's n_samples as the divisor, as the reference does (:249, :260, :355).
+    from_fixture: the model is not fitted here but restored from the reference's fitted state (ws, theta, n_samples - what an
+    unpickled model holds), so that only the evaluated path is compared (a float32 fit of its own ends elsewhere within its bar)."""
     from tests.conftest import load_golden
     from tests.test_oracle_golden import key_name
     g = load_golden("g10_transform_details")
     p = "%s_%s_%s_" % (gz, branch, tag)
     n_fit = int(g["n_fit"])
     x = g1["x_raw"].astype(np.float64)
-    mdl = make_model(gz, branch == "ns").fit(x[:n_fit])
+    mdl = make_model(gz, branch == "ns")
+    if from_fixture:
+        mdl.ws = np.asarray(g[p + "ws"], mdl.dtype)
+        mdl.theta = (np.asarray(g[p + "theta_mean"], mdl.dtype), np.asarray(g[p + "theta_std"], mdl.dtype))
+        mdl.n_samples, mdl.nv, mdl.eps = n_fit, x.shape[1], float(g[p + "eps"])
+        mdl.moments = {"TC": float(g[p + "model_TC"])}
+    else:
+        mdl.fit(x[:n_fit])
     assert mdl.n_samples == n_fit
     tc_before, moments_before = float(mdl.tc), mdl.moments
     y, mo = mdl.transform(x[n_fit:], details=True)
@@ -323,11 +332,12 @@ def check_transform_details(make_model, g1, gz, branch, tag, tol):
     return mdl
 
 
+@pytest.mark.parametrize("restored", [False, True])
 @pytest.mark.parametrize("branch", ["ns", "syn"])
 @pytest.mark.parametrize("gz", ["standard", "outliers"])
-def test_transform_details_evaluates_the_new_batch(g1, gz, branch):
+def test_transform_details_evaluates_the_new_batch(g1, gz, branch, restored):
     check_transform_details(lambda gz_, ov: Corex(n_hidden=5, seed=0, dtype=np.float64, gaussianize=gz_, discourage_overlap=ov,
-                                                  _backend_factory=FACTORY), g1, gz, branch, "f64", 1e-6)
+                                                  _backend_factory=FACTORY), g1, gz, branch, "f64", 1e-6, from_fixture=restored)
 
 
 def test_bench_stdout_line_stays_within_the_drivers_budget(tmp_path):

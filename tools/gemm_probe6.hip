@@ -22,6 +22,18 @@ Variant mk4(const double* A, int64_t lda, int64_t K, int64_t vcols, const double
     snprintf(buf, 200, "tn4 (4x4x4) RT=%d KW=%d U=%d NT=%d SER=%d S=%d blocks=%d bpc=%d lds=%zu", RT, KW, U, (int)NT, (int)SERIAL, S, (int)(vcols / (16 * RT)) * S, bpc, lds);
     return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3((unsigned)(vcols / (16 * RT)), S), dim3(64 * KW), lds, 0, A, lda, B, out, vcols, (int)(K / 16), S, (const int*)nullptr); }, {}, S};
 }
+// round 4: the A stream prefetched two groups ahead (gemm_tn4r_kernel, probe_kernels.hpp)
+template <int CT, int RT, int KW, int U, bool NT = false>
+Variant mk4r(const double* A, int64_t lda, int64_t K, int64_t vcols, const double* B, double* out, int S) {
+    auto kern = gemm_tn4r_kernel<CT, RT, KW, U, NT>;
+    const size_t lds = Tn4Lds<CT, RT, KW, U, false>::bytes;
+    if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int bpc = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, lds));
+    char buf[200];
+    snprintf(buf, 200, "tn4r (A ring of 3) RT=%d KW=%d U=%d NT=%d S=%d blocks=%d bpc=%d lds=%zu", RT, KW, U, (int)NT, S, (int)(vcols / (16 * RT)) * S, bpc, lds);
+    return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3((unsigned)(vcols / (16 * RT)), S), dim3(64 * KW), lds, 0, A, lda, B, out, vcols, (int)(K / 16), S, (const int*)nullptr); }, {}, S};
+}
 template <int CT, int RT, int KW>
 Variant mkprod(const double* A, int64_t lda, int64_t K, int64_t vcols, const double* B, double* out, int S) {
     auto kern = gemm_tn_probe_kernel<double, CT, RT, KW, false, 0, 4>;
@@ -163,6 +175,48 @@ void suite_occ(const char* name, int64_t K, int64_t V, std::initializer_list<int
     CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(out));
 }
 
+template <int CT>
+void suite_ring(const char* name, int64_t K, int64_t V, std::initializer_list<int> splits) {
+    const int Mp = 16 * CT;
+    double *A, *B, *out;
+    CK(hipMalloc(&A, 8 * K * V)); CK(hipMalloc(&B, 8 * K * Mp)); CK(hipMalloc(&out, 8 * 40 * V * Mp));
+    std::vector<double> h((size_t)K * V);
+    for (size_t x = 0; x < h.size(); ++x) h[x] = (double)rand() / RAND_MAX - 0.5;
+    CK(hipMemcpy(A, h.data(), 8 * K * V, hipMemcpyHostToDevice));
+    CK(hipMemcpy(B, h.data() + 7, 8 * K * Mp, hipMemcpyHostToDevice));
+    const double gb = 8 * ((double)K * V + (double)Mp * (K + V)) / 1e9, tf = 2.0 * K * V * Mp / 1e12;
+    printf("== %s: K=%ld V=%ld Mp=%d f64 (A prefetched two groups ahead)\n", name, (long)K, (long)V, Mp);
+    std::vector<Variant> vs;
+    for (int S : splits) {
+        vs.push_back(mk4<CT, 4, 4, 4, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4r<CT, 4, 4, 4, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4r<CT, 4, 4, 4, false>(A, V, K, V, B, out, S));
+        vs.push_back(mk4r<CT, 4, 4, 2, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4r<CT, 4, 8, 2, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4r<CT, 2, 4, 4, true>(A, V, K, V, B, out, S));
+    }
+    const size_t n1 = (size_t)V * Mp;
+    vs[0].launch(); CK(hipDeviceSynchronize());
+    std::vector<double> r((size_t)vs[0].slots * n1);
+    CK(hipMemcpy(r.data(), out, r.size() * 8, hipMemcpyDeviceToHost));
+    for (size_t vi = 1; vi < 6; ++vi) {
+        CK(hipMemset(out, 0xff, 8 * (size_t)vs[vi].slots * n1));
+        vs[vi].launch(); CK(hipDeviceSynchronize());
+        std::vector<double> o((size_t)vs[vi].slots * n1);
+        CK(hipMemcpy(o.data(), out, o.size() * 8, hipMemcpyDeviceToHost));
+        double md = 0, mx = 0;
+        for (size_t x = 0; x < n1; ++x) {
+            double so = 0, sr = 0;
+            for (int s2 = 0; s2 < vs[vi].slots; ++s2) so += o[s2 * n1 + x];
+            for (int s2 = 0; s2 < vs[0].slots; ++s2) sr += r[s2 * n1 + x];
+            md = fmax(md, fabs(so - sr)); mx = fmax(mx, fabs(sr));
+        }
+        printf("check %-66s max |diff| %.3e %s\n", vs[vi].name.c_str(), md, md <= 1e-11 * mx ? "ok" : "FAIL");
+    }
+    bench(vs, gb, tf);
+    CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(out));
+}
+
 // round 3: a merged pass for float64 with <= 32 padded factors - X.[grad | ws + update]^T as ONE 64-column contraction
 // (two 32-column passes read X twice; at config 2 the pass is HBM-bound, so the second read is the cost).  Reference row:
 // the production 32-column kernel; the 64-column candidates must beat TWICE its time.
@@ -213,6 +267,11 @@ void suite_merged(const char* name, int64_t K, int64_t V, std::initializer_list<
 int main(int argc, char** argv) {
     if (argc > 1 && std::string(argv[1]) == "merged") {
         suite_merged("c2_x_gw (X.[grad | ws+update]^T, contraction over the 5056 variables)", 5056, 10048, {1, 2, 3, 4});
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "ring") {
+        suite_ring<2>("c2_xty", 10048, 5120, {3, 6});
+        suite_ring<2>("c2_xw", 5120, 10112, {2, 3});
         return 0;
     }
     if (argc > 1 && std::string(argv[1]) == "occ") {

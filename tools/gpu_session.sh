@@ -1,0 +1,65 @@
+#!/bin/bash
+# One GPU-box session through gpurun, by recipe (replaces the per-session r2_*.sh / r3_*.sh one-offs of earlier rounds; what they
+# ran is in the git history).  Run from the repo root:   gpurun --timeout S -- 'bash tools/gpu_session.sh <recipe> [args]'
+# Everything lands under gpurun_out/ (merged back by gpurun); copy what is to be judged into profiles/.
+#
+#   suite [pytest args]            the GPU suite + smoke, slowest tests listed           -> gpurun_out/<tag>_suite.log
+#   bench [bench args]             the driver's command, stdout line + detail record      -> gpurun_out/<tag>_bench_default.json / _detail.json
+#   profiles <wl> [<wl> ...]       rocprofv3 kernel stats + PMC passes per workload (tools/gpu_prof.sh), stamped with the library hash
+#   wave_states <probe> [args]     SQ wave-state counters of a probe binary (where do the waves of a kernel spend their cycles)
+#   line_search_ab <wl> ...        bench --no-extras under line_search exact / exact-y / linear, one line each
+#   two_ranks [bench args]         the driver's --gpus 2 command rehearsed on ONE GPU (two ranks share GPU 0 over gloo)
+#   probe <name> [args]            build tools/<name>.hip and run it                        -> gpurun_out/<tag>_<name>_<args>.txt
+# TAG (environment, default r04) prefixes the outputs.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${TAG:-r04}
+cd $R; mkdir -p gpurun_out
+recipe=$1; shift
+case "$recipe" in
+  suite)
+    T0=$(date +%s)
+    python -m pytest tests -q -m gpu --durations=20 "$@" > gpurun_out/${TAG}_suite.log 2>&1
+    echo "suite rc=$? in $(( $(date +%s) - T0 )) s" | tee gpurun_out/${TAG}_suite_summary.txt
+    tail -30 gpurun_out/${TAG}_suite.log
+    python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee -a gpurun_out/${TAG}_suite_summary.txt ;;
+  bench)
+    T0=$(date +%s)
+    python bench.py --gpus 1 --steps 20 --warmup 5 --detail-out gpurun_out/${TAG}_bench_detail.json "$@" 2>gpurun_out/${TAG}_bench_default.err > gpurun_out/${TAG}_bench_default.json
+    echo "bench rc=$? wall $(( $(date +%s) - T0 )) s, line $(wc -c < gpurun_out/${TAG}_bench_default.json) bytes"
+    cat gpurun_out/${TAG}_bench_default.json ;;
+  profiles)
+    python3 __graft_entry__.py || exit 1
+    for WL in "$@"; do
+      bash tools/gpu_prof.sh $TAG $WL 2>&1 | tail -30
+      mkdir -p gpurun_out/${TAG}_profiles
+      cp gpurun_out/pmc_traffic_$WL.json gpurun_out/${TAG}_rocprof_kernel_stats_$WL.csv gpurun_out/${TAG}_rocprof_kernel_stats_$WL.meta.json \
+         gpurun_out/${TAG}_trace_gaps_$WL.txt gpurun_out/${TAG}_profiles/ 2>/dev/null
+    done ;;
+  wave_states)
+    P=$1; shift
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/$P tools/$P.hip 2>/dev/null
+    OUT=$R/gpurun_out/${TAG}_pmc_wave_states_${P}_$(echo "$*" | tr ' ' '_').txt
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
+      --output-format csv -d $R/gpurun_out/pmc_ws_$P -o ws -- $R/tools/$P "$@" > $R/gpurun_out/pmc_ws_$P.log 2>&1
+    tail -3 $R/gpurun_out/pmc_ws_$P.log
+    python3 $R/tools/wave_states.py $R/gpurun_out/pmc_ws_$P | tee $OUT
+    find $R/gpurun_out/pmc_ws_$P -name "*.csv" -size +1M -delete ;;
+  line_search_ab)
+    for wl in "$@"; do for ls in exact exact-y linear; do
+      python bench.py --workload $wl --no-extras --steps 20 --warmup 5 --repeats 1 --line-search $ls 2>gpurun_out/${TAG}_ab_${wl}_$ls.err > gpurun_out/${TAG}_ab_${wl}_$ls.json
+      python -c "
+import json; d=json.load(open('gpurun_out/${TAG}_ab_${wl}_$ls.json')); c=d['config']
+print('$wl $ls', round(d['value'],2), 'it/s', round(d['ms_per_step'],3), 'ms; X passes', round(c['x_passes_per_iteration'],3), 'trials', round(c['line_search_trials_per_iteration'],3))"
+    done; done ;;
+  two_ranks)
+    T0=$(date +%s)
+    LCX_BENCH_DEVICE=0 LCX_BENCH_BACKEND=gloo timeout 1500 python bench.py --gpus 2 --steps 20 --warmup 5 --detail-out gpurun_out/${TAG}_two_ranks_detail.json "$@" \
+      2>gpurun_out/${TAG}_two_ranks.err > gpurun_out/${TAG}_two_ranks.json
+    echo "rc=$? wall $(( $(date +%s) - T0 )) s, line $(wc -c < gpurun_out/${TAG}_two_ranks.json) bytes"; cat gpurun_out/${TAG}_two_ranks.json ;;
+  probe)
+    P=$1; shift
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/$P tools/$P.hip 2>/dev/null || exit 1
+    timeout 900 tools/$P "$@" 2>&1 | tee gpurun_out/${TAG}_${P}_$(echo "$*" | tr ' ' '_').txt ;;
+  *) echo "unknown recipe $recipe"; exit 2 ;;
+esac

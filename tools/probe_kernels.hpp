@@ -714,6 +714,130 @@ gemm_cr2_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// round 4: gemm_tn4 with the A operand (the HBM stream) prefetched TWO groups ahead (a ring of three register buffers) - the
+// production kernel issues the loads of group r+1 right before the MFMA burst of group r, i.e. ~2k cycles (about 1 us) ahead of
+// their use.  B (L2 resident) stays one group ahead through the wave's LDS strip as before.  Same decomposition, same summation
+// orders, same outputs as gemm_tn4_kernel<CT, RT, KW, U, NT, false>.
+// ------------------------------------------------------------------------------------------------
+template <int CT, int RT, int KW, int U, bool NT = false>
+__global__ void __launch_bounds__(64 * KW)
+gemm_tn4r_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, double* __restrict__ out,
+                 int64_t out_rows, int kgroups /* K / 16 */, int nsplit, const int* __restrict__ skip_flag) {
+    constexpr int Mp = 16 * CT, NG = Mp / 4;
+    constexpr int ROWS = 4 * U;
+    constexpr int LDB = Mp + 4;
+    constexpr int PPR = Mp / 2;
+    constexpr int PCS = ROWS * PPR;
+    constexpr int PPT = (PCS + 63) / 64;
+    constexpr int STRIP = 2 * ROWS * LDB;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* smem = reinterpret_cast<double*>(smem_raw);
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4, jj = lane & 3;
+    const int64_t v0 = (int64_t)blockIdx.x * (16 * RT);
+    const int part = blockIdx.y * KW + wave, nparts = nsplit * KW;
+    const int ng = kgroups * 4 / U;
+    const int g0 = (int)((int64_t)ng * part / nparts), g1 = (int)((int64_t)ng * (part + 1) / nparts);
+    const int cnt = g1 - g0;
+
+    double acc[RT][NG];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[t][g] = 0.0;
+
+    const double* ap = A + v0 + (int64_t)kq * lda;
+    double* bw = smem + wave * STRIP;
+    double a0[U][RT], a1[U][RT], a2[U][RT];
+    d2 bst[PPT];
+
+#define LCX_T4R_LOADA(R, AA)                                                               \
+    if ((R) < cnt) {                                                                       \
+        const int64_t rb = (int64_t)(g0 + (R)) * ROWS;                                     \
+        _Pragma("unroll") for (int st = 0; st < U; ++st)                                   \
+            load_row_pieces<double, RT, NT>(ap + (rb + 4 * st) * lda, r16, AA[st]);        \
+    }
+#define LCX_T4R_LOADB(R)                                                                   \
+    if ((R) < cnt) {                                                                       \
+        const d2* src = reinterpret_cast<const d2*>(B + (int64_t)(g0 + (R)) * ROWS * Mp);  \
+        _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                                  \
+            const int pc = p * 64 + lane;                                                  \
+            if (PCS % 64 == 0 || pc < PCS) bst[p] = src[pc];                               \
+        }                                                                                  \
+    }
+#define LCX_T4R_STOREB(BUF)                                                                \
+    {                                                                                      \
+        _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                                  \
+            const int pc = p * 64 + lane;                                                  \
+            if (PCS % 64 == 0 || pc < PCS)                                                 \
+                *reinterpret_cast<d2*>(bw + (BUF) * ROWS * LDB + (pc / PPR) * LDB + (pc % PPR) * 2) = bst[p]; \
+        }                                                                                  \
+    }
+#define LCX_T4R_MMA(AA, BUF)                                                               \
+    {                                                                                      \
+        _Pragma("unroll") for (int st = 0; st < U; ++st) {                                 \
+            const double* brow = bw + (BUF) * ROWS * LDB + (4 * st + kq) * LDB + jj;       \
+            double bb[NG];                                                                 \
+            _Pragma("unroll") for (int g = 0; g < NG; ++g) bb[g] = brow[4 * g];            \
+            _Pragma("unroll") for (int t = 0; t < RT; ++t)                                 \
+            _Pragma("unroll") for (int g = 0; g < NG; ++g)                                 \
+                acc[t][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(AA[st][t], bb[g], acc[t][g], 0, 0, 0); \
+        }                                                                                  \
+    }
+    // one group: B of this group into the LDS strip, A two groups ahead and B one group ahead into registers, multiply
+#define LCX_T4R_STEP(CUR, NEXT2, BUF)                                                      \
+    {                                                                                      \
+        LCX_T4R_STOREB(BUF);                                                               \
+        LCX_T4R_LOADA(r + 2, NEXT2);                                                       \
+        LCX_T4R_LOADB(r + 1);                                                              \
+        LCX_T4R_MMA(CUR, BUF);                                                             \
+        if (++r >= cnt) break;                                                             \
+    }
+
+    if (cnt > 0) {
+        LCX_T4R_LOADA(0, a0);
+        LCX_T4R_LOADA(1, a1);
+        LCX_T4R_LOADB(0);
+        int r = 0;
+        while (true) {
+            LCX_T4R_STEP(a0, a2, 0);
+            LCX_T4R_STEP(a1, a0, 1);
+            LCX_T4R_STEP(a2, a1, 0);
+            LCX_T4R_STEP(a0, a2, 1);
+            LCX_T4R_STEP(a1, a0, 0);
+            LCX_T4R_STEP(a2, a1, 1);
+        }
+    }
+#undef LCX_T4R_LOADA
+#undef LCX_T4R_LOADB
+#undef LCX_T4R_STOREB
+#undef LCX_T4R_MMA
+#undef LCX_T4R_STEP
+
+    constexpr int TILE = 16 * RT * Mp;
+    __syncthreads();
+    const int row = ((lane & 15) >> 2) * 4 + (lane >> 4);
+    double* dst = out + ((int64_t)blockIdx.y * out_rows + v0) * Mp;
+    double* mine = smem + wave * TILE;
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            mine[piece_col<double, RT>(t, row) * Mp + 4 * g + jj] = acc[t][g];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TILE; idx += 64 * KW) {
+        double sacc = smem[idx];
+#pragma unroll
+        for (int w = 1; w < KW; ++w) sacc += smem[w * TILE + idx];
+        dst[idx] = sacc;
+    }
+}
+
 template <typename T, int Mp, int ABL = 0>
 __global__ void __launch_bounds__(PV_THREADS)
 moments_epilogue_probe_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride,

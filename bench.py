@@ -776,7 +776,8 @@ def compact_line(out, detail_path):
     c["windows"] = {k: w.get(k) for k in ("walks_timed", "timed_iterations", "timed_seconds", "ms_per_step_walk_min_median_max")}
     c["exchange"] = _pick(cfg, "exchange", "transport") or _pick(cfg, "exchange", "kind")
     c["bytes_resident_total"] = _pick(cfg, "bytes_resident", "total")
-    c["bytes_resident_x"] = _pick(cfg, "bytes_resident", "x_and_transposed_copy")
+    c["bytes_resident_x"] = _pick(cfg, "bytes_resident", "x")
+    c["x_layout"] = _pick(cfg, "bytes_resident", "x_layout")
     if cfg.get("force_exchange"):
         c["force_exchange"] = True
     riders = {

@@ -330,8 +330,15 @@ int lcx_covariance_rows(lcx_ctx* h, double eps, const void* std_host, int64_t ro
  * kernel_seconds (may be NULL): device time of the product kernels alone, from HIP events. */
 int lcx_covariance(lcx_ctx* h, int synergistic, double eps, const void* std_host, void* out_host, int64_t ld_out,
                    double* kernel_seconds);
-/* device bytes owned by the handle; x_bytes: the part that is the resident shard (row-major + transposed copy) */
+/* device bytes owned by the handle; x_bytes: the part that is the resident shard (see lcx_x_layout) */
 int lcx_bytes_resident(lcx_ctx* h, int64_t* total, int64_t* x_bytes);
+/* How the preprocessed shard x~ (what cm.CUDAMatrix(x) holds in the reference, :427-428) is resident - chosen by lcx_create from the
+ * shard's shape, invisible in every result:
+ *   2  ONE panel-major copy [n_variables / P][n_samples][P], P = 64 bytes of a row: large shards, both X passes (:247, :259) on the
+ *      stream-K kernels at full speed from the same bytes (LCX_X_LAYOUT=panel forces it, =rows forbids it);
+ *   0  row-major + a transposed copy: small shards (each pass reads the copy whose contiguous axis it does not contract);
+ *   1  row-major only: models with more than 256 factors, or LCX_SINGLE_COPY=1. */
+int lcx_x_layout(lcx_ctx* h, int* layout);
 /* transform (:386-395): out (n_rows x m) = x (n_rows x nv_local, ld) . ws^T  (per-shard partial) */
 int lcx_project(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, void* out_host);
 

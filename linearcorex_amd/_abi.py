@@ -42,6 +42,7 @@ SIGNATURES = {
     "lcx_set_sample_divisor": [_vp, C.c_double],
     "lcx_comm_selftest": [_vp, _i32, C.POINTER(_i32), C.POINTER(_dbl)],
     "lcx_comm_probe": [],
+    "lcx_x_layout": [_vp, C.POINTER(_i32)],
     "lcx_set_exchange": [_vp, _i32],
     "lcx_exchange_layout": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_vp)],
     "lcx_bind_exchange": [_vp, _vp, _vp],

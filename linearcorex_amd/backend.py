@@ -416,7 +416,10 @@ class HipBackend:
     def bytes_resident(self):
         tot, xb = C.c_int64(), C.c_int64()
         _abi.check(self.lib.lcx_bytes_resident(self.h, C.byref(tot), C.byref(xb)))
-        return {"total": tot.value, "x_and_transposed_copy": xb.value}
+        lay = C.c_int()
+        _abi.check(self.lib.lcx_x_layout(self.h, C.byref(lay)))
+        return {"total": tot.value, "x": xb.value,
+                "x_layout": {0: "row-major + transposed copy", 1: "row-major", 2: "panel-major (one copy)"}[lay.value]}
 
     def predict(self, y, xz=None, syn=False, gaussianize=None, theta=None):
         """predict (linearcorex.py:440-441) for this shard: invert(y . X_i Z_j^T), (n_rows, nv_local).  xz: X_i Z_j

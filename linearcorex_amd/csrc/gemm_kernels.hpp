@@ -316,6 +316,20 @@ template <> struct VecT<float, 4> { typedef float type __attribute__((ext_vector
 template <> struct VecT<float, 2> { typedef float type __attribute__((ext_vector_type(2))); };
 template <> struct VecT<float, 1> { typedef float type; };
 
+// ------------------------------------------------------------------------------------------------
+// PANEL-MAJOR layout of the resident shard (round 4): XP[v / PW][n][PW], PW = 64 bytes of one row (16 floats / 8 doubles) - a panel is
+// ALL rows of PW consecutive variables, contiguous; panel stride = n_padded * PW elements.  ONE copy serves both contractions with
+// whole, contiguous cache lines (tools/gemm_probe4 panel, profiles/r04_gemm_probe4_panel.txt: both passes at or above the speed of
+// the two-copy layout, which this replaces for large shards):
+//   * X.B^T (contraction over v; gemm_cr<.., PANEL>): lane (i, q) loads 16 bytes of row i at chunk q of ONE panel, so the 16 rows of a
+//     load instruction are 16 x 64 B = 1 KB CONTIGUOUS (on the row-major X they are 16 segments of 64 B a row length apart - the
+//     4-6 % of gemm_cr), a wave's 4 row tiles 4 KB, a block's 256 rows 16 KB; a group of 4 U contraction elements = U / E panels;
+//   * X^T.Y (contraction over n; gemm_ct<.., PANEL>): lane (i, q) loads 16 bytes = consecutive v of row 4 st + q; the 16 lanes i cover
+//     256 B / 64 B = 4 panels with 4 rows x 64 B = 256 contiguous bytes in each - the same 4 x 256 B per instruction as on the
+//     row-major X - and the 16 rows of a group make 1 KB contiguous per panel.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct PanelW { static constexpr int v = 64 / (int)sizeof(T); };
+
 // elements per 16-byte piece (capped by the tile count)
 template <typename T, int RT> struct Epl { static constexpr int v = (16 / (int)sizeof(T)) < RT ? (16 / (int)sizeof(T)) : RT; };
 
@@ -342,9 +356,9 @@ __device__ __forceinline__ int piece_col(int t, int r) {
     return (t / EPL) * 16 * EPL + r * EPL + (t % EPL);
 }
 
-template <typename T, int CT, int RT, int KW, int U, bool NT = false>
+template <typename T, int CT, int RT, int KW, int U, bool NT = false, bool PANEL = false>
 __global__ void __launch_bounds__(64 * KW)
-gemm_ct_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T* __restrict__ out,
+gemm_ct_kernel(const T* __restrict__ A, int64_t lda /* PANEL: the panel stride */, const T* __restrict__ B, T* __restrict__ out,
                int64_t out_rows, int64_t vcols, int ng /* groups of 4*U rows */, int nsuper, int maxslots,
                const int* __restrict__ skip_flag) {
     constexpr int Mp = 16 * CT;
@@ -377,15 +391,39 @@ gemm_ct_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T*
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int u = 0; u < CT; ++u) acc[t][u] = (acc_t){0, 0, 0, 0};
+        // row-major A: row stride lda.  PANEL: piece p of this lane = columns v0 + p 16 EPL + i EPL .., i.e. panel (col / PW) at
+        // offset col % PW; rows are PW elements apart inside a panel
+        constexpr int EPLC = Epl<T, RT>::v;
+        constexpr int PWC = PanelW<T>::v;
         const T* ap = A + (active ? v0 : 0) + (int64_t)q * lda;
+        const T* app[RT / EPLC];
+        if constexpr (PANEL) {
+#pragma unroll
+            for (int p = 0; p < RT / EPLC; ++p) {
+                const int64_t col = (active ? v0 : 0) + p * 16 * EPLC + i * EPLC;
+                app[p] = A + (col / PWC) * lda + (col % PWC) + (int64_t)q * PWC;
+            }
+        }
         T a0[U][RT], a1[U][RT];
         f4 bst[PPT];
 
 #define LCX_CT_LOADA(R, AA)                                                               \
         if (active) {                                                                     \
             const int64_t rb = (int64_t)(s0 + (R)) * (4 * U);                             \
-            _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
-                load_row_pieces<T, RT, NT>(ap + (rb + 4 * st) * lda, i, AA[st]);          \
+            if constexpr (PANEL) {                                                        \
+                typedef typename VecT<T, EPLC>::type VP;                                  \
+                _Pragma("unroll") for (int st = 0; st < U; ++st)                          \
+                _Pragma("unroll") for (int p = 0; p < RT / EPLC; ++p) {                   \
+                    const VP* src = reinterpret_cast<const VP*>(app[p] + (rb + 4 * st) * PWC); \
+                    const VP v = NT ? __builtin_nontemporal_load(src) : *src;             \
+                    _Pragma("unroll") for (int e = 0; e < EPLC; ++e) {                    \
+                        if constexpr (EPLC == 1) AA[st][p] = v; else AA[st][p * EPLC + e] = v[e]; \
+                    }                                                                     \
+                }                                                                         \
+            } else {                                                                      \
+                _Pragma("unroll") for (int st = 0; st < U; ++st)                          \
+                    load_row_pieces<T, RT, NT>(ap + (rb + 4 * st) * lda, i, AA[st]);      \
+            }                                                                             \
         }
 #define LCX_CT_LOADB(R)                                                                   \
         {                                                                                 \
@@ -479,9 +517,9 @@ gemm_ct_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T*
 // groups q cover 64 contiguous bytes of the row), i.e. load p of a group holds k = p*4E + q*E + e.  An MFMA step may take its
 // 4 contraction elements in any order as long as both operands agree, so step (p, e) reads the B rows p*4E + q*E + e from LDS.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int CT, int RT, int KW, int U, bool NT = false>
+template <typename T, int CT, int RT, int KW, int U, bool NT = false, bool PANEL = false>
 __global__ void __launch_bounds__(64 * KW)
-gemm_cr_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T* __restrict__ out,
+gemm_cr_kernel(const T* __restrict__ A, int64_t lda /* PANEL: the panel stride */, const T* __restrict__ B, T* __restrict__ out,
                int64_t out_rows, int64_t nrows, int ng /* groups of 4*U contraction elements */, int nsuper, int maxslots,
                const int* __restrict__ skip_flag) {
     constexpr int Mp = 16 * CT;
@@ -518,7 +556,10 @@ gemm_cr_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T*
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int u = 0; u < CT; ++u) acc[t][u] = (acc_t){0, 0, 0, 0};
-        const T* ap = A + ((active ? v0 : 0) + i) * lda + q * E;
+        // row-major A: row i at stride lda, the group's elements along the row.  PANEL: row i at stride PW inside panel
+        // (group * NL + p), panels `lda` elements apart
+        constexpr int PWC = 4 * E;
+        const T* ap = PANEL ? A + ((active ? v0 : 0) + i) * PWC + q * E : A + ((active ? v0 : 0) + i) * lda + q * E;
         AV a0[NL][RT], a1[NL][RT];
         f4 bst[PPT];
 
@@ -527,7 +568,8 @@ gemm_cr_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T*
             const int64_t kb = (int64_t)(s0 + (R)) * (4 * U);                             \
             _Pragma("unroll") for (int p = 0; p < NL; ++p)                                \
             _Pragma("unroll") for (int t = 0; t < RT; ++t) {                              \
-                const AV* src = reinterpret_cast<const AV*>(ap + (int64_t)(16 * t) * lda + kb + p * 4 * E); \
+                const AV* src = PANEL ? reinterpret_cast<const AV*>(ap + ((int64_t)(s0 + (R)) * NL + p) * lda + (int64_t)(16 * t) * PWC) \
+                                      : reinterpret_cast<const AV*>(ap + (int64_t)(16 * t) * lda + kb + p * 4 * E); \
                 AA[p][t] = NT ? __builtin_nontemporal_load(src) : *src;                   \
             }                                                                             \
         }

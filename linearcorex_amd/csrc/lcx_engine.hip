@@ -171,7 +171,9 @@ struct lcx_ctx {
     hipStream_t own_stream, stream;
     void* X;                    // [Npad][ldx]
     void* XT;                   // [ldx][Npad] transposed copy (absent in single-copy mode)
-    bool single_copy;           // X.B^T is read from X itself (gemm_cr): half the resident bytes, a 4-6 % slower pass
+    bool single_copy;           // X.B^T is read from the row-major X itself (gemm_cr): half the resident bytes, a 4-6 % slower pass
+    bool panel;                 // X is the ONE panel-major copy [ldx / PW][Npad][PW] (gemm_kernels.hpp, PanelW): large shards whose two
+                                // passes both run on the stream-K kernels; no transposed copy, both passes at full speed
     void* Wt[2];
     MomentSet set[2];
     void *grad, *update, *sgrad, *scratch;
@@ -450,23 +452,24 @@ static int launch_tn4(hipStream_t st, const double* A, int64_t lda, int64_t K, i
 }
 
 // gemm_ct launch: nb balanced blocks over (super tile, group) units; partial tiles -> out[slot][out_rows][Mp]
-template <typename T, int CT>
+template <typename T, int CT, bool PANEL = false>
 static int launch_ct(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* out, int nb,
                      int nsuper, int maxslots, const int* skip) {
     typedef CtShape<T, CT> S;
     const int ng = (int)(K / (4 * S::U));
-    hipLaunchKernelGGL((gemm_ct_kernel<T, CT, S::RT, S::KW, S::U, true>), dim3((unsigned)nb), dim3(64 * S::KW), 0, st, A, lda, B, out,
+    hipLaunchKernelGGL((gemm_ct_kernel<T, CT, S::RT, S::KW, S::U, true, PANEL>), dim3((unsigned)nb), dim3(64 * S::KW), 0, st, A, lda, B, out,
                        vcols, vcols, ng, nsuper, maxslots, skip);
     KCHECK();
     return LCX_OK;
 }
 // gemm_cr launch (X.B^T from the row-major shard itself): same unit / slot contract as launch_ct
-template <typename T, int CT>
+// (PANEL: the panel-major copy, lda = the panel stride, non-temporal loads - every line is read once per pass)
+template <typename T, int CT, bool PANEL = false>
 static int launch_cr(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t nrows, const T* B, T* out, int nb, int nsuper,
                      int maxslots, const int* skip) {
     typedef CtShape<T, CT> S;
     const int ng = (int)(K / (4 * S::U));
-    hipLaunchKernelGGL((gemm_cr_kernel<T, CT, S::RT, S::KW, S::U, false>), dim3((unsigned)nb), dim3(64 * S::KW), 0, st, A, lda, B, out, nrows,
+    hipLaunchKernelGGL((gemm_cr_kernel<T, CT, S::RT, S::KW, S::U, PANEL, PANEL>), dim3((unsigned)nb), dim3(64 * S::KW), 0, st, A, lda, B, out, nrows,
                        nrows, ng, nsuper, maxslots, skip);
     KCHECK();
     return LCX_OK;
@@ -588,7 +591,7 @@ template <typename T, int CT> struct Impl {
             h->nt_S = h->tn_S = h->tn_slots = 1;
             h->nt_KW = h->tn_KW = 4;
             h->nt_bpc = h->tn_bpc = 1;
-            h->nt_ct = h->tn_ct = h->f64_4x4 = h->merged_ok = false;
+            h->nt_ct = h->tn_ct = h->f64_4x4 = h->merged_ok = h->panel = false;
             h->nt_nb = h->nt_nsuper = h->tn_nb = h->tn_nsuper = h->nt2_nb = h->nt2_nsuper = h->nt2_S = 0;
             // Gram matrices: (Mp / 64)^2 tiles; split the contraction until the chip is about twice covered
             auto gsplit = [&](int64_t K) {
@@ -687,6 +690,18 @@ template <typename T, int CT> struct Impl {
             ct_geometry<T, CT>(cus, h->Npad, h->ldx, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
             h->tn_ct = force ? !strcmp(force, "ct") : use_ct(sl, h->Npad);
             if (h->tn_ct) { h->tn_nb = nb; h->tn_nsuper = ns; h->tn_S = sl; h->tn_KW = CtShape<T, CT>::KW; }
+            // Both passes on the stream-K kernels: ONE panel-major copy of the shard serves both at full speed (gemm_kernels.hpp,
+            // PanelW) - no transposed copy, half the resident bytes.  LCX_X_LAYOUT=rows keeps the row-major layout(s), =panel forces
+            // the stream-K kernels and the panel layout on any shape.
+            const char* lay = getenv("LCX_X_LAYOUT");
+            if (lay && !strcmp(lay, "panel")) {
+                ct_geometry<T, CT>(cus, h->ldx, h->Npad, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
+                h->nt_ct = true; h->nt_nb = nb; h->nt_nsuper = ns; h->nt_S = sl; h->nt_KW = CtShape<T, CT>::KW;
+                ct_geometry<T, CT>(cus, h->Npad, h->ldx, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
+                h->tn_ct = true; h->tn_nb = nb; h->tn_nsuper = ns; h->tn_S = sl; h->tn_KW = CtShape<T, CT>::KW;
+            }
+            h->panel = h->nt_ct && h->tn_ct && !(lay && !strcmp(lay, "rows"));
+            if (h->panel) h->single_copy = false;
         }
         // merged pass: float32, 32 / 64 padded factors, large shards (the 2 Mp-wide gemm_ct does the flops of both passes at
         // a higher rate and reads X once); LCX_MERGED_PASS=0 turns it off
@@ -731,7 +746,10 @@ template <typename T, int CT> struct Impl {
         if constexpr (WIDE) {
             LCXCHECK((wide_gemm<false, false>(h, P<T>(h->X), h->ldx, B, Mp, nullptr, dst, Mp, h->Npad, Mp, h->ldx, 1, skip)));
         } else {
-            if (h->single_copy)
+            if (h->panel)
+                LCXCHECK((launch_cr<T, CT, true>(h->stream, P<T>(h->X), h->Npad * PanelW<T>::v, h->ldx, h->Npad, B, dst, h->nt_nb, h->nt_nsuper,
+                                                 h->nt_S, skip)));
+            else if (h->single_copy)
                 LCXCHECK((launch_cr<T, CT>(h->stream, P<T>(h->X), h->ldx, h->ldx, h->Npad, B, dst, h->nt_nb, h->nt_nsuper, h->nt_S, skip)));
             else if (h->nt_ct)
                 LCXCHECK((launch_ct<T, CT>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, B, dst, h->nt_nb, h->nt_nsuper, h->nt_S, skip)));
@@ -769,7 +787,7 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
     static int make_xt(lcx_ctx* h) {
-        if (h->single_copy) { HIPCHECK(hipStreamSynchronize(h->stream)); return LCX_OK; }
+        if (h->single_copy || h->panel) { HIPCHECK(hipStreamSynchronize(h->stream)); return LCX_OK; }
         dim3 grid((unsigned)(h->ldx / 64), (unsigned)(h->Npad / 64));
         hipLaunchKernelGGL((transpose_kernel<T>), grid, dim3(256), 0, h->stream, P<T>(h->X), h->ldx, P<T>(h->XT), h->Npad);
         KCHECK();
@@ -782,7 +800,10 @@ template <typename T, int CT> struct Impl {
         if constexpr (WIDE) {
             LCXCHECK((wide_gemm<true, false>(h, P<T>(h->X), h->ldx, P<T>(h->ybuf), Mp, nullptr, P<T>(h->dpart), Mp, h->ldx, Mp, h->Npad, 1, skip)));
         } else {
-            if (h->tn_ct)
+            if (h->panel)
+                LCXCHECK((launch_ct<T, CT, true>(h->stream, P<T>(h->X), h->Npad * PanelW<T>::v, h->Npad, h->ldx, P<T>(h->ybuf), P<T>(h->dpart),
+                                                 h->tn_nb, h->tn_nsuper, h->tn_S, skip)));
+            else if (h->tn_ct)
                 LCXCHECK((launch_ct<T, CT>(h->stream, P<T>(h->X), h->ldx, h->Npad, h->ldx, P<T>(h->ybuf), P<T>(h->dpart), h->tn_nb, h->tn_nsuper,
                                            h->tn_S, skip)));
             else if (h->f64_4x4) {
@@ -1038,7 +1059,10 @@ template <typename T, int CT> struct Impl {
             KCHECK();
             TimingPair tp;
             LCXCHECK(timing_begin(h, 2, &tp));
-            if (h->single_copy)
+            if (h->panel)
+                LCXCHECK((launch_cr<T, 2 * CT, true>(h->stream, P<T>(h->X), h->Npad * PanelW<T>::v, h->ldx, h->Npad, P<T>(h->gw), P<T>(h->y2part),
+                                                     h->nt2_nb, h->nt2_nsuper, h->nt2_S, nullptr)));
+            else if (h->single_copy)
                 LCXCHECK((launch_cr<T, 2 * CT>(h->stream, P<T>(h->X), h->ldx, h->ldx, h->Npad, P<T>(h->gw), P<T>(h->y2part), h->nt2_nb,
                                                h->nt2_nsuper, h->nt2_S, nullptr)));
             else
@@ -1774,17 +1798,23 @@ template <typename T, int CT> struct Impl {
         if (kind == 2) {
             if (!h->merged_ok) { buf[0] = 0; return LCX_OK; }
             if constexpr (CT <= 4)
-                snprintf(buf, (size_t)len, h->single_copy ? "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, false>" : "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true>",
+                snprintf(buf, (size_t)len, h->panel ? "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, true, true>"
+                                           : h->single_copy ? "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, false, false>" : "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true, false>",
                          sizeof(T) == 8 ? "double" : "float", 2 * CT, CtShape<T, 2 * CT>::RT, CtShape<T, 2 * CT>::KW, CtShape<T, 2 * CT>::U);
             return LCX_OK;
         }
+        if (h->panel) {
+            snprintf(buf, (size_t)len, kind == 0 ? "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, true, true>" : "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true, true>",
+                     sizeof(T) == 8 ? "double" : "float", CT, CtShape<T, CT>::RT, CtShape<T, CT>::KW, CtShape<T, CT>::U);
+            return LCX_OK;
+        }
         if (kind == 0 && h->single_copy) {
-            snprintf(buf, (size_t)len, "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, false>", sizeof(T) == 8 ? "double" : "float", CT, CtShape<T, CT>::RT,
+            snprintf(buf, (size_t)len, "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, false, false>", sizeof(T) == 8 ? "double" : "float", CT, CtShape<T, CT>::RT,
                      CtShape<T, CT>::KW, CtShape<T, CT>::U);
             return LCX_OK;
         }
         if (kind == 0 ? h->nt_ct : h->tn_ct)
-            snprintf(buf, (size_t)len, "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true>", sizeof(T) == 8 ? "double" : "float", CT,
+            snprintf(buf, (size_t)len, "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true, false>", sizeof(T) == 8 ? "double" : "float", CT,
                      CtShape<T, CT>::RT, CtShape<T, CT>::KW, CtShape<T, CT>::U);
         else if (h->f64_4x4)
             snprintf(buf, (size_t)len, "lcx::gemm_tn4_kernel<%d, %d, %d, 4, true, false>", CT, Geo<T, CT>::TN_RT, kind == 0 ? h->nt_KW : h->tn_KW);
@@ -1794,11 +1824,19 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
 
-    // ---- preprocess on device (:397-429): stats + impute + standardise / tail squash, in place on X ----
-    // mean_io / std_io: host arrays of T (nv_local); nobs_out: int64 (may be null)
+    // ---- preprocess on device (:397-429): stats + impute + standardise / tail squash, in place ----
+    // on a ROW-MAJOR view X[Npad][ldx] of V columns: the resident shard itself, or - panel layout - a staged block of its columns
+    // (every step of :397-429 is per column, so blocks of columns are preprocessed independently).
+    // mean_io / std_io: host arrays of T (V entries: the caller offsets them to the view's first column); nobs_out: int64 (may be null);
+    // xt_view: [ldx][Npad] to leave the transposed copy in when kind is 'empirical' (nullptr: a temporary for the sort)
     static int preprocess_resident(lcx_ctx* h, int kind, int has_missing, double sentinel, int fit, void* mean_io,
                                    void* std_io, int64_t* nobs_out, double* maxabs_out) {
-        const int64_t V = h->V, N = h->N;
+        return preprocess_view(h, P<T>(h->X), h->V, h->ldx, kind, has_missing, sentinel, fit, mean_io, std_io, nobs_out, maxabs_out,
+                               h->single_copy ? (T*)nullptr : P<T>(h->XT));
+    }
+    static int preprocess_view(lcx_ctx* h, T* X, const int64_t V, const int64_t ldx, int kind, int has_missing, double sentinel, int fit,
+                               void* mean_io, void* std_io, int64_t* nobs_out, double* maxabs_out, T* xt_view) {
+        const int64_t N = h->N;
         const int strips = (int)cdiv(V, 64);
         int RS = (int)cdiv(4 * h->n_cus, strips);
         if (RS > 64) RS = 64;
@@ -1815,12 +1853,11 @@ template <typename T, int CT> struct Impl {
         LCXCHECK(tmps.get(&bmax, sizeof(double) * strips * RS));
         const dim3 grid((unsigned)strips, (unsigned)RS);
         const unsigned fgrid = (unsigned)cdiv(V, 256);
-        T* X = P<T>(h->X);
         const bool empirical = kind == PP_KIND_EMPIRICAL;        // (:424-426) imputation as usual, then ranks: no theta
         if (empirical) kind = PP_KIND_NONE;
         const bool need_stats = kind != PP_KIND_NONE;
         if (has_missing || (fit && need_stats)) {
-            hipLaunchKernelGGL((pp_colsum_kernel<T>), grid, dim3(256), 0, h->stream, X, N, V, h->ldx, has_missing, (T)sentinel,
+            hipLaunchKernelGGL((pp_colsum_kernel<T>), grid, dim3(256), 0, h->stream, X, N, V, ldx, has_missing, (T)sentinel,
                                (const double*)nullptr, ps, pn);
             KCHECK();
             hipLaunchKernelGGL((pp_finalize_kernel<T>), dim3(fgrid), dim3(256), 0, h->stream, ps, pn, RS, V, (double)N, kind, 0, nobs, imp, stdv);
@@ -1830,7 +1867,7 @@ template <typename T, int CT> struct Impl {
         if (need_stats) {
             if (fit) {
                 HIPCHECK(hipMemcpyAsync(mean, imp, sizeof(double) * V, hipMemcpyDeviceToDevice, h->stream));
-                hipLaunchKernelGGL((pp_colsum_kernel<T>), grid, dim3(256), 0, h->stream, X, N, V, h->ldx, has_missing, (T)sentinel,
+                hipLaunchKernelGGL((pp_colsum_kernel<T>), grid, dim3(256), 0, h->stream, X, N, V, ldx, has_missing, (T)sentinel,
                                    (const double*)mean, ps, (double*)nullptr);
                 KCHECK();
                 hipLaunchKernelGGL((pp_finalize_kernel<T>), dim3(fgrid), dim3(256), 0, h->stream, ps, (const double*)nullptr, RS, V, (double)N, kind,
@@ -1847,22 +1884,18 @@ template <typename T, int CT> struct Impl {
             }
         }
         if (need_stats || has_missing) {
-            hipLaunchKernelGGL((pp_apply_kernel<T>), grid, dim3(256), 0, h->stream, X, N, V, h->ldx, has_missing, (T)sentinel, imp, mean, stdv,
+            hipLaunchKernelGGL((pp_apply_kernel<T>), grid, dim3(256), 0, h->stream, X, N, V, ldx, has_missing, (T)sentinel, imp, mean, stdv,
                                kind, bmax);
             KCHECK();
         }
         if (empirical) {
-            T* xt = P<T>(h->XT);
-            if (h->single_copy) {                   // the sort works on contiguous columns: a transposed copy for its duration
-                LCXCHECK(tmps.get(&xt, sizeof(T) * (size_t)h->Npad * h->ldx));
-                dim3 tg((unsigned)(h->ldx / 64), (unsigned)(h->Npad / 64));
-                hipLaunchKernelGGL((transpose_kernel<T>), tg, dim3(256), 0, h->stream, X, h->ldx, xt, h->Npad);
-                KCHECK();
-            } else {
-                LCXCHECK(make_xt(h));
-            }
+            T* xt = xt_view;
+            if (!xt) LCXCHECK(tmps.get(&xt, sizeof(T) * (size_t)h->Npad * ldx));      // the sort works on contiguous columns
+            dim3 tg((unsigned)(ldx / 64), (unsigned)(h->Npad / 64));
+            hipLaunchKernelGGL((transpose_kernel<T>), tg, dim3(256), 0, h->stream, X, ldx, xt, h->Npad);
+            KCHECK();
             std::string err;
-            if (empirical_columns<T>(X, h->ldx, xt, h->Npad, N, V, h->stream, &err) != 0) return fail(LCX_ERR_HIP, err);
+            if (empirical_columns<T>(X, ldx, xt, h->Npad, N, V, h->stream, &err) != 0) return fail(LCX_ERR_HIP, err);
         }
         HIPCHECK(hipStreamSynchronize(h->stream));
         if (fit && need_stats && mean_io && std_io) {
@@ -1892,11 +1925,89 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
 
+    // ---- panel layout: the shard is filled through a row-major staging block of columns -------------------------------------
+    // fill(stage, ld, c0, nvalid) produces columns [c0, c0 + nvalid) of the shard (rows [0, N)) row-major in `stage` (leading dimension
+    // ld, zeroed beforehand: that is the padding); the block is then scattered into its panels.  <= 2^28 staged elements.
+    static int64_t panel_block_cols(const lcx_ctx* h) {
+        int64_t w = (((int64_t)1 << 28) / h->Npad) / 64 * 64;
+        const int forced = env_int("LCX_PANEL_BLOCK_COLS", 0);          // test hook: several blocks at small sizes
+        if (forced > 0) w = (int64_t)forced / 64 * 64;
+        if (w < 64) w = 64;
+        return w > h->ldx ? h->ldx : w;
+    }
+    template <typename F> static int panel_fill(lcx_ctx* h, F fill) {
+        const int64_t W = panel_block_cols(h);
+        DevTemps tmps;
+        T* stage = nullptr;
+        LCXCHECK(tmps.get(&stage, sizeof(T) * (size_t)h->Npad * W));
+        for (int64_t c0 = 0; c0 < h->ldx; c0 += W) {
+            const int64_t wp = (h->ldx - c0) < W ? (h->ldx - c0) : W;
+            const int64_t wv = h->V - c0 < 0 ? 0 : (h->V - c0 < wp ? h->V - c0 : wp);
+            HIPCHECK(hipMemsetAsync(stage, 0, sizeof(T) * (size_t)h->Npad * W, h->stream));
+            if (wv > 0) LCXCHECK(fill(stage, W, c0, wv));
+            hipLaunchKernelGGL((panel_block_kernel<T, true>), dim3(4096), dim3(256), 0, h->stream, stage, W, P<T>(h->X), h->Npad * PanelW<T>::v,
+                               h->Npad, c0, wp);
+            KCHECK();
+        }
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        return LCX_OK;
+    }
+    static int upload_x(lcx_ctx* h, const void* x, int64_t ld) {
+        if (!h->panel) {
+            HIPCHECK(hipMemcpy2DAsync(h->X, h->ldx * sizeof(T), x, ld * sizeof(T), h->V * sizeof(T), h->N, hipMemcpyHostToDevice, h->stream));
+            HIPCHECK(hipStreamSynchronize(h->stream));
+            return make_xt(h);
+        }
+        return panel_fill(h, [&](T* stage, int64_t lds, int64_t c0, int64_t wv) -> int {
+            HIPCHECK(hipMemcpy2DAsync(stage, lds * sizeof(T), reinterpret_cast<const T*>(x) + c0, ld * sizeof(T), wv * sizeof(T), h->N,
+                                      hipMemcpyHostToDevice, h->stream));
+            HIPCHECK(hipStreamSynchronize(h->stream));       // (the next block's memset must not overtake a pageable-memory copy)
+            return LCX_OK;
+        });
+    }
+    static int download_x(lcx_ctx* h, void* x, int64_t ld) {
+        if (!h->panel) {
+            HIPCHECK(hipMemcpy2DAsync(x, ld * sizeof(T), h->X, h->ldx * sizeof(T), h->V * sizeof(T), h->N, hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(hipStreamSynchronize(h->stream));
+            return LCX_OK;
+        }
+        const int64_t W = panel_block_cols(h);
+        DevTemps tmps;
+        T* stage = nullptr;
+        LCXCHECK(tmps.get(&stage, sizeof(T) * (size_t)h->Npad * W));
+        for (int64_t c0 = 0; c0 < h->V; c0 += W) {
+            const int64_t wp = (h->ldx - c0) < W ? (h->ldx - c0) : W;
+            const int64_t wv = h->V - c0 < wp ? h->V - c0 : wp;
+            hipLaunchKernelGGL((panel_block_kernel<T, false>), dim3(4096), dim3(256), 0, h->stream, stage, W, P<T>(h->X), h->Npad * PanelW<T>::v,
+                               h->Npad, c0, wp);
+            KCHECK();
+            HIPCHECK(hipMemcpy2DAsync(reinterpret_cast<T*>(x) + c0, ld * sizeof(T), stage, W * sizeof(T), wv * sizeof(T), h->N, hipMemcpyDeviceToHost,
+                                      h->stream));
+            HIPCHECK(hipStreamSynchronize(h->stream));
+        }
+        return LCX_OK;
+    }
+
     static int upload_preprocess(lcx_ctx* h, const void* x, int64_t ld, int kind, int has_missing, double sentinel, int fit,
                                  void* mean_io, void* std_io, int64_t* nobs_out, double* maxabs_out) {
-        HIPCHECK(hipMemcpy2DAsync(h->X, h->ldx * sizeof(T), x, ld * sizeof(T), h->V * sizeof(T), h->N, hipMemcpyHostToDevice, h->stream));
-        LCXCHECK(preprocess_resident(h, kind, has_missing, sentinel, fit, mean_io, std_io, nobs_out, maxabs_out));
-        return make_xt(h);
+        if (!h->panel) {
+            HIPCHECK(hipMemcpy2DAsync(h->X, h->ldx * sizeof(T), x, ld * sizeof(T), h->V * sizeof(T), h->N, hipMemcpyHostToDevice, h->stream));
+            LCXCHECK(preprocess_resident(h, kind, has_missing, sentinel, fit, mean_io, std_io, nobs_out, maxabs_out));
+            return make_xt(h);
+        }
+        double mx_all = 0.0;
+        LCXCHECK(panel_fill(h, [&](T* stage, int64_t lds, int64_t c0, int64_t wv) -> int {
+            HIPCHECK(hipMemcpy2DAsync(stage, lds * sizeof(T), reinterpret_cast<const T*>(x) + c0, ld * sizeof(T), wv * sizeof(T), h->N,
+                                      hipMemcpyHostToDevice, h->stream));
+            double mx = 0.0;
+            LCXCHECK(preprocess_view(h, stage, wv, lds, kind, has_missing, sentinel, fit, mean_io ? (void*)(reinterpret_cast<T*>(mean_io) + c0) : nullptr,
+                                     std_io ? (void*)(reinterpret_cast<T*>(std_io) + c0) : nullptr, nobs_out ? nobs_out + c0 : nullptr, &mx,
+                                     (T*)nullptr));
+            if (mx > mx_all) mx_all = mx;
+            return LCX_OK;
+        }));
+        if (maxabs_out) *maxabs_out = mx_all;
+        return LCX_OK;
     }
 
     // transform (:386-395) of raw rows: standardise with theta on the device, then x~ . ws^T
@@ -1944,6 +2055,13 @@ template <typename T, int CT> struct Impl {
     }
 
     static int generate(lcx_ctx* h, uint64_t seed, int kind, int n_groups, int64_t col_offset) {
+        if (h->panel)          // the generator is keyed by (seed, row, global column): block by block gives the same matrix
+            return panel_fill(h, [&](T* stage, int64_t lds, int64_t c0, int64_t wv) -> int {
+                hipLaunchKernelGGL((generate_kernel<T>), dim3(4096), dim3(256), 0, h->stream, stage, h->N, wv, lds, seed, kind,
+                                   n_groups < 1 ? 1 : n_groups, col_offset + c0);
+                KCHECK();
+                return preprocess_view(h, stage, wv, lds, PP_KIND_STANDARD, 0, 0.0, 1, nullptr, nullptr, nullptr, nullptr, (T*)nullptr);
+            });
         hipLaunchKernelGGL((generate_kernel<T>), dim3(4096), dim3(256), 0, h->stream, P<T>(h->X), h->N, h->V, h->ldx,
                            seed, kind, n_groups < 1 ? 1 : n_groups, col_offset);
         KCHECK();
@@ -2099,7 +2217,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     // a failed allocation releases everything allocated so far (lcx_destroy copes with a half-built handle)
 #define A_(ptr, bytes) do { const size_t b_ = (bytes); int r_ = dev_alloc((void**)&(ptr), b_, st); if (r_ != LCX_OK) { (void)lcx_destroy(h); return r_; } h->bytes_resident += b_ ? b_ : 16; } while (0)
     A_(h->X, (size_t)h->Npad * h->ldx * es);
-    if (!h->single_copy) A_(h->XT, (size_t)h->Npad * h->ldx * es);
+    if (!h->single_copy && !h->panel) A_(h->XT, (size_t)h->Npad * h->ldx * es);
     for (int k = 0; k < 2; ++k) {
         A_(h->Wt[k], mv);
         A_(h->set[k].Y, (size_t)h->Npad * Mp * es);
@@ -2396,9 +2514,7 @@ int lcx_exchange_info(lcx_ctx* h, int* kind, int* world, int64_t* allreduces_iss
 int lcx_upload_x(lcx_ctx* h, const void* x, int64_t ld) {
     NEED_MUT(h);
     if (!x || ld < h->V) return fail(LCX_ERR_ARG, "lcx_upload_x: bad leading dimension");
-    HIPCHECK(hipMemcpy2DAsync(h->X, h->ldx * h->es, x, ld * h->es, h->V * h->es, h->N, hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    DISPATCH(h, make_xt, h);
+    DISPATCH(h, upload_x, h, x, ld);
 }
 
 int lcx_upload_preprocess(lcx_ctx* h, const void* x, int64_t ld, int kind, int has_missing, double missing, int fit, void* mean_io,
@@ -2412,9 +2528,7 @@ int lcx_upload_preprocess(lcx_ctx* h, const void* x, int64_t ld, int kind, int h
 int lcx_download_x(lcx_ctx* h, void* x, int64_t ld) {
     NEED(h);
     if (!x || ld < h->V) return fail(LCX_ERR_ARG, "lcx_download_x: bad leading dimension");
-    HIPCHECK(hipMemcpy2DAsync(x, ld * h->es, h->X, h->ldx * h->es, h->V * h->es, h->N, hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    return LCX_OK;
+    DISPATCH(h, download_x, h, x, ld);
 }
 
 int lcx_generate_x(lcx_ctx* h, uint64_t seed, int kind, int n_groups, int64_t col_offset) {
@@ -2712,10 +2826,17 @@ int lcx_invert(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, int k
     DISPATCH(h, invert_rows, h, x_host, n_rows, ld, kind, mean, stdv, out, ld_out);
 }
 
+int lcx_x_layout(lcx_ctx* h, int* layout) {
+    NEED(h);
+    if (!layout) return fail(LCX_ERR_ARG, "lcx_x_layout: null");
+    *layout = h->panel ? 2 : (h->single_copy ? 1 : 0);
+    return LCX_OK;
+}
+
 int lcx_bytes_resident(lcx_ctx* h, int64_t* total, int64_t* x_bytes) {
     NEED(h);
     if (total) *total = (int64_t)h->bytes_resident;
-    if (x_bytes) *x_bytes = (int64_t)((h->single_copy ? 1 : 2) * (size_t)h->Npad * h->ldx * h->es);
+    if (x_bytes) *x_bytes = (int64_t)((h->single_copy || h->panel ? 1 : 2) * (size_t)h->Npad * h->ldx * h->es);
     return LCX_OK;
 }
 

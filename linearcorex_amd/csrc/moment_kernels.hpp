@@ -1090,6 +1090,28 @@ transpose_kernel(const T* __restrict__ X, int64_t ldx, T* __restrict__ XT, int64
 }
 
 // ------------------------------------------------------------------------------------------------
+// panel-major resident shard (gemm_kernels.hpp, PanelW): a column block staged row-major S[rows][ld] <-> its panels
+// XP[(col0 + c) / PW][n][PW].  One thread moves 16 bytes; consecutive threads walk a panel row, then the rows of the panel: the panel
+// side is fully contiguous, the staging side in 64-byte runs.  TO_PANEL = false copies back (lcx_download_x).
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool TO_PANEL>
+__global__ void __launch_bounds__(256)
+panel_block_kernel(T* __restrict__ S, int64_t ld, T* __restrict__ XP, int64_t panel_stride, int64_t rows, int64_t col0, int64_t ncols) {
+    constexpr int PW = 64 / (int)sizeof(T), E = 16 / (int)sizeof(T), QP = PW / E;       // 4 pieces of 16 B per panel row
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int64_t npan = ncols / PW;                                                     // ncols, col0: multiples of PW
+    const int64_t total = npan * rows * QP;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pn = k / (rows * QP), rem = k - pn * rows * QP;
+        const int64_t n = rem / QP;
+        const int c = (int)(rem % QP);
+        f4* pp = reinterpret_cast<f4*>(XP + (col0 / PW + pn) * panel_stride + n * PW + c * E);
+        f4* sp = reinterpret_cast<f4*>(S + n * ld + pn * PW + c * E);
+        if (TO_PANEL) *pp = *sp; else *sp = *pp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // synthetic data on device: counter-based N(0,1), keyed by (seed, row, global col)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {

@@ -771,7 +771,7 @@ def test_single_copy_mode_end_to_end(tag, monkeypatch):
         be = out._backend
         assert ("gemm_cr_kernel" in be.kernel_name(0)) == (flag == "1")
         br = be.bytes_resident()
-        runs[flag] = (np.asarray(out.history["TC"], np.float64), out.ws.copy(), out.clusters(), br["x_and_transposed_copy"],
+        runs[flag] = (np.asarray(out.history["TC"], np.float64), out.ws.copy(), out.clusters(), br["x"],
                       out.get_covariance(), out.transform(x))
         be.close()
     (h1, w1, c1, b1, cov1, y1), (h0, w0, c0, b0, cov0, y0) = runs["1"], runs["0"]
@@ -888,3 +888,84 @@ def test_later_trials_by_linearity_whole_fit(tag, g1):
     assert b.stats["trials"] > len(hb)
     a._backend.close()
     b._backend.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# round 4: ONE panel-major resident copy of the shard for large shards (include/lcx.h, lcx_x_layout; gemm_kernels.hpp, PanelW)
+# ------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("shape", [(1500, 3000, 8), (1501, 3001, 40), (4096, 8192, 64)])
+def test_panel_layout_matches_row_major(tag, shape, monkeypatch):
+    """The panel-major copy (both X passes on the stream-K kernels from the same bytes) against the row-major + transposed layout on
+    the same kernels: X.B^T contracts in another order (rounding), X^T.Y in the same one; same fit to rounding, both at the usual
+    bars against the oracle; the handle owns HALF the X bytes; the resident matrix reads back identical (ragged shapes, several
+    staging blocks)."""
+    from linearcorex_amd import Corex
+    dt = DT[tag]
+    n, v, m = shape
+    if tag == "f64" and m == 64:
+        pytest.skip("float32 shape")
+    x = O.gen_planted(n, v, 8, seed=1)[0]
+    monkeypatch.setenv("LCX_PANEL_BLOCK_COLS", "832")            # 13 panels of float32 per block: 4 .. 10 blocks, the last one ragged
+    runs = {}
+    for lay in ("panel", "rows"):
+        monkeypatch.setenv("LCX_X_LAYOUT", lay)
+        monkeypatch.setenv("LCX_GEMM", "ct")
+        out = Corex(n_hidden=m, seed=0, dtype=dt, device=0, max_iter=6, tol=0.0).fit(x)
+        be = out._backend
+        br = be.bytes_resident()
+        assert br["x_layout"].startswith("panel-major" if lay == "panel" else "row-major + transposed")
+        assert ("gemm_cr_kernel" in be.kernel_name(0)) == (lay == "panel") and "gemm_ct_kernel" in be.kernel_name(1)
+        assert be.kernel_name(1).endswith("true, true>" if lay == "panel" else "true, false>")
+        runs[lay] = (np.asarray(out.history["TC"], np.float64), out.ws.copy(), out.clusters(), br["x"], be.download_x(), out.transform(x),
+                     out.stats["trials"])
+        be.close()
+    (h1, w1, c1, b1, x1, y1, t1), (h0, w0, c0, b0, x0, y0, t0) = runs["panel"], runs["rows"]
+    assert b1 * 2 == b0 and len(h1) == len(h0) == 42
+    # the preprocessed shard itself: per-column statistics are summed per staging block in the panel path (another split of the rows)
+    assert relerr(x1, x0) < (1e-14 if tag == "f64" else 2e-6)
+    tol = 1e-9 if tag == "f64" else 5e-4
+    assert np.max(np.abs(h1 - h0) / np.maximum(1.0, np.abs(h0))) < tol
+    assert relerr(w1, w0) < tol * 10 and relerr(y1, y0) < tol * 10
+    if tag == "f64":
+        assert t1 == t0 and np.array_equal(c1, c0)
+    ref = O.fit_ns(x, m, seed=0, dtype=dt, max_iter=6, tol=0.0)
+    hr = np.asarray(ref.history_tc, np.float64)
+    assert np.max(np.abs(h1 - hr) / np.maximum(1.0, np.abs(hr))) < (1e-8 if tag == "f64" else 2e-3)
+
+
+@pytest.mark.parametrize("gz,missing", [("outliers", False), ("standard", True), ("empirical", True), ("none", False)])
+def test_panel_layout_preprocess_and_generate(gz, missing, monkeypatch):
+    """Every preprocessing kind of :397-429 through the staged blocks of the panel layout (per-column work: blocks of columns are
+    independent) against the row-major path: theta, n_obs and the resident matrix; and the on-device generator block by block."""
+    from linearcorex_amd.backend import HipBackend
+    rng = np.random.RandomState(3)
+    n, v = 1300, 2100
+    x = rng.randn(n, v) * (1 + rng.rand(v)) + rng.randn(v)
+    x[:, ::7] = np.sign(x[:, ::7]) * np.abs(x[:, ::7]) ** 1.5
+    x[:, 5] = np.round(x[:, 5])                      # ties for the rank transform
+    if missing:
+        x[rng.rand(n, v) < 0.03] = -1e6
+    monkeypatch.setenv("LCX_GEMM", "ct")
+    monkeypatch.setenv("LCX_PANEL_BLOCK_COLS", "512")
+    got = {}
+    for lay in ("panel", "rows"):
+        monkeypatch.setenv("LCX_X_LAYOUT", lay)
+        be = HipBackend(n, v, 8, np.float64, 0)
+        theta, n_obs, mx = be.upload_preprocess(x, gz, -1e6 if missing else None, None)
+        got[lay] = (theta, n_obs, mx, be.download_x())
+        # a second batch with the fitted theta (transform-time preprocessing of a handle of its own)
+        if gz in ("standard", "outliers"):
+            be.upload_preprocess(x[::-1].copy(), gz, -1e6 if missing else None, theta)
+            got[lay] += (be.download_x(),)
+        be.generate_x(7, 1, 5, 1000)
+        got[lay] += (be.download_x(),)
+        be.close()
+    a, b = got["panel"], got["rows"]
+    if gz in ("standard", "outliers"):
+        assert relerr(a[0][0], b[0][0]) < 1e-13 and relerr(a[0][1], b[0][1]) < 1e-13
+    assert np.array_equal(a[1], b[1]) and abs(a[2] - b[2]) <= 1e-12 * max(1.0, abs(b[2]))
+    for u, w in zip(a[3:], b[3:]):
+        assert u.shape == w.shape and relerr(u, w) < 1e-12
+    ref = O.preprocess(x.astype(np.float64), None, gz, -1e6 if missing else None)[0]
+    assert relerr(a[3], ref) < 1e-10

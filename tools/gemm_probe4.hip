@@ -183,6 +183,88 @@ void suite_cr(const char* name, int64_t N, int64_t V) {
     CK(hipFree(X)); CK(hipFree(XT)); CK(hipFree(B)); CK(hipFree(out));
 }
 
+// round 4: both passes from ONE panel-major copy (probe_kernels.hpp: gemm_crp_kernel for X.B^T, gemm_ctp_kernel for X^T.Y)
+template <typename T, int CT, int RT, int KW, int U, bool NT>
+Variant mkcrp(const T* XP, int64_t nrows_pad, int64_t K, int64_t nrows, const T* B, T* out, int bpc_use = 0) {
+    auto kern = gemm_crp_kernel<T, CT, RT, KW, U, NT>;
+    int bpc = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, 0));
+    const int use = bpc_use > 0 ? bpc_use : bpc;
+    const int ng = (int)(K / (4 * U));
+    const int nsuper = (int)((nrows + KW * 16 * RT - 1) / (KW * 16 * RT));
+    int64_t total = (int64_t)nsuper * ng;
+    int nb = 256 * use;
+    if (nb > total) nb = (int)total;
+    const int maxslots = (nb + nsuper - 1) / nsuper + 1;
+    char buf[200];
+    snprintf(buf, 200, "crp X.B^T from the PANEL-major copy U=%d NT=%d bpc=%d(use %d) slots=%d", U, (int)NT, bpc, use, maxslots);
+    const int64_t ps = nrows_pad * PanelW<T>::v;
+    return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, XP, ps, B, out, nrows, nrows, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
+}
+template <typename T, int CT, int RT, int KW, int U, bool NT>
+Variant mkctp(const T* XP, int64_t nrows_pad, int64_t K, int64_t vcols, const T* B, T* out, int bpc_use = 0) {
+    auto kern = gemm_ctp_kernel<T, CT, RT, KW, U, NT>;
+    int bpc = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, 0));
+    const int use = bpc_use > 0 ? bpc_use : bpc;
+    const int ng = (int)(K / (4 * U));
+    const int nsuper = (int)((vcols + KW * 16 * RT - 1) / (KW * 16 * RT));
+    int64_t total = (int64_t)nsuper * ng;
+    int nb = 256 * use;
+    if (nb > total) nb = (int)total;
+    const int maxslots = (nb + nsuper - 1) / nsuper + 1;
+    char buf[200];
+    snprintf(buf, 200, "ctp X^T.Y from the PANEL-major copy U=%d NT=%d bpc=%d(use %d) slots=%d", U, (int)NT, bpc, use, maxslots);
+    const int64_t ps = nrows_pad * PanelW<T>::v;
+    return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, XP, ps, B, out, vcols, vcols, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
+}
+
+template <typename T, int CT>
+void suite_panel(const char* name, int64_t N, int64_t V) {
+    T *X, *XT, *XP, *B, *out;
+    CK(hipMalloc(&X, sizeof(T) * N * V));
+    CK(hipMalloc(&XT, sizeof(T) * N * V));
+    CK(hipMalloc(&XP, sizeof(T) * N * V));
+    const int64_t big = std::max(N, V);
+    CK(hipMalloc(&B, sizeof(T) * big * 16 * CT));
+    CK(hipMalloc(&out, sizeof(T) * 40 * big * 16 * CT));
+    {
+        std::vector<T> h((size_t)4096 * 4096);
+        for (size_t x = 0; x < h.size(); ++x) h[x] = (T)((double)rand() / RAND_MAX - 0.5);
+        for (size_t off = 0; off < (size_t)N * V; off += h.size())
+            CK(hipMemcpy(X + off, h.data(), sizeof(T) * std::min(h.size(), (size_t)N * V - off), hipMemcpyHostToDevice));
+        CK(hipMemcpy(B, h.data() + 11, sizeof(T) * big * 16 * CT, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL((transpose_probe_kernel_t<T>), dim3(4096), dim3(256), 0, 0, X, V, XT, N, N, V);
+    hipLaunchKernelGGL((panelize_kernel<T>), dim3(4096), dim3(256), 0, 0, X, V, XP, N, V);
+    CK(hipDeviceSynchronize());
+    const double tol = sizeof(T) == 8 ? 1e-12 : 2e-5;
+    constexpr int R = CtShape<T, CT>::RT;
+    {
+        const double gb = sizeof(T) * ((double)N * V + 16.0 * CT * (N + V)) / 1e9, tf = 2.0 * N * V * 16 * CT / 1e12;
+        printf("== %s: X %ld x %ld, Mp=%d elt=%zu: X.B^T - transposed copy (ct) / row-major X (cr) / panel-major copy (crp)\n", name, (long)N, (long)V, 16 * CT, sizeof(T));
+        std::vector<Variant> vs;
+        vs.push_back(mkct<T, CT, R, 4, 4, true>(XT, N, V, N, B, out, 2));
+        vs.push_back(mkcr<T, CT, R, 4, 4, false>(X, V, V, N, B, out, 2));
+        vs.push_back(mkcrp<T, CT, R, 4, 4, false>(XP, N, V, N, B, out, 2));
+        vs.push_back(mkcrp<T, CT, R, 4, 4, true>(XP, N, V, N, B, out, 2));
+        vs.push_back(mkcrp<T, CT, R, 4, 8, true>(XP, N, V, N, B, out, 2));
+        for (size_t k = 1; k < vs.size(); ++k) check<T>(name, vs[k], vs[0], out, out, N, 16 * CT, tol);
+        bench(vs, gb, tf);
+    }
+    {
+        const double gb = sizeof(T) * ((double)N * V + 16.0 * CT * (N + V)) / 1e9, tf = 2.0 * N * V * 16 * CT / 1e12;
+        printf("== %s: X %ld x %ld, Mp=%d elt=%zu: X^T.Y - row-major X (ct) / panel-major copy (ctp)\n", name, (long)N, (long)V, 16 * CT, sizeof(T));
+        std::vector<Variant> vs;
+        vs.push_back(mkct<T, CT, R, 4, 4, true>(X, V, N, V, B, out, 2));
+        vs.push_back(mkctp<T, CT, R, 4, 4, true>(XP, N, N, V, B, out, 2));
+        vs.push_back(mkctp<T, CT, R, 4, 4, false>(XP, N, N, V, B, out, 2));
+        for (size_t k = 1; k < vs.size(); ++k) check<T>(name, vs[k], vs[0], out, out, V, 16 * CT, tol);
+        bench(vs, gb, tf);
+    }
+    CK(hipFree(X)); CK(hipFree(XT)); CK(hipFree(XP)); CK(hipFree(B)); CK(hipFree(out));
+}
+
 template <typename T, int CT>
 void suite_cr2(const char* name, int64_t N, int64_t V) {
     T *X, *XT, *B, *out;
@@ -255,6 +337,12 @@ int main(int argc, char** argv) {
         suite_cr<float, 8>("c4shard", 50048, 125056);
         suite_cr<double, 4>("c3f64", 50048, 50048);
         suite_cr<float, 2>("mid32f32", 20032, 20032);
+        return 0;
+    }
+    if (!strcmp(which, "panel")) {
+        suite_panel<float, 4>("c3", 50048, 100032);
+        suite_panel<float, 8>("c4shard", 50048, 125056);
+        suite_panel<double, 4>("c3f64", 50048, 50048);
         return 0;
     }
     if (!strcmp(which, "cr2")) {

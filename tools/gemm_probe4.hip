@@ -183,10 +183,10 @@ void suite_cr(const char* name, int64_t N, int64_t V) {
     CK(hipFree(X)); CK(hipFree(XT)); CK(hipFree(B)); CK(hipFree(out));
 }
 
-// round 4: both passes from ONE panel-major copy (probe_kernels.hpp: gemm_crp_kernel for X.B^T, gemm_ctp_kernel for X^T.Y)
+// round 4: both passes from ONE panel-major copy (the production kernels in PANEL mode: gemm_cr for X.B^T, gemm_ct for X^T.Y)
 template <typename T, int CT, int RT, int KW, int U, bool NT>
 Variant mkcrp(const T* XP, int64_t nrows_pad, int64_t K, int64_t nrows, const T* B, T* out, int bpc_use = 0) {
-    auto kern = gemm_crp_kernel<T, CT, RT, KW, U, NT>;
+    auto kern = gemm_cr_kernel<T, CT, RT, KW, U, NT, true>;
     int bpc = 0;
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, 0));
     const int use = bpc_use > 0 ? bpc_use : bpc;
@@ -203,7 +203,7 @@ Variant mkcrp(const T* XP, int64_t nrows_pad, int64_t K, int64_t nrows, const T*
 }
 template <typename T, int CT, int RT, int KW, int U, bool NT>
 Variant mkctp(const T* XP, int64_t nrows_pad, int64_t K, int64_t vcols, const T* B, T* out, int bpc_use = 0) {
-    auto kern = gemm_ctp_kernel<T, CT, RT, KW, U, NT>;
+    auto kern = gemm_ct_kernel<T, CT, RT, KW, U, NT, true>;
     int bpc = 0;
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, 0));
     const int use = bpc_use > 0 ? bpc_use : bpc;
@@ -263,6 +263,54 @@ void suite_panel(const char* name, int64_t N, int64_t V) {
         bench(vs, gb, tf);
     }
     CK(hipFree(X)); CK(hipFree(XT)); CK(hipFree(XP)); CK(hipFree(B)); CK(hipFree(out));
+}
+
+// geometry sweep of the two panel-layout passes (the balance moved: same speed as the two-copy layout at a 10 % higher shader clock)
+template <typename T, int CT>
+void suite_panel_sweep(const char* name, int64_t N, int64_t V) {
+    T *X, *XP, *B, *out;
+    CK(hipMalloc(&X, sizeof(T) * N * V));
+    CK(hipMalloc(&XP, sizeof(T) * N * V));
+    const int64_t big = std::max(N, V);
+    CK(hipMalloc(&B, sizeof(T) * big * 16 * CT));
+    CK(hipMalloc(&out, sizeof(T) * 40 * big * 16 * CT));
+    {
+        std::vector<T> h((size_t)4096 * 4096);
+        for (size_t x = 0; x < h.size(); ++x) h[x] = (T)((double)rand() / RAND_MAX - 0.5);
+        for (size_t off = 0; off < (size_t)N * V; off += h.size())
+            CK(hipMemcpy(X + off, h.data(), sizeof(T) * std::min(h.size(), (size_t)N * V - off), hipMemcpyHostToDevice));
+        CK(hipMemcpy(B, h.data() + 11, sizeof(T) * big * 16 * CT, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL((panelize_kernel<T>), dim3(4096), dim3(256), 0, 0, X, V, XP, N, V);
+    CK(hipDeviceSynchronize());
+    CK(hipFree(X));
+    constexpr int R = CtShape<T, CT>::RT;
+    const double gb = sizeof(T) * ((double)N * V + 16.0 * CT * (N + V)) / 1e9, tf = 2.0 * N * V * 16 * CT / 1e12;
+    {
+        printf("== %s sweep: X.B^T from the panel-major copy (crp)\n", name);
+        std::vector<Variant> vs;
+        vs.push_back(mkcrp<T, CT, R, 4, 4, true>(XP, N, V, N, B, out, 2));
+        vs.push_back(mkcrp<T, CT, R, 4, 4, true>(XP, N, V, N, B, out, 3));
+        vs.push_back(mkcrp<T, CT, R, 4, 4, true>(XP, N, V, N, B, out, 1));
+        vs.push_back(mkcrp<T, CT, R, 4, 8, true>(XP, N, V, N, B, out, 2));
+        vs.push_back(mkcrp<T, CT, R, 8, 4, true>(XP, N, V, N, B, out, 1));
+        vs.push_back(mkcrp<T, CT, R, 2, 4, true>(XP, N, V, N, B, out, 4));
+        if constexpr (CT <= 4) vs.push_back(mkcrp<T, CT, 2 * R, 4, 4, true>(XP, N, V, N, B, out, 2));
+        if constexpr (CT <= 4) vs.push_back(mkcrp<T, CT, 2 * R, 4, 4, true>(XP, N, V, N, B, out, 1));
+        bench(vs, gb, tf);
+    }
+    {
+        printf("== %s sweep: X^T.Y from the panel-major copy (ctp)\n", name);
+        std::vector<Variant> vs;
+        vs.push_back(mkctp<T, CT, R, 4, 4, true>(XP, N, N, V, B, out, 2));
+        vs.push_back(mkctp<T, CT, R, 4, 4, true>(XP, N, N, V, B, out, 3));
+        vs.push_back(mkctp<T, CT, R, 4, 4, true>(XP, N, N, V, B, out, 1));
+        vs.push_back(mkctp<T, CT, R, 4, 8, true>(XP, N, N, V, B, out, 2));
+        vs.push_back(mkctp<T, CT, R, 8, 4, true>(XP, N, N, V, B, out, 1));
+        vs.push_back(mkctp<T, CT, R, 2, 4, true>(XP, N, N, V, B, out, 4));
+        bench(vs, gb, tf);
+    }
+    CK(hipFree(XP)); CK(hipFree(B)); CK(hipFree(out));
 }
 
 template <typename T, int CT>
@@ -337,6 +385,11 @@ int main(int argc, char** argv) {
         suite_cr<float, 8>("c4shard", 50048, 125056);
         suite_cr<double, 4>("c3f64", 50048, 50048);
         suite_cr<float, 2>("mid32f32", 20032, 20032);
+        return 0;
+    }
+    if (!strcmp(which, "panelsweep")) {
+        suite_panel_sweep<float, 4>("c3", 50048, 100032);
+        suite_panel_sweep<float, 8>("c4shard", 50048, 125056);
         return 0;
     }
     if (!strcmp(which, "panel")) {

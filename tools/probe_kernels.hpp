@@ -840,17 +840,10 @@ gemm_tn4r_kernel(const double* __restrict__ A, int64_t lda, const double* __rest
 
 
 // ------------------------------------------------------------------------------------------------
-// round 4: ONE resident copy of X in PANEL-MAJOR layout  XP[v / PW][n][PW],  PW = 64 bytes of one row (16 floats / 8 doubles):
-// a panel is all rows of PW consecutive variables, contiguous.
-//   * X.B^T (contraction over v, gemm_crp): gemm_cr's lane (i, q) loads 16 bytes of row i at chunk q of ONE panel - the 16 rows of a
-//     load instruction are now 16 x 64 B = 1 KB CONTIGUOUS (row-major X: 16 segments of 64 B, a row length apart), a wave's 4 row tiles
-//     4 KB, a block's 256 rows 16 KB; a group of 4 U contraction elements = U / E panels;
-//   * X^T.Y (contraction over n, gemm_ctp): gemm_ct's lane (i, q) loads 16 bytes = 4 consecutive v of row 4 st + q: the 16 lanes i cover
-//     4 panels, 4 rows x 64 B = 256 contiguous bytes in each - the same 4 x 256 B per instruction as on the row-major X, and the 16 rows
-//     of a group make 1 KB contiguous per panel.
+// round 4: ONE resident copy of X in PANEL-MAJOR layout XP[v / PW][n][PW] (gemm_kernels.hpp, PanelW): the probes run the production
+// kernels in their PANEL mode (gemm_cr_kernel<.., PANEL> for X.B^T, gemm_ct_kernel<.., PANEL> for X^T.Y); this is the probe's own
+// layout conversion.
 // ------------------------------------------------------------------------------------------------
-template <typename T> struct PanelW { static constexpr int v = 64 / (int)sizeof(T); };
-
 template <typename T>
 __global__ void panelize_kernel(const T* __restrict__ X, int64_t ldx, T* __restrict__ XP, int64_t nrows, int64_t ncols) {
     constexpr int PW = PanelW<T>::v;
@@ -858,278 +851,6 @@ __global__ void panelize_kernel(const T* __restrict__ X, int64_t ldx, T* __restr
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t n = k / ncols, v = k % ncols;
         XP[(v / PW) * nrows * PW + n * PW + (v % PW)] = X[n * ldx + v];
-    }
-}
-
-template <typename T, int CT, int RT, int KW, int U, bool NT = false>
-__global__ void __launch_bounds__(64 * KW)
-gemm_crp_kernel(const T* __restrict__ A, int64_t panel_stride /* nrows_padded * PW */, const T* __restrict__ B, T* __restrict__ out,
-                int64_t out_rows, int64_t nrows, int ng, int nsuper, int maxslots, const int* __restrict__ skip_flag) {
-    constexpr int Mp = 16 * CT;
-    constexpr int E = 16 / (int)sizeof(T);
-    constexpr int PW = 4 * E;
-    constexpr int NL = U / E;
-    static_assert(U % E == 0, "a group must be whole panels");
-    constexpr int CHUNK = 4 * U * Mp;
-    constexpr int PCS = CHUNK * (int)sizeof(T) / 16;
-    constexpr int NTH = 64 * KW;
-    constexpr int PPT = (PCS + NTH - 1) / NTH;
-    typedef typename MF<T>::acc_t acc_t;
-    typedef typename VecT<T, E>::type AV;
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) T Bs[2][CHUNK];
-    if (skip_flag != nullptr && *skip_flag != 0) return;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 15, q = lane >> 4;
-    const int64_t total = (int64_t)nsuper * ng;
-    const int nb = gridDim.x;
-    int64_t L0 = total * blockIdx.x / nb;
-    const int64_t L1 = total * (blockIdx.x + 1) / nb;
-
-    while (L0 < L1) {
-        const int st_ = (int)(L0 / ng);
-        const int s0 = (int)(L0 - (int64_t)st_ * ng);
-        const int s1 = (L1 - L0) < (int64_t)(ng - s0) ? s0 + (int)(L1 - L0) : ng;
-        const int cnt = s1 - s0;
-        const int64_t v0 = ((int64_t)st_ * KW + wave) * (16 * RT);
-        const bool active = v0 < nrows;
-
-        acc_t acc[RT][CT];
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int u = 0; u < CT; ++u) acc[t][u] = (acc_t){0, 0, 0, 0};
-        const T* ap = A + ((active ? v0 : 0) + i) * PW + q * E;
-        AV a0[NL][RT], a1[NL][RT];
-        f4 bst[PPT];
-
-#define LCX_CRP_LOADA(R, AA)                                                              \
-        if (active) {                                                                     \
-            const int64_t pb = (int64_t)(s0 + (R)) * NL;                                  \
-            _Pragma("unroll") for (int p = 0; p < NL; ++p)                                \
-            _Pragma("unroll") for (int t = 0; t < RT; ++t) {                              \
-                const AV* src = reinterpret_cast<const AV*>(ap + (pb + p) * panel_stride + (int64_t)(16 * t) * PW); \
-                AA[p][t] = NT ? __builtin_nontemporal_load(src) : *src;                   \
-            }                                                                             \
-        }
-#define LCX_CRP_LOADB(R)                                                                  \
-        {                                                                                 \
-            const f4* src = reinterpret_cast<const f4*>(B + (int64_t)(s0 + (R)) * CHUNK); \
-            _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                             \
-                const int pc = p * NTH + (int)threadIdx.x;                                \
-                if (PCS % NTH == 0 || pc < PCS) bst[p] = src[pc];                         \
-            }                                                                             \
-        }
-#define LCX_CRP_STOREB(BUF)                                                               \
-        {                                                                                 \
-            f4* dstp = reinterpret_cast<f4*>(&Bs[BUF][0]);                                \
-            _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                             \
-                const int pc = p * NTH + (int)threadIdx.x;                                \
-                if (PCS % NTH == 0 || pc < PCS) dstp[pc] = bst[p];                        \
-            }                                                                             \
-        }
-#define LCX_CRP_MMA(AA, BUF)                                                              \
-        if (active) {                                                                     \
-            Pk<T, CT> bb[U];                                                              \
-            _Pragma("unroll") for (int p = 0; p < NL; ++p)                                \
-            _Pragma("unroll") for (int e = 0; e < E; ++e)                                 \
-                bb[p * E + e] = *reinterpret_cast<const Pk<T, CT>*>(&Bs[BUF][(p * 4 * E + q * E + e) * Mp + i * CT]); \
-            _Pragma("unroll") for (int p = 0; p < NL; ++p)                                \
-            _Pragma("unroll") for (int e = 0; e < E; ++e)                                 \
-            _Pragma("unroll") for (int t = 0; t < RT; ++t)                                \
-            _Pragma("unroll") for (int u = 0; u < CT; ++u)                                \
-                acc[t][u] = MF<T>::mma(AA[p][t][e], bb[p * E + e].v[u], acc[t][u]);       \
-        }
-
-        LCX_CRP_LOADA(0, a0);
-        LCX_CRP_LOADB(0);
-        int r = 0;
-        while (true) {
-            LCX_CRP_STOREB(0);
-            if (r + 1 < cnt) { LCX_CRP_LOADA(r + 1, a1); LCX_CRP_LOADB(r + 1); }
-            __syncthreads();
-            LCX_CRP_MMA(a0, 0);
-            if (++r >= cnt) break;
-            LCX_CRP_STOREB(1);
-            if (r + 1 < cnt) { LCX_CRP_LOADA(r + 1, a0); LCX_CRP_LOADB(r + 1); }
-            __syncthreads();
-            LCX_CRP_MMA(a1, 1);
-            if (++r >= cnt) break;
-        }
-#undef LCX_CRP_LOADA
-#undef LCX_CRP_LOADB
-#undef LCX_CRP_STOREB
-#undef LCX_CRP_MMA
-
-        const int fb = sk_owner((int64_t)st_ * ng, total, nb);
-        if (active) {
-            T* dst = out + ((int64_t)(blockIdx.x - fb) * out_rows + v0) * Mp;
-#pragma unroll
-            for (int t = 0; t < RT; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    Pk<T, CT> o;
-#pragma unroll
-                    for (int u = 0; u < CT; ++u) o.v[u] = acc[t][u][g];
-                    *reinterpret_cast<Pk<T, CT>*>(dst + (16 * t + MF<T>::row(lane, g)) * Mp + i * CT) = o;
-                }
-            if (s1 == ng) {
-                const int lb = sk_owner((int64_t)st_ * ng + ng - 1, total, nb);
-                Pk<T, CT> z;
-#pragma unroll
-                for (int u = 0; u < CT; ++u) z.v[u] = (T)0;
-                for (int sl = lb - fb + 1; sl < maxslots; ++sl) {
-                    T* zd = out + ((int64_t)sl * out_rows + v0) * Mp;
-#pragma unroll
-                    for (int t = 0; t < RT; ++t)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            *reinterpret_cast<Pk<T, CT>*>(zd + (16 * t + 4 * g + q) * Mp + i * CT) = z;
-                }
-            }
-        }
-        __syncthreads();
-        L0 += cnt;
-    }
-}
-
-// gemm_ct reading its A operand from the panel-major copy: D[v][j] = sum_n X[n][v] B[n][j]
-template <typename T, int CT, int RT, int KW, int U, bool NT = false>
-__global__ void __launch_bounds__(64 * KW)
-gemm_ctp_kernel(const T* __restrict__ A, int64_t panel_stride, const T* __restrict__ B, T* __restrict__ out,
-                int64_t out_rows, int64_t vcols, int ng, int nsuper, int maxslots, const int* __restrict__ skip_flag) {
-    constexpr int Mp = 16 * CT;
-    constexpr int PW = PanelW<T>::v;
-    constexpr int EPL = Epl<T, RT>::v;
-    constexpr int CHUNK = 4 * U * Mp;
-    constexpr int PCS = CHUNK * (int)sizeof(T) / 16;
-    constexpr int NTH = 64 * KW;
-    constexpr int PPT = (PCS + NTH - 1) / NTH;
-    typedef typename MF<T>::acc_t acc_t;
-    typedef typename VecT<T, EPL>::type V;
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) T Bs[2][CHUNK];
-    if (skip_flag != nullptr && *skip_flag != 0) return;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 15, q = lane >> 4;
-    const int64_t total = (int64_t)nsuper * ng;
-    const int nb = gridDim.x;
-    int64_t L0 = total * blockIdx.x / nb;
-    const int64_t L1 = total * (blockIdx.x + 1) / nb;
-
-    while (L0 < L1) {
-        const int st_ = (int)(L0 / ng);
-        const int s0 = (int)(L0 - (int64_t)st_ * ng);
-        const int s1 = (L1 - L0) < (int64_t)(ng - s0) ? s0 + (int)(L1 - L0) : ng;
-        const int cnt = s1 - s0;
-        const int64_t v0 = ((int64_t)st_ * KW + wave) * (16 * RT);
-        const bool active = v0 < vcols;
-
-        acc_t acc[RT][CT];
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int u = 0; u < CT; ++u) acc[t][u] = (acc_t){0, 0, 0, 0};
-        // piece p of this lane: columns v0 + p * 16 EPL + i EPL .. + EPL - 1  ->  panel (col / PW), offset col % PW
-        const T* app[RT / EPL];
-#pragma unroll
-        for (int p = 0; p < RT / EPL; ++p) {
-            const int64_t col = (active ? v0 : 0) + p * 16 * EPL + i * EPL;
-            app[p] = A + (col / PW) * panel_stride + (col % PW) + (int64_t)q * PW;
-        }
-        T a0[U][RT], a1[U][RT];
-        f4 bst[PPT];
-
-#define LCX_CTP_LOADA(R, AA)                                                              \
-        if (active) {                                                                     \
-            const int64_t rb = (int64_t)(s0 + (R)) * (4 * U);                             \
-            _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
-            _Pragma("unroll") for (int p = 0; p < RT / EPL; ++p) {                        \
-                const V* src = reinterpret_cast<const V*>(app[p] + (rb + 4 * st) * PW);   \
-                const V v = NT ? __builtin_nontemporal_load(src) : *src;                  \
-                _Pragma("unroll") for (int e = 0; e < EPL; ++e) {                         \
-                    if constexpr (EPL == 1) AA[st][p] = v; else AA[st][p * EPL + e] = v[e]; \
-                }                                                                         \
-            }                                                                             \
-        }
-#define LCX_CTP_LOADB(R)                                                                  \
-        {                                                                                 \
-            const f4* src = reinterpret_cast<const f4*>(B + (int64_t)(s0 + (R)) * CHUNK); \
-            _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                             \
-                const int pc = p * NTH + (int)threadIdx.x;                                \
-                if (PCS % NTH == 0 || pc < PCS) bst[p] = src[pc];                         \
-            }                                                                             \
-        }
-#define LCX_CTP_STOREB(BUF)                                                               \
-        {                                                                                 \
-            f4* dstp = reinterpret_cast<f4*>(&Bs[BUF][0]);                                \
-            _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                             \
-                const int pc = p * NTH + (int)threadIdx.x;                                \
-                if (PCS % NTH == 0 || pc < PCS) dstp[pc] = bst[p];                        \
-            }                                                                             \
-        }
-#define LCX_CTP_MMA(AA, BUF)                                                              \
-        if (active) {                                                                     \
-            Pk<T, CT> bb[U];                                                              \
-            _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
-                bb[st] = *reinterpret_cast<const Pk<T, CT>*>(&Bs[BUF][(4 * st + q) * Mp + i * CT]); \
-            _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
-            _Pragma("unroll") for (int t = 0; t < RT; ++t)                                \
-            _Pragma("unroll") for (int u = 0; u < CT; ++u)                                \
-                acc[t][u] = MF<T>::mma(AA[st][t], bb[st].v[u], acc[t][u]);                \
-        }
-
-        LCX_CTP_LOADA(0, a0);
-        LCX_CTP_LOADB(0);
-        int r = 0;
-        while (true) {
-            LCX_CTP_STOREB(0);
-            if (r + 1 < cnt) { LCX_CTP_LOADA(r + 1, a1); LCX_CTP_LOADB(r + 1); }
-            __syncthreads();
-            LCX_CTP_MMA(a0, 0);
-            if (++r >= cnt) break;
-            LCX_CTP_STOREB(1);
-            if (r + 1 < cnt) { LCX_CTP_LOADA(r + 1, a0); LCX_CTP_LOADB(r + 1); }
-            __syncthreads();
-            LCX_CTP_MMA(a1, 1);
-            if (++r >= cnt) break;
-        }
-#undef LCX_CTP_LOADA
-#undef LCX_CTP_LOADB
-#undef LCX_CTP_STOREB
-#undef LCX_CTP_MMA
-
-        const int fb = sk_owner((int64_t)st_ * ng, total, nb);
-        if (active) {
-            T* dst = out + ((int64_t)(blockIdx.x - fb) * out_rows + v0) * Mp;
-#pragma unroll
-            for (int t = 0; t < RT; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    Pk<T, CT> o;
-#pragma unroll
-                    for (int u = 0; u < CT; ++u) o.v[u] = acc[t][u][g];
-                    *reinterpret_cast<Pk<T, CT>*>(dst + piece_col<T, RT>(t, MF<T>::row(lane, g)) * Mp + i * CT) = o;
-                }
-            if (s1 == ng) {
-                const int lb = sk_owner((int64_t)st_ * ng + ng - 1, total, nb);
-                Pk<T, CT> z;
-#pragma unroll
-                for (int u = 0; u < CT; ++u) z.v[u] = (T)0;
-                for (int sl = lb - fb + 1; sl < maxslots; ++sl) {
-                    T* zd = out + ((int64_t)sl * out_rows + v0) * Mp;
-#pragma unroll
-                    for (int t = 0; t < RT; ++t)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            *reinterpret_cast<Pk<T, CT>*>(zd + (16 * t + 4 * g + q) * Mp + i * CT) = z;
-                }
-            }
-        }
-        __syncthreads();
-        L0 += cnt;
     }
 }
 

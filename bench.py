@@ -547,6 +547,7 @@ def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_s
         },
         "bytes_resident": be.bytes_resident() if hasattr(be, "bytes_resident") else None,
         "exchange": dict(be.exchange_info(), transport=getattr(model, "_engine_exchange", None),
+                         selftest_seconds_per_y_allreduce=getattr(comm, "selftest_seconds", None),
                          line_search_in_library=bool(getattr(model, "_iterated_in_library", False))),
     }
     return res, model, be
@@ -775,6 +776,8 @@ def compact_line(out, detail_path):
     w = cfg.get("windows") or {}
     c["windows"] = {k: w.get(k) for k in ("walks_timed", "timed_iterations", "timed_seconds", "ms_per_step_walk_min_median_max")}
     c["exchange"] = _pick(cfg, "exchange", "transport") or _pick(cfg, "exchange", "kind")
+    if _pick(cfg, "exchange", "selftest_seconds_per_y_allreduce"):
+        c["y_allreduce_selftest_ms"] = 1e3 * _pick(cfg, "exchange", "selftest_seconds_per_y_allreduce")
     c["bytes_resident_total"] = _pick(cfg, "bytes_resident", "total")
     c["bytes_resident_x"] = _pick(cfg, "bytes_resident", "x")
     c["x_layout"] = _pick(cfg, "bytes_resident", "x_layout")

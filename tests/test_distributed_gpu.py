@@ -226,7 +226,9 @@ def test_sharded_float32_large_kernels_match_single_gpu(m, tmp_path, monkeypatch
     _launch_f32(2, tmp_path, n, v, m, iters)
     got = np.load(os.path.join(tmp_path, "dist_f32.npz"))
     assert int(got["world"]) == 2 and str(got["transport"]) == "hook" and bool(got["in_library"])
-    assert ("gemm_ct_kernel<float, %d" % (m // 16)) in str(got["kernel_nt"]) and "gemm_ct_kernel" in str(got["kernel_tn"])
+    # (the stream-K pair on the panel-major copy: X.B^T = gemm_cr<.., true, true>, X^T.Y = gemm_ct<.., true, true>)
+    assert ("gemm_cr_kernel<float, %d" % (m // 16)) in str(got["kernel_nt"]) and "gemm_ct_kernel" in str(got["kernel_tn"])
+    assert str(got["kernel_nt"]).endswith("true, true>") and str(got["kernel_tn"]).endswith("true, true>")
     monkeypatch.setenv("LCX_GEMM", "ct")
     xt = planted_f32(n, v, m)
     single = Corex(n_hidden=m, seed=0, dtype=np.float32, tol=0.0, device=0)
@@ -260,7 +262,7 @@ def test_sharded_merged_pass_under_exchange(m, tmp_path, monkeypatch):
     _launch_f32(2, tmp_path, n, v, m, iters)
     got = np.load(os.path.join(tmp_path, "dist_f32.npz"))
     assert int(got["world"]) == 2 and str(got["transport"]) == "hook" and bool(got["in_library"])
-    assert "gemm_ct_kernel<float" in str(got["kernel_merged"]) and int(got["merged_passes"]) > 0
+    assert "gemm_cr_kernel<float" in str(got["kernel_merged"]) and int(got["merged_passes"]) > 0
     monkeypatch.setenv("LCX_GEMM", "ct")
     xt = planted_f32(n, v, m)
     single = Corex(n_hidden=m, seed=0, dtype=np.float32, tol=0.0, device=0)

@@ -24,7 +24,8 @@ def test_full_size_properties(shape):
     from linearcorex_amd.backend import HipBackend
     n, v, m = shape
     be = HipBackend(n, v, m, np.float32, 0)
-    assert "gemm_ct_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)
+    assert "gemm_cr_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)         # the stream-K pair ...
+    assert be.bytes_resident()["x_layout"].startswith("panel-major")                                 # ... on ONE panel-major copy
     be.generate_x(1, 1, m, 0)                                     # planted groups, standardised on the device
     cols = np.unique(np.concatenate([[0, 1, v - 1, v - 2, 63, 64, 255, 256], np.linspace(0, v - 1, m).astype(int)]))[:m]
     assert len(cols) == m
@@ -140,7 +141,8 @@ def _full_size_step(shape, kind, HipBackend, O, reuse=False):
     be = HipBackend(n, v, m, np.float32, 0)
     be.set_linear_mode(False)                                    # what `Corex(line_search="exact")` runs
     be.set_trial_reuse(reuse)                                    # True: line_search="exact-y" (trials 2..8 of the shard's iteration by linearity)
-    assert "gemm_ct_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)
+    assert "gemm_cr_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)         # the stream-K pair ...
+    assert be.bytes_resident()["x_layout"].startswith("panel-major")                                 # ... on ONE panel-major copy
     be.generate_x(1, kind, m, 0)
     x = be.download_x()
     assert x.dtype == np.float32 and x.shape == (n, v)

@@ -261,7 +261,7 @@ def test_column_tiled_gemm_end_to_end(tag, g2_small, monkeypatch):
     n, v, m = (int(t) for t in g["shape"])
     x, grp = O.gen_planted(n, v, m)
     out = _fit(x, m, tag)
-    assert "gemm_ct" in out._backend.kernel_name(0) and "gemm_ct" in out._backend.kernel_name(1)
+    assert "gemm_cr" in out._backend.kernel_name(0) and "gemm_ct" in out._backend.kernel_name(1)    # (the stream-K pair, panel-major copy)
     assert np.array_equal(out.clusters(), g[tag + "_clusters"])
     h_ref = g[tag + "_history_tc"]
     h = np.asarray(out.history["TC"], dtype=np.float64)
@@ -506,7 +506,7 @@ def test_ct_many_slots_end_to_end(tag, m):
     ref = O.fit_ns(x, m, seed=0, dtype=DT[tag], max_iter=6)
     out = Corex(n_hidden=m, seed=0, max_iter=6, dtype=DT[tag], device=0).fit(x)
     be = out._backend
-    assert "gemm_ct_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)
+    assert "gemm_cr_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)
     geo = be.geometry()
     assert min(geo["nt_split"], geo["tn_split"]) >= 12, geo
     h_ref, h_out = np.array(ref.history_tc, np.float64), np.array(out.history["TC"], dtype=np.float64)
@@ -545,7 +545,7 @@ def test_large_shard_kernels_inside_a_float32_fit(m, monkeypatch):
     ref = O.fit_ns_preprocessed(xt, m, seed=0, dtype=np.float32, max_iter=3, tol=0.0, finish=False)
     model = Corex(n_hidden=m, seed=0, dtype=np.float32, tol=0.0, device=0)
     be = model._attach_shard(xt, v)
-    assert ("gemm_ct_kernel<float, %d" % (m // 16)) in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)
+    assert ("gemm_cr_kernel<float, %d" % (m // 16)) in be.kernel_name(0) and ("gemm_ct_kernel<float, %d" % (m // 16)) in be.kernel_name(1)
     for i_eps, eps in enumerate(model._init_weights()):
         model._begin_stage(i_eps, eps)
         for k in range(3):

@@ -78,7 +78,10 @@ class Comm:
                     err = "lcx_comm_selftest (%s): %s" % (what, e)
             return err
 
-        if self._dist.get_backend(self.group) == "nccl" and mode != "hook":
+        # (LCX_TEST_FORCE_RCCL_NEGOTIATION: a test hook - run the negotiation below on a non-RCCL group, where two ranks can share one
+        # GPU, to exercise a ONE-SIDED failure; only meaningful together with a forced failure before ncclCommInitRank)
+        negotiate = self._dist.get_backend(self.group) == "nccl" or bool(os.environ.get("LCX_TEST_FORCE_RCCL_NEGOTIATION"))
+        if negotiate and mode != "hook":
             # The group agrees on every step BEFORE a rank commits to a collective the others might not enter:
             #   1. every rank probes librccl locally (dlopen) and the flags are MAX-reduced on this group - ncclCommInitRank is
             #      collective, a rank that raised before entering it would leave the others blocked inside it;

@@ -182,13 +182,16 @@ class SynMoments(DeviceMoments):
 class Corex(object):
     """Linear Total Correlation Explanation on MI355X (reference docstring: linearcorex.py:22-70).
 
-    Parameters are the reference's.  Keyword-only extras:
+    Parameters are the reference's.  `gpu` is accepted for signature compatibility and IGNORED: the reference's `gpu=False` selects its
+    NumPy path and `gpu=True` its cudamat path (:84-86); this class has exactly one path, the HIP one, and raises `LcxError` where there
+    is no MI355X or no liblcx_hip.so - it never computes on the host (BASELINE configs[0], "NumPy CPU reference path", is the reference
+    itself / the oracle of tests/, not something this package ships).  Keyword-only extras:
       dtype   working precision on the device: np.float32 (what the reference computes, :108) or
               np.float64 (the precision the 1e-6 get_covariance tolerance is defined in);
       device  HIP device index (default: LOCAL_RANK or 0);
       comm    a `linearcorex_amd.comm.Comm` to shard n_variables over ranks;
       eliminate_synergy  alias of discourage_overlap (the name used by the reference docstring);
-      line_search  "exact": every back-tracking trial re-evaluates the moments with two passes over
+      line_search  None (default) = DEFAULT_LINE_SEARCH ("exact"; LCX_LINE_SEARCH overrides).  "exact": every back-tracking trial re-evaluates the moments with two passes over
               X, as the reference does (:321); "linear": X^T.(X.u^T) is linear in u, so the trial
               moments follow from the direction already computed for `_sig` (:301) and cost no pass
               over X - same mathematics, different rounding; the solution is re-evaluated exactly

@@ -93,6 +93,28 @@ def test_sharded_fit_on_device_matches_oracle(world, mode, shape, exchange, tmp_
     check_covariance(got, ref, 1e-6)           # sharded get_covariance (the north-star tolerance)
 
 
+def test_one_sided_rccl_failure_is_agreed_on(tmp_path, monkeypatch):
+    """Advisor, round 3: ncclCommInitRank is collective - if ONE rank cannot even load librccl and raises before entering it, the
+    others must not be left blocked inside.  Two ranks (gloo group, both on GPU 0) run the RCCL negotiation of Comm.bind_engine with
+    the library probe forced to fail on rank 1 ONLY: the flags are compared before any rank calls lcx_comm_init, both ranks say so
+    and take the hook transport, and the fit equals the oracle's."""
+    monkeypatch.setenv("LCX_TEST_FORCE_RCCL_NEGOTIATION", "1")
+    monkeypatch.setenv("LCX_TEST_FAIL_COMM_INIT", "probe:1")
+    n, v, m = 400, 331, 5
+    timed_out, procs, outs = _launch_once(2, tmp_path, n, v, m, "exact", 150, "engine")
+    assert not timed_out, "\n-----\n".join(o[-3000:] for o in outs)
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    assert "librccl probe: LCX_TEST_FAIL_COMM_INIT=probe:1" in outs[1] and "another rank cannot load librccl" in outs[0]
+    got = np.load(os.path.join(tmp_path, "dist_result.npz"))
+    assert str(got["transport"]) == "hook" and bool(got["in_library"])
+    x, _ = O.gen_planted(n, v, m, seed=2)
+    ref = O.fit_ns(x, m, seed=0, dtype=np.float64, max_iter=MAX_ITER)
+    h, h_ref = got["history"], np.asarray(ref.history_tc)
+    assert len(h) == len(h_ref) and np.max(np.abs(h - h_ref) / np.maximum(1, np.abs(h_ref))) < 1e-8
+    assert int(got["trials"]) == ref.n_trials
+
+
 def test_rccl_exchange_path_single_rank(tmp_path):
     """The multi-rank device path with the REAL transport in a group of one rank: world>1 engine kernels and RCCL launches
     interleaved with them on the handle's stream.  In-engine exchange (lcx_comm_init: a communicator owned by the handle,

@@ -147,10 +147,10 @@ def spawn_ranks(args):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE)
     lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.strip()]
-    rec = None
+    rec, raw = None, None
     for ln in reversed(lines):
         try:
-            rec = json.loads(ln)
+            rec, raw = json.loads(ln), ln
             break
         except ValueError:
             continue
@@ -160,7 +160,7 @@ def spawn_ranks(args):
     if rec.get("n_gpus") != args.gpus:
         sys.stderr.write("bench.py: asked for %d GPUs, the ranks report n_gpus=%r\n" % (args.gpus, rec.get("n_gpus")))
         return 1
-    sys.stdout.write(json.dumps(rec) + "\n")
+    sys.stdout.write(raw.strip() + "\n")          # rank 0's compact line, byte for byte
     sys.stdout.flush()
     return 0
 
@@ -609,6 +609,11 @@ def roofline_of(workload, r, world):
                     arithmetic_intensity_flop_per_byte=intensity, use_sites=kernels)
     roofline.update(tinfo)
     roofline["by_kernel"] = by_fn
+    # per use site, whatever function is the dominant row (on the panel-major copy X.B^T and X^T.Y run on two kernel functions,
+    # gemm_cr / gemm_ct, and the merged pass on a third): every site's fraction of the same peak
+    peak_site = HBM_PEAK_GBS if roofline["bound"] == "hbm" else mfma_peak
+    roofline["frac_by_site"] = {name: (k["GBps"] if roofline["bound"] == "hbm" else k["TFLOPs"]) / peak_site for name, k in kernels.items()}
+    roofline["kernel_by_site"] = {name: r["kernel_names"][name] for name in kernels}
     if "gemm_nt2" in kernels and not dom_wide:
         # the merged 2 x n_hidden-column pass (one read of X, twice the flops): its own fraction of the same peak
         k2 = kernels["gemm_nt2"]
@@ -789,6 +794,8 @@ def compact_line(out, detail_path):
         "exact_y_value": _pick(cfg, "later_trials_by_linearity", "fit_iterations_per_sec"),
         "linear_value": _pick(cfg, "linear_trial_mode", "fit_iterations_per_sec"),
         "merged_pass_roofline_frac": _pick(out, "roofline", "merged_pass", "frac"),
+        "xbt_pass_roofline_frac": _pick(out, "roofline", "frac_by_site", "gemm_nt"),
+        "xty_pass_roofline_frac": _pick(out, "roofline", "frac_by_site", "gemm_tn"),
         "fit_to_convergence_planted_seconds": _pick(cfg, "fit_to_convergence_planted", "seconds"),
         "fit_to_convergence_planted_iterations": _pick(cfg, "fit_to_convergence_planted", "iterations"),
         "weak_scaling_vs_same_shard": cfg.get("weak_scaling_vs_same_shard"),
@@ -801,6 +808,8 @@ def compact_line(out, detail_path):
             riders[name + "_line_search"] = b.get("line_search")
             riders[name + "_ms_per_step"] = b.get("ms_per_step")
             riders[name + "_roofline_frac"] = _pick(b, "roofline", "frac")
+            riders[name + "_xbt_pass_roofline_frac"] = _pick(b, "roofline", "frac_by_site", "gemm_nt")
+            riders[name + "_xty_pass_roofline_frac"] = _pick(b, "roofline", "frac_by_site", "gemm_tn")
             riders[name + "_roofline_bound"] = _pick(b, "roofline", "bound")
             riders[name + "_reference_shaped_value"] = _pick(b, "reference_shaped", "fit_iterations_per_sec")
             riders[name + "_cpu_baseline_value"] = _pick(b, "cpu_baseline", "value")
@@ -843,7 +852,7 @@ def emit(out, args, real_stdout):
     text = json.dumps(line, separators=(",", ":"))
     # a budget, not a hope: shed riders, then the sample sentence, until the line fits
     droppable = [k for k in list(line["config"]) if k.endswith(("_cpu_baseline_value", "_fit_to_convergence_seconds", "_line_search",
-                                                                "_roofline_bound", "_ms_per_step"))]
+                                                                "_roofline_bound", "_ms_per_step", "_pass_roofline_frac"))]
     while len(text) > args.max_line_bytes and droppable:
         line["config"].pop(droppable.pop())
         text = json.dumps(line, separators=(",", ":"))

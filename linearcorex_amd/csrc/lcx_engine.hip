@@ -451,14 +451,36 @@ static int launch_tn4(hipStream_t st, const double* A, int64_t lda, int64_t K, i
     return LCX_OK;
 }
 
+// waves per block of the stream-K kernels: CtShape's, except that 128 float32 factors can be switched between 4 and 8 at run time
+// (LCX_CT8_KW) - the A/B knob behind CtShape<float, 8>::KW
+template <typename T, int CT> static inline int ct_kw() {
+    if constexpr (sizeof(T) == 4 && CT == 8) {
+        static const int kw = []() {
+            const char* e = getenv("LCX_CT8_KW");
+            const int v = (e && *e) ? atoi(e) : CtShape<T, CT>::KW;
+            return v == 8 ? 8 : 4;
+        }();
+        return kw;
+    }
+    return CtShape<T, CT>::KW;
+}
 // gemm_ct launch: nb balanced blocks over (super tile, group) units; partial tiles -> out[slot][out_rows][Mp]
 template <typename T, int CT, bool PANEL = false>
 static int launch_ct(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* out, int nb,
                      int nsuper, int maxslots, const int* skip) {
     typedef CtShape<T, CT> S;
     const int ng = (int)(K / (4 * S::U));
-    hipLaunchKernelGGL((gemm_ct_kernel<T, CT, S::RT, S::KW, S::U, true, PANEL>), dim3((unsigned)nb), dim3(64 * S::KW), 0, st, A, lda, B, out,
-                       vcols, vcols, ng, nsuper, maxslots, skip);
+    if constexpr (sizeof(T) == 4 && CT == 8) {
+        if (ct_kw<T, CT>() == 8)
+            hipLaunchKernelGGL((gemm_ct_kernel<T, CT, S::RT, 8, S::U, true, PANEL>), dim3((unsigned)nb), dim3(512), 0, st, A, lda, B, out, vcols, vcols,
+                               ng, nsuper, maxslots, skip);
+        else
+            hipLaunchKernelGGL((gemm_ct_kernel<T, CT, S::RT, 4, S::U, true, PANEL>), dim3((unsigned)nb), dim3(256), 0, st, A, lda, B, out, vcols, vcols,
+                               ng, nsuper, maxslots, skip);
+    } else {
+        hipLaunchKernelGGL((gemm_ct_kernel<T, CT, S::RT, S::KW, S::U, true, PANEL>), dim3((unsigned)nb), dim3(64 * S::KW), 0, st, A, lda, B, out,
+                           vcols, vcols, ng, nsuper, maxslots, skip);
+    }
     KCHECK();
     return LCX_OK;
 }
@@ -469,8 +491,17 @@ static int launch_cr(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t
                      int maxslots, const int* skip) {
     typedef CtShape<T, CT> S;
     const int ng = (int)(K / (4 * S::U));
-    hipLaunchKernelGGL((gemm_cr_kernel<T, CT, S::RT, S::KW, S::U, PANEL, PANEL>), dim3((unsigned)nb), dim3(64 * S::KW), 0, st, A, lda, B, out, nrows,
-                       nrows, ng, nsuper, maxslots, skip);
+    if constexpr (sizeof(T) == 4 && CT == 8) {
+        if (ct_kw<T, CT>() == 8)
+            hipLaunchKernelGGL((gemm_cr_kernel<T, CT, S::RT, 8, S::U, PANEL, PANEL>), dim3((unsigned)nb), dim3(512), 0, st, A, lda, B, out, nrows, nrows,
+                               ng, nsuper, maxslots, skip);
+        else
+            hipLaunchKernelGGL((gemm_cr_kernel<T, CT, S::RT, 4, S::U, PANEL, PANEL>), dim3((unsigned)nb), dim3(256), 0, st, A, lda, B, out, nrows, nrows,
+                               ng, nsuper, maxslots, skip);
+    } else {
+        hipLaunchKernelGGL((gemm_cr_kernel<T, CT, S::RT, S::KW, S::U, PANEL, PANEL>), dim3((unsigned)nb), dim3(64 * S::KW), 0, st, A, lda, B, out, nrows,
+                           nrows, ng, nsuper, maxslots, skip);
+    }
     KCHECK();
     return LCX_OK;
 }
@@ -478,15 +509,23 @@ static int launch_cr(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t
 template <typename T, int CT>
 static void ct_geometry(int n_cus, int64_t K, int64_t vcols, int force_nb, int* nb_o, int* nsuper_o, int* slots_o) {
     typedef CtShape<T, CT> S;
+    const int KW = ct_kw<T, CT>();
     int bpc = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)gemm_ct_kernel<T, CT, S::RT, S::KW, S::U, true>, 64 * S::KW, 0) != hipSuccess || bpc < 1) bpc = 1;
+    hipError_t oe;
+    if constexpr (sizeof(T) == 4 && CT == 8) {
+        oe = KW == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)gemm_ct_kernel<T, CT, S::RT, 8, S::U, true>, 512, 0)
+                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)gemm_ct_kernel<T, CT, S::RT, 4, S::U, true>, 256, 0);
+    } else {
+        oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)gemm_ct_kernel<T, CT, S::RT, S::KW, S::U, true>, 64 * S::KW, 0);
+    }
+    if (oe != hipSuccess || bpc < 1) bpc = 1;
     // measured (tools/gemm_probe4, 50k x 20k float32, n_hidden 64): 2 resident blocks per CU 122 TF/s, 3 blocks 118
     {
         const char* e = getenv("LCX_CT_BPC");
         const int cap = (e && *e) ? atoi(e) : 2;
         if (cap > 0 && bpc > cap) bpc = cap;
     }
-    const int nsuper = (int)cdiv(vcols, S::KW * 16 * S::RT);
+    const int nsuper = (int)cdiv(vcols, KW * 16 * S::RT);
     const int64_t total = (int64_t)nsuper * (K / (4 * S::U));
     int64_t nb = force_nb > 0 ? force_nb : (int64_t)n_cus * bpc;
     if (nb > total) nb = total;
@@ -686,19 +725,19 @@ template <typename T, int CT> struct Impl {
             int nb, ns, sl;
             ct_geometry<T, CT>(cus, h->ldx, h->Npad, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
             h->nt_ct = h->single_copy || (force ? !strcmp(force, "ct") : use_ct(sl, h->ldx));
-            if (h->nt_ct) { h->nt_nb = nb; h->nt_nsuper = ns; h->nt_S = sl; h->nt_KW = CtShape<T, CT>::KW; }
+            if (h->nt_ct) { h->nt_nb = nb; h->nt_nsuper = ns; h->nt_S = sl; h->nt_KW = ct_kw<T, CT>(); }
             ct_geometry<T, CT>(cus, h->Npad, h->ldx, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
             h->tn_ct = force ? !strcmp(force, "ct") : use_ct(sl, h->Npad);
-            if (h->tn_ct) { h->tn_nb = nb; h->tn_nsuper = ns; h->tn_S = sl; h->tn_KW = CtShape<T, CT>::KW; }
+            if (h->tn_ct) { h->tn_nb = nb; h->tn_nsuper = ns; h->tn_S = sl; h->tn_KW = ct_kw<T, CT>(); }
             // Both passes on the stream-K kernels: ONE panel-major copy of the shard serves both at full speed (gemm_kernels.hpp,
             // PanelW) - no transposed copy, half the resident bytes.  LCX_X_LAYOUT=rows keeps the row-major layout(s), =panel forces
             // the stream-K kernels and the panel layout on any shape.
             const char* lay = getenv("LCX_X_LAYOUT");
             if (lay && !strcmp(lay, "panel")) {
                 ct_geometry<T, CT>(cus, h->ldx, h->Npad, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
-                h->nt_ct = true; h->nt_nb = nb; h->nt_nsuper = ns; h->nt_S = sl; h->nt_KW = CtShape<T, CT>::KW;
+                h->nt_ct = true; h->nt_nb = nb; h->nt_nsuper = ns; h->nt_S = sl; h->nt_KW = ct_kw<T, CT>();
                 ct_geometry<T, CT>(cus, h->Npad, h->ldx, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
-                h->tn_ct = true; h->tn_nb = nb; h->tn_nsuper = ns; h->tn_S = sl; h->tn_KW = CtShape<T, CT>::KW;
+                h->tn_ct = true; h->tn_nb = nb; h->tn_nsuper = ns; h->tn_S = sl; h->tn_KW = ct_kw<T, CT>();
             }
             h->panel = h->nt_ct && h->tn_ct && !(lay && !strcmp(lay, "rows"));
             if (h->panel) h->single_copy = false;
@@ -1800,22 +1839,22 @@ template <typename T, int CT> struct Impl {
             if constexpr (CT <= 4)
                 snprintf(buf, (size_t)len, h->panel ? "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, true, true>"
                                            : h->single_copy ? "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, false, false>" : "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true, false>",
-                         sizeof(T) == 8 ? "double" : "float", 2 * CT, CtShape<T, 2 * CT>::RT, CtShape<T, 2 * CT>::KW, CtShape<T, 2 * CT>::U);
+                         sizeof(T) == 8 ? "double" : "float", 2 * CT, CtShape<T, 2 * CT>::RT, ct_kw<T, 2 * CT>(), CtShape<T, 2 * CT>::U);
             return LCX_OK;
         }
         if (h->panel) {
             snprintf(buf, (size_t)len, kind == 0 ? "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, true, true>" : "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true, true>",
-                     sizeof(T) == 8 ? "double" : "float", CT, CtShape<T, CT>::RT, CtShape<T, CT>::KW, CtShape<T, CT>::U);
+                     sizeof(T) == 8 ? "double" : "float", CT, CtShape<T, CT>::RT, ct_kw<T, CT>(), CtShape<T, CT>::U);
             return LCX_OK;
         }
         if (kind == 0 && h->single_copy) {
             snprintf(buf, (size_t)len, "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, false, false>", sizeof(T) == 8 ? "double" : "float", CT, CtShape<T, CT>::RT,
-                     CtShape<T, CT>::KW, CtShape<T, CT>::U);
+                     ct_kw<T, CT>(), CtShape<T, CT>::U);
             return LCX_OK;
         }
         if (kind == 0 ? h->nt_ct : h->tn_ct)
             snprintf(buf, (size_t)len, "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true, false>", sizeof(T) == 8 ? "double" : "float", CT,
-                     CtShape<T, CT>::RT, CtShape<T, CT>::KW, CtShape<T, CT>::U);
+                     CtShape<T, CT>::RT, ct_kw<T, CT>(), CtShape<T, CT>::U);
         else if (h->f64_4x4)
             snprintf(buf, (size_t)len, "lcx::gemm_tn4_kernel<%d, %d, %d, 4, true, false>", CT, Geo<T, CT>::TN_RT, kind == 0 ? h->nt_KW : h->tn_KW);
         else

@@ -100,11 +100,10 @@ int         lcx_device_count(int* out_count);
  * 256 columns on the tuned kernels, to 512 / 1024 on the wide path (257+ factors: every contraction on one generic LDS-staged MFMA
  * GEMM with the factor axis tiled like any other, one thread per factor in the per-variable kernels - correct, untuned).
  * A failed allocation releases what was allocated before it.
- * The shard is normally resident twice, row-major and transposed, so that both X-streaming contractions read their big operand
- * in their preferred layout.  When two copies would not leave room for the rest (or LCX_SINGLE_COPY=1) only the row-major
- * copy is kept and X.B^T contracts along its rows (gemm_cr: 4-6 % slower per pass): half the resident bytes - a 50 000 x
- * 1 000 000 float32 problem (BASELINE configs[3], unsharded) then fits one 288 GB MI355X.  lcx_kernel_name(h, 0, ..) names
- * the kernel in use; lcx_bytes_resident reports the copies. */
+ * How the shard is kept resident follows from its shape (lcx_x_layout): large shards - both X-streaming contractions on the stream-K
+ * kernels - as ONE panel-major copy that serves both at full speed (a 50 000 x 1 000 000 float32 problem, BASELINE configs[3]
+ * unsharded, fits one 288 GB MI355X); small shards row-major plus a transposed copy, so that each wave-split pass reads its big
+ * operand along its preferred axis.  lcx_kernel_name(h, 0 | 1 | 2, ..) names the kernels in use; lcx_bytes_resident reports the bytes. */
 int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
                int dtype, int device);
 int lcx_destroy(lcx_ctx* h);
@@ -181,7 +180,8 @@ int lcx_upload_x(lcx_ctx* h, const void* x_host, int64_t ld);
  * at 1e-10) or take the given one (fit == 0), standardise, and for kind 2 squash the tails with g (:483-487).
  * kind: 0 pass-through ('none' and any unknown name, :404-405), 1 'standard', 2 'outliers', 3 'empirical' (:424-426: every
  * column becomes norm.ppf((rankdata(column) - 0.5) / n_samples), ties get their average rank; no theta - a per-column
- * segmented sort of the transposed copy, so a new batch is transformed by uploading it into a handle of its own).
+ * segmented sort of a transposed copy of the columns, so a new batch is transformed by uploading it into a handle of its own).
+ * Every step is per column: a panel-major shard is filled through row-major staging blocks of columns, each preprocessed on its own.
  * mean_io / std_io: nv_local values of the working dtype; n_obs_out: nv_local int64 or NULL;
  * max_abs_out: max |x~| (for the "more than 6 stds" warning, :416-417) or NULL. */
 int lcx_upload_preprocess(lcx_ctx* h, const void* x_raw_host, int64_t ld, int kind, int has_missing, double missing,

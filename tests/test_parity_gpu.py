@@ -894,18 +894,19 @@ def test_later_trials_by_linearity_whole_fit(tag, g1):
 # round 4: ONE panel-major resident copy of the shard for large shards (include/lcx.h, lcx_x_layout; gemm_kernels.hpp, PanelW)
 # ------------------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("tag", ["f32", "f64"])
-@pytest.mark.parametrize("shape", [(1500, 3000, 8), (1501, 3001, 40), (4096, 8192, 64)])
+@pytest.mark.parametrize("shape", [(1500, 3000, 8), (1501, 3001, 40), (4096, 8192, 64), (1300, 2500, 100), (900, 2100, 200)])
 def test_panel_layout_matches_row_major(tag, shape, monkeypatch):
     """The panel-major copy (both X passes on the stream-K kernels from the same bytes) against the row-major + transposed layout on
     the same kernels: X.B^T contracts in another order (rounding), X^T.Y in the same one; same fit to rounding, both at the usual
     bars against the oracle; the handle owns HALF the X bytes; the resident matrix reads back identical (ragged shapes, several
-    staging blocks)."""
+    staging blocks).  Factor counts across the tile shapes of CtShape: 16 / 64 padded columns (4 row tiles per wave, float64 2), 128
+    (float32: 8 waves per block), 256 (2 / 1 row tiles: 8-byte pieces in float64)."""
     from linearcorex_amd import Corex
     dt = DT[tag]
     n, v, m = shape
     if tag == "f64" and m == 64:
         pytest.skip("float32 shape")
-    x = O.gen_planted(n, v, 8, seed=1)[0]
+    x = O.gen_planted(n, v, min(m, 8), seed=1)[0]
     monkeypatch.setenv("LCX_PANEL_BLOCK_COLS", "832")            # 13 panels of float32 per block: 4 .. 10 blocks, the last one ragged
     runs = {}
     for lay in ("panel", "rows"):

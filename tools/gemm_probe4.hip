@@ -197,7 +197,7 @@ Variant mkcrp(const T* XP, int64_t nrows_pad, int64_t K, int64_t nrows, const T*
     if (nb > total) nb = (int)total;
     const int maxslots = (nb + nsuper - 1) / nsuper + 1;
     char buf[200];
-    snprintf(buf, 200, "crp X.B^T from the PANEL-major copy U=%d NT=%d bpc=%d(use %d) slots=%d", U, (int)NT, bpc, use, maxslots);
+    snprintf(buf, 200, "crp X.B^T from the PANEL-major copy RT=%d KW=%d U=%d NT=%d bpc=%d(use %d) slots=%d", RT, KW, U, (int)NT, bpc, use, maxslots);
     const int64_t ps = nrows_pad * PanelW<T>::v;
     return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, XP, ps, B, out, nrows, nrows, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
 }
@@ -214,7 +214,7 @@ Variant mkctp(const T* XP, int64_t nrows_pad, int64_t K, int64_t vcols, const T*
     if (nb > total) nb = (int)total;
     const int maxslots = (nb + nsuper - 1) / nsuper + 1;
     char buf[200];
-    snprintf(buf, 200, "ctp X^T.Y from the PANEL-major copy U=%d NT=%d bpc=%d(use %d) slots=%d", U, (int)NT, bpc, use, maxslots);
+    snprintf(buf, 200, "ctp X^T.Y from the PANEL-major copy RT=%d KW=%d U=%d NT=%d bpc=%d(use %d) slots=%d", RT, KW, U, (int)NT, bpc, use, maxslots);
     const int64_t ps = nrows_pad * PanelW<T>::v;
     return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, XP, ps, B, out, vcols, vcols, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
 }
@@ -295,6 +295,8 @@ void suite_panel_sweep(const char* name, int64_t N, int64_t V) {
         vs.push_back(mkcrp<T, CT, R, 4, 8, true>(XP, N, V, N, B, out, 2));
         vs.push_back(mkcrp<T, CT, R, 8, 4, true>(XP, N, V, N, B, out, 1));
         vs.push_back(mkcrp<T, CT, R, 2, 4, true>(XP, N, V, N, B, out, 4));
+        vs.push_back(mkcrp<T, CT, R, 8, 8, true>(XP, N, V, N, B, out, 1));
+        vs.push_back(mkcrp<T, CT, R, 4, 8, true>(XP, N, V, N, B, out, 3));
         if constexpr (CT <= 4) vs.push_back(mkcrp<T, CT, 2 * R, 4, 4, true>(XP, N, V, N, B, out, 2));
         if constexpr (CT <= 4) vs.push_back(mkcrp<T, CT, 2 * R, 4, 4, true>(XP, N, V, N, B, out, 1));
         bench(vs, gb, tf);
@@ -308,6 +310,8 @@ void suite_panel_sweep(const char* name, int64_t N, int64_t V) {
         vs.push_back(mkctp<T, CT, R, 4, 8, true>(XP, N, N, V, B, out, 2));
         vs.push_back(mkctp<T, CT, R, 8, 4, true>(XP, N, N, V, B, out, 1));
         vs.push_back(mkctp<T, CT, R, 2, 4, true>(XP, N, N, V, B, out, 4));
+        vs.push_back(mkctp<T, CT, R, 8, 8, true>(XP, N, N, V, B, out, 1));
+        vs.push_back(mkctp<T, CT, R, 4, 8, true>(XP, N, N, V, B, out, 3));
         bench(vs, gb, tf);
     }
     CK(hipFree(XP)); CK(hipFree(B)); CK(hipFree(out));

@@ -190,6 +190,9 @@ def test_big5_end_to_end(tag, g1, ls):
         assert relerr(h, h_ref) < 1e-6
         assert relerr(out.ws, g1["f64_ws"]) < 1e-6
         assert relerr(out.get_covariance(), g1["f64_cov"]) < 1e-6           # north_star tolerance
+        assert relerr(out.get_covariance(rows=(7, 23)), g1["f64_cov"][7:23]) < 1e-6 and out.get_covariance(rows=slice(48, 50)).shape == (2, 50)
+        with pytest.raises(ValueError):
+            out.get_covariance(rows=(40, 51))
         assert relerr(out.transform(g1["x_raw"].astype(np.float64)), g1["f64_transform"]) < 1e-6
         assert relerr(out.moments["TCs"], g1["f64_mom_TCs"]) < 1e-6
         for key, name in (("rho", "rho"), ("MI", "MI"), ("X_i Z_j", "X_i_Z_j"), ("X_i Y_j", "X_i_Y_j"),

@@ -59,6 +59,7 @@ def test_syn_end_to_end(tag, g1):
             assert relerr(h, h_ref) < 1e-6
             assert relerr(out.ws, g[p + "ws"]) < 1e-6
             assert relerr(out.get_covariance(), g[p + "cov"]) < 1e-6           # north_star tolerance, syn branch
+            assert relerr(out.get_covariance(rows=(3, 11)), g[p + "cov"][3:11]) < 1e-6
             assert relerr(out.transform(x), g[p + "transform"]) < 1e-6
             assert np.array_equal(out.clusters(), g[p + "clusters"])
             for k in ("TCs", "rho", "X_i Z_j", "X_i Y_j", "X_i^2 | Y", "cy", "ry", "Qij", "Qi", "Si", "MI", "Y_j^2"):

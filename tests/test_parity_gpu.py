@@ -78,10 +78,19 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("layout", ["auto", "panel"])
 @pytest.mark.parametrize("tag", ["f32", "f64"])
 @pytest.mark.parametrize("case", CASES)
-def test_step_level(tag, case):
+def test_step_level(tag, case, layout, monkeypatch):
+    """One evaluation, the detail moments, one update direction and one trial against the oracle, array by array.  layout "panel":
+    the same on the stream-K kernel pair reading ONE panel-major copy of the shard (forced here on shapes down to 70 x 3 x 1; what
+    large shards get by themselves) - same bars."""
     n, v, m, eps, seed = case
+    if layout == "panel":
+        if m > 256:
+            pytest.skip("more than 256 factors: the wide path keeps its row-major copy")
+        monkeypatch.setenv("LCX_X_LAYOUT", "panel")
+        monkeypatch.setenv("LCX_PANEL_BLOCK_COLS", "192")
     dt = DT[tag]
     rng = np.random.RandomState(seed)
     x, _ = O.gen_planted(n, v, max(2, m // 2), seed=seed)
@@ -91,6 +100,7 @@ def test_step_level(tag, case):
     w *= 3.0                                            # uj ~ 0.09: away from the trivial start
     ref = O.moments_ns(x, w, eps, quick=False)
     be = make_backend(x, w, dt)
+    assert layout != "panel" or be.bytes_resident()["x_layout"].startswith("panel-major")
     assert relerr(be.download_x(), x) == 0.0
     assert relerr(be.get_ws(0), w) == 0.0
     st = run_moments(be, 0, eps, True)

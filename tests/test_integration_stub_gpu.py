@@ -132,3 +132,44 @@ def test_integration_stub_update_ns_in_one_call():
     cov_ref = O.covariance_ns(mo, eps, (np.zeros(v, np.float32), np.ones(v, np.float32)))
     assert np.max(np.abs(cov - cov_ref)) < 5e-3 * np.max(np.abs(cov_ref))
     dev.close()
+
+
+def test_round4_entry_points_through_raw_ctypes(monkeypatch):
+    """The entry points round 4 added, bound the way a reference maintainer would bind them (no package code in between):
+    lcx_x_layout (what lcx_create chose for the shard), lcx_set_sample_divisor (the reference's `self.n_samples` when a handle holds
+    another batch than the fitted one, :249 / :260 / :392-394), lcx_comm_probe (local: can librccl be bound?), and lcx_comm_selftest
+    refusing a handle without a transport."""
+    lib = C.CDLL(os.path.join(ROOT, "linearcorex_amd", "liblcx_hip.so"))
+    lib.lcx_last_error.restype = C.c_char_p
+    _p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rng = np.random.RandomState(4)
+    n, v, m = 640, 900, 6
+    x = O.preprocess(rng.randn(n, v))[0]
+    w = rng.randn(m, v)
+    w /= (10.0 * O.norm(x, w, 0))[:, np.newaxis]
+    for lay, want in (("panel", 2), ("rows", 0)):
+        monkeypatch.setenv("LCX_X_LAYOUT", lay)
+        h = C.c_void_p()
+        assert lib.lcx_create(C.byref(h), C.c_int64(n), C.c_int64(v), m, 1, 0) == 0, lib.lcx_last_error()     # 1 = LCX_F64
+        layout = C.c_int(-1)
+        assert lib.lcx_x_layout(h, C.byref(layout)) == 0 and layout.value == want
+        assert lib.lcx_x_layout(h, None) != 0
+        assert lib.lcx_upload_x(h, _p(np.ascontiguousarray(x)), C.c_int64(v)) == 0
+        assert lib.lcx_set_ws(h, _p(np.ascontiguousarray(w))) == 0
+        tcs = []
+        for n_div in (n, 2 * n):
+            assert lib.lcx_set_sample_divisor(h, C.c_double(n_div)) == 0
+            assert lib.lcx_moments_a(h, 0) == 0 and lib.lcx_moments_b(h, 0, C.c_double(0.0), 0) == 0 and lib.lcx_moments_c(h, 0) == 0
+            s = (C.c_double * 8)()
+            assert lib.lcx_read_state(h, 0, s) == 0
+            ref = O.moments_ns(x, w, 0.0, quick=False, n_samples=n_div)
+            assert abs(s[0] - float(ref["TC"])) < 1e-9 * max(1.0, abs(float(ref["TC"])))
+            assert abs(s[1] - float(ref["uj"].max())) < 1e-12
+            tcs.append(s[0])
+        assert abs(tcs[0] - tcs[1]) > 1e-3                       # the divisor matters
+        assert lib.lcx_set_sample_divisor(h, C.c_double(0.0)) != 0
+        ok, sec = C.c_int(7), C.c_double()
+        assert lib.lcx_comm_selftest(h, 0, C.byref(ok), C.byref(sec)) != 0 and ok.value == 0
+        assert b"no transport" in lib.lcx_last_error()
+        assert lib.lcx_destroy(h) == 0
+    assert lib.lcx_comm_probe() == 0, lib.lcx_last_error()       # librccl ships with the ROCm image

@@ -364,8 +364,14 @@ def test_config2_steps(tag, g3):
     assert relerr(h, h_ref) < (1e-7 if tag == "f64" else 2e-3)
 
 
+@pytest.mark.parametrize("layout", ["auto", "panel"])
 @pytest.mark.parametrize("tag", ["f32", "f64"])
-def test_outliers_and_missing(tag, g5, g6, ls):
+def test_outliers_and_missing(tag, g5, g6, ls, layout, monkeypatch):
+    """gaussianize='outliers' and missing values (-1e6 sentinel) end to end against the reference's fixtures - also with the shard
+    kept as ONE panel-major copy (forced here; what large shards get by themselves), filled through two staging blocks."""
+    if layout == "panel":
+        monkeypatch.setenv("LCX_X_LAYOUT", "panel")
+        monkeypatch.setenv("LCX_PANEL_BLOCK_COLS", "128")
     n, v, m = (int(t) for t in g5["shape"])
     x, grp = O.gen_planted(n, v, m, seed=3)
     heavy = np.arange(v) % 20 == 0

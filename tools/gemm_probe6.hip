@@ -175,6 +175,90 @@ void suite_occ(const char* name, int64_t K, int64_t V, std::initializer_list<int
     CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(out));
 }
 
+// round 4: config 2's two passes from ONE panel-major copy (gemm_tn4p / gemm_tn4c, probe_kernels.hpp) vs the two-copy production layout
+template <int CT, int RT, int KW, int U, bool NT, bool CSTYLE>
+Variant mk4panel(const double* XP, int64_t nrows_pad, int64_t K, int64_t out_rows, const double* B, double* out, int S) {
+    const size_t lds = Tn4Lds<CT, RT, KW, U, false>::bytes;
+    char buf[200];
+    int bpc = 0;
+    if constexpr (CSTYLE) {
+        auto kern = gemm_tn4c_kernel<CT, RT, KW, U, NT>;
+        if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, lds));
+        snprintf(buf, 200, "tn4c X.B^T from the PANEL copy RT=%d KW=%d U=%d NT=%d S=%d blocks=%d bpc=%d", RT, KW, U, (int)NT, S, (int)(out_rows / (16 * RT)) * S, bpc);
+        return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3((unsigned)(out_rows / (16 * RT)), S), dim3(64 * KW), lds, 0, XP, nrows_pad * 8, B, out, out_rows, (int)(K / 16), S, (const int*)nullptr); }, {}, S};
+    } else {
+        auto kern = gemm_tn4p_kernel<CT, RT, KW, U, NT>;
+        if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, lds));
+        snprintf(buf, 200, "tn4p X^T.Y from the PANEL copy RT=%d KW=%d U=%d NT=%d S=%d blocks=%d bpc=%d", RT, KW, U, (int)NT, S, (int)(out_rows / (16 * RT)) * S, bpc);
+        return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3((unsigned)(out_rows / (16 * RT)), S), dim3(64 * KW), lds, 0, XP, nrows_pad * 8, B, out, out_rows, (int)(K / 16), S, (const int*)nullptr); }, {}, S};
+    }
+}
+__global__ void transpose_f64_kernel(const double* X, int64_t ldx, double* XT, int64_t ldt, int64_t rows, int64_t cols) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < rows * cols; k += (int64_t)gridDim.x * blockDim.x)
+        XT[(k % cols) * ldt + k / cols] = X[(k / cols) * ldx + k % cols];
+}
+static void compare(const char* what, std::vector<Variant>& vs, double* out, size_t n1) {
+    vs[0].launch(); CK(hipDeviceSynchronize());
+    std::vector<double> r((size_t)vs[0].slots * n1);
+    CK(hipMemcpy(r.data(), out, r.size() * 8, hipMemcpyDeviceToHost));
+    for (size_t vi = 1; vi < vs.size(); ++vi) {
+        CK(hipMemset(out, 0xff, 8 * (size_t)vs[vi].slots * n1));
+        vs[vi].launch(); CK(hipDeviceSynchronize());
+        std::vector<double> o((size_t)vs[vi].slots * n1);
+        CK(hipMemcpy(o.data(), out, o.size() * 8, hipMemcpyDeviceToHost));
+        double md = 0, mx = 0;
+        for (size_t x = 0; x < n1; ++x) {
+            double so = 0, sr = 0;
+            for (int s2 = 0; s2 < vs[vi].slots; ++s2) so += o[s2 * n1 + x];
+            for (int s2 = 0; s2 < vs[0].slots; ++s2) sr += r[s2 * n1 + x];
+            md = fmax(md, fabs(so - sr)); mx = fmax(mx, fabs(sr));
+        }
+        printf("check %s %-72s max |diff| %.3e %s\n", what, vs[vi].name.c_str(), md, md <= 1e-11 * mx ? "ok" : "FAIL");
+    }
+}
+void suite_c2panel(int64_t N, int64_t V) {
+    constexpr int CT = 2;
+    const int Mp = 16 * CT;
+    double *X, *XT, *XP, *B, *out;
+    const int64_t big = std::max(N, V);
+    CK(hipMalloc(&X, 8 * N * V)); CK(hipMalloc(&XT, 8 * N * V)); CK(hipMalloc(&XP, 8 * N * V));
+    CK(hipMalloc(&B, 8 * big * Mp)); CK(hipMalloc(&out, 8 * 40 * big * Mp));
+    std::vector<double> h((size_t)N * V);
+    for (size_t x = 0; x < h.size(); ++x) h[x] = (double)rand() / RAND_MAX - 0.5;
+    CK(hipMemcpy(X, h.data(), 8 * N * V, hipMemcpyHostToDevice));
+    CK(hipMemcpy(B, h.data() + 7, 8 * big * Mp, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(transpose_f64_kernel, dim3(4096), dim3(256), 0, 0, X, V, XT, N, N, V);
+    hipLaunchKernelGGL((panelize_kernel<double>), dim3(4096), dim3(256), 0, 0, X, V, XP, N, V);
+    CK(hipDeviceSynchronize());
+    const double gb = 8 * ((double)N * V + (double)Mp * (N + V)) / 1e9, tf = 2.0 * N * V * Mp / 1e12;
+    {
+        printf("== c2 X^T.Y: X %ld x %ld f64, 32 factors: row-major X (production tn4) vs the panel copy (tn4p)\n", (long)N, (long)V);
+        std::vector<Variant> vs;
+        vs.push_back(mk4<CT, 4, 4, 4, true>(X, V, N, V, B, out, 3));
+        vs.push_back(mk4panel<CT, 4, 4, 4, true, false>(XP, N, N, V, B, out, 3));
+        vs.push_back(mk4panel<CT, 4, 4, 4, false, false>(XP, N, N, V, B, out, 3));
+        vs.push_back(mk4<CT, 4, 4, 4, true>(X, V, N, V, B, out, 6));
+        vs.push_back(mk4panel<CT, 4, 4, 4, true, false>(XP, N, N, V, B, out, 6));
+        compare("xty", vs, out, (size_t)V * Mp);
+        bench(vs, gb, tf);
+    }
+    {
+        printf("== c2 X.B^T: transposed copy (production tn4) vs the panel copy (tn4c)\n");
+        std::vector<Variant> vs;
+        vs.push_back(mk4<CT, 4, 4, 4, true>(XT, N, V, N, B, out, 3));
+        vs.push_back(mk4panel<CT, 4, 4, 4, true, true>(XP, N, V, N, B, out, 3));
+        vs.push_back(mk4panel<CT, 4, 4, 4, false, true>(XP, N, V, N, B, out, 3));
+        vs.push_back(mk4<CT, 4, 4, 4, true>(XT, N, V, N, B, out, 2));
+        vs.push_back(mk4panel<CT, 4, 4, 4, true, true>(XP, N, V, N, B, out, 2));
+        vs.push_back(mk4panel<CT, 4, 4, 2, true, true>(XP, N, V, N, B, out, 3));
+        compare("xbt", vs, out, (size_t)N * Mp);
+        bench(vs, gb, tf);
+    }
+    CK(hipFree(X)); CK(hipFree(XT)); CK(hipFree(XP)); CK(hipFree(B)); CK(hipFree(out));
+}
+
 template <int CT>
 void suite_ring(const char* name, int64_t K, int64_t V, std::initializer_list<int> splits) {
     const int Mp = 16 * CT;
@@ -267,6 +351,10 @@ void suite_merged(const char* name, int64_t K, int64_t V, std::initializer_list<
 int main(int argc, char** argv) {
     if (argc > 1 && std::string(argv[1]) == "merged") {
         suite_merged("c2_x_gw (X.[grad | ws+update]^T, contraction over the 5056 variables)", 5056, 10048, {1, 2, 3, 4});
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "c2panel") {
+        suite_c2panel(10048, 5056);
         return 0;
     }
     if (argc > 1 && std::string(argv[1]) == "ring") {

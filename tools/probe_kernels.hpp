@@ -854,6 +854,210 @@ __global__ void panelize_kernel(const T* __restrict__ X, int64_t ldx, T* __restr
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// round 4: the small-shard float64 kernel (gemm_tn4, v_mfma_f64_4x4x4) on ONE panel-major copy of X - would config 2's passes gain
+// from the contiguous request stream that made the large shards' X.B^T pass 8 % faster?
+//   gemm_tn4p: X^T.Y - gemm_tn4 with panel addressing of its A operand (lane r16 loads 2 x 16 B of row 4 st + kq: 8 panels, 4 rows x
+//              64 B = 256 contiguous bytes in each);
+//   gemm_tn4c: X.B^T - contraction along the panel rows: lane (r16, kq) loads 16 B = 2 consecutive contraction elements of output
+//              row r16 (a load instruction = 16 rows x 64 B = 1 KB contiguous); MFMA step e of piece p meets the B rows p 8 + 2 kq + e
+//              from the wave's LDS strip.  Same K-split over the block's waves and grid.y, same LDS reduction as gemm_tn4.
+// ------------------------------------------------------------------------------------------------
+template <int CT, int RT, int KW, int U, bool NT = false>
+__global__ void __launch_bounds__(64 * KW)
+gemm_tn4p_kernel(const double* __restrict__ A, int64_t ps /* panel stride */, const double* __restrict__ B, double* __restrict__ out,
+                 int64_t out_rows, int kgroups /* K / 16 */, int nsplit, const int* __restrict__ skip_flag) {
+    constexpr int Mp = 16 * CT, NG = Mp / 4;
+    constexpr int ROWS = 4 * U, LDB = Mp + 4, PPR = Mp / 2, PCS = ROWS * PPR, PPT = (PCS + 63) / 64, STRIP = 2 * ROWS * LDB;
+    constexpr int PW = 8;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* smem = reinterpret_cast<double*>(smem_raw);
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4, jj = lane & 3;
+    const int64_t v0 = (int64_t)blockIdx.x * (16 * RT);
+    const int part = blockIdx.y * KW + wave, nparts = nsplit * KW;
+    const int ng = kgroups * 4 / U;
+    const int g0 = (int)((int64_t)ng * part / nparts), g1 = (int)((int64_t)ng * (part + 1) / nparts);
+    const int cnt = g1 - g0;
+    double acc[RT][NG];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[t][g] = 0.0;
+    static_assert(RT % 2 == 0, "pieces of two doubles");
+    const double* app[RT / 2];
+#pragma unroll
+    for (int p = 0; p < RT / 2; ++p) {
+        const int64_t col = v0 + p * 32 + r16 * 2;
+        app[p] = A + (col / PW) * ps + (col % PW) + (int64_t)kq * PW;
+    }
+    double* bw = smem + wave * STRIP;
+    double a0[U][RT], a1[U][RT];
+    d2 bst[PPT];
+#define LCX_P_LOADA(R, AA)                                                                 \
+    {                                                                                      \
+        const int64_t rb = (int64_t)(g0 + (R)) * ROWS;                                     \
+        _Pragma("unroll") for (int st = 0; st < U; ++st)                                   \
+        _Pragma("unroll") for (int p = 0; p < RT / 2; ++p) {                               \
+            const d2* src = reinterpret_cast<const d2*>(app[p] + (rb + 4 * st) * PW);      \
+            const d2 v = NT ? __builtin_nontemporal_load(src) : *src;                      \
+            AA[st][2 * p] = v[0]; AA[st][2 * p + 1] = v[1];                                \
+        }                                                                                  \
+    }
+#define LCX_P_LOADB(R)                                                                     \
+    {                                                                                      \
+        const d2* src = reinterpret_cast<const d2*>(B + (int64_t)(g0 + (R)) * ROWS * Mp);  \
+        _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                                  \
+            const int pc = p * 64 + lane;                                                  \
+            if (PCS % 64 == 0 || pc < PCS) bst[p] = src[pc];                               \
+        }                                                                                  \
+    }
+#define LCX_P_STOREB(BUF)                                                                  \
+    {                                                                                      \
+        _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                                  \
+            const int pc = p * 64 + lane;                                                  \
+            if (PCS % 64 == 0 || pc < PCS)                                                 \
+                *reinterpret_cast<d2*>(bw + (BUF) * ROWS * LDB + (pc / PPR) * LDB + (pc % PPR) * 2) = bst[p]; \
+        }                                                                                  \
+    }
+#define LCX_P_MMA(AA, BUF)                                                                 \
+    {                                                                                      \
+        _Pragma("unroll") for (int st = 0; st < U; ++st) {                                 \
+            const double* brow = bw + (BUF) * ROWS * LDB + (4 * st + kq) * LDB + jj;       \
+            double bb[NG];                                                                 \
+            _Pragma("unroll") for (int g = 0; g < NG; ++g) bb[g] = brow[4 * g];            \
+            _Pragma("unroll") for (int t = 0; t < RT; ++t)                                 \
+            _Pragma("unroll") for (int g = 0; g < NG; ++g)                                 \
+                acc[t][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(AA[st][t], bb[g], acc[t][g], 0, 0, 0); \
+        }                                                                                  \
+    }
+    if (cnt > 0) {
+        LCX_P_LOADA(0, a0);
+        LCX_P_LOADB(0);
+        int r = 0;
+        while (true) {
+            LCX_P_STOREB(0);
+            if (r + 1 < cnt) { LCX_P_LOADA(r + 1, a1); LCX_P_LOADB(r + 1); }
+            LCX_P_MMA(a0, 0);
+            if (++r >= cnt) break;
+            LCX_P_STOREB(1);
+            if (r + 1 < cnt) { LCX_P_LOADA(r + 1, a0); LCX_P_LOADB(r + 1); }
+            LCX_P_MMA(a1, 1);
+            if (++r >= cnt) break;
+        }
+    }
+#undef LCX_P_LOADA
+#undef LCX_P_MMA
+    constexpr int TILE = 16 * RT * Mp;
+    __syncthreads();
+    const int row = ((lane & 15) >> 2) * 4 + (lane >> 4);
+    double* dst = out + ((int64_t)blockIdx.y * out_rows + v0) * Mp;
+    double* mine = smem + wave * TILE;
+    // a lane's element t is column p 32 + r16 2 + e of the tile (t = 2 p + e): the pieces of gemm_tn4 with EPL = 2
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            mine[((t / 2) * 32 + row * 2 + (t % 2)) * Mp + 4 * g + jj] = acc[t][g];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TILE; idx += 64 * KW) {
+        double sacc = smem[idx];
+#pragma unroll
+        for (int w = 1; w < KW; ++w) sacc += smem[w * TILE + idx];
+        dst[idx] = sacc;
+    }
+}
+
+template <int CT, int RT, int KW, int U, bool NT = false>
+__global__ void __launch_bounds__(64 * KW)
+gemm_tn4c_kernel(const double* __restrict__ A, int64_t ps /* panel stride */, const double* __restrict__ B, double* __restrict__ out,
+                 int64_t out_rows, int kgroups /* K / 16 */, int nsplit, const int* __restrict__ skip_flag) {
+    constexpr int Mp = 16 * CT, NG = Mp / 4;
+    constexpr int ROWS = 4 * U, LDB = Mp + 4, PPR = Mp / 2, PCS = ROWS * PPR, PPT = (PCS + 63) / 64, STRIP = 2 * ROWS * LDB;
+    constexpr int PW = 8, NL = ROWS / PW;                 // panels per group
+    static_assert(ROWS % PW == 0, "a group must be whole panels");
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* smem = reinterpret_cast<double*>(smem_raw);
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4, jj = lane & 3;
+    const int64_t v0 = (int64_t)blockIdx.x * (16 * RT);   // first output row of the block's tile
+    const int part = blockIdx.y * KW + wave, nparts = nsplit * KW;
+    const int ng = kgroups * 4 / U;
+    const int g0 = (int)((int64_t)ng * part / nparts), g1 = (int)((int64_t)ng * (part + 1) / nparts);
+    const int cnt = g1 - g0;
+    double acc[RT][NG];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[t][g] = 0.0;
+    const double* ap = A + (v0 + r16) * PW + kq * 2;
+    double* bw = smem + wave * STRIP;
+    d2 a0[NL][RT], a1[NL][RT];
+    d2 bst[PPT];
+#define LCX_C_LOADA(R, AA)                                                                 \
+    {                                                                                      \
+        const int64_t pb = (int64_t)(g0 + (R)) * NL;                                       \
+        _Pragma("unroll") for (int p = 0; p < NL; ++p)                                     \
+        _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                   \
+            const d2* src = reinterpret_cast<const d2*>(ap + (pb + p) * ps + (int64_t)(16 * t) * PW); \
+            AA[p][t] = NT ? __builtin_nontemporal_load(src) : *src;                        \
+        }                                                                                  \
+    }
+#define LCX_C_MMA(AA, BUF)                                                                 \
+    {                                                                                      \
+        _Pragma("unroll") for (int p = 0; p < NL; ++p)                                     \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                    \
+            const double* brow = bw + (BUF) * ROWS * LDB + (p * PW + kq * 2 + e) * LDB + jj; \
+            double bb[NG];                                                                 \
+            _Pragma("unroll") for (int g = 0; g < NG; ++g) bb[g] = brow[4 * g];            \
+            _Pragma("unroll") for (int t = 0; t < RT; ++t)                                 \
+            _Pragma("unroll") for (int g = 0; g < NG; ++g)                                 \
+                acc[t][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(AA[p][t][e], bb[g], acc[t][g], 0, 0, 0); \
+        }                                                                                  \
+    }
+    if (cnt > 0) {
+        LCX_C_LOADA(0, a0);
+        LCX_P_LOADB(0);
+        int r = 0;
+        while (true) {
+            LCX_P_STOREB(0);
+            if (r + 1 < cnt) { LCX_C_LOADA(r + 1, a1); LCX_P_LOADB(r + 1); }
+            LCX_C_MMA(a0, 0);
+            if (++r >= cnt) break;
+            LCX_P_STOREB(1);
+            if (r + 1 < cnt) { LCX_C_LOADA(r + 1, a0); LCX_P_LOADB(r + 1); }
+            LCX_C_MMA(a1, 1);
+            if (++r >= cnt) break;
+        }
+    }
+#undef LCX_C_LOADA
+#undef LCX_C_MMA
+#undef LCX_P_LOADB
+#undef LCX_P_STOREB
+    constexpr int TILE = 16 * RT * Mp;
+    __syncthreads();
+    const int row = ((lane & 15) >> 2) * 4 + (lane >> 4);       // blk * 4 + i: the output row inside a 16-row tile
+    double* dst = out + ((int64_t)blockIdx.y * out_rows + v0) * Mp;
+    double* mine = smem + wave * TILE;
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            mine[(16 * t + row) * Mp + 4 * g + jj] = acc[t][g];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TILE; idx += 64 * KW) {
+        double sacc = smem[idx];
+#pragma unroll
+        for (int w = 1; w < KW; ++w) sacc += smem[w * TILE + idx];
+        dst[idx] = sacc;
+    }
+}
+
 template <typename T, int Mp, int ABL = 0>
 __global__ void __launch_bounds__(PV_THREADS)
 moments_epilogue_probe_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride,

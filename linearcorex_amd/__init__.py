@@ -2,7 +2,7 @@
 
     from linearcorex_amd import Corex        # drop-in for `from linearcorex import Corex`
 """
-from .corex import Corex, DeviceMoments  # noqa: F401
+from .corex import Corex, DeviceMoments, pick_n_hidden  # noqa: F401
 from .preprocess import g, g_inv, mean_impute, random_impute  # noqa: F401
 
 __version__ = "0.1.0"

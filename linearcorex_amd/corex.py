@@ -1040,6 +1040,35 @@ class Corex(object):
         self.__dict__.update(d)
 
 
+def pick_n_hidden(data, repeat=1, verbose=False, **kwargs):
+    """The reference's helper of the same name (linearcorex.py:458-480), a caller of the fit path: fit models with 1, 2, ... factors
+    and record `TC_no_overlap` until the score drops below 0.95 of the best one; returns the list of (score, n).  kwargs go to `Corex`
+    (seed, dtype, device, ...).  (`Corex(n_hidden=None)`, which the reference routes here (:111-112), is broken upstream - the list this
+    returns is assigned to `self.m` - and refused by this package; the helper itself works there and here.)"""
+    max_score = - np.inf
+    n = 1
+    all_scores = []
+    while True:
+        scores = []
+        for _ in range(repeat):
+            out = Corex(n_hidden=n, **kwargs).fit(data)
+            scores.append(out.moments["TC_no_overlap"])
+            if out._backend is not None:                # n grows by one per round: do not keep every model's shard resident
+                out._backend.close()
+                out._backend = None
+        score = max(scores)
+        if verbose:
+            print(("n: {}, score: {}".format(n, score)))
+        all_scores.append((score, n))
+        if score < 0.95 * max_score:
+            break
+        else:
+            n += 1
+            if score > max_score:
+                max_score = score
+    return all_scores
+
+
 def be_mp2(be):
     """number of doubles of H in the scalar exchange buffer (m_pad^2)."""
     mp = getattr(be, "m_pad", None)

@@ -340,6 +340,26 @@ def test_transform_details_evaluates_the_new_batch(g1, gz, branch, restored):
                                                   _backend_factory=FACTORY), g1, gz, branch, "f64", 1e-6, from_fixture=restored)
 
 
+def check_pick_n_hidden(g1, tag, tol, **kw):
+    """`pick_n_hidden` (reference :458-480: models with 1, 2, ... factors until TC_no_overlap drops below 0.95 of the best) against
+    the reference's own scan of the first 30 big5 columns (g11_pick_n_hidden.npz): same stopping point, same scores."""
+    from linearcorex_amd import pick_n_hidden
+    from tests.conftest import load_golden
+    g = load_golden("g11_pick_n_hidden")
+    x = g1["x_raw"][:, :int(g["n_cols"])].astype(np.float64)
+    got = pick_n_hidden(x, seed=0, **kw)
+    assert [n for _, n in got] == list(g[tag + "_n"]) == list(range(1, len(got) + 1))
+    ref = g[tag + "_scores"]
+    assert np.max(np.abs(np.array([float(s) for s, _ in got]) - ref)) < tol * np.max(np.abs(ref))
+    assert got[-1][0] < 0.95 * max(s for s, _ in got[:-1])
+
+
+def test_pick_n_hidden_matches_reference(g1):
+    check_pick_n_hidden(g1, "f64", 1e-6, dtype=np.float64, _backend_factory=FACTORY)
+    with pytest.raises(NotImplementedError):             # the reference's own use of it (n_hidden=None, :111-112) is broken upstream
+        Corex(n_hidden=None, _backend_factory=FACTORY).fit(g1["x_raw"][:100, :8])
+
+
 def test_bench_stdout_line_stays_within_the_drivers_budget(tmp_path):
     """bench.emit: the stdout line is the compact record (contract keys, roofline, cpu_baseline, scalar riders) and fits
     4 KB whatever the nested blocks weigh - fed with round 3's 21 KB record, the one the driver could not parse; the full

@@ -130,3 +130,11 @@ def test_transform_details_evaluates_the_new_batch(g1, gz, branch, tag):
     mdl = check_transform_details(lambda gz_, ov: Corex(n_hidden=5, seed=0, dtype=dt, device=0, gaussianize=gz_, discourage_overlap=ov),
                                   g1, gz, branch, tag, 1e-6 if tag == "f64" else 1e-3, from_fixture=(tag == "f32"))
     mdl._backend.close()
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_pick_n_hidden_on_device(g1, tag):
+    """The reference's exported helper `pick_n_hidden` (:458-480), a caller of the fit path, on the device: the scan over 1, 2, ...
+    factors stops where the reference's stops, with its scores (float64 1e-6; float32 at the end-to-end bar of a float32 fit)."""
+    from tests.test_host_logic_cpu import check_pick_n_hidden
+    check_pick_n_hidden(g1, tag, 1e-6 if tag == "f64" else 2e-3, dtype=np.float64 if tag == "f64" else np.float32, device=0)

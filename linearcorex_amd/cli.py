@@ -178,6 +178,11 @@ def main(argv=None, corex_factory=None):
     print('Variable groups in summary/groups.txt')
     print('Latent factors for each sample in summary/labels.txt')
     write_summaries(models[0], x, opt.output, column_label=names, row_label=labels)
+    # the text half of vis_hierarchy (vis_corex.py:219-225): total and per-factor TC of every layer (the graph half is out of scope)
+    with _open(os.path.join(opt.output, "summary", "higher_layer_group_tcs.txt"), "w") as f:
+        for j, mdl in enumerate(models):
+            f.write('At layer: %d, Total TC: %0.3f\n' % (j, mdl.tc))
+            f.write('Individual TCS:' + str(mdl.tcs) + '\n')
     return models
 
 

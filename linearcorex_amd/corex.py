@@ -1045,28 +1045,24 @@ def pick_n_hidden(data, repeat=1, verbose=False, **kwargs):
     and record `TC_no_overlap` until the score drops below 0.95 of the best one; returns the list of (score, n).  kwargs go to `Corex`
     (seed, dtype, device, ...).  (`Corex(n_hidden=None)`, which the reference routes here (:111-112), is broken upstream - the list this
     returns is assigned to `self.m` - and refused by this package; the helper itself works there and here.)"""
-    max_score = - np.inf
-    n = 1
-    all_scores = []
+    def one_score(n_factors):
+        out = Corex(n_hidden=n_factors, **kwargs).fit(data)
+        score = out.moments["TC_no_overlap"]
+        if out._backend is not None:                    # the scan grows one factor per round: do not keep every model's shard resident
+            out._backend.close()
+            out._backend = None
+        return score
+
+    results, best, n_factors = [], -np.inf, 1
     while True:
-        scores = []
-        for _ in range(repeat):
-            out = Corex(n_hidden=n, **kwargs).fit(data)
-            scores.append(out.moments["TC_no_overlap"])
-            if out._backend is not None:                # n grows by one per round: do not keep every model's shard resident
-                out._backend.close()
-                out._backend = None
-        score = max(scores)
+        score = max(one_score(n_factors) for _ in range(repeat))
         if verbose:
-            print(("n: {}, score: {}".format(n, score)))
-        all_scores.append((score, n))
-        if score < 0.95 * max_score:
-            break
-        else:
-            n += 1
-            if score > max_score:
-                max_score = score
-    return all_scores
+            print(("n: {}, score: {}".format(n_factors, score)))
+        results.append((score, n_factors))
+        if score < 0.95 * best:                         # (:474) the first count whose score falls 5 % below the best so far ends the scan
+            return results
+        best = max(best, score)
+        n_factors += 1
 
 
 def be_mp2(be):

@@ -8,8 +8,9 @@ may import it; the product package never does (it fails loudly without its HIP l
 
 Pinning: the reference ships no tests or golden vectors for this path, so the oracle
 is pinned against outputs of the reference itself, generated in the build container by
-`tests/golden/make_golden.py` (which imports the reference read-only) and committed as `.npz`
-fixtures under `tests/golden/`.  `tests/test_oracle_golden.py` checks every function below against
+`tests/golden/make_golden*.py` (which import the reference read-only) and committed as `.npz`
+fixtures under `tests/golden/` (g1-g11: big5, planted clusters, the config-2 shape, edge cases, 'outliers', missing values, the
+stacking loop, the synergistic branch, predict / invert / 'empirical', transform(details=True), pick_n_hidden).  `tests/test_oracle_golden.py` checks every function below against
 those fixtures for both working precisions:
 
   * dtype=float32  - "oracle-32", what the reference literally computes (it hard-casts, ref :108,:116)

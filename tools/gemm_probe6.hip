@@ -34,6 +34,17 @@ Variant mk4r(const double* A, int64_t lda, int64_t K, int64_t vcols, const doubl
     snprintf(buf, 200, "tn4r (A ring of 3) RT=%d KW=%d U=%d NT=%d S=%d blocks=%d bpc=%d lds=%zu", RT, KW, U, (int)NT, S, (int)(vcols / (16 * RT)) * S, bpc, lds);
     return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3((unsigned)(vcols / (16 * RT)), S), dim3(64 * KW), lds, 0, A, lda, B, out, vcols, (int)(K / 16), S, (const int*)nullptr); }, {}, S};
 }
+template <int CT, int RT, int KW, int U, int SCHED>
+Variant mk4s(const double* A, int64_t lda, int64_t K, int64_t vcols, const double* B, double* out, int S) {
+    auto kern = gemm_tn4s_kernel<CT, RT, KW, U, true, SCHED>;
+    const size_t lds = Tn4Lds<CT, RT, KW, U, false>::bytes;
+    if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int bpc = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 64 * KW, lds));
+    char buf[200];
+    snprintf(buf, 200, "tn4s (interleaved schedule %d) RT=%d KW=%d U=%d S=%d blocks=%d bpc=%d", SCHED, RT, KW, U, S, (int)(vcols / (16 * RT)) * S, bpc);
+    return Variant{buf, [=] { hipLaunchKernelGGL(kern, dim3((unsigned)(vcols / (16 * RT)), S), dim3(64 * KW), lds, 0, A, lda, B, out, vcols, (int)(K / 16), S, (const int*)nullptr); }, {}, S};
+}
 template <int CT, int RT, int KW>
 Variant mkprod(const double* A, int64_t lda, int64_t K, int64_t vcols, const double* B, double* out, int S) {
     auto kern = gemm_tn_probe_kernel<double, CT, RT, KW, false, 0, 4>;
@@ -273,8 +284,9 @@ void suite_ring(const char* name, int64_t K, int64_t V, std::initializer_list<in
     std::vector<Variant> vs;
     for (int S : splits) {
         vs.push_back(mk4<CT, 4, 4, 4, true>(A, V, K, V, B, out, S));
+        vs.push_back(mk4s<CT, 4, 4, 4, 1>(A, V, K, V, B, out, S));
+        vs.push_back(mk4s<CT, 4, 4, 4, 2>(A, V, K, V, B, out, S));
         vs.push_back(mk4r<CT, 4, 4, 4, true>(A, V, K, V, B, out, S));
-        vs.push_back(mk4r<CT, 4, 4, 4, false>(A, V, K, V, B, out, S));
         vs.push_back(mk4r<CT, 4, 4, 2, true>(A, V, K, V, B, out, S));
         vs.push_back(mk4r<CT, 4, 8, 2, true>(A, V, K, V, B, out, S));
         vs.push_back(mk4r<CT, 2, 4, 4, true>(A, V, K, V, B, out, S));
@@ -283,7 +295,7 @@ void suite_ring(const char* name, int64_t K, int64_t V, std::initializer_list<in
     vs[0].launch(); CK(hipDeviceSynchronize());
     std::vector<double> r((size_t)vs[0].slots * n1);
     CK(hipMemcpy(r.data(), out, r.size() * 8, hipMemcpyDeviceToHost));
-    for (size_t vi = 1; vi < 6; ++vi) {
+    for (size_t vi = 1; vi < 7; ++vi) {
         CK(hipMemset(out, 0xff, 8 * (size_t)vs[vi].slots * n1));
         vs[vi].launch(); CK(hipDeviceSynchronize());
         std::vector<double> o((size_t)vs[vi].slots * n1);

@@ -1058,6 +1058,164 @@ gemm_tn4c_kernel(const double* __restrict__ A, int64_t ps /* panel stride */, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// round 4: gemm_tn4 (the production config-2 kernel, copied) with scheduler hints that interleave a group's global loads and LDS reads
+// with its MFMAs (__builtin_amdgcn_sched_group_barrier) instead of issuing them in front of the burst
+// ------------------------------------------------------------------------------------------------
+template <int CT, int RT, int KW, int U, bool NT = false, int SCHED = 1>
+__global__ void __launch_bounds__(64 * KW)
+gemm_tn4s_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, double* __restrict__ out,
+                int64_t out_rows, int kgroups /* K / 16 */, int nsplit, const int* __restrict__ skip_flag) {
+    constexpr int Mp = 16 * CT, NG = Mp / 4;
+    constexpr int ROWS = 4 * U;                      // rows of B per group
+    constexpr int LDB = Mp + 4;                      // padded LDS row (doubles)
+    constexpr int PPR = Mp / 2;                      // 16-byte pieces per row
+    constexpr int PCS = ROWS * PPR;
+    constexpr int PPT = (PCS + 63) / 64;             // pieces per lane
+    constexpr int STRIP = 2 * ROWS * LDB;            // doubles per wave (double buffered)
+    constexpr bool SERIAL = false;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* smem = reinterpret_cast<double*>(smem_raw);
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4, jj = lane & 3;
+    const int64_t v0 = (int64_t)blockIdx.x * (16 * RT);
+    const int part = blockIdx.y * KW + wave, nparts = nsplit * KW;
+    const int ng = kgroups * 4 / U;                  // groups of 4*U rows
+    const int g0 = (int)((int64_t)ng * part / nparts), g1 = (int)((int64_t)ng * (part + 1) / nparts);
+    const int cnt = g1 - g0;
+
+    double acc[RT][NG];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[t][g] = 0.0;
+
+    const double* ap = A + v0 + (int64_t)kq * lda;
+    double* bw = smem + wave * STRIP;
+    double a0[U][RT], a1[U][RT];
+    d2 bst[PPT];
+
+#define LCX_T4_LOADA(R, AA)                                                                \
+    {                                                                                      \
+        const int64_t rb = (int64_t)(g0 + (R)) * ROWS;                                     \
+        _Pragma("unroll") for (int st = 0; st < U; ++st)                                   \
+            load_row_pieces<double, RT, NT>(ap + (rb + 4 * st) * lda, r16, AA[st]);        \
+    }
+#define LCX_T4_LOADB(R)                                                                    \
+    {                                                                                      \
+        const d2* src = reinterpret_cast<const d2*>(B + (int64_t)(g0 + (R)) * ROWS * Mp);  \
+        _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                                  \
+            const int pc = p * 64 + lane;                                                  \
+            if (PCS % 64 == 0 || pc < PCS) bst[p] = src[pc];                               \
+        }                                                                                  \
+    }
+#define LCX_T4_STOREB(BUF)                                                                 \
+    {                                                                                      \
+        _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                                  \
+            const int pc = p * 64 + lane;                                                  \
+            if (PCS % 64 == 0 || pc < PCS)                                                 \
+                *reinterpret_cast<d2*>(bw + (BUF) * ROWS * LDB + (pc / PPR) * LDB + (pc % PPR) * 2) = bst[p]; \
+        }                                                                                  \
+    }
+#define LCX_T4_MMA(AA, BUF)                                                                \
+    {                                                                                      \
+        _Pragma("unroll") for (int st = 0; st < U; ++st) {                                 \
+            const double* brow = bw + (BUF) * ROWS * LDB + (4 * st + kq) * LDB + jj;       \
+            double bb[NG];                                                                 \
+            _Pragma("unroll") for (int g = 0; g < NG; ++g) bb[g] = brow[4 * g];            \
+            _Pragma("unroll") for (int t = 0; t < RT; ++t)                                 \
+            _Pragma("unroll") for (int g = 0; g < NG; ++g)                                 \
+                acc[t][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(AA[st][t], bb[g], acc[t][g], 0, 0, 0); \
+        }                                                                                  \
+    }
+
+    // interleave the group's memory instructions with its MFMAs instead of issuing them in front of the burst:
+    //   SCHED 1: per MFMA step (8 LDS reads, then 3 x {1 global load, ~11 MFMAs}); SCHED 2: {1 global load, 4 MFMAs} x 12, the rest behind
+#define LCX_T4_SCHED()                                                                     \
+    {                                                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x200, PPT, 0);                               \
+        if (SCHED == 1) {                                                                  \
+            _Pragma("unroll") for (int st = 0; st < U; ++st) {                             \
+                __builtin_amdgcn_sched_group_barrier(0x100, NG, 0);                        \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                         \
+                __builtin_amdgcn_sched_group_barrier(0x008, (RT * NG) / 3, 0);             \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                         \
+                __builtin_amdgcn_sched_group_barrier(0x008, (RT * NG) / 3, 0);             \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                         \
+                __builtin_amdgcn_sched_group_barrier(0x008, RT * NG - 2 * ((RT * NG) / 3), 0); \
+            }                                                                              \
+        } else {                                                                           \
+            __builtin_amdgcn_sched_group_barrier(0x100, NG, 0);                            \
+            _Pragma("unroll") for (int k = 0; k < 12; ++k) {                               \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                         \
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                         \
+            }                                                                              \
+        }                                                                                  \
+    }
+    if (cnt > 0) {
+        LCX_T4_LOADA(0, a0);
+        LCX_T4_LOADB(0);
+        int r = 0;
+        while (true) {
+            LCX_T4_STOREB(0);
+            { const int rn = (r + 1 < cnt) ? r + 1 : cnt - 1; LCX_T4_LOADA(rn, a1); LCX_T4_LOADB(rn); }   /* branch-free: one basic block */
+            LCX_T4_MMA(a0, 0);
+            LCX_T4_SCHED();
+            if (++r >= cnt) break;
+            LCX_T4_STOREB(1);
+            { const int rn = (r + 1 < cnt) ? r + 1 : cnt - 1; LCX_T4_LOADA(rn, a0); LCX_T4_LOADB(rn); }
+            LCX_T4_MMA(a1, 1);
+            LCX_T4_SCHED();
+            if (++r >= cnt) break;
+        }
+    }
+#undef LCX_T4_LOADA
+#undef LCX_T4_LOADB
+#undef LCX_T4_STOREB
+#undef LCX_T4_MMA
+#undef LCX_T4_SCHED
+
+    // ---- reduce the KW partial tiles through LDS in a fixed order and write the tile ----------------
+    constexpr int TILE = 16 * RT * Mp;
+    __syncthreads();                                  // the B strips are dead: the same LDS holds the tiles now
+    const int row = ((lane & 15) >> 2) * 4 + (lane >> 4);          // blk*4 + i: the column of X inside the 16-wide piece
+    double* dst = out + ((int64_t)blockIdx.y * out_rows + v0) * Mp;
+    if (SERIAL) {
+        // one tile of LDS: the waves add their tiles one after the other (fixed order), so that wide tiles do not
+        // cost KW times their size in LDS (occupancy)
+        for (int w = 0; w < KW; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        double* p = &smem[piece_col<double, RT>(t, row) * Mp + 4 * g + jj];
+                        *p = (w == 0) ? acc[t][g] : *p + acc[t][g];
+                    }
+            }
+            __syncthreads();
+        }
+        for (int idx = threadIdx.x; idx < TILE; idx += 64 * KW) dst[idx] = smem[idx];
+        return;
+    }
+    double* mine = smem + wave * TILE;
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            mine[piece_col<double, RT>(t, row) * Mp + 4 * g + jj] = acc[t][g];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TILE; idx += 64 * KW) {
+        double sacc = smem[idx];
+#pragma unroll
+        for (int w = 1; w < KW; ++w) sacc += smem[w * TILE + idx];
+        dst[idx] = sacc;
+    }
+}
+
 template <typename T, int Mp, int ABL = 0>
 __global__ void __launch_bounds__(PV_THREADS)
 moments_epilogue_probe_kernel(const T* __restrict__ dpart, int nsplit, int64_t pstride,

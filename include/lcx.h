@@ -339,6 +339,18 @@ int lcx_bytes_resident(lcx_ctx* h, int64_t* total, int64_t* x_bytes);
  *   0  row-major + a transposed copy: small shards (each pass reads the copy whose contiguous axis it does not contract);
  *   1  row-major only: models with more than 256 factors, or LCX_SINGLE_COPY=1. */
 int lcx_x_layout(lcx_ctx* h, int* layout);
+/* Arithmetic of the two X-streaming contractions (:247 / :210 x.dot(ws.T), :259 / :211 x.T.dot(y)) of a FLOAT32 shard in the
+ * panel-major layout; switchable at any time between two launches, results of both modes within float32 rounding of each other:
+ *   0  (default) v_mfma_f32_16x16x4_f32: exact float32 products, float32 accumulation - the float32 MATRIX rate of gfx950 equals
+ *      its float32 VECTOR rate (157 TF/s), 1/16 of the bf16 rate, and bounds these passes;
+ *   1  every operand element split exactly into three bf16 numbers (8 + 8 + 8 significand bits), 6 of the 9 partial products
+ *      (all terms down to 2^-16 of the product; the dropped ones are below 2^-23, one float32 rounding of it) accumulated in float32
+ *      by v_mfma_f32_16x16x32_bf16 - 2.5 x less matrix-pipe time, the passes become HBM / power bound (1.3-1.5 x faster at the
+ *      config-3 / config-4 shards).  Error against a float64 contraction: 1.1-1.4 x that of mode 0 (profiles/r04_gemm_probe9_split.txt).
+ * Mode 1 needs layout 2 and 32 / 64 / 128 padded factors; on any other handle the call succeeds and leaves mode 0 (read it back with
+ * lcx_f32_gemm).  Environment default: LCX_F32_GEMM=split.  Costs 6 bytes per element of the small operand (one scratch buffer). */
+int lcx_set_f32_gemm(lcx_ctx* h, int mode);
+int lcx_f32_gemm(lcx_ctx* h, int* mode);
 /* transform (:386-395): out (n_rows x m) = x (n_rows x nv_local, ld) . ws^T  (per-shard partial) */
 int lcx_project(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, void* out_host);
 

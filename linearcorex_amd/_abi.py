@@ -43,6 +43,8 @@ SIGNATURES = {
     "lcx_comm_selftest": [_vp, _i32, C.POINTER(_i32), C.POINTER(_dbl)],
     "lcx_comm_probe": [],
     "lcx_x_layout": [_vp, C.POINTER(_i32)],
+    "lcx_set_f32_gemm": [_vp, _i32],
+    "lcx_f32_gemm": [_vp, C.POINTER(_i32)],
     "lcx_set_exchange": [_vp, _i32],
     "lcx_exchange_layout": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_vp)],
     "lcx_bind_exchange": [_vp, _vp, _vp],

@@ -413,6 +413,20 @@ class HipBackend:
         """device time of the product kernels of the last get_covariance call (HIP events)"""
         return getattr(self, "_cov_kernel_seconds", None)
 
+    F32_GEMM = {"mfma": 0, "split": 1}
+
+    def set_f32_gemm(self, mode):
+        """Arithmetic of the two X passes of a float32 panel-layout shard (include/lcx.h, lcx_set_f32_gemm): "mfma" = float32
+        MFMA (default), "split" = exact three-way bf16 split of every operand, 6 partial products on the bf16 pipe.  Returns
+        the mode in force ("split" is only taken where the shard supports it)."""
+        _abi.check(self.lib.lcx_set_f32_gemm(self.h, self.F32_GEMM[mode]))
+        return self.f32_gemm()
+
+    def f32_gemm(self):
+        m = C.c_int()
+        _abi.check(self.lib.lcx_f32_gemm(self.h, C.byref(m)))
+        return "split" if m.value == 1 else "mfma"
+
     def bytes_resident(self):
         tot, xb = C.c_int64(), C.c_int64()
         _abi.check(self.lib.lcx_bytes_resident(self.h, C.byref(tot), C.byref(xb)))

@@ -199,16 +199,23 @@ class Corex(object):
               "exact-y": as "exact", except that the trials AFTER the first one of an iteration take X.w_update^T by
               linearity from this iteration's own exact products (one pass over X per such trial instead of two; no drift,
               no re-anchoring - include/lcx.h, lcx_set_trial_reuse).  Needs the line search inside the library.
+      f32_gemm  arithmetic of the two passes over X of a float32 fit (include/lcx.h, lcx_set_f32_gemm): "mfma" = float32 MFMA,
+              exact float32 products (what None gives unless LCX_F32_GEMM=split is set); "split" = every operand split exactly
+              into three bf16 numbers, 6 of the 9 partial products on the bf16 matrix pipe with float32 accumulation: results
+              within float32 rounding of "mfma", passes 1.3-1.5 x faster on large shards.  Taken only where the shard supports
+              it (panel-major layout, 32 / 64 / 128 padded factors); `self.f32_gemm` tells which one the fit ran.
     """
 
     # defaults for models pickled by an earlier build
     _ex = None
     _engine_exchange = None
+    _f32_gemm_asked = None
+    f32_gemm = "mfma"
 
     def __init__(self, n_hidden=10, max_iter=10000, tol=1e-5, anneal=True, missing_values=None,
                  discourage_overlap=True, gaussianize='standard', gpu=False,
                  verbose=False, seed=None, *, dtype=np.float32, device=None, comm=None,
-                 eliminate_synergy=None, line_search=None, refresh_every=16, _backend_factory=None):
+                 eliminate_synergy=None, line_search=None, refresh_every=16, f32_gemm=None, _backend_factory=None):
         if eliminate_synergy is not None:
             discourage_overlap = bool(eliminate_synergy)
         self.m = n_hidden
@@ -252,6 +259,10 @@ class Corex(object):
         if line_search not in ("exact", "linear", "exact-y"):
             raise ValueError("line_search must be 'exact', 'linear' or 'exact-y'")
         self.line_search = self._line_search_wanted = line_search
+        if f32_gemm not in (None, "mfma", "split"):
+            raise ValueError("f32_gemm must be None, 'mfma' or 'split'")
+        self._f32_gemm_asked = f32_gemm         # None: the library's default (float32 MFMA unless LCX_F32_GEMM=split)
+        self.f32_gemm = "mfma"                  # what the fit ran, settled in _make_backend
         self.refresh_every = int(refresh_every)
         self._since_exact = 0
         self.stats = {"iterations": 0, "moment_evals": 0, "trials": 0, "invalid_trials": 0}
@@ -322,6 +333,10 @@ class Corex(object):
             be.set_linear_mode(ls == "linear")
         if hasattr(be, "set_trial_reuse"):
             be.set_trial_reuse(ls == "exact-y")
+        # arithmetic of the X passes of a float32 shard: asked for explicitly, or the library's default (LCX_F32_GEMM)
+        if hasattr(be, "set_f32_gemm"):
+            asked = getattr(self, "_f32_gemm_asked", None)
+            self.f32_gemm = be.set_f32_gemm(asked) if asked is not None else be.f32_gemm()
         return be
 
     def _allreduce(self, tensor):

@@ -26,6 +26,7 @@
 
 #include "../../include/lcx.h"
 #include "gemm_kernels.hpp"
+#include "gemm_split_kernels.hpp"
 #include "moment_kernels.hpp"
 
 using namespace lcx;
@@ -174,6 +175,11 @@ struct lcx_ctx {
     bool single_copy;           // X.B^T is read from the row-major X itself (gemm_cr): half the resident bytes, a 4-6 % slower pass
     bool panel;                 // X is the ONE panel-major copy [ldx / PW][Npad][PW] (gemm_kernels.hpp, PanelW): large shards whose two
                                 // passes both run on the stream-K kernels; no transposed copy, both passes at full speed
+    bool split;                 // float32 panel shards only: the two X passes run on the bf16 matrix pipe, every operand split exactly
+                                // into three bf16 parts and 6 of the 9 partial products accumulated in float32 (gemm_split_kernels.hpp);
+                                // off by default (LCX_F32_GEMM=split / lcx_set_f32_gemm)
+    void* bsp;                  // the small operand of a pass in split form (split_b_kernel), 6 bytes per element
+    size_t bsp_bytes;
     void* Wt[2];
     MomentSet set[2];
     void *grad, *update, *sgrad, *scratch;
@@ -451,6 +457,32 @@ static int launch_tn4(hipStream_t st, const double* A, int64_t lda, int64_t K, i
     return LCX_OK;
 }
 
+// The same pass on the bf16 matrix pipe (float32 panel shards in split mode): B is split once (split_b_kernel), then the contraction
+// kernel with the unit / slot contract of launch_ct / launch_cr - same rows per block (KW x 64), same slot count; a unit is 32
+// contraction elements instead of 16, so nb is clamped to the unit count (every block must own at least one unit).
+template <int CT> struct SplitShape { static constexpr int KW = CT == 8 ? 8 : 4; };
+template <int CT, bool CONTRACT_N>
+static int launch_split(hipStream_t st, const float* A, int64_t ps, int64_t K, int64_t rows, const float* B, float* out, int nb, int nsuper,
+                        int maxslots, const int* skip, void* bsp) {
+    if constexpr (CT == 2 || CT == 4 || CT == 8) {
+        constexpr int KW = SplitShape<CT>::KW;
+        const int ng = (int)(K / SPLIT_KG);
+        u32x4_t* sp = reinterpret_cast<u32x4_t*>(bsp);
+        const int64_t tasks = (int64_t)ng * 64 * CT;
+        hipLaunchKernelGGL((split_b_kernel<CT, CONTRACT_N>), dim3((unsigned)(cdiv(tasks, 256) < 2048 ? cdiv(tasks, 256) : 2048)), dim3(256), 0, st, B, sp,
+                           ng, skip);
+        const int64_t total = (int64_t)nsuper * ng;
+        if (nb > total) nb = (int)total;
+        hipLaunchKernelGGL((gemm_split_kernel<CT, KW, 6, CONTRACT_N, true, false, 2>), dim3((unsigned)nb), dim3(64 * KW), 0, st, A, ps,
+                           (const u32x4_t*)sp, out, rows, rows, ng, nsuper, maxslots, skip);
+        KCHECK();
+        return LCX_OK;
+    } else {
+        return fail(LCX_ERR_ARG, "launch_split: unsupported factor count");
+    }
+}
+// split mode exists for float32 with 32 / 64 / 128 padded factors (and the merged pass of the first two)
+template <typename T, int CT> static constexpr bool split_capable() { return sizeof(T) == 4 && (CT == 2 || CT == 4 || CT == 8); }
 // waves per block of the stream-K kernels: CtShape's, except that 128 float32 factors can be switched between 4 and 8 at run time
 // (LCX_CT8_KW) - the A/B knob behind CtShape<float, 8>::KW
 template <typename T, int CT> static inline int ct_kw() {
@@ -467,8 +499,11 @@ template <typename T, int CT> static inline int ct_kw() {
 // gemm_ct launch: nb balanced blocks over (super tile, group) units; partial tiles -> out[slot][out_rows][Mp]
 template <typename T, int CT, bool PANEL = false>
 static int launch_ct(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* out, int nb,
-                     int nsuper, int maxslots, const int* skip) {
+                     int nsuper, int maxslots, const int* skip, void* bsp = nullptr) {
     typedef CtShape<T, CT> S;
+    if constexpr (PANEL && split_capable<T, CT>()) {
+        if (bsp) return launch_split<CT, true>(st, A, lda, K, vcols, B, out, nb, nsuper, maxslots, skip, bsp);
+    }
     const int ng = (int)(K / (4 * S::U));
     if constexpr (sizeof(T) == 4 && CT == 8) {
         if (ct_kw<T, CT>() == 8)
@@ -488,8 +523,11 @@ static int launch_ct(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t
 // (PANEL: the panel-major copy, lda = the panel stride, non-temporal loads - every line is read once per pass)
 template <typename T, int CT, bool PANEL = false>
 static int launch_cr(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t nrows, const T* B, T* out, int nb, int nsuper,
-                     int maxslots, const int* skip) {
+                     int maxslots, const int* skip, void* bsp = nullptr) {
     typedef CtShape<T, CT> S;
+    if constexpr (PANEL && split_capable<T, CT>()) {
+        if (bsp) return launch_split<CT, false>(st, A, lda, K, nrows, B, out, nb, nsuper, maxslots, skip, bsp);
+    }
     const int ng = (int)(K / (4 * S::U));
     if constexpr (sizeof(T) == 4 && CT == 8) {
         if (ct_kw<T, CT>() == 8)
@@ -787,7 +825,7 @@ template <typename T, int CT> struct Impl {
         } else {
             if (h->panel)
                 LCXCHECK((launch_cr<T, CT, true>(h->stream, P<T>(h->X), h->Npad * PanelW<T>::v, h->ldx, h->Npad, B, dst, h->nt_nb, h->nt_nsuper,
-                                                 h->nt_S, skip)));
+                                                 h->nt_S, skip, h->split ? h->bsp : nullptr)));
             else if (h->single_copy)
                 LCXCHECK((launch_cr<T, CT>(h->stream, P<T>(h->X), h->ldx, h->ldx, h->Npad, B, dst, h->nt_nb, h->nt_nsuper, h->nt_S, skip)));
             else if (h->nt_ct)
@@ -841,7 +879,7 @@ template <typename T, int CT> struct Impl {
         } else {
             if (h->panel)
                 LCXCHECK((launch_ct<T, CT, true>(h->stream, P<T>(h->X), h->Npad * PanelW<T>::v, h->Npad, h->ldx, P<T>(h->ybuf), P<T>(h->dpart),
-                                                 h->tn_nb, h->tn_nsuper, h->tn_S, skip)));
+                                                 h->tn_nb, h->tn_nsuper, h->tn_S, skip, h->split ? h->bsp : nullptr)));
             else if (h->tn_ct)
                 LCXCHECK((launch_ct<T, CT>(h->stream, P<T>(h->X), h->ldx, h->Npad, h->ldx, P<T>(h->ybuf), P<T>(h->dpart), h->tn_nb, h->tn_nsuper,
                                            h->tn_S, skip)));
@@ -1100,7 +1138,7 @@ template <typename T, int CT> struct Impl {
             LCXCHECK(timing_begin(h, 2, &tp));
             if (h->panel)
                 LCXCHECK((launch_cr<T, 2 * CT, true>(h->stream, P<T>(h->X), h->Npad * PanelW<T>::v, h->ldx, h->Npad, P<T>(h->gw), P<T>(h->y2part),
-                                                     h->nt2_nb, h->nt2_nsuper, h->nt2_S, nullptr)));
+                                                     h->nt2_nb, h->nt2_nsuper, h->nt2_S, nullptr, h->split ? h->bsp : nullptr)));
             else if (h->single_copy)
                 LCXCHECK((launch_cr<T, 2 * CT>(h->stream, P<T>(h->X), h->ldx, h->ldx, h->Npad, P<T>(h->gw), P<T>(h->y2part), h->nt2_nb,
                                                h->nt2_nsuper, h->nt2_S, nullptr)));
@@ -1822,6 +1860,21 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
 
+    // split mode (gemm_split_kernels.hpp) needs the panel-major copy, float32, 32 / 64 / 128 padded factors, and the block shapes the
+    // geometry was laid out for (rows per block of the float32 kernels = those of the split kernels)
+    static int split_supported(lcx_ctx* h) {
+        if constexpr (!WIDE && split_capable<T, CT>()) {
+            if (!h->panel || ct_kw<T, CT>() != SplitShape<CT>::KW) return 0;
+            if constexpr (CT <= 4) {
+                if (h->merged_ok && ct_kw<T, 2 * CT>() != SplitShape<2 * CT>::KW) return 0;
+            }
+            return 1;
+        } else {
+            (void)h;
+            return 0;
+        }
+    }
+
     // Name of the kernel instantiation behind the two X-streaming passes, as rocprofv3 prints it (both
     // passes run the same function: X.B^T contracts over the rows of the transposed copy).
     static int kernel_name(lcx_ctx* h, int kind, char* buf, int64_t len) {
@@ -1834,6 +1887,12 @@ template <typename T, int CT> struct Impl {
         }
     }
     static int kernel_name_tuned(lcx_ctx* h, int kind, char* buf, int64_t len) {
+        if (h->split) {
+            if (kind == 2 && !h->merged_ok) { buf[0] = 0; return LCX_OK; }
+            const int ct = kind == 2 ? 2 * CT : CT;
+            snprintf(buf, (size_t)len, "lcx::gemm_split_kernel<%d, %d, 6, %s, true, false, 2>", ct, ct == 8 ? 8 : 4, kind == 1 ? "true" : "false");
+            return LCX_OK;
+        }
         if (kind == 2) {
             if (!h->merged_ok) { buf[0] = 0; return LCX_OK; }
             if constexpr (CT <= 4)
@@ -2203,6 +2262,9 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     HIPCHECK(hipGetDeviceProperties(&prop, device));
 
     lcx_ctx* h = new lcx_ctx();
+    h->split = false;
+    h->bsp = nullptr;
+    h->bsp_bytes = 0;
     h->device = device;
     h->dtype = dtype;
     h->es = dtype == LCX_F32 ? 4 : 8;
@@ -2342,6 +2404,13 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     h->early_grad = h->grad_ready = false;
     h->spec_eps = 0.0;
     HIPCHECK(hipStreamSynchronize(st));
+    {
+        const char* e = getenv("LCX_F32_GEMM");           // "split": the bf16-pipe contractions where the shard supports them
+        if (e && !strcmp(e, "split")) {
+            const int rc2 = lcx_set_f32_gemm(h, 1);
+            if (rc2 != LCX_OK) { (void)lcx_destroy(h); return rc2; }
+        }
+    }
     *out = h;
     return LCX_OK;
 }
@@ -2352,7 +2421,7 @@ int lcx_destroy(lcx_ctx* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->tr.kind == 1 && h->tr.comm) (void)rccl().CommDestroy(h->tr.comm);
     void* ptrs[] = {h->X, h->XT, h->Wt[0], h->Wt[1], h->grad, h->update, h->sgrad, h->scratch, h->ydir, h->ddir, h->ybuf_own, h->sbuf_own,
-                    h->gw, h->y2part, h->bjg,
+                    h->gw, h->y2part, h->bjg, h->bsp,
                     h->ypart, h->dpart, h->gpart, h->gpartw, h->tcpart, h->bjpart, h->tanpart, h->detpart, h->ryinv, h->invwork,
                     h->states, h->order_dev, h->ticket};
     for (void* p : ptrs) (void)hipFree(p);
@@ -2869,6 +2938,33 @@ int lcx_x_layout(lcx_ctx* h, int* layout) {
     NEED(h);
     if (!layout) return fail(LCX_ERR_ARG, "lcx_x_layout: null");
     *layout = h->panel ? 2 : (h->single_copy ? 1 : 0);
+    return LCX_OK;
+}
+
+static int split_supported_dispatch(lcx_ctx* h) { DISPATCH(h, split_supported, h); }
+
+int lcx_set_f32_gemm(lcx_ctx* h, int mode) {
+    NEED(h);
+    if (mode != 0 && mode != 1) return fail(LCX_ERR_ARG, "lcx_set_f32_gemm: mode must be 0 (float32 MFMA) or 1 (bf16 split)");
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (mode == 0 || split_supported_dispatch(h) != 1) { h->split = false; return LCX_OK; }
+    if (!h->bsp) {
+        const int64_t k = h->ldx > h->Npad ? h->ldx : h->Npad;
+        const size_t bytes = (size_t)k * (size_t)(h->merged_ok ? 2 * h->Mp : h->Mp) * 6;
+        int rc = dev_alloc(&h->bsp, bytes, h->stream);
+        if (rc != LCX_OK) { h->bsp = nullptr; return rc; }
+        h->bsp_bytes = bytes;
+        h->bytes_resident += bytes;
+    }
+    h->split = true;
+    return LCX_OK;
+}
+
+int lcx_f32_gemm(lcx_ctx* h, int* mode) {
+    NEED(h);
+    if (!mode) return fail(LCX_ERR_ARG, "lcx_f32_gemm: null");
+    *mode = h->split ? 1 : 0;
     return LCX_OK;
 }
 

@@ -18,14 +18,25 @@ def _moments(be, eps, quick=0):
     return be.read_state(0)
 
 
+def _check_kernels(be, gemm):
+    """the stream-K pair on ONE panel-major copy; gemm = "split": the same passes on the bf16 matrix pipe (lcx_set_f32_gemm)"""
+    assert be.bytes_resident()["x_layout"].startswith("panel-major")
+    assert be.set_f32_gemm(gemm) == gemm
+    if gemm == "split":
+        assert "gemm_split_kernel" in be.kernel_name(0) and "gemm_split_kernel" in be.kernel_name(1)
+        assert ", false, true, false, 2>" in be.kernel_name(0) and ", true, true, false, 2>" in be.kernel_name(1)
+    else:
+        assert "gemm_cr_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)
+
+
+@pytest.mark.parametrize("gemm", ["mfma", "split"])
 @pytest.mark.parametrize("shape", [(50000, 100000, 64), (50000, 125000, 128)], ids=["config3", "config4_shard"])
-def test_full_size_properties(shape):
+def test_full_size_properties(shape, gemm):
     from linearcorex_amd import Corex
     from linearcorex_amd.backend import HipBackend
     n, v, m = shape
     be = HipBackend(n, v, m, np.float32, 0)
-    assert "gemm_cr_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)         # the stream-K pair ...
-    assert be.bytes_resident()["x_layout"].startswith("panel-major")                                 # ... on ONE panel-major copy
+    _check_kernels(be, gemm)
     be.generate_x(1, 1, m, 0)                                     # planted groups, standardised on the device
     cols = np.unique(np.concatenate([[0, 1, v - 1, v - 2, 63, 64, 255, 256], np.linspace(0, v - 1, m).astype(int)]))[:m]
     assert len(cols) == m
@@ -53,8 +64,9 @@ def test_full_size_properties(shape):
     assert np.max(np.abs(ys[2] - (ys[0] + ys[1]))) < 2e-5 * scale * 4
     be.close()
     # a short fit at full size
-    mdl = Corex(n_hidden=m, seed=0, dtype=np.float32, device=0, max_iter=2)
+    mdl = Corex(n_hidden=m, seed=0, dtype=np.float32, device=0, max_iter=2, f32_gemm=gemm)
     mdl.fit_generated(n, v, seed=1, kind=1, n_groups=m)
+    assert mdl.f32_gemm == gemm
     h = np.asarray(mdl.history["TC"], np.float64)
     assert len(h) == 14 and np.all(np.isfinite(h))
     for s in range(7):
@@ -117,32 +129,34 @@ def _rel(a, b):
     return float(np.max(np.abs(a - b)) / max(1e-300, float(np.max(np.abs(b)))))
 
 
-@pytest.mark.parametrize("shape,kind,reuse", [((50000, 100000, 64), 0, False), ((50000, 125000, 128), 1, False),
-                                              ((50000, 125000, 128), 1, True)],
-                         ids=["config3", "config4_shard", "config4_shard_later_trials_by_linearity"])
-def test_full_size_step_vs_oracle(shape, kind, reuse):
+@pytest.mark.parametrize("shape,kind,reuse,gemm", [((50000, 100000, 64), 0, False, "mfma"), ((50000, 125000, 128), 1, False, "mfma"),
+                                                   ((50000, 125000, 128), 1, True, "mfma"), ((50000, 100000, 64), 0, False, "split"),
+                                                   ((50000, 125000, 128), 1, False, "split")],
+                         ids=["config3", "config4_shard", "config4_shard_later_trials_by_linearity", "config3_bf16_split",
+                              "config4_shard_bf16_split"])
+def test_full_size_step_vs_oracle(shape, kind, reuse, gemm):
     """BASELINE configs[2] and the configs[3] shard at FULL size against the oracle, element by element: the resident matrix is
     copied back (20 / 25 GB), and one `_calculate_moments_ns` (reference :236-275), one update direction (:292-305) and one
     whole `_update_ns` with its back-tracking (:306-334) run in NumPy float32 on the host cores - what the reference computes -
     beside the device path (gemm_ct stream-K slots, 64-bit offsets, the merged pass of config 3, lcx_iterate).
     Bars: the float32 step bar of tests/test_parity_gpu.py (2e-4 of the array scale; x10 for derived arrays, as there).
     Third case: the same with lcx_set_trial_reuse (the iteration of the configs[3] shard back-tracks 7 times: trials 2..8 take
-    X.w_update^T by linearity) - same accepted step, same trial count, same bars against the oracle's two-pass trials."""
+    X.w_update^T by linearity) - same accepted step, same trial count, same bars against the oracle's two-pass trials.
+    Last two: the X passes on the bf16 matrix pipe (lcx_set_f32_gemm 1: three-way exact split, 6 partial products) - the SAME bars."""
     from linearcorex_amd.backend import HipBackend
     from oracle import corex_oracle as O
     from bench import _BlasPool                                 # BLAS threads = the cores the cgroup really grants
     with _BlasPool():
-        _full_size_step(shape, kind, HipBackend, O, reuse)
+        _full_size_step(shape, kind, HipBackend, O, reuse, gemm)
 
 
-def _full_size_step(shape, kind, HipBackend, O, reuse=False):
+def _full_size_step(shape, kind, HipBackend, O, reuse=False, gemm="mfma"):
     n, v, m = shape
     tol, eps = 2e-4, 0.36
     be = HipBackend(n, v, m, np.float32, 0)
     be.set_linear_mode(False)                                    # what `Corex(line_search="exact")` runs
     be.set_trial_reuse(reuse)                                    # True: line_search="exact-y" (trials 2..8 of the shard's iteration by linearity)
-    assert "gemm_cr_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)         # the stream-K pair ...
-    assert be.bytes_resident()["x_layout"].startswith("panel-major")                                 # ... on ONE panel-major copy
+    _check_kernels(be, gemm)
     be.generate_x(1, kind, m, 0)
     x = be.download_x()
     assert x.dtype == np.float32 and x.shape == (n, v)
@@ -181,7 +195,7 @@ def _full_size_step(shape, kind, HipBackend, O, reuse=False):
     errs["ws"] = _rel(be.get_ws(0), w_new)
     errs["rho_new"] = _rel(be.get_moment(0, "rho"), m_new["rho"])
     assert errs["ws"] < tol and errs["rho_new"] < tol * 10, errs
-    print("full-size step vs oracle", shape, {k: "%.2e" % e for k, e in errs.items()},
+    print("full-size step vs oracle", shape, gemm, {k: "%.2e" % e for k, e in errs.items()},
           "TC %.6f / %.6f -> %.6f / %.6f, trials %d" % (st[0], tc_ref, out[1], tc_new, int(out[3])))
     be.close()
 

@@ -990,3 +990,122 @@ def test_panel_layout_preprocess_and_generate(gz, missing, monkeypatch):
         assert u.shape == w.shape and relerr(u, w) < 1e-12
     ref = O.preprocess(x.astype(np.float64), None, gz, -1e6 if missing else None)[0]
     assert relerr(a[3], ref) < 1e-10
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# round 4: the X passes of a float32 panel shard on the bf16 matrix pipe (include/lcx.h, lcx_set_f32_gemm; gemm_split_kernels.hpp)
+# ------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1500, 3000, 20), (1501, 3001, 40), (4096, 8192, 64), (1300, 2500, 100), (2048, 1100, 128),
+                                   (20000, 1200, 20), (20000, 1500, 40)])
+def test_split_gemm_matches_mfma(shape, monkeypatch):
+    """f32_gemm="split" (every operand split exactly into three bf16 numbers, 6 partial products, float32 accumulation) against
+    f32_gemm="mfma" (float32 MFMA) on the same panel-major shard: same fit to float32 rounding, both at the float32 bar against the
+    oracle, and - the precision claim - the split moments are as close to a FLOAT64 fit as the float32-MFMA moments are (within 2 x).
+    Factor counts over the three tile widths (32 / 64 / 128 padded columns), ragged sizes, contractions that are an odd number of
+    32-element groups; the two 20 000-row shapes also run the merged pass (twice the columns: 64 / 128)."""
+    from linearcorex_amd import Corex
+    n, v, m = shape
+    x = O.gen_planted(n, v, min(m, 8), seed=1)[0]
+    monkeypatch.setenv("LCX_X_LAYOUT", "panel")
+    monkeypatch.setenv("LCX_GEMM", "ct")
+    runs = {}
+    merged = False
+    for gemm in ("split", "mfma"):
+        out = Corex(n_hidden=m, seed=0, dtype=np.float32, device=0, max_iter=6, tol=0.0, f32_gemm=gemm).fit(x)
+        be = out._backend
+        assert out.f32_gemm == gemm == be.f32_gemm()
+        assert ("gemm_split_kernel" in be.kernel_name(0)) == (gemm == "split") == ("gemm_split_kernel" in be.kernel_name(1))
+        if be.kernel_name(2):                                    # the merged pass, where the shard runs one
+            assert ("gemm_split_kernel" in be.kernel_name(2)) == (gemm == "split")
+            merged = True
+        runs[gemm] = (np.asarray(out.history["TC"], np.float64), out.ws.copy(), out.transform(x), out.moments["rho"].copy(),
+                      out.moments["uj"].copy(), out.clusters())
+        be.close()
+    (h1, w1, y1, r1, u1, c1), (h0, w0, y0, r0, u0, c0) = runs["split"], runs["mfma"]
+    assert merged == (n >= 20000)                                # the shapes here whose merged launch needs <= 8 slots
+    assert len(h1) == len(h0) == 42
+    assert np.max(np.abs(h1 - h0) / np.maximum(1.0, np.abs(h0))) < 5e-4
+    # the rows of ws are sorted by TCs at the end of a fit (:160-163): factors whose TCs tie to rounding may swap places
+    cn = (w1 / np.linalg.norm(w1, axis=1, keepdims=True)).dot((w0 / np.linalg.norm(w0, axis=1, keepdims=True)).T)
+    perm = np.argmax(np.abs(cn), axis=1)
+    assert sorted(perm) == list(range(m)) and np.sum(perm != np.arange(m)) <= m // 2
+    assert relerr(w1, w0[perm]) < 5e-3 and relerr(y1, y0[:, perm]) < 5e-3
+    r0, u0 = r0[perm], u0[perm]
+    ref = O.fit_ns(x, m, seed=0, dtype=np.float32, max_iter=6, tol=0.0)
+    hr = np.asarray(ref.history_tc, np.float64)
+    assert np.max(np.abs(h1 - hr) / np.maximum(1.0, np.abs(hr))) < 2e-3
+    # against float64: the split fit is no further from it than the float32-MFMA fit (x 2) - or both are at the noise floor
+    r64 = O.fit_ns(x, m, seed=0, dtype=np.float64, max_iter=6, tol=0.0)
+    h64 = np.asarray(r64.history_tc, np.float64)
+    e1 = np.max(np.abs(h1 - h64) / np.maximum(1.0, np.abs(h64)))
+    e0 = np.max(np.abs(h0 - h64) / np.maximum(1.0, np.abs(h64)))
+    assert e1 < 2.0 * e0 + 2e-6, (e1, e0)
+    c64 = (w1 / np.linalg.norm(w1, axis=1, keepdims=True)).dot((r64.ws / np.linalg.norm(r64.ws, axis=1, keepdims=True)).T)
+    p64 = np.argmax(np.abs(c64), axis=1)
+    assert sorted(p64) == list(range(m))
+    for a1, a0, key in ((r1, r0, "rho"), (u1, u0, "uj")):
+        d1, d0 = relerr(a1, r64.moments[key][p64]), relerr(a0, r64.moments[key][p64])
+        assert d1 < 2.0 * d0 + 2e-6, (key, d1, d0)
+
+
+def test_split_gemm_one_pass_error_vs_float64(monkeypatch):
+    """One evaluation of the moments (both X passes) of the same W in both float32 modes against the float64 oracle, element by
+    element: Y = X.W^T, rho (from X^T.Y) and uj.  The split contraction's error is within 2 x that of the float32 MFMA."""
+    from linearcorex_amd.backend import HipBackend
+    monkeypatch.setenv("LCX_X_LAYOUT", "panel")
+    monkeypatch.setenv("LCX_GEMM", "ct")
+    n, v, m = 6000, 9000, 64
+    x = O.gen_planted(n, v, 8, seed=2)[0].astype(np.float32)
+    x = (x - x.mean(0)) / x.std(0)
+    rng = np.random.RandomState(5)
+    w = rng.randn(m, v).astype(np.float32)
+    w /= (10.0 * O.norm(x, w, 0))[:, np.newaxis]
+    w *= np.float32(3.0)
+    ref = O.moments_ns(x.astype(np.float64), w.astype(np.float64), 0.36, quick=True)
+    y64 = x.astype(np.float64).dot(w.astype(np.float64).T)
+    be = HipBackend(n, v, m, np.float32, 0)
+    be.upload_x(x)
+    be.set_ws(w)
+    err = {}
+    for gemm in ("mfma", "split", "mfma"):                       # switchable between launches, and back
+        assert be.set_f32_gemm(gemm) == gemm
+        be.moments_a(0); be.moments_b(0, 0.36, 1); be.moments_c(0)
+        st = be.read_state(0)
+        assert st[2] == 0
+        err[gemm] = (relerr(be.get_moment(0, "Y")[:n], y64), relerr(be.get_moment(0, "rho"), ref["rho"]), relerr(be.get_moment(0, "uj"), ref["uj"]),
+                     abs(st[0] - float(ref["TC"])) / abs(float(ref["TC"])))
+    be.close()
+    print("one pass vs float64 (Y, rho, uj, TC):", {k: ["%.2e" % e for e in v_] for k, v_ in err.items()})
+    for k in range(4):
+        assert err["split"][k] < 2.0 * err["mfma"][k] + 1e-6, (k, err)
+        assert err["split"][k] < 1e-4
+
+
+@pytest.mark.parametrize("tag,m", [("f64", 40), ("f32", 8), ("f32", 200)])
+def test_split_gemm_is_refused_where_it_does_not_apply(tag, m, monkeypatch):
+    """float64, 16 padded factors and more than 128: the call succeeds, the mode stays "mfma", the fit is the float32 / float64 one."""
+    from linearcorex_amd import Corex
+    monkeypatch.setenv("LCX_X_LAYOUT", "panel")
+    monkeypatch.setenv("LCX_GEMM", "ct")
+    x = O.gen_planted(900, 2100, 8, seed=1)[0]
+    out = Corex(n_hidden=m, seed=0, dtype=DT[tag], device=0, max_iter=2, tol=0.0, f32_gemm="split").fit(x)
+    assert out.f32_gemm == "mfma" and "split" not in out._backend.kernel_name(0)
+    out._backend.close()
+    monkeypatch.setenv("LCX_X_LAYOUT", "rows")                   # and a float32 shard that is not in the panel layout
+    out = Corex(n_hidden=40, seed=0, dtype=np.float32, device=0, max_iter=2, tol=0.0, f32_gemm="split").fit(x)
+    assert out.f32_gemm == "mfma"
+    out._backend.close()
+
+
+def test_split_gemm_env_default(monkeypatch):
+    """LCX_F32_GEMM=split makes it the library's default for the handles that support it; an explicit f32_gemm="mfma" wins."""
+    from linearcorex_amd import Corex
+    monkeypatch.setenv("LCX_X_LAYOUT", "panel")
+    monkeypatch.setenv("LCX_GEMM", "ct")
+    monkeypatch.setenv("LCX_F32_GEMM", "split")
+    x = O.gen_planted(900, 2100, 8, seed=1)[0]
+    a = Corex(n_hidden=40, seed=0, dtype=np.float32, device=0, max_iter=2, tol=0.0).fit(x)
+    b = Corex(n_hidden=40, seed=0, dtype=np.float32, device=0, max_iter=2, tol=0.0, f32_gemm="mfma").fit(x)
+    assert a.f32_gemm == "split" and b.f32_gemm == "mfma"
+    assert "gemm_split_kernel" in a._backend.kernel_name(0) and "gemm_split_kernel" not in b._backend.kernel_name(0)
+    a._backend.close(); b._backend.close()

@@ -45,6 +45,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6
 FP32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense; the split float32 contraction issues 6 bf16 products per float32 product
+SPLIT_PRODUCTS = 6
 # What this chip has been seen to sustain (profiles/r01_read_probe_c2.txt, r01_mfma_peak.txt, the c3f64* workloads):
 # reported beside the spec-based fraction, never instead of it.
 MEASURED_CEILINGS = {"hbm_read_GBps": 6470.0, "mfma_f64_TFLOPs": 72.0, "mfma_f64_16x16x4_TFLOPs": 59.9,
@@ -120,6 +122,9 @@ def parse(argv=None):
                     help="exact (default, the headline): reference-shaped, every trial makes 2 passes over X "
                          "(linearcorex.py:321); linear: trials cost no pass over X")
     ap.add_argument("--repeats", type=int, default=0, help="walks of the schedule (0 = as many as MIN_TIMED_SECONDS needs)")
+    ap.add_argument("--f32-gemm", default="mfma", choices=["mfma", "split"],
+                    help="arithmetic of the X passes of the float32 workloads behind `value` (include/lcx.h lcx_set_f32_gemm): float32 MFMA "
+                         "(default) or the exact three-way bf16 split on the bf16 matrix pipe; the other one is measured beside it")
     args = ap.parse_args(argv)
     _adhoc(args.workload)
     return args
@@ -404,14 +409,14 @@ def load_rocprof_avg(workload, kernel):
 # ------------------------------------------------------------------------------------------------------
 # the measurement
 # ------------------------------------------------------------------------------------------------------
-def make_model(workload, comm, world, rank, local_rank, line_search, keep_x=False):
+def make_model(workload, comm, world, rank, local_rank, line_search, keep_x=False, f32_gemm=None):
     import numpy as np
     from linearcorex_amd import Corex
     n, v_per, m, tag = WORKLOADS[workload]
     dtype = np.float64 if tag == "f64" else np.float32
     v_total = v_per * world
     model = Corex(n_hidden=m, seed=0, dtype=dtype, tol=0.0, max_iter=10 ** 9, device=local_rank, comm=comm,
-                  line_search=line_search)
+                  line_search=line_search, f32_gemm=f32_gemm if tag == "f32" else None)
     x_host = None
     if n * v_per * 8 <= (4 << 30):
         # Gen-A: iid N(0,1); rank r draws its own columns from RandomState(1 + r)
@@ -430,13 +435,14 @@ def make_model(workload, comm, world, rank, local_rank, line_search, keep_x=Fals
 
 
 def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_search, keep_x=False, repeats=0,
-            kernel_timing=True, min_repeats=1):
+            kernel_timing=True, min_repeats=1, f32_gemm=None):
     """Walk the 7-stage schedule; per stage: the stage change (timed on its own), then a window of exactly `steps`
     iterations (barrier + synchronize on both sides).  Repeat the walk from the same start until MIN_TIMED_SECONDS
     of windows have been timed."""
     import numpy as np
     import torch
-    model, be, x_host = make_model(workload, comm, world, rank, local_rank, line_search, keep_x)
+    model, be, x_host = make_model(workload, comm, world, rank, local_rank, line_search, keep_x,
+                                   f32_gemm if f32_gemm is not None else args.f32_gemm)
 
     def sync():
         be.synchronize()
@@ -546,6 +552,7 @@ def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_s
             "iterations_per_sec_incl_stage_changes": float(n_stages * steps / (stage_med.sum() + np.median(chgs, axis=0).sum())),
         },
         "bytes_resident": be.bytes_resident() if hasattr(be, "bytes_resident") else None,
+        "f32_gemm": getattr(model, "f32_gemm", "mfma"),
         "exchange": dict(be.exchange_info(), transport=getattr(model, "_engine_exchange", None),
                          selftest_seconds_per_y_allreduce=getattr(comm, "selftest_seconds", None),
                          line_search_in_library=bool(getattr(model, "_iterated_in_library", False))),
@@ -592,7 +599,13 @@ def roofline_of(workload, r, world):
         alg_bytes, alg_flops = site_bytes["gemm_nt2"], site_flops["gemm_nt2"]
     intensity = alg_flops / alg_bytes
     mfma_peak = FP64_MFMA_PEAK_TFLOPS if tag == "f64" else FP32_MFMA_PEAK_TFLOPS
-    traffic, tinfo = load_pmc_traffic(workload, dom)
+    split = r.get("f32_gemm") == "split" and "gemm_split_kernel" in dom
+    if split:
+        # float32 products on the bf16 pipe: 6 bf16 MFMA products per float32 product - the matrix roof of the USEFUL float32 flops
+        # is the dense bf16 peak / 6 (417 TF/s), and 64 factors then sit under the HBM roof
+        mfma_peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
+    prof_name = workload + ("_split" if split else "")       # the profiles of the split mode are a run of their own (tools/gpu_prof.sh)
+    traffic, tinfo = load_pmc_traffic(prof_name, dom)
     if intensity < mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9):
         roofline = {"bound": "hbm", "achieved": by_fn[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": by_fn[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic}
@@ -600,6 +613,12 @@ def roofline_of(workload, r, world):
         roofline = {"bound": "mfma", "achieved": by_fn[dom]["TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s",
                     "frac": by_fn[dom]["TFLOPs"] / mfma_peak, "traffic": traffic}
     mfma_ceiling = MEASURED_CEILINGS["mfma_f64_TFLOPs" if tag == "f64" else "mfma_f32_TFLOPs"]
+    if split:
+        roofline["f32_gemm"] = ("split: every operand = 3 bf16 parts (exact), %d of 9 partial products, float32 accumulation; TFLOP/s "
+                                "figures count the float32 flops of the contraction once" % SPLIT_PRODUCTS)
+        roofline["bf16_pipe_TFLOPs"] = SPLIT_PRODUCTS * by_fn[dom]["TFLOPs"]
+        roofline["frac_of_bf16_mfma_peak"] = SPLIT_PRODUCTS * by_fn[dom]["TFLOPs"] / BF16_MFMA_PEAK_TFLOPS
+        roofline["x_float32_mfma_peak"] = by_fn[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS
     roofline.update(workload=workload, achieved_GBps=by_fn[dom]["GBps"], achieved_TFLOPs=by_fn[dom]["TFLOPs"],
                     frac_of_measured_hbm_read_ceiling=by_fn[dom]["GBps"] / MEASURED_CEILINGS["hbm_read_GBps"],
                     frac_of_measured_mfma_ceiling=by_fn[dom]["TFLOPs"] / mfma_ceiling,
@@ -619,7 +638,7 @@ def roofline_of(workload, r, world):
         k2 = kernels["gemm_nt2"]
         roofline["merged_pass"] = {"kernel": r["kernel_names"]["gemm_nt2"], "avg_launch_us": k2["avg_us"], "launches": k2["launches"],
                                    "achieved_TFLOPs": k2["TFLOPs"], "frac": k2["TFLOPs"] / mfma_peak}
-    rp_us, rp_src = load_rocprof_avg(workload, dom)
+    rp_us, rp_src = load_rocprof_avg(prof_name, dom)
     roofline.update(rocprofv3_avg_kernel_us=rp_us, rocprofv3_source=rp_src)
     # whole-iteration view: algorithmic bytes / flops of the X passes an iteration makes over the iteration time
     if r["x_passes"]:
@@ -645,7 +664,7 @@ def config_of(workload, r, world, line_search, force_exchange=False):
             "n_samples": n, "n_variables_total": v_total, "n_variables_per_gpu": v_per, "n_hidden": m,
             "fit_iterations_per_sec": r["its_per_s"],
             "line_search_trials_per_iteration": r["trials"], "invalid_trials_per_iteration": r["invalid"],
-            "line_search": line_search,
+            "line_search": line_search, "f32_gemm": r.get("f32_gemm") if tag == "f32" else None,
             "x_passes_per_iteration": r["x_passes"],
             "x_passes_per_iteration_reference_shaped": 2 + 2 * r["trials"] - r["invalid"],
             "windows": r["windows"], "launch_geometry": r["geo"], "final_TC": r["final_tc"],
@@ -654,6 +673,32 @@ def config_of(workload, r, world, line_search, force_exchange=False):
             # (include/lcx.h lcx_comm_init); "hook" = the library through the caller's transport; None / "caller" = the
             # host-sequenced path (LCX_EXCHANGE=torch); kind "none" = one rank, no exchange steps
             "exchange": r.get("exchange")}
+
+
+def other_gemm_name(args):
+    return "f32_gemm_split" if args.f32_gemm == "mfma" else "f32_gemm_mfma"
+
+
+def other_gemm_block(args, comm, world, rank, local_rank, workload, steps, warmup, line_search, r_head):
+    """The same workload with the OTHER arithmetic of the float32 X passes (lcx_set_f32_gemm): reported beside `value`, never as it.
+    With the default --f32-gemm mfma this is the bf16 split: same iterations, same trajectory to float32 rounding (the final TC
+    of both is in the block), X passes 1.3-1.5 x faster."""
+    other = "split" if args.f32_gemm == "mfma" else "mfma"
+    r7, model7, be7 = measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_search, f32_gemm=other)
+    rl = roofline_of(workload, r7, world) or {}
+    blk = {"f32_gemm": r7["f32_gemm"], "fit_iterations_per_sec": r7["its_per_s"] * world, "ms_per_step": r7["per_step_s"] * 1e3,
+           "speedup_vs_value_mode": r7["its_per_s"] / r_head["its_per_s"],
+           "x_passes_per_iteration": r7["x_passes"], "line_search_trials_per_iteration": r7["trials"],
+           "final_TC": r7["final_tc"], "final_TC_value_mode": r_head["final_tc"],
+           "final_TC_relative_difference": abs(r7["final_tc"] - r_head["final_tc"]) / max(1.0, abs(r_head["final_tc"])),
+           "ms_per_step_walk_min_median_max": r7["windows"]["ms_per_step_walk_min_median_max"],
+           "roofline": {k: rl.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_us", "launches", "achieved_GBps",
+                                               "achieved_TFLOPs", "bf16_pipe_TFLOPs", "frac_of_bf16_mfma_peak", "x_float32_mfma_peak",
+                                               "frac_by_site", "kernel_by_site", "f32_gemm")},
+           "pass_ms": {k: v["avg_us"] / 1e3 for k, v in (rl.get("use_sites") or {}).items()}}
+    be7.close()
+    model7._backend = None
+    return blk
 
 
 def linear_mode_block(workload, r3, world):
@@ -793,6 +838,13 @@ def compact_line(out, detail_path):
         "reference_shaped_value": _pick(cfg, "reference_shaped", "fit_iterations_per_sec"),
         "exact_y_value": _pick(cfg, "later_trials_by_linearity", "fit_iterations_per_sec"),
         "linear_value": _pick(cfg, "linear_trial_mode", "fit_iterations_per_sec"),
+        # the X passes of the float32 workload on the bf16 matrix pipe (exact 3-way split, lcx_set_f32_gemm): beside `value`
+        "f32_gemm": cfg.get("f32_gemm"),
+        "f32_gemm_split_value": _pick(cfg, "f32_gemm_split", "fit_iterations_per_sec"),
+        "f32_gemm_split_final_TC_rel_diff": _pick(cfg, "f32_gemm_split", "final_TC_relative_difference"),
+        "f32_gemm_split_roofline_bound": _pick(cfg, "f32_gemm_split", "roofline", "bound"),
+        "f32_gemm_split_roofline_frac": _pick(cfg, "f32_gemm_split", "roofline", "frac"),
+        "f32_gemm_mfma_value": _pick(cfg, "f32_gemm_mfma", "fit_iterations_per_sec"),
         "merged_pass_roofline_frac": _pick(out, "roofline", "merged_pass", "frac"),
         "xbt_pass_roofline_frac": _pick(out, "roofline", "frac_by_site", "gemm_nt"),
         "xty_pass_roofline_frac": _pick(out, "roofline", "frac_by_site", "gemm_tn"),
@@ -812,6 +864,7 @@ def compact_line(out, detail_path):
             riders[name + "_xty_pass_roofline_frac"] = _pick(b, "roofline", "frac_by_site", "gemm_tn")
             riders[name + "_roofline_bound"] = _pick(b, "roofline", "bound")
             riders[name + "_reference_shaped_value"] = _pick(b, "reference_shaped", "fit_iterations_per_sec")
+            riders[name + "_f32_gemm_split_value"] = _pick(b, "f32_gemm_split", "fit_iterations_per_sec")
             riders[name + "_cpu_baseline_value"] = _pick(b, "cpu_baseline", "value")
             riders[name + "_fit_to_convergence_seconds"] = _pick(b, "fit_to_convergence", "seconds")
     c.update({k: v for k, v in riders.items() if v is not None})
@@ -979,6 +1032,8 @@ def main():
             be3.close()
             model3._backend = None
             del model3, be3
+    if args.extras and generated and tag == "f32":
+        cfg[other_gemm_name(args)] = other_gemm_block(args, comm, world, rank, local_rank, head, args.steps, args.warmup, args.line_search, r)
     if args.extras and world == 1 and comm is None and generated and args.convergence_max_iter > 0:
         # BASELINE.json's second figure for the headline workload.  On the iid matrix of the throughput run there is nothing to
         # converge to (every stage runs into the cap): that run is labelled as capped, and the convergence measurement proper is
@@ -995,7 +1050,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": r["per_step_s"] * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": tag, "data": "synthetic",
+        "dtype": tag if r.get("f32_gemm") != "split" else "f32 as 3 x bf16 (exact split, 6 partial products, f32 accumulate)",
+        "data": "synthetic",
         "config": cfg,
         "roofline": roofline,
         "cpu_baseline": None,
@@ -1080,6 +1136,7 @@ def main():
                 be5.close()
                 model5._backend = None
                 del model5, be5
+            c4[other_gemm_name(args)] = other_gemm_block(args, comm, world, rank, local_rank, "c4shard", 10, 3, c4_ls, r4)
             out["config"]["c4shard"] = c4
             # ---- configs[3] as ONE problem on this one GPU: 50 000 x 1 000 000 x 128 float32, 200 GB of X.  Two resident copies
             # do not fit 288 GB, so the engine keeps the row-major copy only and X.B^T runs on gemm_cr (chosen by itself).  The

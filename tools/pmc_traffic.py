@@ -82,6 +82,7 @@ def main():
         # MOPS counters are in units of 512 flop (rocprofv3 -L: MfmaFlopsF64 = SQ_INSTS_VALU_MFMA_MOPS_F64 * 512)
         busy, act = collect(a.mfma, "SQ_VALU_MFMA_BUSY_CYCLES"), collect(a.mfma, "GRBM_GUI_ACTIVE")
         m64, m32 = collect(a.mfma, "SQ_INSTS_VALU_MFMA_MOPS_F64"), collect(a.mfma, "SQ_INSTS_VALU_MFMA_MOPS_F32")
+        mb16 = collect(a.mfma, "SQ_INSTS_VALU_MFMA_MOPS_BF16")       # the split float32 contraction: 6 bf16 products per float32 product
         for k in busy:
             d = kernels.setdefault(k, {})
             n = busy[k]["launches"]
@@ -94,6 +95,8 @@ def main():
             flops = 512.0 * ((m64[k]["sum"] / m64[k]["launches"] if k in m64 else 0.0) +
                              (m32[k]["sum"] / m32[k]["launches"] if k in m32 else 0.0))
             d["mfma_flops_per_launch"] = flops
+            if k in mb16 and mb16[k]["sum"] > 0:
+                d["mfma_bf16_flops_per_launch"] = 512.0 * mb16[k]["sum"] / mb16[k]["launches"]
     lib_hash = a.lib_src_hash
     if lib_hash is None:
         try:

@@ -40,10 +40,11 @@ def main():
     comm = Comm()
     mark("rendezvous done")
     x, _ = O.gen_planted(n, v, m, seed=2)
+    dt = np.float32 if os.environ.get("LCX_TEST_DTYPE") == "f32" else np.float64
     if backend == "hip":
         # every rank drives its own engine handle on GPU 0; the exchange tensors are CUDA tensors and the
         # collectives go through gloo (RCCL refuses two ranks on one device) - same host code as bench.py
-        model = Corex(n_hidden=m, seed=0, dtype=np.float64, comm=comm, line_search=mode, device=0, max_iter=max_iter,
+        model = Corex(n_hidden=m, seed=0, dtype=dt, comm=comm, line_search=mode, device=0, max_iter=max_iter,
                       discourage_overlap=not syn)
     else:
         model = Corex(n_hidden=m, seed=0, dtype=np.float64, comm=comm, line_search=mode, max_iter=max_iter,
@@ -55,7 +56,7 @@ def main():
     c0, c1 = comm.shard(v)
     assert model._backend.nv == c1 - c0
     y = model.transform(x)
-    assert y_resident.shape == y.shape and np.max(np.abs(y_resident - y)) < 1e-11 * max(1.0, float(np.max(np.abs(y))))
+    assert y_resident.shape == y.shape and np.max(np.abs(y_resident - y)) < (1e-11 if dt == np.float64 else 2e-5) * max(1.0, float(np.max(np.abs(y))))
     xr = model.predict(y[:50])              # sharded columns of the product, gathered: a collective like transform
     if os.environ.get("LCX_EAGER_GATHER_ELEMS") == "0":
         # sharded moments were NOT put together at the end of fit: touching one must raise (never a hidden collective that
@@ -92,7 +93,8 @@ def main():
         np.savez(os.path.join(out_dir, "dist_result.npz"), history=np.asarray(model.history["TC"], np.float64),
                  ws=model.ws, clusters=model.clusters(), transform=y, predict=xr, rho=rho, xz=xz, si=si, cov=cov, cov_rows=cov_rows, cov_row0=max(0, b - 100),
                  tcs=model.tcs, world=comm.world, trials=model.stats["trials"],
-                 transport=str(getattr(model, "_engine_exchange", None)),
+                 transport=str(getattr(model, "_engine_exchange", None)), f32_gemm=str(getattr(model, "f32_gemm", "mfma")),
+                 kernel=str(model._backend.kernel_name(0)) if hasattr(model._backend, "kernel_name") else "",
                  in_library=np.array(bool(getattr(model, "_iterated_in_library", False))),
                  calls=np.array(len(getattr(model._backend, "calls", []))))
     mark("results gathered")

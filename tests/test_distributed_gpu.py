@@ -93,6 +93,34 @@ def test_sharded_fit_on_device_matches_oracle(world, mode, shape, exchange, tmp_
     check_covariance(got, ref, 1e-6)           # sharded get_covariance (the north-star tolerance)
 
 
+def test_sharded_float32_fit_on_the_bf16_pipe(tmp_path, monkeypatch):
+    """Two ranks, float32, each shard in the panel-major layout with its X passes on the bf16 matrix pipe (LCX_F32_GEMM=split: exact
+    three-way split, 6 partial products) and the exchange steps inside the engine: the fit equals the float32 oracle's at the float32
+    bars of tests/test_parity_gpu.py, and the one-rank run of the same library in the same mode."""
+    for k, v_ in (("LCX_X_LAYOUT", "panel"), ("LCX_GEMM", "ct"), ("LCX_F32_GEMM", "split"), ("LCX_TEST_DTYPE", "f32")):
+        monkeypatch.setenv(k, v_)
+    n, v, m = 1500, 3000, 40
+    launch_hip(2, tmp_path, n, v, m, "exact", "engine")
+    got = np.load(os.path.join(tmp_path, "dist_result.npz"))
+    assert str(got["f32_gemm"]) == "split" and "gemm_split_kernel" in str(got["kernel"]) and bool(got["in_library"])
+    x, _ = O.gen_planted(n, v, m, seed=2)
+    ref = O.fit_ns(x, m, seed=0, dtype=np.float32, max_iter=MAX_ITER)
+    h, h_ref = got["history"], np.asarray(ref.history_tc, np.float64)
+    # float32: a stage stops one or two iterations earlier or later when |dTC| sits at the tolerance (the 6 % band of
+    # tests/test_parity_gpu.py); the first stage runs into the cap on every path and is compared element by element
+    def same_fit(a, b, tol):
+        assert abs(len(a) - len(b)) <= 0.06 * len(b), (len(a), len(b))
+        assert np.max(np.abs(a[:MAX_ITER] - b[:MAX_ITER]) / np.maximum(1, np.abs(b[:MAX_ITER]))) < tol
+        assert abs(a[-1] - b[-1]) < tol * abs(b[-1])
+    same_fit(h, h_ref, 2e-3)
+    from linearcorex_amd import Corex
+    one = Corex(n_hidden=m, seed=0, dtype=np.float32, device=0, max_iter=MAX_ITER).fit(x)
+    assert one.f32_gemm == "split"
+    same_fit(h, np.asarray(one.history["TC"], np.float64), 5e-4)
+    assert np.mean(got["clusters"] == one.clusters()) > 0.995
+    one._backend.close()
+
+
 def test_one_sided_rccl_failure_is_agreed_on(tmp_path, monkeypatch):
     """Advisor, round 3: ncclCommInitRank is collective - if ONE rank cannot even load librccl and raises before entering it, the
     others must not be left blocked inside.  Two ranks (gloo group, both on GPU 0) run the RCCL negotiation of Comm.bind_engine with

@@ -94,12 +94,13 @@ split_b_kernel(const float* __restrict__ B /* [K][Mp] */, u32x4_t* __restrict__ 
     }
 }
 
-template <int CT, int KW, int NP, bool CONTRACT_N, bool NT, bool PREFETCH_B, int WPE = 2>
+template <int CT, int KW, int NP, bool CONTRACT_N, bool NT, bool PREFETCH_B, int WPE = 2, int KS = 1, int PRIO = 0>
 __global__ void __launch_bounds__(64 * KW, WPE)
 gemm_split_kernel(const float* __restrict__ A /* panel-major */, int64_t ps, const u32x4_t* __restrict__ Bsp, float* __restrict__ out, int64_t out_rows,
-                   int64_t nrows, int ng, int nsuper, int maxslots, const int* __restrict__ skip_flag) {
+                   int64_t nrows, int ng /* groups of KS x 32 */, int nsuper, int maxslots, const int* __restrict__ skip_flag) {
     constexpr int Mp = 16 * CT, RT = 4, NTH = 64 * KW;
-    constexpr int PCS = 3 * CT * 64;                         // 16-byte pieces of one group of B
+    constexpr int PC1 = 3 * CT * 64;                         // 16-byte pieces of 32 contraction elements of B
+    constexpr int PCS = KS * PC1;                            // ... of one group
     constexpr int PPT = (PCS + NTH - 1) / NTH;
     __shared__ u32x4_t Bs[2][PCS];
     if (skip_flag != nullptr && *skip_flag != 0) return;
@@ -127,17 +128,18 @@ gemm_split_kernel(const float* __restrict__ A /* panel-major */, int64_t ps, con
 
         const float* ap = CONTRACT_N ? A + ((active ? v0 : 0) / 16 + (i >> 2)) * ps + (int64_t)g * 16 + (i & 3) * 4
                                      : A + ((active ? v0 : 0) + i) * 16 + g * 4;
-        f32x4_t raw[8];
+        f32x4_t raw[KS][8];
         u32x4_t bst[PPT];
         Split3 as[RT];
 
-#define LCX_SP_LOADA(R)                                                                   \
+        // the 8 x 16 bytes of k-step S of group R (clamped to the segment: the tail re-loads its last group instead of branching)
+#define LCX_SP_LOADA(R, S)                                                                \
         {                                                                                 \
-            const int64_t G = s0 + ((R) < cnt ? (R) : cnt - 1);                           \
+            const int64_t G = (int64_t)(s0 + ((R) < cnt ? (R) : cnt - 1)) * KS + (S);     \
             _Pragma("unroll") for (int m = 0; m < 8; ++m) {                               \
                 const f32x4_t* src = CONTRACT_N ? reinterpret_cast<const f32x4_t*>(ap + (32 * G + 4 * m) * 16) \
                                                 : reinterpret_cast<const f32x4_t*>(ap + (2 * G + (m & 1)) * ps + (int64_t)(16 * (m >> 1)) * 16); \
-                raw[m] = NT ? __builtin_nontemporal_load(src) : *src;                     \
+                raw[S][m] = NT ? __builtin_nontemporal_load(src) : *src;                  \
             }                                                                             \
         }
 #define LCX_SP_LOADB(R)                                                                   \
@@ -155,22 +157,22 @@ gemm_split_kernel(const float* __restrict__ A /* panel-major */, int64_t ps, con
                 if (PCS % NTH == 0 || pc < PCS) Bs[BUF][pc] = bst[p];                     \
             }                                                                             \
         }
-#define LCX_SP_SPLITA()                                                                   \
+#define LCX_SP_SPLITA(S)                                                                  \
         {                                                                                 \
             _Pragma("unroll") for (int t = 0; t < RT; ++t) {                              \
                 float x[8];                                                               \
                 _Pragma("unroll") for (int e = 0; e < 8; ++e)                             \
-                    x[e] = CONTRACT_N ? raw[e][t] : raw[2 * t + (e >> 2)][e & 3];         \
+                    x[e] = CONTRACT_N ? raw[S][e][t] : raw[S][2 * t + (e >> 2)][e & 3];   \
                 as[t] = split8(x);                                                        \
             }                                                                             \
         }
-#define LCX_SP_MMA(BUF)                                                                   \
+#define LCX_SP_MMA(BUF, S)                                                                \
         if constexpr (PREFETCH_B) {                                                       \
             Split3 bf[2];                                                                 \
-            _Pragma("unroll") for (int q = 0; q < 3; ++q) bf[0].p[q] = Bs[BUF][(q * CT) * 64 + lane]; \
+            _Pragma("unroll") for (int q = 0; q < 3; ++q) bf[0].p[q] = Bs[BUF][(S) * PC1 + (q * CT) * 64 + lane]; \
             _Pragma("unroll") for (int u = 0; u < CT; ++u) {                              \
                 if (u + 1 < CT) {                                                         \
-                    _Pragma("unroll") for (int q = 0; q < 3; ++q) bf[(u + 1) & 1].p[q] = Bs[BUF][(q * CT + u + 1) * 64 + lane]; \
+                    _Pragma("unroll") for (int q = 0; q < 3; ++q) bf[(u + 1) & 1].p[q] = Bs[BUF][(S) * PC1 + (q * CT + u + 1) * 64 + lane]; \
                 }                                                                         \
                 _Pragma("unroll") for (int k = 8 - NP; k < 8; ++k)                        \
                 _Pragma("unroll") for (int t = 0; t < RT; ++t)                            \
@@ -179,23 +181,36 @@ gemm_split_kernel(const float* __restrict__ A /* panel-major */, int64_t ps, con
         } else {                                                                          \
             _Pragma("unroll") for (int u = 0; u < CT; ++u) {                              \
                 Split3 b;                                                                 \
-                _Pragma("unroll") for (int q = 0; q < 3; ++q) b.p[q] = Bs[BUF][(q * CT + u) * 64 + lane]; \
+                _Pragma("unroll") for (int q = 0; q < 3; ++q) b.p[q] = Bs[BUF][(S) * PC1 + (q * CT + u) * 64 + lane]; \
                 _Pragma("unroll") for (int k = 8 - NP; k < 8; ++k)                        \
                 _Pragma("unroll") for (int t = 0; t < RT; ++t)                            \
                     acc[t][u] = mma_bf16(as[t].p[SPLIT_PA[k]], b.p[SPLIT_PB[k]], acc[t][u]); \
             }                                                                             \
         }
 
+        // one barrier per group; the loads of the next group's k-step S are issued as soon as this group's k-step S has been split
+        // (B first: the in-order load counter then lets the staging wait on B without waiting on the younger A loads)
         LCX_SP_LOADB(0);
-        LCX_SP_LOADA(0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) LCX_SP_LOADA(0, ks);
         for (int r = 0; r < cnt; ++r) {
             const int buf = r & 1;
             LCX_SP_STOREB(buf);
-            LCX_SP_SPLITA();
+            LCX_SP_SPLITA(0);
             LCX_SP_LOADB(r + 1);
-            LCX_SP_LOADA(r + 1);
+            LCX_SP_LOADA(r + 1, 0);
             __syncthreads();
-            LCX_SP_MMA(buf);
+            if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
+            LCX_SP_MMA(buf, 0);
+#pragma unroll
+            for (int ks = 1; ks < KS; ++ks) {
+                if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
+                LCX_SP_SPLITA(ks);
+                LCX_SP_LOADA(r + 1, ks);
+                if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
+                LCX_SP_MMA(buf, ks);
+            }
+            if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
         }
 #undef LCX_SP_LOADA
 #undef LCX_SP_LOADB

@@ -460,21 +460,27 @@ static int launch_tn4(hipStream_t st, const double* A, int64_t lda, int64_t K, i
 // The same pass on the bf16 matrix pipe (float32 panel shards in split mode): B is split once (split_b_kernel), then the contraction
 // kernel with the unit / slot contract of launch_ct / launch_cr - same rows per block (KW x 64), same slot count; a unit is 32
 // contraction elements instead of 16, so nb is clamped to the unit count (every block must own at least one unit).
-template <int CT> struct SplitShape { static constexpr int KW = CT == 8 ? 8 : 4; };
+// 8 waves per block at 128 columns, 4 below; two 32-element steps per barrier where the LDS image allows two blocks per CU with it
+// (up to 64 columns), MFMA phase at raised wave priority (tools/gemm_probe9: -6 % on the 64-column passes, nil at 128)
+template <int CT> struct SplitShape {
+    static constexpr int KW = CT == 8 ? 8 : 4;
+    static constexpr int KS = CT <= 4 ? 2 : 1;
+    static constexpr int PRIO = 1;
+};
 template <int CT, bool CONTRACT_N>
 static int launch_split(hipStream_t st, const float* A, int64_t ps, int64_t K, int64_t rows, const float* B, float* out, int nb, int nsuper,
                         int maxslots, const int* skip, void* bsp) {
     if constexpr (CT == 2 || CT == 4 || CT == 8) {
-        constexpr int KW = SplitShape<CT>::KW;
-        const int ng = (int)(K / SPLIT_KG);
+        constexpr int KW = SplitShape<CT>::KW, KS = SplitShape<CT>::KS;
+        const int ng32 = (int)(K / SPLIT_KG), ng = ng32 / KS;          // K is a multiple of 64 (padded sizes)
         u32x4_t* sp = reinterpret_cast<u32x4_t*>(bsp);
-        const int64_t tasks = (int64_t)ng * 64 * CT;
+        const int64_t tasks = (int64_t)ng32 * 64 * CT;
         hipLaunchKernelGGL((split_b_kernel<CT, CONTRACT_N>), dim3((unsigned)(cdiv(tasks, 256) < 2048 ? cdiv(tasks, 256) : 2048)), dim3(256), 0, st, B, sp,
-                           ng, skip);
+                           ng32, skip);
         const int64_t total = (int64_t)nsuper * ng;
         if (nb > total) nb = (int)total;
-        hipLaunchKernelGGL((gemm_split_kernel<CT, KW, 6, CONTRACT_N, true, false, 2>), dim3((unsigned)nb), dim3(64 * KW), 0, st, A, ps,
-                           (const u32x4_t*)sp, out, rows, rows, ng, nsuper, maxslots, skip);
+        hipLaunchKernelGGL((gemm_split_kernel<CT, KW, 6, CONTRACT_N, true, false, 2, KS, SplitShape<CT>::PRIO>), dim3((unsigned)nb), dim3(64 * KW), 0, st,
+                           A, ps, (const u32x4_t*)sp, out, rows, rows, ng, nsuper, maxslots, skip);
         KCHECK();
         return LCX_OK;
     } else {
@@ -1890,7 +1896,8 @@ template <typename T, int CT> struct Impl {
         if (h->split) {
             if (kind == 2 && !h->merged_ok) { buf[0] = 0; return LCX_OK; }
             const int ct = kind == 2 ? 2 * CT : CT;
-            snprintf(buf, (size_t)len, "lcx::gemm_split_kernel<%d, %d, 6, %s, true, false, 2>", ct, ct == 8 ? 8 : 4, kind == 1 ? "true" : "false");
+            snprintf(buf, (size_t)len, "lcx::gemm_split_kernel<%d, %d, 6, %s, true, false, 2, %d, 1>", ct, ct == 8 ? 8 : 4, kind == 1 ? "true" : "false",
+                     ct <= 4 ? 2 : 1);
             return LCX_OK;
         }
         if (kind == 2) {

@@ -24,7 +24,7 @@ def _check_kernels(be, gemm):
     assert be.set_f32_gemm(gemm) == gemm
     if gemm == "split":
         assert "gemm_split_kernel" in be.kernel_name(0) and "gemm_split_kernel" in be.kernel_name(1)
-        assert ", false, true, false, 2>" in be.kernel_name(0) and ", true, true, false, 2>" in be.kernel_name(1)
+        assert ", false, true, false, 2," in be.kernel_name(0) and ", true, true, false, 2," in be.kernel_name(1)
     else:
         assert "gemm_cr_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)
 

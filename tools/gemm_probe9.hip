@@ -44,17 +44,17 @@ Variant mkprod(const float* XP, int64_t nrows_pad, int64_t K, int64_t rows, cons
     return Variant{buf, [=] { hipLaunchKernelGGL((gemm_cr_kernel<float, CT, RT, KW, U, true, true>), dim3(nb), dim3(64 * KW), 0, 0, XP, ps, B, out, rows, rows, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
 }
 
-template <int CT, int KW, int NP, bool CONTRACT_N, bool NT, bool PF, int WPE>
+template <int CT, int KW, int NP, bool CONTRACT_N, bool NT, bool PF, int WPE, int KS = 1, int PRIO = 0>
 Variant mksplit(const float* XP, int64_t nrows_pad, int64_t K, int64_t rows, const float* B, u32x4_t* Bsp, float* out, int bpc_use) {
-    auto kern = gemm_split_kernel<CT, KW, NP, CONTRACT_N, NT, PF, WPE>;
+    auto kern = gemm_split_kernel<CT, KW, NP, CONTRACT_N, NT, PF, WPE, KS, PRIO>;
     int nb, nsuper, maxslots, bpc;
-    const int ng = (int)(K / SPLIT_KG);
+    const int ng = (int)(K / (SPLIT_KG * KS));
     geometry((const void*)kern, 64 * KW, bpc_use, rows, KW * 64, ng, &nb, &nsuper, &maxslots, &bpc);
     char buf[200];
-    snprintf(buf, 200, "bf16 x %d, B split ahead KW=%d prefetch=%d wpe=%d bpc=%d(use %d) slots=%d", NP, KW, (int)PF, WPE, bpc, bpc_use, maxslots);
+    snprintf(buf, 200, "bf16 x %d KW=%d pf=%d wpe=%d ks=%d prio=%d nt=%d bpc=%d(use %d) slots=%d", NP, KW, (int)PF, WPE, KS, PRIO, (int)NT, bpc, bpc_use, maxslots);
     const int64_t ps = nrows_pad * 16;
     return Variant{buf, [=] {
-        hipLaunchKernelGGL((split_b_kernel<CT, CONTRACT_N>), dim3(1024), dim3(256), 0, 0, B, Bsp, ng, (const int*)nullptr);
+        hipLaunchKernelGGL((split_b_kernel<CT, CONTRACT_N>), dim3(1024), dim3(256), 0, 0, B, Bsp, ng * KS, (const int*)nullptr);
         hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, XP, ps, (const u32x4_t*)Bsp, out, rows, rows, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
 }
 
@@ -154,12 +154,19 @@ void suite(const char* name, int64_t N, int64_t V) {
             vs.push_back(mkprod<CT, CtShape<float, CT>::KW, CN>(XP, N, K, rows, B, out, CT == 8 ? 1 : 2));
             if constexpr (CT <= 4) {
                 vs.push_back(mksplit<CT, 4, 6, CN, true, false, 2>(XP, N, K, rows, B, Bsp, out, 0));
-                vs.push_back(mksplit<CT, 4, 6, CN, true, true, 2>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 4, 6, CN, false, false, 2>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 4, 6, CN, true, false, 2, 1, 1>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 4, 6, CN, true, false, 2, 2, 0>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 4, 6, CN, true, true, 2, 2, 0>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 4, 6, CN, true, false, 2, 2, 1>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 2, 0>(XP, N, K, rows, B, Bsp, out, 0));
+            } else {
+                vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 8, 6, CN, false, false, 2>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 1, 1>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 4, 6, CN, true, false, 1, 1, 0>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 4, 6, CN, true, true, 1, 1, 1>(XP, N, K, rows, B, Bsp, out, 0));
             }
-            vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2>(XP, N, K, rows, B, Bsp, out, 0));
-            vs.push_back(mksplit<CT, 8, 6, CN, true, true, 2>(XP, N, K, rows, B, Bsp, out, 0));
-            vs.push_back(mksplit<CT, 4, 6, CN, true, true, 1>(XP, N, K, rows, B, Bsp, out, 0));
-            vs.push_back(mksplit<CT, 8, 3, CN, true, false, 2>(XP, N, K, rows, B, Bsp, out, 0));
         };
         if (cn) add(std::true_type{}); else add(std::false_type{});
         for (auto& v : vs) accuracy(v, out, rows, Mp, href, row0, row_step, NREF);

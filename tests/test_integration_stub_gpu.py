@@ -173,3 +173,43 @@ def test_round4_entry_points_through_raw_ctypes(monkeypatch):
         assert b"no transport" in lib.lcx_last_error()
         assert lib.lcx_destroy(h) == 0
     assert lib.lcx_comm_probe() == 0, lib.lcx_last_error()       # librccl ships with the ROCm image
+
+
+def test_f32_gemm_entry_points_through_raw_ctypes(monkeypatch):
+    """lcx_set_f32_gemm / lcx_f32_gemm bound the way a reference maintainer would bind them: a float32 panel shard switches between the
+    float32 MFMA and the bf16-split X passes between two launches (same moments to float32 rounding, both at the float32 bar against
+    the oracle); a float64 handle and a row-major shard accept the call and stay in mode 0; a bad mode is refused."""
+    lib = C.CDLL(os.path.join(ROOT, "linearcorex_amd", "liblcx_hip.so"))
+    lib.lcx_last_error.restype = C.c_char_p
+    _p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rng = np.random.RandomState(4)
+    n, v, m = 1280, 1900, 40
+    x = O.preprocess(rng.randn(n, v))[0].astype(np.float32)
+    w = rng.randn(m, v).astype(np.float32)
+    w /= (10.0 * O.norm(x, w, 0))[:, np.newaxis]
+    ref = O.moments_ns(x.astype(np.float64), w.astype(np.float64), 0.0, quick=False)
+    for lay, dt, can in (("panel", 0, True), ("rows", 0, False), ("panel", 1, False)):       # 0 = LCX_F32, 1 = LCX_F64
+        monkeypatch.setenv("LCX_X_LAYOUT", lay)
+        monkeypatch.setenv("LCX_GEMM", "ct")
+        h = C.c_void_p()
+        assert lib.lcx_create(C.byref(h), C.c_int64(n), C.c_int64(v), m, dt, 0) == 0, lib.lcx_last_error()
+        mode = C.c_int(-1)
+        assert lib.lcx_f32_gemm(h, C.byref(mode)) == 0 and mode.value == 0          # the default
+        assert lib.lcx_f32_gemm(h, None) != 0 and lib.lcx_set_f32_gemm(h, 2) != 0
+        xx, ww = (x, w) if dt == 0 else (x.astype(np.float64), w.astype(np.float64))
+        assert lib.lcx_upload_x(h, _p(np.ascontiguousarray(xx)), C.c_int64(v)) == 0
+        assert lib.lcx_set_ws(h, _p(np.ascontiguousarray(ww))) == 0
+        tcs = []
+        for want in (1, 0):
+            assert lib.lcx_set_f32_gemm(h, want) == 0
+            assert lib.lcx_f32_gemm(h, C.byref(mode)) == 0 and mode.value == (want if can else 0)
+            name = C.create_string_buffer(256)
+            assert lib.lcx_kernel_name(h, 0, name, C.c_int64(256)) == 0
+            assert (b"gemm_split_kernel" in name.value) == (mode.value == 1)
+            assert lib.lcx_moments_a(h, 0) == 0 and lib.lcx_moments_b(h, 0, C.c_double(0.0), 0) == 0 and lib.lcx_moments_c(h, 0) == 0
+            s = (C.c_double * 8)()
+            assert lib.lcx_read_state(h, 0, s) == 0
+            assert abs(s[0] - float(ref["TC"])) < (2e-4 if dt == 0 else 1e-9) * max(1.0, abs(float(ref["TC"])))
+            tcs.append(s[0])
+        assert abs(tcs[0] - tcs[1]) < 1e-5 * max(1.0, abs(tcs[1]))
+        assert lib.lcx_destroy(h) == 0

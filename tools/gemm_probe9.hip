@@ -160,6 +160,10 @@ void suite(const char* name, int64_t N, int64_t V) {
                 vs.push_back(mksplit<CT, 4, 6, CN, true, true, 2, 2, 0>(XP, N, K, rows, B, Bsp, out, 0));
                 vs.push_back(mksplit<CT, 4, 6, CN, true, false, 2, 2, 1>(XP, N, K, rows, B, Bsp, out, 0));
                 vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 2, 0>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 2, 1>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 1, 1>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 4, 6, CN, true, false, 2, 2, 2>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 4, 6, CN, true, false, 2, 2, 3>(XP, N, K, rows, B, Bsp, out, 0));
             } else {
                 vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2>(XP, N, K, rows, B, Bsp, out, 0));
                 vs.push_back(mksplit<CT, 8, 6, CN, false, false, 2>(XP, N, K, rows, B, Bsp, out, 0));

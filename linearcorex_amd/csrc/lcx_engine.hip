@@ -458,18 +458,21 @@ static int launch_tn4(hipStream_t st, const double* A, int64_t lda, int64_t K, i
 }
 
 // The same pass on the bf16 matrix pipe (float32 panel shards in split mode): B is split once (split_b_kernel), then the contraction
-// kernel with the unit / slot contract of launch_ct / launch_cr - same rows per block (KW x 64), same slot count; a unit is 32
-// contraction elements instead of 16, so nb is clamped to the unit count (every block must own at least one unit).
-// 8 waves per block at 128 columns, 4 below; two 32-element steps per barrier where the LDS image allows two blocks per CU with it
-// (up to 64 columns), MFMA phase at raised wave priority (tools/gemm_probe9: -6 % on the 64-column passes, nil at 128)
+// kernel with the slot contract of launch_ct / launch_cr (out[slot][rows][Mp], `maxslots` slots, unused ones zero-filled) on a
+// geometry of its own: 64 and 128 columns run 8-wave blocks of 512 rows, one per CU (tools/gemm_probe9: -3 % against 2 x 4 waves at
+// 64 columns - B is re-read once per super tile, and every block must own at least one unit), so nsuper and nb are re-derived here;
+// the slot count cdiv(nb, nsuper) + 1 then stays within what lcx_create allocated for the float32 kernels (half the blocks on half
+// the super tiles).  Two 32-element steps per barrier where the LDS image allows it (up to 64 columns); MFMA phase at raised wave
+// priority (-1 ... -6 %).
 template <int CT> struct SplitShape {
-    static constexpr int KW = CT == 8 ? 8 : 4;
+    static constexpr int KW = CT >= 4 ? 8 : 4;
     static constexpr int KS = CT <= 4 ? 2 : 1;
-    static constexpr int PRIO = 1;
+    static constexpr int PRIO = CT == 8 ? 2 : 1;
+    static constexpr int BPC = KW == 8 ? 1 : 2;                  // resident blocks per CU (registers: 2 waves per SIMD)
 };
 template <int CT, bool CONTRACT_N>
-static int launch_split(hipStream_t st, const float* A, int64_t ps, int64_t K, int64_t rows, const float* B, float* out, int nb, int nsuper,
-                        int maxslots, const int* skip, void* bsp) {
+static int launch_split(hipStream_t st, const float* A, int64_t ps, int64_t K, int64_t rows, const float* B, float* out, int nb_f32, int maxslots,
+                        const int* skip, void* bsp, int n_cus) {
     if constexpr (CT == 2 || CT == 4 || CT == 8) {
         constexpr int KW = SplitShape<CT>::KW, KS = SplitShape<CT>::KS;
         const int ng32 = (int)(K / SPLIT_KG), ng = ng32 / KS;          // K is a multiple of 64 (padded sizes)
@@ -477,8 +480,13 @@ static int launch_split(hipStream_t st, const float* A, int64_t ps, int64_t K, i
         const int64_t tasks = (int64_t)ng32 * 64 * CT;
         hipLaunchKernelGGL((split_b_kernel<CT, CONTRACT_N>), dim3((unsigned)(cdiv(tasks, 256) < 2048 ? cdiv(tasks, 256) : 2048)), dim3(256), 0, st, B, sp,
                            ng32, skip);
+        const int nsuper = (int)cdiv(rows, KW * 64);
         const int64_t total = (int64_t)nsuper * ng;
-        if (nb > total) nb = (int)total;
+        int64_t nb = (int64_t)n_cus * SplitShape<CT>::BPC;
+        if (nb > nb_f32) nb = nb_f32;                                  // a forced block count (LCX_CT_NB) binds this launch too
+        if (nb > (int64_t)(maxslots - 1) * nsuper) nb = (int64_t)(maxslots - 1) * nsuper;
+        if (nb > total) nb = total;
+        if (nb < 1) nb = 1;
         hipLaunchKernelGGL((gemm_split_kernel<CT, KW, 6, CONTRACT_N, true, false, 2, KS, SplitShape<CT>::PRIO>), dim3((unsigned)nb), dim3(64 * KW), 0, st,
                            A, ps, (const u32x4_t*)sp, out, rows, rows, ng, nsuper, maxslots, skip);
         KCHECK();
@@ -505,10 +513,10 @@ template <typename T, int CT> static inline int ct_kw() {
 // gemm_ct launch: nb balanced blocks over (super tile, group) units; partial tiles -> out[slot][out_rows][Mp]
 template <typename T, int CT, bool PANEL = false>
 static int launch_ct(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t vcols, const T* B, T* out, int nb,
-                     int nsuper, int maxslots, const int* skip, void* bsp = nullptr) {
+                     int nsuper, int maxslots, const int* skip, void* bsp = nullptr, int n_cus = 0) {
     typedef CtShape<T, CT> S;
     if constexpr (PANEL && split_capable<T, CT>()) {
-        if (bsp) return launch_split<CT, true>(st, A, lda, K, vcols, B, out, nb, nsuper, maxslots, skip, bsp);
+        if (bsp) return launch_split<CT, true>(st, A, lda, K, vcols, B, out, nb, maxslots, skip, bsp, n_cus);
     }
     const int ng = (int)(K / (4 * S::U));
     if constexpr (sizeof(T) == 4 && CT == 8) {
@@ -529,10 +537,10 @@ static int launch_ct(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t
 // (PANEL: the panel-major copy, lda = the panel stride, non-temporal loads - every line is read once per pass)
 template <typename T, int CT, bool PANEL = false>
 static int launch_cr(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t nrows, const T* B, T* out, int nb, int nsuper,
-                     int maxslots, const int* skip, void* bsp = nullptr) {
+                     int maxslots, const int* skip, void* bsp = nullptr, int n_cus = 0) {
     typedef CtShape<T, CT> S;
     if constexpr (PANEL && split_capable<T, CT>()) {
-        if (bsp) return launch_split<CT, false>(st, A, lda, K, nrows, B, out, nb, nsuper, maxslots, skip, bsp);
+        if (bsp) return launch_split<CT, false>(st, A, lda, K, nrows, B, out, nb, maxslots, skip, bsp, n_cus);
     }
     const int ng = (int)(K / (4 * S::U));
     if constexpr (sizeof(T) == 4 && CT == 8) {
@@ -831,7 +839,7 @@ template <typename T, int CT> struct Impl {
         } else {
             if (h->panel)
                 LCXCHECK((launch_cr<T, CT, true>(h->stream, P<T>(h->X), h->Npad * PanelW<T>::v, h->ldx, h->Npad, B, dst, h->nt_nb, h->nt_nsuper,
-                                                 h->nt_S, skip, h->split ? h->bsp : nullptr)));
+                                                 h->nt_S, skip, h->split ? h->bsp : nullptr, h->n_cus)));
             else if (h->single_copy)
                 LCXCHECK((launch_cr<T, CT>(h->stream, P<T>(h->X), h->ldx, h->ldx, h->Npad, B, dst, h->nt_nb, h->nt_nsuper, h->nt_S, skip)));
             else if (h->nt_ct)
@@ -885,7 +893,7 @@ template <typename T, int CT> struct Impl {
         } else {
             if (h->panel)
                 LCXCHECK((launch_ct<T, CT, true>(h->stream, P<T>(h->X), h->Npad * PanelW<T>::v, h->Npad, h->ldx, P<T>(h->ybuf), P<T>(h->dpart),
-                                                 h->tn_nb, h->tn_nsuper, h->tn_S, skip, h->split ? h->bsp : nullptr)));
+                                                 h->tn_nb, h->tn_nsuper, h->tn_S, skip, h->split ? h->bsp : nullptr, h->n_cus)));
             else if (h->tn_ct)
                 LCXCHECK((launch_ct<T, CT>(h->stream, P<T>(h->X), h->ldx, h->Npad, h->ldx, P<T>(h->ybuf), P<T>(h->dpart), h->tn_nb, h->tn_nsuper,
                                            h->tn_S, skip)));
@@ -1144,7 +1152,7 @@ template <typename T, int CT> struct Impl {
             LCXCHECK(timing_begin(h, 2, &tp));
             if (h->panel)
                 LCXCHECK((launch_cr<T, 2 * CT, true>(h->stream, P<T>(h->X), h->Npad * PanelW<T>::v, h->ldx, h->Npad, P<T>(h->gw), P<T>(h->y2part),
-                                                     h->nt2_nb, h->nt2_nsuper, h->nt2_S, nullptr, h->split ? h->bsp : nullptr)));
+                                                     h->nt2_nb, h->nt2_nsuper, h->nt2_S, nullptr, h->split ? h->bsp : nullptr, h->n_cus)));
             else if (h->single_copy)
                 LCXCHECK((launch_cr<T, 2 * CT>(h->stream, P<T>(h->X), h->ldx, h->ldx, h->Npad, P<T>(h->gw), P<T>(h->y2part), h->nt2_nb,
                                                h->nt2_nsuper, h->nt2_S, nullptr)));
@@ -1866,15 +1874,10 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
 
-    // split mode (gemm_split_kernels.hpp) needs the panel-major copy, float32, 32 / 64 / 128 padded factors, and the block shapes the
-    // geometry was laid out for (rows per block of the float32 kernels = those of the split kernels)
+    // split mode (gemm_split_kernels.hpp) needs the panel-major copy, float32 and 32 / 64 / 128 padded factors
     static int split_supported(lcx_ctx* h) {
         if constexpr (!WIDE && split_capable<T, CT>()) {
-            if (!h->panel || ct_kw<T, CT>() != SplitShape<CT>::KW) return 0;
-            if constexpr (CT <= 4) {
-                if (h->merged_ok && ct_kw<T, 2 * CT>() != SplitShape<2 * CT>::KW) return 0;
-            }
-            return 1;
+            return h->panel ? 1 : 0;
         } else {
             (void)h;
             return 0;
@@ -1896,8 +1899,8 @@ template <typename T, int CT> struct Impl {
         if (h->split) {
             if (kind == 2 && !h->merged_ok) { buf[0] = 0; return LCX_OK; }
             const int ct = kind == 2 ? 2 * CT : CT;
-            snprintf(buf, (size_t)len, "lcx::gemm_split_kernel<%d, %d, 6, %s, true, false, 2, %d, 1>", ct, ct == 8 ? 8 : 4, kind == 1 ? "true" : "false",
-                     ct <= 4 ? 2 : 1);
+            snprintf(buf, (size_t)len, "lcx::gemm_split_kernel<%d, %d, 6, %s, true, false, 2, %d, %d>", ct, ct >= 4 ? 8 : 4, kind == 1 ? "true" : "false",
+                     ct <= 4 ? 2 : 1, ct == 8 ? 2 : 1);
             return LCX_OK;
         }
         if (kind == 2) {

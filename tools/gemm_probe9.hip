@@ -153,23 +153,20 @@ void suite(const char* name, int64_t N, int64_t V) {
             constexpr bool CN = decltype(cn_tag)::value;
             vs.push_back(mkprod<CT, CtShape<float, CT>::KW, CN>(XP, N, K, rows, B, out, CT == 8 ? 1 : 2));
             if constexpr (CT <= 4) {
-                vs.push_back(mksplit<CT, 4, 6, CN, true, false, 2>(XP, N, K, rows, B, Bsp, out, 0));
-                vs.push_back(mksplit<CT, 4, 6, CN, false, false, 2>(XP, N, K, rows, B, Bsp, out, 0));
-                vs.push_back(mksplit<CT, 4, 6, CN, true, false, 2, 1, 1>(XP, N, K, rows, B, Bsp, out, 0));
-                vs.push_back(mksplit<CT, 4, 6, CN, true, false, 2, 2, 0>(XP, N, K, rows, B, Bsp, out, 0));
-                vs.push_back(mksplit<CT, 4, 6, CN, true, true, 2, 2, 0>(XP, N, K, rows, B, Bsp, out, 0));
                 vs.push_back(mksplit<CT, 4, 6, CN, true, false, 2, 2, 1>(XP, N, K, rows, B, Bsp, out, 0));
-                vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 2, 0>(XP, N, K, rows, B, Bsp, out, 0));
-                vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 2, 1>(XP, N, K, rows, B, Bsp, out, 0));
-                vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 1, 1>(XP, N, K, rows, B, Bsp, out, 0));
                 vs.push_back(mksplit<CT, 4, 6, CN, true, false, 2, 2, 2>(XP, N, K, rows, B, Bsp, out, 0));
-                vs.push_back(mksplit<CT, 4, 6, CN, true, false, 2, 2, 3>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 2, 1>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 2, 2>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 8, 6, CN, true, true, 2, 2, 1>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 8, 3, CN, true, false, 2, 2, 1>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 8, 8, CN, true, false, 2, 2, 1>(XP, N, K, rows, B, Bsp, out, 0));
             } else {
-                vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2>(XP, N, K, rows, B, Bsp, out, 0));
-                vs.push_back(mksplit<CT, 8, 6, CN, false, false, 2>(XP, N, K, rows, B, Bsp, out, 0));
                 vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 1, 1>(XP, N, K, rows, B, Bsp, out, 0));
-                vs.push_back(mksplit<CT, 4, 6, CN, true, false, 1, 1, 0>(XP, N, K, rows, B, Bsp, out, 0));
-                vs.push_back(mksplit<CT, 4, 6, CN, true, true, 1, 1, 1>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 1, 2>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 1, 0>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 4, 6, CN, true, false, 1, 1, 1>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 8, 3, CN, true, false, 2, 1, 1>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplit<CT, 8, 8, CN, true, false, 2, 1, 1>(XP, N, K, rows, B, Bsp, out, 0));
             }
         };
         if (cn) add(std::true_type{}); else add(std::false_type{});

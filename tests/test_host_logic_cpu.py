@@ -70,6 +70,33 @@ def test_line_search_is_settled_before_any_data_moves(g1, monkeypatch):
         Corex(line_search="armijo")
 
 
+def test_f32_gemm_option_is_validated_and_settled_by_the_backend(g1):
+    """Corex(f32_gemm=...): validated in the constructor; what the fit RAN is what the backend says after being asked (the library
+    takes "split" only where the shard supports it; a backend without the entry point - the NumPy double - leaves "mfma");
+    pickles of earlier builds read back as "mfma"."""
+    import pickle
+    x = g1["x_raw"].astype(np.float64)
+    with pytest.raises(ValueError):
+        Corex(n_hidden=5, f32_gemm="bf16")
+    out = Corex(n_hidden=5, seed=0, dtype=np.float64, max_iter=2, f32_gemm="split", _backend_factory=FACTORY).fit(x)
+    assert out.f32_gemm == "mfma" and out._f32_gemm_asked == "split"
+
+    class Asked(ShardDouble):
+        def set_f32_gemm(self, mode):
+            self.asked = mode
+            return "split" if mode == "split" else "mfma"
+
+        def f32_gemm(self):
+            return "mfma"
+    for asked, ran in (("split", "split"), ("mfma", "mfma"), (None, "mfma")):
+        out = Corex(n_hidden=5, seed=0, dtype=np.float64, max_iter=2, f32_gemm=asked, _backend_factory=lambda *a: Asked(*a)).fit(x)
+        assert out.f32_gemm == ran and getattr(out._backend, "asked", None) == asked
+    back = pickle.loads(pickle.dumps(out))
+    state = back.__dict__
+    state.pop("f32_gemm", None); state.pop("_f32_gemm_asked", None)
+    assert back.f32_gemm == "mfma" and back._f32_gemm_asked is None
+
+
 @pytest.mark.parametrize("refresh", [1, 8, 10 ** 9])
 def test_linear_line_search_matches_exact(g1, refresh):
     """line_search='linear' evaluates trials without passes over X (linearity of X^T.(X.u^T));
@@ -287,6 +314,32 @@ def test_bench_roofline_accounting_with_the_merged_pass():
     assert 0.9 < it["fraction_of_step_inside_the_x_passes"] < 1.0
     # committed profiles are only quoted for the library they were taken from
     assert rf["traffic"] is None or rf["traffic_profile_matches_library"] is True
+
+
+def test_bench_roofline_of_the_split_float32_mode():
+    """bench.roofline_of for --f32-gemm split: the matrix roof of the useful float32 flops is the dense bf16 peak / 6, so 64 factors sit
+    under the HBM roof and 128 under the matrix one; the bf16-pipe rate and the multiple of the float32 MFMA peak are reported too;
+    committed profiles are looked up under <workload>_split."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    for wl, ct, ms in (("c3", 4, 3.6), ("c4shard", 8, 7.2)):
+        n, v, m, _ = bench.WORKLOADS[wl]
+        kn = lambda cn: "lcx::gemm_split_kernel<%d, 8, 6, %s, true, false, 2, %d, %d>" % (ct, cn, 2 if ct == 4 else 1, 1 if ct == 4 else 2)  # noqa: E731
+        r = {"timing": {"gemm_nt": (100, 100 * ms), "gemm_tn": (160, 160 * ms)}, "f32_gemm": "split",
+             "kernel_names": {"gemm_nt": kn("false"), "gemm_tn": kn("true"), "gemm_nt2": ""},
+             "every": 1, "x_passes": 2.6, "per_step_s": 2.7 * ms * 1e-3, "passes_by_site": {"gemm_nt": 1.0, "gemm_tn": 1.6}}
+        rf = bench.roofline_of(wl, r, 1)
+        flops, byts = 2.0 * n * v * m, 4.0 * (n * v + m * v + n * m)
+        assert rf["kernel"] == kn("true") and "split" in rf["f32_gemm"]
+        if wl == "c3":
+            assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["achieved"] - byts / (ms * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+        else:
+            assert rf["bound"] == "mfma" and abs(rf["peak"] - 2500.0 / 6) < 1e-9
+            assert abs(rf["achieved"] - flops / (ms * 1e-3) / 1e12) < 1e-6 * rf["achieved"]
+        assert abs(rf["bf16_pipe_TFLOPs"] - 6 * flops / (ms * 1e-3) / 1e12) < 1e-6 * rf["bf16_pipe_TFLOPs"]
+        assert abs(rf["x_float32_mfma_peak"] - flops / (ms * 1e-3) / 1e12 / 157.3) < 1e-9
+        assert rf["traffic_source"] in (None, "profiles/pmc_traffic_%s_split.json" % wl)
 
 
 def check_transform_details(make_model, g1, gz, branch, tag, tol, from_fixture=False):

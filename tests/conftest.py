@@ -16,6 +16,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def xpass_names_ok(name_xbt, name_xty, ct=None, panel=True):
+    """The kernel functions behind the two X passes of a shard on the stream-K pair: gemm_cr<.., true, true> / gemm_ct<.., true, true>
+    on the panel-major copy - or, when the suite is run with LCX_F32_GEMM=split (the float32 passes on the bf16 pipe by default),
+    gemm_split_kernel<CT, ..> for both."""
+    name_xbt, name_xty = str(name_xbt), str(name_xty)
+    if "gemm_split_kernel" in name_xbt or "gemm_split_kernel" in name_xty:
+        ok = os.environ.get("LCX_F32_GEMM") == "split" and "gemm_split_kernel" in name_xbt and "gemm_split_kernel" in name_xty
+        return ok and (ct is None or (("gemm_split_kernel<%d," % ct) in name_xbt and ("gemm_split_kernel<%d," % ct) in name_xty))
+    ok = "gemm_cr_kernel" in name_xbt and "gemm_ct_kernel" in name_xty
+    if ct is not None:
+        ok = ok and ("_kernel<float, %d," % ct) in name_xbt and ("_kernel<float, %d," % ct) in name_xty
+    if panel:
+        ok = ok and name_xbt.endswith("true, true>") and name_xty.endswith("true, true>")
+    return ok
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 

@@ -277,8 +277,8 @@ def test_sharded_float32_large_kernels_match_single_gpu(m, tmp_path, monkeypatch
     got = np.load(os.path.join(tmp_path, "dist_f32.npz"))
     assert int(got["world"]) == 2 and str(got["transport"]) == "hook" and bool(got["in_library"])
     # (the stream-K pair on the panel-major copy: X.B^T = gemm_cr<.., true, true>, X^T.Y = gemm_ct<.., true, true>)
-    assert ("gemm_cr_kernel<float, %d" % (m // 16)) in str(got["kernel_nt"]) and "gemm_ct_kernel" in str(got["kernel_tn"])
-    assert str(got["kernel_nt"]).endswith("true, true>") and str(got["kernel_tn"]).endswith("true, true>")
+    from tests.conftest import xpass_names_ok
+    assert xpass_names_ok(got["kernel_nt"], got["kernel_tn"], m // 16)
     monkeypatch.setenv("LCX_GEMM", "ct")
     xt = planted_f32(n, v, m)
     single = Corex(n_hidden=m, seed=0, dtype=np.float32, tol=0.0, device=0)
@@ -312,7 +312,8 @@ def test_sharded_merged_pass_under_exchange(m, tmp_path, monkeypatch):
     _launch_f32(2, tmp_path, n, v, m, iters)
     got = np.load(os.path.join(tmp_path, "dist_f32.npz"))
     assert int(got["world"]) == 2 and str(got["transport"]) == "hook" and bool(got["in_library"])
-    assert "gemm_cr_kernel<float" in str(got["kernel_merged"]) and int(got["merged_passes"]) > 0
+    km = str(got["kernel_merged"])          # (gemm_split_kernel when the suite runs with LCX_F32_GEMM=split)
+    assert ("gemm_cr_kernel<float" in km or (os.environ.get("LCX_F32_GEMM") == "split" and "gemm_split_kernel" in km)) and int(got["merged_passes"]) > 0
     monkeypatch.setenv("LCX_GEMM", "ct")
     xt = planted_f32(n, v, m)
     single = Corex(n_hidden=m, seed=0, dtype=np.float32, tol=0.0, device=0)

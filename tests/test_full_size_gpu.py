@@ -209,7 +209,8 @@ def test_config4_unsharded_on_one_gpu():
     from linearcorex_amd.backend import HipBackend
     n, v, m = 50000, 1000000, 128
     be = HipBackend(n, v, m, np.float32, 0)
-    assert "gemm_cr_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)
+    from tests.conftest import xpass_names_ok
+    assert xpass_names_ok(be.kernel_name(0), be.kernel_name(1), 8)
     br = be.bytes_resident()
     assert br["x_layout"].startswith("panel-major")
     assert br["x"] < 1.01 * 4 * 50048 * 1000000 and br["total"] < 250e9

@@ -194,7 +194,8 @@ def test_f32_gemm_entry_points_through_raw_ctypes(monkeypatch):
         h = C.c_void_p()
         assert lib.lcx_create(C.byref(h), C.c_int64(n), C.c_int64(v), m, dt, 0) == 0, lib.lcx_last_error()
         mode = C.c_int(-1)
-        assert lib.lcx_f32_gemm(h, C.byref(mode)) == 0 and mode.value == 0          # the default
+        dflt = 1 if (os.environ.get("LCX_F32_GEMM") == "split" and can) else 0     # the default: float32 MFMA unless the environment says split
+        assert lib.lcx_f32_gemm(h, C.byref(mode)) == 0 and mode.value == dflt
         assert lib.lcx_f32_gemm(h, None) != 0 and lib.lcx_set_f32_gemm(h, 2) != 0
         xx, ww = (x, w) if dt == 0 else (x.astype(np.float64), w.astype(np.float64))
         assert lib.lcx_upload_x(h, _p(np.ascontiguousarray(xx)), C.c_int64(v)) == 0

@@ -526,7 +526,8 @@ def test_ct_many_slots_end_to_end(tag, m):
     ref = O.fit_ns(x, m, seed=0, dtype=DT[tag], max_iter=6)
     out = Corex(n_hidden=m, seed=0, max_iter=6, dtype=DT[tag], device=0).fit(x)
     be = out._backend
-    assert "gemm_cr_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)
+    from tests.conftest import xpass_names_ok
+    assert xpass_names_ok(be.kernel_name(0), be.kernel_name(1))
     geo = be.geometry()
     assert min(geo["nt_split"], geo["tn_split"]) >= 12, geo
     h_ref, h_out = np.array(ref.history_tc, np.float64), np.array(out.history["TC"], dtype=np.float64)
@@ -565,7 +566,8 @@ def test_large_shard_kernels_inside_a_float32_fit(m, monkeypatch):
     ref = O.fit_ns_preprocessed(xt, m, seed=0, dtype=np.float32, max_iter=3, tol=0.0, finish=False)
     model = Corex(n_hidden=m, seed=0, dtype=np.float32, tol=0.0, device=0)
     be = model._attach_shard(xt, v)
-    assert ("gemm_cr_kernel<float, %d" % (m // 16)) in be.kernel_name(0) and ("gemm_ct_kernel<float, %d" % (m // 16)) in be.kernel_name(1)
+    from tests.conftest import xpass_names_ok
+    assert xpass_names_ok(be.kernel_name(0), be.kernel_name(1), m // 16)
     for i_eps, eps in enumerate(model._init_weights()):
         model._begin_stage(i_eps, eps)
         for k in range(3):
@@ -936,8 +938,11 @@ def test_panel_layout_matches_row_major(tag, shape, monkeypatch):
         be = out._backend
         br = be.bytes_resident()
         assert br["x_layout"].startswith("panel-major" if lay == "panel" else "row-major + transposed")
-        assert ("gemm_cr_kernel" in be.kernel_name(0)) == (lay == "panel") and "gemm_ct_kernel" in be.kernel_name(1)
-        assert be.kernel_name(1).endswith("true, true>" if lay == "panel" else "true, false>")
+        from tests.conftest import xpass_names_ok
+        if lay == "panel":
+            assert xpass_names_ok(be.kernel_name(0), be.kernel_name(1))
+        else:
+            assert "gemm_ct_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1) and be.kernel_name(1).endswith("true, false>")
         runs[lay] = (np.asarray(out.history["TC"], np.float64), out.ws.copy(), out.clusters(), br["x"], be.download_x(), out.transform(x),
                      out.stats["trials"])
         be.close()

@@ -497,6 +497,12 @@ static int launch_split(hipStream_t st, const float* A, int64_t ps, int64_t K, i
 }
 // split mode exists for float32 with 32 / 64 / 128 padded factors (and the merged pass of the first two)
 template <typename T, int CT> static constexpr bool split_capable() { return sizeof(T) == 4 && (CT == 2 || CT == 4 || CT == 8); }
+// LCX_PV_MFMA=0 keeps the thread-per-(variable, factor) forms of moments_epilogue / grad where the matrix-pipe forms exist
+// (read at every launch - two per iteration - so that a test can compare both forms inside one process)
+static inline bool pv_mfma() {
+    const char* e = getenv("LCX_PV_MFMA");
+    return !(e && *e && atoi(e) == 0);
+}
 // waves per block of the stream-K kernels: CtShape's, except that 128 float32 factors can be switched between 4 and 8 at run time
 // (LCX_CT8_KW) - the A/B knob behind CtShape<float, 8>::KW
 template <typename T, int CT> static inline int ct_kw() {
@@ -1007,14 +1013,32 @@ template <typename T, int CT> struct Impl {
     static int epilogue(lcx_ctx* h, int which, double eps, bool linear, double eta) {
         MomentSet& s = h->set[which];
         const int* skip = &s.st->invalid;
-        const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * Mp : 0) + (size_t)VPB * Mp) * sizeof(T);
-        LCXCHECK(allow_lds(moments_epilogue_kernel<T, Mp>, lds));
-        hipLaunchKernelGGL((moments_epilogue_kernel<T, Mp>), dim3(h->pv_grid), dim3(NTV), lds, h->stream,
-                           P<T>(h->dpart), h->tn_slots, h->ldx * Mp,
-                           linear ? P<T>(h->set[0].D) : (const T*)nullptr, P<T>(h->ddir), (T)eta, P<T>(s.D),
-                           P<T>(h->Wt[which]), s.ry, h->V, h->Ndiv, eps,
-                           P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), P<T>(s.hscale),
-                           h->tcpart, skip);
+        bool on_mfma = false;
+        if constexpr (sizeof(T) == 4 && (Mp == 64 || Mp == 128)) {
+            // the m x m operator product on the matrix pipe, a wave per 16 variables (moment_kernels.hpp, PvMfma); LCX_PV_MFMA=0:
+            // the thread-per-(variable, factor) form
+            if (pv_mfma()) {
+                const size_t lds = PvMfma<Mp>::lds_bytes;
+                LCXCHECK(allow_lds(moments_epilogue_mfma_kernel<Mp>, lds));
+                hipLaunchKernelGGL((moments_epilogue_mfma_kernel<Mp>), dim3(h->pv_grid), dim3(64 * PvMfma<Mp>::NW), lds, h->stream,
+                                   P<float>(h->dpart), h->tn_slots, h->ldx * Mp,
+                                   linear ? P<float>(h->set[0].D) : (const float*)nullptr, P<float>(h->ddir), (float)eta, P<float>(s.D),
+                                   P<float>(h->Wt[which]), s.ry, h->V, h->Ndiv, eps,
+                                   P<float>(s.rho), P<float>(s.rir), P<float>(s.qij), P<float>(s.si), P<float>(s.q2), P<float>(s.hscale),
+                                   h->tcpart, skip);
+                on_mfma = true;
+            }
+        }
+        if (!on_mfma) {
+            const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * Mp : 0) + (size_t)VPB * Mp) * sizeof(T);
+            LCXCHECK(allow_lds(moments_epilogue_kernel<T, Mp>, lds));
+            hipLaunchKernelGGL((moments_epilogue_kernel<T, Mp>), dim3(h->pv_grid), dim3(NTV), lds, h->stream,
+                               P<T>(h->dpart), h->tn_slots, h->ldx * Mp,
+                               linear ? P<T>(h->set[0].D) : (const T*)nullptr, P<T>(h->ddir), (T)eta, P<T>(s.D),
+                               P<T>(h->Wt[which]), s.ry, h->V, h->Ndiv, eps,
+                               P<T>(s.rho), P<T>(s.rir), P<T>(s.qij), P<T>(s.si), P<T>(s.q2), P<T>(s.hscale),
+                               h->tcpart, skip);
+        }
         KCHECK();
         // H partial of THIS set (:294), so that the update that follows an accepted trial needs no exchange of
         // its own: it rides in the scalar all-reduce of the evaluation.  The same launch carries the tail block of the
@@ -1104,6 +1128,17 @@ template <typename T, int CT> struct Impl {
     // grad (:296-300) and the per-block Bj partials (:302) of set `which`, from its moments and the H its evaluation left in sbuf
     static int launch_grad(lcx_ctx* h, int which) {
         MomentSet& s = h->set[which];
+        if constexpr (sizeof(T) == 4 && (Mp == 64 || Mp == 128)) {
+            if (pv_mfma()) {
+                const size_t lds = PvMfma<Mp>::lds_bytes;
+                LCXCHECK(allow_lds(grad_mfma_kernel<Mp>, lds));
+                hipLaunchKernelGGL((grad_mfma_kernel<Mp>), dim3(h->pv_grid), dim3(64 * PvMfma<Mp>::NW), lds, h->stream, P<float>(h->Wt[which]),
+                                   P<float>(s.rho), P<float>(s.rir), P<float>(s.qij), P<float>(s.si), P<float>(s.q2), s.uj, h->sbuf + SB_H, h->V,
+                                   P<float>(h->grad), h->bjpart, use_merged(h) ? P<float>(h->gw) : (float*)nullptr);
+                KCHECK();
+                return LCX_OK;
+            }
+        }
         const size_t lds = ((size_t)(OpInLds<Mp>::v ? Mp * (Mp + 1) : 0) + (size_t)VPB * Mp) * sizeof(T) + (size_t)VPB * Mp * sizeof(double) + 8;
         LCXCHECK(allow_lds(grad_kernel<T, Mp>, lds));
         hipLaunchKernelGGL((grad_kernel<T, Mp>), dim3(h->pv_grid), dim3(NTV), lds, h->stream, P<T>(h->Wt[which]),

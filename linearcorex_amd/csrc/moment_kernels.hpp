@@ -1262,4 +1262,233 @@ pp_apply_kernel(T* __restrict__ X, int64_t N, int64_t V, int64_t ldx, int has_mi
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The two per-variable kernels with an m x m operator - moments_epilogue (Qij = ry . rhoinvrho, :266) and grad (H0 . ws, :300) - with
+// that product on the MATRIX pipe (float32, 64 / 128 padded factors: the large-shard configurations).  The thread-per-(variable,
+// factor) forms above walk the operator out of LDS once per variable: 2 LDS operands per FMA, LDS-issue bound (128 factors:
+// 555 / 337 us for 450 MB of traffic, profiles/r04_trace_gaps_c4shard*.txt).  Here a WAVE owns 16 consecutive variables:
+//   * elementwise phases in the FLAT layout - the 16 x Mp block of a [V][Mp] array is 16 Mp contiguous floats, lane l takes the
+//     float4 pieces r*64 + l (r < Mp/16): every load / store instruction covers 1 KB contiguous; a variable's Mp factors sit in
+//     Mp/4 = 32 / 16 consecutive lanes, so the per-variable sums (Si, Qi-Si^2, :268-269) are xor-shuffles inside the wave;
+//   * the operator product as 16 x 16 x 4 float32 MFMAs: A = the wave's 16 x Mp tile (through the wave's own LDS tile: written
+//     flat, read as 4 consecutive contraction elements per lane), B = the operator, staged once per block [Mp][Mp + 4] (the
+//     4 contraction rows of a step land on distinct banks), D back through the same LDS tile into the flat layout;
+//     Mp^2 / 64 MFMAs per 16 variables: 30 us of matrix pipe for 125 000 x 128.
+// Same outputs, same per-block partial sums (tcpart / bjpart, one slot per block of the same pv_grid) as the kernels above; the
+// operator product rounds in another order (MFMA chain over k instead of a serial loop).
+// ------------------------------------------------------------------------------------------------
+template <int Mp> struct PvMfma {
+    static constexpr int NW = 8;                    // waves per block
+    static constexpr int LD = Mp + 4;               // padded LDS row (floats)
+    static constexpr int F4 = Mp / 16;              // float4 pieces per lane and 16-variable group
+    static constexpr int LPV = Mp / 4;              // lanes per variable in the flat layout
+    static constexpr size_t lds_bytes = ((size_t)Mp * LD + (size_t)NW * 16 * LD) * sizeof(float);
+};
+typedef float pv_f4 __attribute__((ext_vector_type(4)));
+
+// sum over the LPV consecutive lanes that hold one variable
+template <int LPV>
+__device__ __forceinline__ float lanes_sum(float v) {
+#pragma unroll
+    for (int off = LPV / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// D tile (16 variables x Mp) = A tile (in `tile`, flat rows of LD floats) . op_s (Mp x Mp, rows of LD floats, B[k][j] = op_s[k*LD + j]);
+// the result replaces the A tile.  One wave; LDS operations of a wave execute in order.
+template <int Mp>
+__device__ __forceinline__ void pv_tile_product(float* tile, const float* op_s, int lane) {
+    constexpr int LD = PvMfma<Mp>::LD, NT16 = Mp / 16;
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    const int i = lane & 15, kq = lane >> 4;
+    pv_f4 a[NT16];
+#pragma unroll
+    for (int S = 0; S < NT16; ++S) a[S] = *reinterpret_cast<const pv_f4*>(&tile[i * LD + 16 * S + 4 * kq]);
+    acc_t acc[NT16];
+#pragma unroll
+    for (int u = 0; u < NT16; ++u) acc[u] = (acc_t){0, 0, 0, 0};
+#pragma unroll
+    for (int S = 0; S < NT16; ++S)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* brow = op_s + (16 * S + 4 * kq + e) * LD + i;
+#pragma unroll
+            for (int u = 0; u < NT16; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[S][e], brow[16 * u], acc[u], 0, 0, 0);
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < NT16; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[(4 * kq + r) * LD + 16 * u + i] = acc[u][r];
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int Mp>
+__global__ void __launch_bounds__(64 * PvMfma<Mp>::NW)
+moments_epilogue_mfma_kernel(const float* __restrict__ dpart, int nsplit, int64_t pstride, const float* __restrict__ d_base,
+                             const float* __restrict__ d_dir, float eta, float* __restrict__ d_out, const float* __restrict__ W,
+                             const double* __restrict__ ry, int64_t V, double n_samples, double eps, float* __restrict__ rho_o,
+                             float* __restrict__ rir_o, float* __restrict__ qij_o, float* __restrict__ si_o, float* __restrict__ q2_o,
+                             float* __restrict__ hscale_o, double* __restrict__ tcpart, const int* __restrict__ skip_flag) {
+    constexpr int NW = PvMfma<Mp>::NW, LD = PvMfma<Mp>::LD, F4 = PvMfma<Mp>::F4, LPV = PvMfma<Mp>::LPV, NTH = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* ry_s = reinterpret_cast<float*>(smem_raw);
+    __shared__ double bs_scratch[NW];
+    if (skip_flag != nullptr && *skip_flag != 0) return;       // invalid trial (:250-251): the tail block still publishes
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* tile = ry_s + Mp * LD + wave * 16 * LD;
+    for (int idx = tid; idx < Mp * Mp; idx += NTH) ry_s[(idx / Mp) * LD + idx % Mp] = (float)ry[idx];     // symmetric
+    __syncthreads();
+
+    const float c1 = (float)(1.0 - eps * eps), c2 = (float)(eps * eps), ns = (float)n_samples;
+    double s1 = 0.0, s2 = 0.0;
+    const int64_t ngroups = (V + 15) / 16;
+    for (int64_t grp = (int64_t)blockIdx.x * NW + wave; grp < ngroups; grp += (int64_t)gridDim.x * NW) {
+        const int64_t base4 = grp * (16 * Mp / 4);
+        pv_f4 rho[F4], rir[F4];
+        float si[F4];
+#pragma unroll
+        for (int r = 0; r < F4; ++r) {
+            const int f = r * 64 + lane, vloc = (4 * f) / Mp, j0 = (4 * f) % Mp;
+            const bool ok = grp * 16 + vloc < V;
+            pv_f4 d;
+            if (d_base != nullptr) {
+                d = reinterpret_cast<const pv_f4*>(d_base)[base4 + f] + eta * reinterpret_cast<const pv_f4*>(d_dir)[base4 + f];
+            } else {
+                d = reinterpret_cast<const pv_f4*>(dpart)[base4 + f];
+                for (int k = 1; k < nsplit; ++k) d += reinterpret_cast<const pv_f4*>(dpart + k * pstride)[base4 + f];
+            }
+            if (ok) reinterpret_cast<pv_f4*>(d_out)[base4 + f] = d;
+            const pv_f4 w = reinterpret_cast<const pv_f4*>(W)[base4 + f];
+            pv_f4 rh, rr;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                rh[c] = ok ? (c1 * d[c] / ns + c2 * w[c]) : 0.f;
+                rr[c] = rh[c] * (1.f / (1.f - rh[c] * rh[c]));
+            }
+            rho[r] = rh;
+            rir[r] = rr;
+            si[r] = lanes_sum<LPV>(rh[0] * rr[0] + rh[1] * rr[1] + rh[2] * rr[2] + rh[3] * rr[3]);
+            *reinterpret_cast<pv_f4*>(&tile[vloc * LD + j0]) = rr;
+        }
+        __builtin_amdgcn_wave_barrier();
+        pv_tile_product<Mp>(tile, ry_s, lane);                 // Qij = ry . rhoinvrho (:266)
+#pragma unroll
+        for (int r = 0; r < F4; ++r) {
+            const int f = r * 64 + lane, vloc = (4 * f) / Mp, j0 = (4 * f) % Mp;
+            const int64_t v = grp * 16 + vloc;
+            const bool ok = v < V;
+            const pv_f4 q = *reinterpret_cast<const pv_f4*>(&tile[vloc * LD + j0]);
+            float p = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) p += rir[r][c] * (q[c] - si[r] * rho[r][c]);
+            const float q2 = lanes_sum<LPV>(p);
+            if (ok) {
+                reinterpret_cast<pv_f4*>(rho_o)[base4 + f] = rho[r];
+                reinterpret_cast<pv_f4*>(rir_o)[base4 + f] = rir[r];
+                reinterpret_cast<pv_f4*>(qij_o)[base4 + f] = q;
+                if ((lane & (LPV - 1)) == 0) {
+                    si_o[v] = si[r];
+                    q2_o[v] = q2;
+                    hscale_o[v] = 1.f / (1.f + q2);
+                    s1 += (double)logf(1.f + si[r]);
+                    s2 += (double)logf(1.f + q2);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                       // the tile is rewritten by the next group
+    }
+    s1 = block_sum<double, NTH>(s1, bs_scratch, tid);
+    s2 = block_sum<double, NTH>(s2, bs_scratch, tid);
+    if (tid == 0) {
+        tcpart[2 * blockIdx.x] = s1;
+        tcpart[2 * blockIdx.x + 1] = s2;
+    }
+}
+
+// grad (:296-300) + the per-block Bj partials (:302); grad2_o: columns [0, Mp) of the merged operand [V][2 Mp]
+template <int Mp>
+__global__ void __launch_bounds__(64 * PvMfma<Mp>::NW)
+grad_mfma_kernel(const float* __restrict__ W, const float* __restrict__ rho_i, const float* __restrict__ rir_i,
+                 const float* __restrict__ qij_i, const float* __restrict__ si_i, const float* __restrict__ q2_i,
+                 const double* __restrict__ uj, const double* __restrict__ H /* sbuf, diag ignored */, int64_t V,
+                 float* __restrict__ grad_o, double* __restrict__ bjpart, float* __restrict__ grad2_o) {
+    constexpr int NW = PvMfma<Mp>::NW, LD = PvMfma<Mp>::LD, F4 = PvMfma<Mp>::F4, LPV = PvMfma<Mp>::LPV, NTH = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* h_s = reinterpret_cast<float*>(smem_raw);           // h_s[k][j] = H0[j][k]: the B operand of hw[v][j] = sum_k H0[j][k] w[v][k]
+    __shared__ double bj_s[NW][Mp];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* tile = h_s + Mp * LD + wave * 16 * LD;
+    for (int idx = tid; idx < Mp * Mp; idx += NTH) {
+        const int a = idx / Mp, b = idx % Mp;                  // H[a][b]
+        h_s[b * LD + a] = (a == b) ? 0.f : (float)H[idx];      // fill_diagonal(H, 0), :295
+    }
+    __syncthreads();
+    const int j0 = (4 * lane) % Mp;                            // the 4 factors of this lane (the same for every piece r)
+    float rj[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rj[c] = 1.f - (float)uj[j0 + c];
+    double bj[4] = {0.0, 0.0, 0.0, 0.0};
+    const int64_t ngroups = (V + 15) / 16;
+    for (int64_t grp = (int64_t)blockIdx.x * NW + wave; grp < ngroups; grp += (int64_t)gridDim.x * NW) {
+        const int64_t base4 = grp * (16 * Mp / 4);
+        pv_f4 w[F4];
+#pragma unroll
+        for (int r = 0; r < F4; ++r) {
+            const int f = r * 64 + lane, vloc = (4 * f) / Mp;
+            const bool ok = grp * 16 + vloc < V;
+            w[r] = reinterpret_cast<const pv_f4*>(W)[base4 + f];
+            if (!ok) w[r] = (pv_f4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<pv_f4*>(&tile[vloc * LD + j0]) = w[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        pv_tile_product<Mp>(tile, h_s, lane);                  // H0 . ws (:300)
+#pragma unroll
+        for (int r = 0; r < F4; ++r) {
+            const int f = r * 64 + lane, vloc = (4 * f) / Mp;
+            const int64_t v = grp * 16 + vloc;
+            const bool ok = v < V;
+            const int64_t vv = ok ? v : 0;
+            const pv_f4 hw = *reinterpret_cast<const pv_f4*>(&tile[vloc * LD + j0]);
+            const pv_f4 rho = reinterpret_cast<const pv_f4*>(rho_i)[base4 + f], rir = reinterpret_cast<const pv_f4*>(rir_i)[base4 + f],
+                        qij = reinterpret_cast<const pv_f4*>(qij_i)[base4 + f];
+            const float si = si_i[vv], q2 = q2_i[vv];
+            pv_f4 g;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float inv = 1.f / (1.f - rho[c] * rho[c]);
+                float t = w[r][c] / rj[c];                                                               // :296
+                t -= 2.f * inv * rir[c] / (1.f + si);                                                    // :297
+                t += inv * inv * ((1.f + rho[c] * rho[c]) * qij[c] - 2.f * rho[c] * si) / (1.f + q2);    // :298-299
+                g[c] = t + hw[c];                                                                        // :300
+            }
+            if (ok) {
+                reinterpret_cast<pv_f4*>(grad_o)[base4 + f] = g;
+                if (grad2_o != nullptr) *reinterpret_cast<pv_f4*>(&grad2_o[v * (2 * Mp) + j0]) = g;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) bj[c] += (double)(rho[c] * g[c]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // Bj partial of the block: the 64 / LPV lanes of a wave that hold the same factors, then the waves, in a fixed order
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int off = LPV; off < 64; off <<= 1) bj[c] += __shfl_xor(bj[c], off, 64);
+    }
+    if (lane < LPV) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bj_s[wave][j0 + c] = bj[c];
+    }
+    __syncthreads();
+    if (tid < Mp) {
+        double s = bj_s[0][tid];
+        for (int k = 1; k < NW; ++k) s += bj_s[k][tid];
+        bjpart[(int64_t)blockIdx.x * Mp + tid] = s;
+    }
+}
+
 }  // namespace lcx

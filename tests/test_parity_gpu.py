@@ -1114,3 +1114,53 @@ def test_split_gemm_env_default(monkeypatch):
     assert a.f32_gemm == "split" and b.f32_gemm == "mfma"
     assert "gemm_split_kernel" in a._backend.kernel_name(0) and "gemm_split_kernel" not in b._backend.kernel_name(0)
     a._backend.close(); b._backend.close()
+
+
+@pytest.mark.parametrize("shape", [(2048, 8200, 64), (1100, 5003, 100), (3000, 1037, 128), (20000, 1500, 40)])
+def test_per_variable_kernels_on_the_matrix_pipe(shape, monkeypatch):
+    """moments_epilogue / grad with the m x m operator product on MFMA (a wave per 16 variables, float32, 64 / 128 padded factors)
+    against the thread-per-(variable, factor) forms (LCX_PV_MFMA=0) on the same handle: every array they write - D, rho, rhoinvrho,
+    Qij, Si, Qi-Si^2, grad and the scalars built from their per-block partials (TC, the Bj of the direction, update_tangent) - to
+    float32 rounding, on variable counts that are not multiples of 16, with and without the merged pass; and a whole exact-mode and
+    linear-mode fit (the linear trials feed the epilogue from D + eta D(update)) lands on the same history."""
+    from linearcorex_amd import Corex
+    from linearcorex_amd.backend import HipBackend
+    n, v, m = shape
+    monkeypatch.setenv("LCX_X_LAYOUT", "panel")
+    monkeypatch.setenv("LCX_GEMM", "ct")
+    x = O.gen_planted(n, v, 8, seed=3)[0].astype(np.float32)
+    x = (x - x.mean(0)) / x.std(0)
+    rng = np.random.RandomState(6)
+    w = rng.randn(m, v).astype(np.float32)
+    w /= (10.0 * O.norm(x, w, 0))[:, np.newaxis]
+    w *= np.float32(3.0)
+    be = HipBackend(n, v, m, np.float32, 0)
+    be.upload_x(x)
+    got = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("LCX_PV_MFMA", flag)
+        be.set_ws(w)
+        be.moments_a(0); be.moments_b(0, 0.36, 1); be.moments_c(0)
+        st = be.read_state(0)
+        assert st[2] == 0
+        arrays = {k: be.get_moment(0, k) for k in ("rho", "rhoinvrho", "Qij", "Si", "Qi-Si^2")}
+        be.update_a()
+        out = be.iterate(0.36, 1e-5, st[0], False)
+        arrays["grad"] = be.get_moment(0, "grad")
+        arrays["update"] = be.get_moment(0, "update")
+        got[flag] = (st[0], out[1], out[2], int(out[3]), arrays)
+    be.close()
+    (tc0, tcn0, tan0, tr0, a0), (tc1, tcn1, tan1, tr1, a1) = got["0"], got["1"]
+    assert abs(tc1 - tc0) < 2e-6 * max(1.0, abs(tc0)) and abs(tcn1 - tcn0) < 2e-5 * max(1.0, abs(tcn0)) and tr0 == tr1
+    assert abs(tan1 - tan0) < 2e-5 * abs(tan0)
+    for k in a0:
+        assert relerr(a1[k], a0[k]) < 2e-5, (k, relerr(a1[k], a0[k]))
+    for ls in ("exact", "linear"):
+        hist = {}
+        for flag in ("0", "1"):
+            monkeypatch.setenv("LCX_PV_MFMA", flag)
+            mdl = Corex(n_hidden=m, seed=0, dtype=np.float32, device=0, max_iter=5, tol=0.0, line_search=ls).fit(x)
+            hist[flag] = np.asarray(mdl.history["TC"], np.float64)
+            mdl._backend.close()
+        assert len(hist["0"]) == len(hist["1"]) == 35
+        assert np.max(np.abs(hist["1"] - hist["0"]) / np.maximum(1.0, np.abs(hist["0"]))) < 5e-4, ls

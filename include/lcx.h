@@ -345,8 +345,9 @@ int lcx_x_layout(lcx_ctx* h, int* layout);
  *      its float32 VECTOR rate (157 TF/s), 1/16 of the bf16 rate, and bounds these passes;
  *   1  every operand element split exactly into three bf16 numbers (8 + 8 + 8 significand bits), 6 of the 9 partial products
  *      (all terms down to 2^-16 of the product; the dropped ones are below 2^-23, one float32 rounding of it) accumulated in float32
- *      by v_mfma_f32_16x16x32_bf16 - 2.5 x less matrix-pipe time, the passes become HBM / power bound (1.3-1.5 x faster at the
- *      config-3 / config-4 shards).  Error against a float64 contraction: 1.1-1.4 x that of mode 0 (profiles/r04_gemm_probe9_split.txt).
+ *      by v_mfma_f32_16x16x32_bf16 - 2.5 x less matrix-pipe time, the passes become HBM / power bound (1.45-1.5 x the fit
+ *      iterations per second at the config-3 / config-4 shards).  Error against a float64 contraction: 1.1-1.4 x that of mode 0
+ *      (profiles/r04_gemm_probe9_split.txt); every parity fixture holds at the float32 bars in both modes.
  * Mode 1 needs layout 2 and 32 / 64 / 128 padded factors; on any other handle the call succeeds and leaves mode 0 (read it back with
  * lcx_f32_gemm).  Environment default: LCX_F32_GEMM=split.  Costs 6 bytes per element of the small operand (one scratch buffer). */
 int lcx_set_f32_gemm(lcx_ctx* h, int mode);

@@ -11,13 +11,16 @@
 // and NP = 6 products drop terms below 2^-23 |a||b| (the [..] pair is at most 2^-23, typically 2^-25; {..} 2^-32) - the size of ONE
 // float32 rounding of the product, which the float32 MFMA chain commits at every one of its K steps anyway; NP = 8 keeps the [..]
 // pair as well.  One v_mfma_f32_16x16x32_bf16 (~17 cycles) covers 32 contraction elements, for which the float32 MFMA needs 8
-// instructions of 32 cycles: 6 products are 2.5 x less matrix-pipe time, and the contraction becomes HBM bound.
-// Measured error against a float64 contraction: tools/gemm_probe9 (profiles/r04_gemm_probe9_split.txt).
+// instructions of 32 cycles: 6 products are 2.5 x less matrix-pipe time; 64-column passes become HBM bound (5.6-5.8 TB/s), 128-column
+// passes run the bf16 pipe 0.75 busy under the power cap (1.66 GHz) - 1.45-1.5 x the float32-MFMA passes either way.
+// Measured error against a float64 contraction: tools/gemm_probe9 (profiles/r04_gemm_probe9_split.txt): 1.1-1.4 x the float32 MFMA's.
 //
 // Same machine as gemm_ct / gemm_cr (gemm_kernels.hpp): a block's KW waves own KW adjacent 64-row output tiles and walk the same
-// contraction range; the small operand B is staged once per block through LDS, double buffered, one barrier per 32 contraction
-// elements; (super tile, group) units are split stream-K style over one round of resident blocks; partial tiles go to slots
-// (fixed count, zero-filled by the last contributor, summed in fixed order by the consumers).  What is new:
+// contraction range; the small operand B is staged once per block through LDS, double buffered, one barrier per group of KS x 32
+// contraction elements (KS = 2 up to 64 columns); (super tile, group) units are split stream-K style over one round of resident
+// blocks; partial tiles go to slots (fixed count, zero-filled by the last contributor, summed in fixed order by the consumers).
+// The engine launches 8-wave blocks of 512 rows, one per CU, from 64 columns on (B is re-read once per super tile: its L2 -> fabric
+// traffic halves against 4-wave blocks), with the MFMA phase at raised wave priority (lcx_engine.hip, SplitShape).  What is new:
 //   * the A operand (X from the PANEL-major copy XP[v / 16][n][16]) goes global -> VGPR as 16-byte loads exactly as in the float32
 //     kernels (1 KB contiguous per load instruction for X.B^T, 4 x 256 B for X^T.Y) and is split in registers (4 VALU operations per
 //     element + 3 v_perm_b32 per pair) right before use;

@@ -810,8 +810,14 @@ template <typename T, int CT> struct Impl {
                 if (sl <= 8) { h->merged_ok = true; h->nt2_nb = nb; h->nt2_nsuper = ns; h->nt2_S = sl; }
             }
         }
-        h->gn_S = pick_split(Mp / (16 * Geo<T, CT>::G_RT), pick_kw(kgn), kgn, h->target_waves / 4, 64);
-        h->gv_S = pick_split(Mp / (16 * Geo<T, CT>::G_RT), pick_kw(kgv), kgv, h->target_waves / 4, 64);
+        {
+            // contraction splits of the m x m Gram launches (Y^T.Y, W.W^T, H): up to 128, aiming at 12 waves per CU (round 4: with 64 /
+            // a quarter of that the launches of the large shards left CUs idle - config 3: 65 + 59 -> 38 + 34 us, config-4 shard
+            // 124 + 121 -> 70 + 86 us, the slot reductions 5 us dearer); short contractions are capped by work as before
+            const int gdiv = env_int("LCX_GRAM_WAVES_DIV", 1), gcap = env_int("LCX_GRAM_CAP", 128);
+            h->gn_S = pick_split(Mp / (16 * Geo<T, CT>::G_RT), pick_kw(kgn), kgn, h->target_waves / (gdiv > 0 ? gdiv : 1), gcap);
+            h->gv_S = pick_split(Mp / (16 * Geo<T, CT>::G_RT), pick_kw(kgv), kgv, h->target_waves / (gdiv > 0 ? gdiv : 1), gcap);
+        }
         int64_t groups = cdiv(h->V, VPB);
         h->pv_grid = (int)(groups < 1024 ? (groups < 1 ? 1 : groups) : 1024);
         // many slots (few column tiles): one wide reduction after the pass instead of a long serial sum per element in

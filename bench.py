@@ -735,18 +735,19 @@ def cluster_purity(clusters, groups, n_groups):
     return float(table.max(axis=1).sum() / len(clusters))
 
 
-def convergence_block(n, v, m, dtype, device, kind, max_iter, seed=1):
+def convergence_block(n, v, m, dtype, device, kind, max_iter, seed=1, f32_gemm=None):
     """BASELINE.json's second figure: wall-clock of a whole fit() of a generated workload - data generation and
     standardisation on the device, 7 annealing stages each to |dTC| < tol = 1e-5 (reference defaults :72-74, :152-155)
     or `max_iter` iterations, final detail moments and factor sort (:160-163)."""
     import numpy as np
     from linearcorex_amd import Corex
     t0 = time.perf_counter()
-    mdl = Corex(n_hidden=m, seed=0, dtype=dtype, device=device, max_iter=max_iter)
+    mdl = Corex(n_hidden=m, seed=0, dtype=dtype, device=device, max_iter=max_iter, f32_gemm=f32_gemm)
     mdl.fit_generated(n, v, seed=seed, kind=kind, n_groups=m)
     t1 = time.perf_counter()
     n_it = len(mdl.history["TC"])
-    blk = {"data": "planted: %d latent groups + unit noise per variable (lcx_generate_x kind 1)" % m if kind == 1
+    blk = {"f32_gemm": getattr(mdl, "f32_gemm", None) if np.dtype(dtype) == np.float32 else None,
+           "data": "planted: %d latent groups + unit noise per variable (lcx_generate_x kind 1)" % m if kind == 1
                    else "iid N(0,1) (lcx_generate_x kind 0): no structure to converge to",
            "seconds": t1 - t0, "iterations": n_it, "TC": float(mdl.tc), "tol": 1e-5,
            "max_iter_per_stage": max_iter, "iterations_by_stage": list(mdl.stage_iterations),
@@ -844,6 +845,8 @@ def compact_line(out, detail_path):
         "f32_gemm_split_final_TC_rel_diff": _pick(cfg, "f32_gemm_split", "final_TC_relative_difference"),
         "f32_gemm_split_roofline_bound": _pick(cfg, "f32_gemm_split", "roofline", "bound"),
         "f32_gemm_split_roofline_frac": _pick(cfg, "f32_gemm_split", "roofline", "frac"),
+        "f32_gemm_split_fit_to_convergence_planted_seconds": _pick(cfg, "f32_gemm_split", "fit_to_convergence_planted", "seconds"),
+        "f32_gemm_split_fit_to_convergence_planted_iterations": _pick(cfg, "f32_gemm_split", "fit_to_convergence_planted", "iterations"),
         "f32_gemm_mfma_value": _pick(cfg, "f32_gemm_mfma", "fit_iterations_per_sec"),
         "merged_pass_roofline_frac": _pick(out, "roofline", "merged_pass", "frac"),
         "xbt_pass_roofline_frac": _pick(out, "roofline", "frac_by_site", "gemm_nt"),
@@ -1040,7 +1043,13 @@ def main():
         # the planted matrix of the same shape, each stage to |dTC| < 1e-5
         cfg["fit_to_convergence"] = convergence_block(n, v_per, m, dtype, local_rank, 0, args.convergence_max_iter)
         cfg["fit_to_convergence"]["capped"] = True
-        cfg["fit_to_convergence_planted"] = convergence_block(n, v_per, m, dtype, local_rank, 1, args.convergence_planted_max_iter)
+        cfg["fit_to_convergence_planted"] = convergence_block(n, v_per, m, dtype, local_rank, 1, args.convergence_planted_max_iter,
+                                                              f32_gemm=args.f32_gemm if tag == "f32" else None)
+        if tag == "f32" and other_gemm_name(args) in cfg:
+            # the same whole fit with the other arithmetic of the X passes: iterations, TC and the recovered clusters beside it
+            other = "split" if args.f32_gemm == "mfma" else "mfma"
+            cfg[other_gemm_name(args)]["fit_to_convergence_planted"] = convergence_block(
+                n, v_per, m, dtype, local_rank, 1, args.convergence_planted_max_iter, f32_gemm=other)
 
     out = {
         "metric": "corex_fit_iterations_per_sec",

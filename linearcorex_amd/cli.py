@@ -49,6 +49,9 @@ def build_parser():
     g.add_argument("-n", "--gpu", action="store_true", default=False,
                    help="Accepted for compatibility: this build always runs on the GPU.")
     g.add_argument("--device", type=int, default=None, help="HIP device index.")
+    g.add_argument("--f32_gemm", choices=["mfma", "split"], default=None,
+                   help="float32 fits: arithmetic of the two passes over X - 'mfma' (float32 MFMA, the default) or 'split' (exact "
+                        "three-way bf16 split on the bf16 matrix pipe: same results to float32 rounding, faster on large inputs).")
     g = p.add_argument_group("Output Options")
     g.add_argument("-o", "--output", default="corex_output", help="A directory to put all output files.")
     g.add_argument("-v", "--verbose", type=int, default=0, help="Verbosity 0, 1, 2.")
@@ -163,7 +166,7 @@ def main(argv=None, corex_factory=None):
         def corex_factory(n_hidden, layer, **kw):
             return Corex(n_hidden=n_hidden, verbose=opt.verbose, gaussianize=opt.gaussianize,
                          discourage_overlap=opt.additive, gpu=True, max_iter=opt.max_iter, seed=opt.seed,
-                         dtype=np.dtype(opt.dtype), device=opt.device, **kw)
+                         dtype=np.dtype(opt.dtype), device=opt.device, f32_gemm=opt.f32_gemm, **kw)
     if not opt.regraph:
         models = fit_layers(x, layers, corex_factory, missing=opt.missing, verbose=opt.verbose)
         for l, mdl in enumerate(models):

@@ -1000,14 +1000,14 @@ def test_panel_layout_preprocess_and_generate(gz, missing, monkeypatch):
 # ------------------------------------------------------------------------------------------------------------------------------
 # round 4: the X passes of a float32 panel shard on the bf16 matrix pipe (include/lcx.h, lcx_set_f32_gemm; gemm_split_kernels.hpp)
 # ------------------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(1500, 3000, 20), (1501, 3001, 40), (4096, 8192, 64), (1300, 2500, 100), (2048, 1100, 128),
-                                   (20000, 1200, 20), (20000, 1500, 40)])
+@pytest.mark.parametrize("shape", [(1500, 3000, 20), (1501, 3001, 40), (2048, 4096, 64), (1300, 2500, 100), (2048, 1100, 128),
+                                   (20000, 1500, 40)])
 def test_split_gemm_matches_mfma(shape, monkeypatch):
     """f32_gemm="split" (every operand split exactly into three bf16 numbers, 6 partial products, float32 accumulation) against
     f32_gemm="mfma" (float32 MFMA) on the same panel-major shard: same fit to float32 rounding, both at the float32 bar against the
     oracle, and - the precision claim - the split moments are as close to a FLOAT64 fit as the float32-MFMA moments are (within 2 x).
     Factor counts over the three tile widths (32 / 64 / 128 padded columns), ragged sizes, contractions that are an odd number of
-    32-element groups; the two 20 000-row shapes also run the merged pass (twice the columns: 64 / 128)."""
+    32-element groups; the 20 000-row shape also runs the merged pass (twice the columns: 128)."""
     from linearcorex_amd import Corex
     n, v, m = shape
     x = O.gen_planted(n, v, min(m, 8), seed=1)[0]

@@ -344,7 +344,8 @@ int lcx_x_layout(lcx_ctx* h, int* layout);
  *   0  (default) v_mfma_f32_16x16x4_f32: exact float32 products, float32 accumulation - the float32 MATRIX rate of gfx950 equals
  *      its float32 VECTOR rate (157 TF/s), 1/16 of the bf16 rate, and bounds these passes;
  *   1  every operand element split exactly into three bf16 numbers (8 + 8 + 8 significand bits), 6 of the 9 partial products
- *      (all terms down to 2^-16 of the product; the dropped ones are below 2^-23, one float32 rounding of it) accumulated in float32
+ *      (all terms down to 2^-16 of the product; the dropped ones are 2^-24 of it in the rms and at most 2^-21 - the size of one float32
+ *      rounding of the product) accumulated in float32
  *      by v_mfma_f32_16x16x32_bf16 - 2.5 x less matrix-pipe time, the passes become HBM / power bound (1.45-1.5 x the fit
  *      iterations per second at the config-3 / config-4 shards).  Error against a float64 contraction: 1.1-1.4 x that of mode 0
  *      (profiles/r04_gemm_probe9_split.txt); every parity fixture holds at the float32 bars in both modes.

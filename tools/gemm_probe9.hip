@@ -15,6 +15,7 @@
 #include "../linearcorex_amd/csrc/gemm_split_kernels.hpp"
 #include "split32_probe.hpp"
 #include "split_pp_probe.hpp"
+#include "split_rne_probe.hpp"
 using namespace lcx;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
@@ -88,6 +89,21 @@ Variant mksplitpp(const float* XP, int64_t nrows_pad, int64_t K, int64_t rows, c
     return Variant{buf, [=] {
         hipLaunchKernelGGL((split_b_kernel<CT, CONTRACT_N>), dim3(1024), dim3(256), 0, 0, B, Bsp, ng, (const int*)nullptr);
         hipLaunchKernelGGL(kern, dim3(nb), dim3(512), 0, 0, XP, ps, (const u32x4_t*)Bsp, out, rows, rows, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
+}
+
+// lab: the production kernel with the round-to-nearest split (split_rne_probe.hpp)
+template <int CT, int KW, bool CONTRACT_N, int KS, int PRIO>
+Variant mksplitrne(const float* XP, int64_t nrows_pad, int64_t K, int64_t rows, const float* B, u32x4_t* Bsp, float* out) {
+    auto kern = gemm_split_rne_kernel<CT, KW, 6, CONTRACT_N, true, false, 2, KS, PRIO>;
+    int nb, nsuper, maxslots, bpc;
+    const int ng = (int)(K / (SPLIT_KG * KS));
+    geometry((const void*)kern, 64 * KW, 0, rows, KW * 64, ng, &nb, &nsuper, &maxslots, &bpc);
+    char buf[200];
+    snprintf(buf, 200, "bf16 x 6, ROUND-TO-NEAREST split KW=%d ks=%d prio=%d bpc=%d slots=%d", KW, KS, PRIO, bpc, maxslots);
+    const int64_t ps = nrows_pad * 16;
+    return Variant{buf, [=] {
+        hipLaunchKernelGGL((split_b_rne_kernel<CT, CONTRACT_N>), dim3(1024), dim3(256), 0, 0, B, Bsp, ng * KS, (const int*)nullptr);
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, XP, ps, (const u32x4_t*)Bsp, out, rows, rows, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
 }
 
 static void bench(std::vector<Variant>& vs, double gbytes, double tflop, int rounds = 5, int iters = 5) {
@@ -192,7 +208,9 @@ void suite(const char* name, int64_t N, int64_t V) {
                 vs.push_back(mksplit<CT, 8, 6, CN, true, true, 2, 2, 1>(XP, N, K, rows, B, Bsp, out, 0));
                 vs.push_back(mksplit<CT, 8, 3, CN, true, false, 2, 2, 1>(XP, N, K, rows, B, Bsp, out, 0));
                 vs.push_back(mksplit<CT, 8, 8, CN, true, false, 2, 2, 1>(XP, N, K, rows, B, Bsp, out, 0));
+                vs.push_back(mksplitrne<CT, 8, CN, 2, 1>(XP, N, K, rows, B, Bsp, out));
             } else {
+                vs.push_back(mksplitrne<CT, 8, CN, 1, 2>(XP, N, K, rows, B, Bsp, out));
                 vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 1, 1>(XP, N, K, rows, B, Bsp, out, 0));
                 vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 1, 2>(XP, N, K, rows, B, Bsp, out, 0));
                 vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 1, 0>(XP, N, K, rows, B, Bsp, out, 0));

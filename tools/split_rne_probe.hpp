@@ -1,77 +1,31 @@
-// gemm_split_kernels.hpp - the two float32 X-streaming contractions on the bf16 matrix pipe (gfx950), float32 in, float32 out.
-//
-// Why: on MI355X the float32 MFMA (v_mfma_f32_16x16x4_f32) runs at the float32 VECTOR rate, 1/16 of the bf16 MFMA
-// (/opt/skills/guides/MI355X_MICROARCH.md: 157 TF/s against 2.5 PF/s), and the large float32 shards of the fit loop are bound by it
-// (gemm_cr / gemm_ct at 0.80-0.92 of that peak, 4-5.5 TB/s of the 8 TB/s HBM).  A float32 number is EXACTLY the sum of three bf16
-// numbers (24 significand bits = 8 + 8 + 8: hi = the top 16 bits of the word, mid = the top 16 bits of x - hi, lo = x - hi - mid,
-// every subtraction exact), a bf16 x bf16 product is exact in float32, and the matrix pipe accumulates in float32.  So
-//
-//     a.b = (ah + am + al).(bh + bm + bl) = ah.bh + (ah.bm + am.bh) + (am.bm + ah.bl + al.bh) + [am.bl + al.bm] + {al.bl}
-//
-// and NP = 6 products drop the [..] pair and {..}: with this truncation split (|mid| < 2^-7 |x|, |lo| < 2^-15 |x|) at most 2^-21.3 of
-// the product and 2^-24 of it in the rms (tests/test_split_arithmetic_cpu.py) - the size of ONE float32 rounding of the product,
-// which the float32 MFMA chain commits at every one of its K steps anyway; NP = 8 keeps the [..] pair as well (no measurable
-// difference in a contraction: what is left is the float32 accumulation).  A round-to-nearest split (v_cvt_pk_bf16_f32, the same
-// instruction count) would make the dropped terms 2^-24.4 / 2^-27 (tools/split_rne_probe.hpp).  One v_mfma_f32_16x16x32_bf16 (~17 cycles) covers 32 contraction elements, for which the float32 MFMA needs 8
-// instructions of 32 cycles: 6 products are 2.5 x less matrix-pipe time; 64-column passes become HBM bound (5.6-5.8 TB/s), 128-column
-// passes run the bf16 pipe 0.75 busy under the power cap (1.66 GHz) - 1.45-1.5 x the float32-MFMA passes either way.
-// Measured error against a float64 contraction: tools/gemm_probe9 (profiles/r04_gemm_probe9_split.txt): 1.1-1.4 x the float32 MFMA's.
-//
-// Same machine as gemm_ct / gemm_cr (gemm_kernels.hpp): a block's KW waves own KW adjacent 64-row output tiles and walk the same
-// contraction range; the small operand B is staged once per block through LDS, double buffered, one barrier per group of KS x 32
-// contraction elements (KS = 2 up to 64 columns); (super tile, group) units are split stream-K style over one round of resident
-// blocks; partial tiles go to slots (fixed count, zero-filled by the last contributor, summed in fixed order by the consumers).
-// The engine launches 8-wave blocks of 512 rows, one per CU, from 64 columns on (B is re-read once per super tile: its L2 -> fabric
-// traffic halves against 4-wave blocks), with the MFMA phase at raised wave priority (lcx_engine.hip, SplitShape).  What is new:
-//   * the A operand (X from the PANEL-major copy XP[v / 16][n][16]) goes global -> VGPR as 16-byte loads exactly as in the float32
-//     kernels (1 KB contiguous per load instruction for X.B^T, 4 x 256 B for X^T.Y) and is split in registers (4 VALU operations per
-//     element + 3 v_perm_b32 per pair) right before use;
-//   * B is split ONCE per pass by split_b_kernel into MFMA operand order (1.5 x its bytes; 10-20 us for 25-50 MB), so the staging of
-//     the contraction kernel is a plain copy of 16-byte pieces global -> VGPR -> LDS and a wave's operand fetch is one conflict-free
-//     ds_read_b128 per (column tile, part).  (Splitting B inside the contraction kernel, per block, measured 3-9 % slower.)
-// Any permutation of the 32 contraction elements of a group over (lane group g, element e) is legal as long as A and B agree:
-//   X.B^T  (CONTRACT_N = false; contraction over variables): lane (i, g) loads row v0 + 16 t + i, chunk g of panels 2G and 2G + 1:
-//          element e = 4 h + c is variable 32 G + 16 h + 4 g + c;
-//   X^T.Y  (CONTRACT_N = true; contraction over samples): lane (i, g) loads the 4 variables v0 + 4 i .. + 3 of samples
-//          32 G + 4 m + g, m = 0..7 (the 16 lanes i cover 4 panels, the 4 lane groups g 4 consecutive samples = 256 contiguous bytes
-//          per panel); element e of row tile t is sample 32 G + 4 e + g of variable v0 + 4 i + t.
+// split_rne_probe.hpp - lab only (tools/gemm_probe9 rne): the production split contraction with a ROUND-TO-NEAREST three-way split
+// (v_cvt_pk_bf16_f32 for hi and mid, the residuals by exact float32 subtractions) instead of the truncation split: the same 11
+// instructions per pair of elements, residuals half the size and signed, so the 3 dropped partial products are at most 2^-24.4 of a
+// product (2^-27 rms) instead of 2^-21.3 (2^-24 rms) - tests/test_split_arithmetic_cpu.py.  Caveat: rounding to nearest overflows
+// to infinity within half a bf16 ulp of FLT_MAX; the truncation split never does.  Generated from the production kernel text.
 #pragma once
-#include "gemm_kernels.hpp"
+#include "../linearcorex_amd/csrc/gemm_split_kernels.hpp"
 
 namespace lcx {
 
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float lab_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 lab_b2 __attribute__((ext_vector_type(2)));
 
-struct Split3 { u32x4_t p[3]; };             // hi, mid, lo
-
-// 8 floats -> three packed bf16x8 operands (element 2p in the low half of word p)
-__device__ __forceinline__ Split3 split8(const float (&x)[8]) {
+__device__ __forceinline__ Split3 split8_rne(const float (&x)[8]) {
     Split3 s;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const float a = x[2 * p], b = x[2 * p + 1];
-        const unsigned ah = __float_as_uint(a) & 0xffff0000u, bh = __float_as_uint(b) & 0xffff0000u;
-        const float ra = a - __uint_as_float(ah), rb = b - __uint_as_float(bh);
-        const unsigned am = __float_as_uint(ra) & 0xffff0000u, bm = __float_as_uint(rb) & 0xffff0000u;
-        const float la = ra - __uint_as_float(am), lb = rb - __uint_as_float(bm);
-        s.p[0][p] = __builtin_amdgcn_perm(bh, ah, 0x07060302u);
-        s.p[1][p] = __builtin_amdgcn_perm(bm, am, 0x07060302u);
+        const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector((lab_f2){a, b}, lab_b2));
+        const float ra = a - __uint_as_float(hp << 16), rb = b - __uint_as_float(hp & 0xffff0000u);
+        const unsigned mp = __builtin_bit_cast(unsigned, __builtin_convertvector((lab_f2){ra, rb}, lab_b2));
+        const float la = ra - __uint_as_float(mp << 16), lb = rb - __uint_as_float(mp & 0xffff0000u);
+        s.p[0][p] = hp;
+        s.p[1][p] = mp;
         s.p[2][p] = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
     }
     return s;
 }
-
-__device__ __forceinline__ f32x4_t mma_bf16(u32x4_t a, u32x4_t b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-
-// the products in the order they are accumulated, smallest terms first: (part of A, part of B); NP = 3 / 6 / 8 takes the LAST NP
-__device__ constexpr int SPLIT_PA[8] = {1, 2, 2, 0, 1, 1, 0, 0};
-__device__ constexpr int SPLIT_PB[8] = {2, 1, 0, 2, 1, 0, 1, 0};
-
-constexpr int SPLIT_KG = 32;                 // contraction elements per group (one bf16 MFMA step)
 
 // ------------------------------------------------------------------------------------------------
 // split_b_kernel: the small operand B[K][Mp] split once per pass, in MFMA operand order:
@@ -79,7 +33,7 @@ constexpr int SPLIT_KG = 32;                 // contraction elements per group (
 // ------------------------------------------------------------------------------------------------
 template <int CT, bool CONTRACT_N>
 __global__ void __launch_bounds__(256)
-split_b_kernel(const float* __restrict__ B /* [K][Mp] */, u32x4_t* __restrict__ Bsp, int ng, const int* __restrict__ skip_flag) {
+split_b_rne_kernel(const float* __restrict__ B /* [K][Mp] */, u32x4_t* __restrict__ Bsp, int ng, const int* __restrict__ skip_flag) {
     constexpr int Mp = 16 * CT, TASKS = 4 * Mp;
     if (skip_flag != nullptr && *skip_flag != 0) return;
     for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < (int64_t)ng * TASKS; w += (int64_t)gridDim.x * blockDim.x) {
@@ -93,7 +47,7 @@ split_b_kernel(const float* __restrict__ B /* [K][Mp] */, u32x4_t* __restrict__ 
             const int row = CONTRACT_N ? 4 * e + gg : 16 * (e >> 2) + 4 * gg + (e & 3);
             x[e] = src[row * Mp + j * CT + u];
         }
-        const Split3 s = split8(x);
+        const Split3 s = split8_rne(x);
 #pragma unroll
         for (int q = 0; q < 3; ++q) Bsp[(G * 3 + q) * (CT * 64) + u * 64 + gg * 16 + j] = s.p[q];
     }
@@ -101,7 +55,7 @@ split_b_kernel(const float* __restrict__ B /* [K][Mp] */, u32x4_t* __restrict__ 
 
 template <int CT, int KW, int NP, bool CONTRACT_N, bool NT, bool PREFETCH_B, int WPE = 2, int KS = 1, int PRIO = 0>
 __global__ void __launch_bounds__(64 * KW, WPE)
-gemm_split_kernel(const float* __restrict__ A /* panel-major */, int64_t ps, const u32x4_t* __restrict__ Bsp, float* __restrict__ out, int64_t out_rows,
+gemm_split_rne_kernel(const float* __restrict__ A /* panel-major */, int64_t ps, const u32x4_t* __restrict__ Bsp, float* __restrict__ out, int64_t out_rows,
                    int64_t nrows, int ng /* groups of KS x 32 */, int nsuper, int maxslots, const int* __restrict__ skip_flag) {
     constexpr int Mp = 16 * CT, RT = 4, NTH = 64 * KW;
     constexpr int PC1 = 3 * CT * 64;                         // 16-byte pieces of 32 contraction elements of B
@@ -168,7 +122,7 @@ gemm_split_kernel(const float* __restrict__ A /* panel-major */, int64_t ps, con
                 float x[8];                                                               \
                 _Pragma("unroll") for (int e = 0; e < 8; ++e)                             \
                     x[e] = CONTRACT_N ? raw[S][e][t] : raw[S][2 * t + (e >> 2)][e & 3];   \
-                as[t] = split8(x);                                                        \
+                as[t] = split8_rne(x);                                                        \
             }                                                                             \
         }
 #define LCX_SP_MMA(BUF, S)                                                                \

@@ -675,6 +675,32 @@ def config_of(workload, r, world, line_search, force_exchange=False):
             "exchange": r.get("exchange")}
 
 
+def series_of(out, head, world):
+    """The weak-scaling series, readable from the lines alone (top level, every line): which workload the series is measured on,
+    one GPU's rate inside THIS job, the same shard on one GPU without exchange steps, and their ratio.  The N = 1 line headlines
+    configs[2] (`value`), the N > 1 lines headline N x the configs[3] shard, so value(N) / (N x value(1)) is NOT an efficiency -
+    `series.per_gpu_value / series.n1_value_same_workload` is:
+        N = 1, default job:   from the nested config.c4shard block (the workload the --gpus N lines headline); efficiency 1.0
+        N = 1, one workload:  that workload is its own one-GPU point
+        N > 1:                per_gpu_value = value / N; n1_value_same_workload = the same shard measured on every GPU alone in this
+                              job (config.single_gpu_same_shard, slowest rank); null with --no-extras"""
+    cfg = out["config"]
+    if world == 1:
+        c4 = cfg.get("c4shard")
+        if isinstance(c4, dict) and c4.get("value"):
+            wl, per_gpu = "c4shard", c4["value"]
+        else:
+            wl, per_gpu = head, out["value"]
+        n1, eff = per_gpu, 1.0
+    else:
+        wl, per_gpu = head, out["value"] / world
+        n1 = _pick(cfg, "single_gpu_same_shard", "iterations_per_sec_slowest_rank")
+        eff = (per_gpu / n1) if n1 else None
+    n, v_per, m, tag = WORKLOADS[wl]
+    return {"workload": wl, "shard": "%d x %d x %d %s per GPU" % (n, v_per, m, tag), "n_gpus": world, "per_gpu_value": per_gpu,
+            "n1_value_same_workload": n1, "efficiency": eff, "unit": "fit iterations/s per GPU"}
+
+
 def other_gemm_name(args):
     return "f32_gemm_split" if args.f32_gemm == "mfma" else "f32_gemm_mfma"
 
@@ -886,6 +912,8 @@ def compact_line(out, detail_path):
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                 "scaling", "vs_baseline", "dtype", "data")}
     line.update(config=c, roofline=rl, cpu_baseline=cb)
+    if out.get("series"):
+        line["series"] = out["series"]
     return _r(line)
 
 
@@ -1182,6 +1210,8 @@ def main():
             if world > 1:
                 out["cpu_baseline"]["sample"] += ("; one shard's iteration (n_variables per GPU = %d): `value` counts every "
                                                   "rank's shard iterations, so the two are in the same unit" % v_per)
+
+    out["series"] = series_of(out, head, world)
 
     # tear the process group down first and push out whatever C-level stdio still buffers (now on stderr), so that the JSON
     # line is the last thing this job writes even when the caller merges the two streams

@@ -12,10 +12,13 @@ import numpy as np
 
 
 class Comm:
-    def __init__(self, group=None, always_exchange=False):
+    def __init__(self, group=None, always_exchange=False, bounds=None):
         """always_exchange: issue every exchange step even in a group of one rank (the all-reduces are then
         identities).  Used to run the multi-rank device path - the world>1 kernels of the engine, the bound
-        exchange tensors and real RCCL launches on the engine's stream - on a single GPU."""
+        exchange tensors and real RCCL launches on the engine's stream - on a single GPU.
+        bounds: explicit column boundaries of the shards, `world + 1` non-decreasing integers from 0 to n_variables (rank r
+        holds columns [bounds[r], bounds[r+1]), at least one each) instead of the balanced split - GPUs with unequal free
+        memory, and the tests' awkward shards.  The same on every rank."""
         import torch.distributed as dist
         self._dist = dist
         self.group = group
@@ -23,10 +26,20 @@ class Comm:
         self.world = dist.get_world_size(group)
         self.exchange = self.world > 1 or bool(always_exchange)
         self.selftest_seconds = None       # seconds one Y-buffer all-reduce took in the transport's first-contact test (bind_engine)
+        self.bounds = None
+        if bounds is not None:
+            b = [int(t) for t in bounds]
+            if len(b) != self.world + 1 or b[0] != 0 or any(b[k + 1] <= b[k] for k in range(self.world)):
+                raise ValueError("bounds must be %d increasing column boundaries starting at 0" % (self.world + 1))
+            self.bounds = b
 
-    # contiguous, balanced column ranges
+    # contiguous column ranges: balanced, or the caller's boundaries
     def shard(self, nv, rank=None):
         r = self.rank if rank is None else rank
+        if self.bounds is not None:
+            if self.bounds[-1] != nv:
+                raise ValueError("shard boundaries end at %d, the data have %d variables" % (self.bounds[-1], nv))
+            return self.bounds[r], self.bounds[r + 1]
         return (nv * r) // self.world, (nv * (r + 1)) // self.world
 
     def allreduce(self, tensor):

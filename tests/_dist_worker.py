@@ -37,7 +37,8 @@ def main():
 
     mark("before rendezvous")
     dist.init_process_group("gloo")
-    comm = Comm()
+    bounds = os.environ.get("LCX_TEST_BOUNDS")          # explicit (uneven) shard boundaries instead of the balanced split
+    comm = Comm(bounds=[int(t) for t in bounds.split(",")] if bounds else None)
     mark("rendezvous done")
     x, _ = O.gen_planted(n, v, m, seed=2)
     dt = np.float32 if os.environ.get("LCX_TEST_DTYPE") == "f32" else np.float64

@@ -57,15 +57,29 @@ def test_single_rank_rccl_stdout_is_one_json_line():
     assert w["stages"] == 7 and w["steps_per_window"] == 3 and w["timed_iterations"] == 21
 
 
-def test_default_line_is_the_c3_line_with_the_c2_block(tmp_path):
-    """The driver's command: the headline must be BASELINE configs[2] (MFMA-bound), the line must fit the driver's stdout
-    budget, c2 and the config-4 shard ride along as scalars on the line and as nested blocks in the detail record, the CPU
-    baselines are real, and the figure must not depend on the driver's --steps 20 --warmup 5."""
+def _series_ok(line):
+    """the weak-scaling series is readable from the line alone (top level): per_gpu_value / n1_value_same_workload = efficiency"""
+    sr = line["series"]
+    assert set(("workload", "n_gpus", "per_gpu_value", "n1_value_same_workload", "efficiency")) <= set(sr)
+    assert sr["n_gpus"] == line["n_gpus"] and sr["per_gpu_value"] > 0
+    if sr["n1_value_same_workload"] is not None:
+        assert sr["efficiency"] == pytest.approx(sr["per_gpu_value"] / sr["n1_value_same_workload"], rel=1e-4)
+    if line["n_gpus"] > 1:
+        assert sr["per_gpu_value"] == pytest.approx(line["value"] / line["n_gpus"], rel=1e-4)
+    return sr
+
+
+def test_c3_headline_alone(tmp_path):
+    """BASELINE configs[2] as the driver's command measures it, without the nested blocks (`--no-extras --repeats 1`): the MFMA-bound
+    headline, its roofline object from live HIP events, the line inside the driver's stdout budget.  The nested blocks of the
+    default job (c2, the config-4 shard, the opt-in line searches, the convergence runs, CPU baselines: ~2 minutes, what the
+    driver's own bench step runs at round end) are checked on the CPU side against the committed record of such a run
+    (tests/test_host_logic_cpu.py::test_bench_default_record_*)."""
     detail = str(tmp_path / "detail.json")
     t0 = time.time()
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
-                        "--cpu-seconds", "5", "--detail-out", detail], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       timeout=1500)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--workload", "c3",
+                        "--no-extras", "--repeats", "1", "--detail-out", detail], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600)
     wall = time.time() - t0
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     line = _one_json_line(p.stdout)
@@ -74,51 +88,15 @@ def test_default_line_is_the_c3_line_with_the_c2_block(tmp_path):
     assert rl["bound"] == "mfma" and rl["unit"] == "TFLOP/s" and 0.3 < rl["frac"] < 1.0
     assert rl["kernel"].startswith("lcx::gemm_c") and rl["avg_launch_us"] > 0 and rl["launches"] > 0
     assert abs(rl["achieved"] / rl["peak"] - rl["frac"]) < 1e-4
-    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
-    assert len(line["cpu_baseline"]["sample"]) <= 300
     c = line["config"]
-    assert c["detail"] == detail and c["windows"]["walks_timed"] >= 3 and c["windows"]["timed_seconds"] >= 0.5
-    lo, med, hi = c["windows"]["ms_per_step_walk_min_median_max"]
-    assert lo <= med <= hi and med / lo < 1.05 and hi / lo < 1.3, (lo, med, hi)
-    # the value is consistent with what was timed, and the whole job fits the driver's patience
+    assert c["detail"] == detail and c["windows"]["walks_timed"] == 1 and c["windows"]["timed_iterations"] == 140
     assert abs(line["value"] * line["ms_per_step"] / 1e3 - 1.0) < 1e-3
-    assert wall < 400, wall
-    for k in ("c2_value", "c2_roofline_frac", "c2_cpu_baseline_value", "c4shard_value", "c4shard_roofline_frac", "linear_value",
-              "fit_to_convergence_planted_seconds"):
-        assert c[k] > 0, k
-    assert ("exact_y_value" in c) != (c["line_search"] == "exact-y") and ("reference_shaped_value" in c) != (c["line_search"] == "exact")
-
-    # ---- the detail record: everything the line used to carry
+    assert wall < 200, wall
+    sr = _series_ok(line)
+    assert sr["workload"] == "c3" and sr["efficiency"] == 1.0 and sr["per_gpu_value"] == pytest.approx(line["value"], rel=1e-5)
     d = _detail(detail, p.stderr)
     assert d["value"] == pytest.approx(line["value"], rel=1e-5) and d["roofline"]["frac"] == pytest.approx(rl["frac"], rel=1e-5)
-    assert d["config"]["windows"]["timed_seconds"] >= 0.5
-    c2 = d["config"]["c2"]
-    assert c2["roofline"]["bound"] == "hbm" and c2["windows"]["timed_seconds"] >= 0.5
-    assert c2["cpu_baseline"]["value"] > 0 and c2["value"] == pytest.approx(c["c2_value"], rel=1e-5)
-    ratios = sorted(w / c2["windows"]["ms_per_step_walk_min_median_max"][0] for w in c2["windows"]["ms_per_step_by_walk"])
-    # (one of ~10 walks may catch a host hiccup: the figure is the per-stage median; 9 of 10 walks must agree)
-    assert ratios[len(ratios) // 2] < 1.1 and ratios[int(0.9 * (len(ratios) - 1))] < 1.25, ratios
-    assert c2["get_covariance"]["n_variables"] == 5000 and c2["get_covariance"]["seconds"] > 0
-    assert d["config"]["get_covariance_c5_standin"]["n_variables"] == 20000
-    # the one-GPU point of the weak-scaling series that --gpus N headlines
-    c4 = d["config"]["c4shard"]
-    assert c4["value"] > 0 and c4["n_hidden"] == 128 and c4["n_variables_per_gpu"] == 125000
-    assert c4["roofline"]["bound"] == "mfma" and 0.3 < c4["roofline"]["frac"] < 1.0
-    assert c4["cpu_baseline"]["value"] > 0 and c4["cpu_baseline"]["n_variables_timed"] <= 100000
-    # the 209 GB block is opt-in now (--c4full-steps / --workload c4full)
-    assert "c4_unsharded_one_gpu" not in d["config"]
-    # the other line searches, reported beside the headline at the sizes where a trial costs two long passes
-    names = {"exact": "reference_shaped", "exact-y": "later_trials_by_linearity", "linear": "linear_trial_mode"}
-    for blk, own in ((d["config"], d["value"]), (c4, c4["value"])):
-        its = {ls: own if ls == blk["line_search"] else blk[names[ls]]["fit_iterations_per_sec"] for ls in names}
-        xp = {ls: blk["x_passes_per_iteration"] if ls == blk["line_search"] else blk[names[ls]]["x_passes_per_iteration"] for ls in names}
-        assert xp["linear"] < xp["exact-y"] < xp["exact"] and its["linear"] > its["exact-y"] > its["exact"] > 0, (its, xp)
-        assert 1.9 < xp["linear"] < 2.6 and blk["linear_trial_mode"]["roofline"]["bound"] == "mfma"
-    # a convergence measurement that converges: planted data, every annealing stage below tol before the cap
-    cv = d["config"]["fit_to_convergence_planted"]
-    assert cv["stages_converged_before_the_cap"] == 7 and cv["seconds"] > 0
-    assert cv["cluster_purity_vs_planted_groups"] > 0.99
-    assert d["config"]["fit_to_convergence"]["capped"] is True
+    assert 3.0 < d["config"]["x_passes_per_iteration"] < 3.6 and d["config"]["bytes_resident"]["x_layout"].startswith("panel")
 
 
 def _two_rank_env():
@@ -135,6 +113,8 @@ def test_two_ranks_one_gpu_stdout_is_one_json_line():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["config"]["n_variables_total"] == 2 * d["config"]["n_variables_per_gpu"]
     assert d["cpu_baseline"] is None
+    sr = _series_ok(d)            # --no-extras: no same-shard pre-run, the one-GPU point is absent and says so
+    assert sr["workload"] == "tiny" and sr["n1_value_same_workload"] is None and sr["efficiency"] is None
 
 
 def test_gpus_2_without_a_launcher_starts_two_ranks():
@@ -167,6 +147,10 @@ def test_two_ranks_full_line_has_the_same_shard_reference_and_the_c2_block(tmp_p
     assert line["n_gpus"] == 2 and line["cpu_baseline"]["value"] > 0 and line["roofline"]["frac"] > 0
     assert line["config"]["single_gpu_same_shard_value"] > 0 and line["config"]["weak_scaling_vs_same_shard"] > 0
     assert line["config"]["c2_weak_value"] > 0
+    # the series from the line alone: per-GPU rate of this job / the same shard on one GPU alone in this job
+    sr = _series_ok(line)
+    assert sr["workload"] == "tiny" and sr["n1_value_same_workload"] == pytest.approx(line["config"]["single_gpu_same_shard_value"], rel=1e-4)
+    assert sr["efficiency"] == pytest.approx(line["config"]["weak_scaling_vs_same_shard"], rel=1e-4)
     d = _detail(detail)
     assert d["n_gpus"] == 2
     # the multi-GPU line carries a CPU baseline too (rank 0, one shard's iteration) and a roofline

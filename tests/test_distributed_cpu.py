@@ -80,6 +80,22 @@ def test_sharded_fit_matches_oracle(world, mode, tmp_path):
     check_covariance(got, ref)
 
 
+def test_caller_chosen_uneven_shards(tmp_path):
+    """Comm(bounds=...): the caller's column boundaries instead of the balanced split - three ranks holding 1, 149 and 53 of 203
+    variables (a rank with a single variable), same fit as the oracle's."""
+    n, v, m = 300, 203, 4
+    launch(3, tmp_path, n, v, m, "exact", extra_env={"LCX_TEST_BOUNDS": "0,1,150,203"})
+    got = np.load(os.path.join(tmp_path, "dist_result.npz"))
+    x, _ = O.gen_planted(n, v, m, seed=2)
+    ref = O.fit_ns(x, m, seed=0, dtype=np.float64, keep_x=True)
+    h, h_ref = got["history"], np.asarray(ref.history_tc)
+    assert len(h) == len(h_ref) and np.max(np.abs(h - h_ref) / np.maximum(1, np.abs(h_ref))) < 1e-9
+    assert np.max(np.abs(got["ws"] - ref.ws)) < 1e-8 and np.array_equal(got["clusters"], ref.clusters())
+    assert np.max(np.abs(got["rho"] - ref.moments["rho"])) < 1e-8
+    assert int(got["trials"]) == ref.n_trials
+    check_covariance(got, ref)
+
+
 def test_sharded_synergistic_fit_matches_oracle(tmp_path):
     """discourage_overlap=False over two ranks: Y all-reduce, the m+3 sums, H."""
     n, v, m = 300, 203, 4

@@ -79,7 +79,7 @@ def test_full_size_properties(shape, gemm):
 _C2_CACHE = {}
 
 
-def test_config2_full_fit_vs_oracle(ls):
+def test_config2_full_fit_vs_oracle(ls_both):
     """BASELINE.json configs[1] end to end: synthetic Gaussian X 10k x 5k, n_hidden = 32, float64, the whole fit to
     tol = 1e-5 on the device against the NumPy oracle on the host cores (about half a minute of CPU on the GPU box):
     same number of iterations and line-search trials, TC history / weights / covariance within the north-star 1e-6,
@@ -93,7 +93,7 @@ def test_config2_full_fit_vs_oracle(ls):
         _C2_CACHE["ref"] = O.fit_ns(x, m, seed=0, dtype=np.float64)
     ref = _C2_CACHE["ref"]
     out = Corex(n_hidden=m, seed=0, dtype=np.float64, device=0).fit(x)
-    assert out.line_search == ls
+    assert out.line_search == ls_both
     h_ref, h = np.asarray(ref.history_tc, np.float64), np.asarray(out.history["TC"], np.float64)
     assert len(h) == len(h_ref), (len(h), len(h_ref))
     assert np.max(np.abs(h - h_ref) / np.maximum(1.0, np.abs(h_ref))) < 1e-6

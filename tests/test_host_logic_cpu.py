@@ -455,6 +455,52 @@ def test_bench_stdout_line_stays_within_the_drivers_budget(tmp_path):
     assert len(text) <= 2601 and json.loads(text)["roofline"]["frac"] > 0 and "c2_value" in json.loads(text)["config"]
 
 
+def test_bench_default_record_riders_and_series():
+    """The nested blocks of the default job, checked on the record of such a run (the GPU suite measures the c3 headline alone; the
+    whole job is what the driver's bench step runs): profiles/r04_bench_default_detail.json through bench.series_of /
+    bench.compact_line - c2, the config-4 shard and the opt-in modes ride on the line as scalars, and the weak-scaling series is
+    readable from the lines alone: at N = 1 from the c4shard block, at N > 1 from the same-shard reference of that job."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r04_bench_default_detail.json")) as f:
+        full = json.load(f)
+    full["series"] = bench.series_of(full, "c3", 1)
+    line = bench.compact_line(full, "d.json")
+    assert len(json.dumps(line, separators=(",", ":"))) <= 4096
+    c, sr = line["config"], line["series"]
+    for k in ("c2_value", "c2_roofline_frac", "c2_cpu_baseline_value", "c4shard_value", "c4shard_roofline_frac", "linear_value",
+              "exact_y_value", "fit_to_convergence_planted_seconds"):
+        assert c[k] > 0, k
+    assert sr["workload"] == "c4shard" and sr["n_gpus"] == 1 and sr["efficiency"] == 1.0
+    assert sr["per_gpu_value"] == sr["n1_value_same_workload"] == pytest.approx(full["config"]["c4shard"]["value"], rel=1e-5)
+    assert sr["per_gpu_value"] != pytest.approx(line["value"], rel=0.2)       # NOT the c3 headline: that is the point of the key
+    d = full["config"]
+    assert d["c2"]["roofline"]["bound"] == "hbm" and d["c2"]["get_covariance"]["n_variables"] == 5000
+    assert d["get_covariance_c5_standin"]["n_variables"] == 20000
+    c4 = d["c4shard"]
+    assert c4["n_hidden"] == 128 and c4["n_variables_per_gpu"] == 125000 and c4["roofline"]["bound"] == "mfma"
+    assert c4["cpu_baseline"]["n_variables_timed"] <= 100000
+    names = {"exact": "reference_shaped", "exact-y": "later_trials_by_linearity", "linear": "linear_trial_mode"}
+    for blk, own in ((d, full["value"]), (c4, c4["value"])):
+        its = {ls: own if ls == blk["line_search"] else blk[names[ls]]["fit_iterations_per_sec"] for ls in names}
+        assert its["linear"] > its["exact-y"] > its["exact"] > 0, its
+    cv = d["fit_to_convergence_planted"]
+    assert cv["stages_converged_before_the_cap"] == 7 and cv["cluster_purity_vs_planted_groups"] > 0.99
+    # N > 1: the two-rank rehearsal's record
+    with open(os.path.join(ROOT, "profiles", "r04_two_ranks_full_one_gpu_gloo_detail.json")) as f:
+        two = json.load(f)
+    two["series"] = bench.series_of(two, "c4shard", 2)
+    sr = bench.compact_line(two, "d2.json")["series"]
+    assert sr["workload"] == "c4shard" and sr["n_gpus"] == 2
+    assert sr["per_gpu_value"] == pytest.approx(two["value"] / 2, rel=1e-5)
+    assert sr["n1_value_same_workload"] == pytest.approx(two["config"]["single_gpu_same_shard"]["iterations_per_sec_slowest_rank"], rel=1e-5)
+    assert sr["efficiency"] == pytest.approx(two["config"]["weak_scaling_vs_same_shard"], rel=1e-5)
+    # four lines N = 1, 2, 4, 8 and no prose: the curve is efficiency(N), and N x per_gpu_value(N) over n1_value gives the speed-up
+    assert sr["efficiency"] == pytest.approx(sr["per_gpu_value"] / sr["n1_value_same_workload"], rel=1e-5)
+
+
 def test_headers_are_plain_c_and_a_c_program_links_the_library(tmp_path):
     """include/lcx.h is the boundary a non-Python host binds: it must compile as C (not only as C++), a C program must link
     against liblcx_hip.so and resolve every call it makes, and the probe library must export the boundary too (its handles are

@@ -191,7 +191,8 @@ def _fit(x, m, tag, **kw):
 
 
 @pytest.mark.parametrize("tag", ["f32", "f64"])
-def test_big5_end_to_end(tag, g1, ls):
+def test_big5_end_to_end(tag, g1, ls_both):
+    ls = ls_both
     out = _fit(g1["x_raw"].astype(np.float64), 5, tag)
     h_ref = g1[tag + "_history_tc"]
     h = np.asarray(out.history["TC"], dtype=np.float64)

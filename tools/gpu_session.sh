@@ -9,10 +9,11 @@
 #   wave_states <probe> [args]     SQ wave-state counters of a probe binary (where do the waves of a kernel spend their cycles)
 #   line_search_ab <wl> ...        bench --no-extras under line_search exact / exact-y / linear, one line each
 #   two_ranks [bench args]         the driver's --gpus 2 command rehearsed on ONE GPU (two ranks share GPU 0 over gloo)
+#   n_ranks <N> <head> [args]     the driver's --gpus N command on ONE GPU at a reduced shard (N ranks share GPU 0 over gloo)
 #   probe <name> [args]            build tools/<name>.hip and run it                        -> gpurun_out/<tag>_<name>_<args>.txt
-# TAG (environment, default r04) prefixes the outputs.
+# TAG (environment, default r05) prefixes the outputs.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 cd $R; mkdir -p gpurun_out
 recipe=$1; shift
 case "$recipe" in
@@ -57,6 +58,16 @@ print('$wl $ls', round(d['value'],2), 'it/s', round(d['ms_per_step'],3), 'ms; X 
     LCX_BENCH_DEVICE=0 LCX_BENCH_BACKEND=gloo timeout 1500 python bench.py --gpus 2 --steps 20 --warmup 5 --detail-out gpurun_out/${TAG}_two_ranks_detail.json "$@" \
       2>gpurun_out/${TAG}_two_ranks.err > gpurun_out/${TAG}_two_ranks.json
     echo "rc=$? wall $(( $(date +%s) - T0 )) s, line $(wc -c < gpurun_out/${TAG}_two_ranks.json) bytes"; cat gpurun_out/${TAG}_two_ranks.json ;;
+  n_ranks)
+    # the driver's --gpus N command rehearsed on ONE GPU: N ranks share GPU 0, the library's exchange goes through its hook (gloo).
+    #   n_ranks <N> <head workload | auto> [bench args]     e.g.  n_ranks 8 50000x16000x128:f32 --steps 5 --warmup 2
+    N=$1; HEAD=$2; shift 2
+    T0=$(date +%s)
+    if [ "$HEAD" != auto ]; then export LCX_BENCH_HEAD=$HEAD; fi
+    LCX_BENCH_DEVICE=0 LCX_BENCH_BACKEND=gloo timeout 1700 python bench.py --gpus $N --detail-out gpurun_out/${TAG}_${N}_ranks_detail.json "$@" \
+      2>gpurun_out/${TAG}_${N}_ranks.err > gpurun_out/${TAG}_${N}_ranks.json
+    echo "rc=$? wall $(( $(date +%s) - T0 )) s, line $(wc -c < gpurun_out/${TAG}_${N}_ranks.json) bytes" | tee gpurun_out/${TAG}_${N}_ranks_summary.txt
+    cat gpurun_out/${TAG}_${N}_ranks.json; grep -v BENCH_DETAIL gpurun_out/${TAG}_${N}_ranks.err | tail -40 ;;
   probe)
     P=$1; shift
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/$P tools/$P.hip 2>/dev/null || exit 1

@@ -154,8 +154,19 @@ class Comm:
                 self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4" if dtype == 0 else "<f8",
                                                  "data": (ptr, False), "version": 2}
 
+        streams = {}
+
         def allreduce(ptr, count, dtype, stream):
-            with backend.stream_context():
+            # the stream the library hands over: its main stream (= backend.torch_stream), or the second stream of the pipelined
+            # Y exchange (LCX_Y_PIPELINE=chunks) - the collective must be ordered with THAT one
+            sid = int(stream or 0)
+            if sid == backend.torch_stream.cuda_stream or sid == 0:
+                ctx = backend.stream_context()
+            else:
+                if sid not in streams:
+                    streams[sid] = torch.cuda.ExternalStream(sid, device=torch.device("cuda", backend.device))
+                ctx = torch.cuda.stream(streams[sid])
+            with ctx:
                 t = torch.as_tensor(_View(ptr, count, dtype), device=torch.device("cuda", backend.device))
                 self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
         backend.set_exchange_hook(allreduce)

@@ -977,6 +977,8 @@ class Corex(object):
             r0, r1 = (int(t) for t in rows)
         if not 0 <= r0 <= r1 <= self.nv:
             raise ValueError("get_covariance(rows=(%d, %d)): outside [0, %d]" % (r0, r1, self.nv))
+        if r0 == r1:                       # an empty block of rows: the same (0, nv) array from one rank and from several
+            return np.empty((0, self.nv), dtype=self.dtype)
         if self._comm.world == 1:
             return be.covariance_rows(self.eps, std, r0, r1 - r0, syn)
         return self._covariance_rows_sharded(r0, r1, std, syn)

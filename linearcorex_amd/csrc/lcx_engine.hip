@@ -196,6 +196,10 @@ struct lcx_ctx {
     SetState* host_states;      // pinned [2]
     int* order_dev;
     unsigned int* ticket;       // arrival counters: [0] small_moments_kernel, [1] moments_epilogue_kernel, [2] update_kernel
+    // ytail_kernel (one GPU, <= 32 padded factors): slot reduction of Y + both Grams + the per-factor moments of a trial in ONE launch
+    bool ytail_ok, y_pending;   // y_pending: ypart holds the unreduced slots of the Y in flight (lcx_iterate's trials only)
+    int yt_Sy, yt_Sw;
+    void* ytpart;               // [yt_Sy + yt_Sw][Mp][Mp] partial Gram tiles
     bool full_sig;              // run the second pass of _sig (X^T.Y_g): the linear trial mode needs D(update)
     bool exchange;              // the exchange steps are live (several ranks, or forced for testing)
     bool w1_ready;              // Wt[1] already holds ws + update (written by update_kernel)
@@ -239,6 +243,11 @@ struct lcx_ctx {
     bool early_grad, grad_ready;
     double spec_eps;
     size_t bytes_resident;      // device bytes owned by the handle (X, its transposed copy, moments, work space)
+    // LCX_Y_PIPELINE=chunks[:n]: the Y all-reduce of lcx_moments_a in n row chunks on a second stream, each behind the event of its
+    // chunk's slot reduction (and, for the wave-split kernels, behind its own row chunk of the pass); default off
+    int ypipe;
+    hipStream_t comm_stream;
+    hipEvent_t ypipe_ev[17];
     Transport tr;               // in-library exchange (kind != 0): every level sums what it produced over the ranks itself
     int64_t n_exchanges;        // all-reduces issued by the library (diagnostics)
 };
@@ -249,17 +258,18 @@ static inline void cancel_speculation(lcx_ctx* h);
 
 // Sum `count` elements at `buf` (device memory) over the ranks, in place, stream-ordered with the handle's kernels.
 // Without a bound transport this is the caller's job between the level calls; without exchange steps there is nothing to sum.
-static int exchange(lcx_ctx* h, void* buf, int64_t count, int dtype) {
+static int exchange_on(lcx_ctx* h, hipStream_t st, void* buf, int64_t count, int dtype) {
     if (!h->exchange || h->tr.kind == 0 || count <= 0) return LCX_OK;
     h->n_exchanges += 1;
     if (h->tr.kind == 1) {
-        RCCLCHECK(rccl().AllReduce(buf, buf, (size_t)count, dtype == LCX_F32 ? ncclFloat : ncclDouble, ncclSum, h->tr.comm, h->stream));
+        RCCLCHECK(rccl().AllReduce(buf, buf, (size_t)count, dtype == LCX_F32 ? ncclFloat : ncclDouble, ncclSum, h->tr.comm, st));
         return LCX_OK;
     }
-    const int rc = h->tr.hook(h->tr.user, buf, count, dtype, (void*)h->stream);
+    const int rc = h->tr.hook(h->tr.user, buf, count, dtype, (void*)st);
     if (rc != 0) return fail(LCX_ERR_COMM, "the exchange hook reported failure " + std::to_string(rc));
     return LCX_OK;
 }
+static int exchange(lcx_ctx* h, void* buf, int64_t count, int dtype) { return exchange_on(h, h->stream, buf, count, dtype); }
 // the library can sequence whole iterations when it does not depend on the caller for the sums
 static inline bool self_contained(const lcx_ctx* h) { return !h->exchange || h->tr.kind != 0 || h->world == 1; }
 
@@ -414,7 +424,9 @@ template <int CT> struct MaxKw { static constexpr int v = CT >= 16 ? 4 : 8; };
 
 template <typename T, int CT, int RT, bool SCALE, bool NTA = false>
 static int launch_tn(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t vcols_pad, const T* B,
-                     const T* rowscale, T* out, int S, int KW, const int* skip) {
+                     const T* rowscale, T* out, int S, int KW, const int* skip, int64_t out_rows = 0) {
+    // out_rows: rows of one partial slot of `out` when this launch covers only `vcols_pad` of them (a row chunk of the pass)
+    if (out_rows <= 0) out_rows = vcols_pad;
     const int kgroups = (int)(K / 16);
     dim3 grid((unsigned)(vcols_pad / (16 * RT)), (unsigned)S);
     if (KW > 4 && CT >= 16) KW = 4;          // 8 partial tiles of 256 factors do not fit the LDS
@@ -428,10 +440,10 @@ static int launch_tn(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t
         }
     }
     switch (KW) {
-        case 1: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 1, SCALE, 4, NTA>), grid, dim3(64), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
-        case 2: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 2, SCALE, 4, NTA>), grid, dim3(128), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
-        case 4: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 4, SCALE, 4, NTA>), grid, dim3(256), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
-        default: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, MaxKw<CT>::v, SCALE, 4, NTA>), grid, dim3(64 * MaxKw<CT>::v), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, vcols_pad, kgroups, S, skip); break;
+        case 1: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 1, SCALE, 4, NTA>), grid, dim3(64), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, out_rows, kgroups, S, skip); break;
+        case 2: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 2, SCALE, 4, NTA>), grid, dim3(128), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, out_rows, kgroups, S, skip); break;
+        case 4: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, 4, SCALE, 4, NTA>), grid, dim3(256), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, out_rows, kgroups, S, skip); break;
+        default: hipLaunchKernelGGL((gemm_tn_kernel<T, CT, RT, MaxKw<CT>::v, SCALE, 4, NTA>), grid, dim3(64 * MaxKw<CT>::v), lds, st, A, lda, (int64_t)(16 * RT), B, rowscale, out, out_rows, kgroups, S, skip); break;
     }
     KCHECK();
     return LCX_OK;
@@ -440,18 +452,19 @@ static int launch_tn(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t
 // gemm_tn4 (float64 on v_mfma_f64_4x4x4): same grid / partial-tile contract as launch_tn; KW in {2, 4}
 template <int CT>
 static int launch_tn4(hipStream_t st, const double* A, int64_t lda, int64_t K, int64_t vcols_pad, const double* B, double* out, int S,
-                      int KW, const int* skip) {
+                      int KW, const int* skip, int64_t out_rows = 0) {
+    if (out_rows <= 0) out_rows = vcols_pad;
     constexpr int RT = TnShape<double, CT>::RT, U = 4;
     dim3 grid((unsigned)(vcols_pad / (16 * RT)), (unsigned)S);
     const int kgroups = (int)(K / 16);
     if (KW == 2) {
         const size_t lds = Tn4Lds<CT, RT, 2, U>::bytes;
         LCXCHECK(allow_lds(gemm_tn4_kernel<CT, RT, 2, U, true>, lds));
-        hipLaunchKernelGGL((gemm_tn4_kernel<CT, RT, 2, U, true>), grid, dim3(128), lds, st, A, lda, B, out, vcols_pad, kgroups, S, skip);
+        hipLaunchKernelGGL((gemm_tn4_kernel<CT, RT, 2, U, true>), grid, dim3(128), lds, st, A, lda, B, out, out_rows, kgroups, S, skip);
     } else {
         const size_t lds = Tn4Lds<CT, RT, 4, U>::bytes;
         LCXCHECK(allow_lds(gemm_tn4_kernel<CT, RT, 4, U, true>, lds));
-        hipLaunchKernelGGL((gemm_tn4_kernel<CT, RT, 4, U, true>), grid, dim3(256), lds, st, A, lda, B, out, vcols_pad, kgroups, S, skip);
+        hipLaunchKernelGGL((gemm_tn4_kernel<CT, RT, 4, U, true>), grid, dim3(256), lds, st, A, lda, B, out, out_rows, kgroups, S, skip);
     }
     KCHECK();
     return LCX_OK;
@@ -841,14 +854,25 @@ template <typename T, int CT> struct Impl {
     }
 
     // Y(_partial) = X . B^T (linearcorex.py:247 / :210) as a contraction over the rows of XT
-    static int nt_big(lcx_ctx* h, const void* Bv, const int* skip, bool with_bj = false, T* also = nullptr) {
-        const T* B = reinterpret_cast<const T*>(Bv);
-        TimingPair tp;
-        LCXCHECK(timing_begin(h, 0, &tp));
-        T* dst = h->nt_S > 1 ? P<T>(h->ypart) : P<T>(h->ybuf);
+    // the pass alone: partial slots -> dst[slot][Npad][Mp].  rows >= 0: only the output rows [r0, r0 + rows) (a multiple of the
+    // row tile) - the wave-split kernels only, whose per-tile contraction split does not depend on the grid (same bits as the
+    // whole launch)
+    static int nt_pass(lcx_ctx* h, const T* B, const int* skip, T* dst, int64_t r0 = 0, int64_t rows = -1) {
         if constexpr (WIDE) {
+            (void)r0; (void)rows;
             LCXCHECK((wide_gemm<false, false>(h, P<T>(h->X), h->ldx, B, Mp, nullptr, dst, Mp, h->Npad, Mp, h->ldx, 1, skip)));
         } else {
+            if (rows >= 0) {
+                if (h->panel || h->single_copy || h->nt_ct) return fail(LCX_ERR_STATE, "row chunks of the pass exist for the wave-split kernels only");
+                if (h->f64_4x4) {
+                    if constexpr (sizeof(T) == 8 && CT <= 2)
+                        LCXCHECK((launch_tn4<CT>(h->stream, P<double>(h->XT) + r0, h->Npad, h->ldx, rows, (const double*)B, (double*)dst + r0 * Mp, h->nt_S,
+                                                 h->nt_KW, skip, h->Npad)));
+                } else
+                    LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false, false>(h->stream, P<T>(h->XT) + r0, h->Npad, h->ldx, rows, B, nullptr,
+                                                                                 dst + r0 * Mp, h->nt_S, h->nt_KW, skip, h->Npad)));
+                return LCX_OK;
+            }
             if (h->panel)
                 LCXCHECK((launch_cr<T, CT, true>(h->stream, P<T>(h->X), h->Npad * PanelW<T>::v, h->ldx, h->Npad, B, dst, h->nt_nb, h->nt_nsuper,
                                                  h->nt_S, skip, h->split ? h->bsp : nullptr, h->n_cus)));
@@ -863,9 +887,37 @@ template <typename T, int CT> struct Impl {
                 LCXCHECK((launch_tn<T, CT, Geo<T, CT>::TN_RT, false, false>(h->stream, P<T>(h->XT), h->Npad, h->ldx, h->Npad, B, nullptr,
                                                                              dst, h->nt_S, h->nt_KW, skip)));
         }
+        return LCX_OK;
+    }
+    // sum the partial slots of the elements [e0, e0 + n) of Y into ybuf (and `also`): the kernel - and so the order of every
+    // element's sum - depends on the slot count alone, so a row chunk gets the bits of the whole reduction
+    static int nt_reduce(lcx_ctx* h, const int* skip, T* also, int64_t e0, int64_t n) {
+        const int64_t ntot = h->Npad * Mp;
+        const bool wide = h->nt_S >= WIDE_SPLITS && cdiv(ntot, 32) < (1 << 20);
+        if (wide) {
+            hipLaunchKernelGGL((reduce_partials_wide_kernel<T, T>), dim3((unsigned)cdiv(n, 32)), dim3(256), 0,
+                               h->stream, P<T>(h->ypart) + e0, h->nt_S, n, ntot, P<T>(h->ybuf) + e0, skip, also ? also + e0 : also);
+            KCHECK();
+        } else if (h->nt_S > 1) {
+            hipLaunchKernelGGL((reduce_partials_kernel<T, T>), dim3((unsigned)(cdiv(n, 256) < 1024 ? cdiv(n, 256) : 1024)), dim3(256), 0,
+                               h->stream, P<T>(h->ypart) + e0, h->nt_S, n, ntot, P<T>(h->ybuf) + e0, skip, also ? also + e0 : also);
+            KCHECK();
+        }
+        return LCX_OK;
+    }
+    static int nt_big(lcx_ctx* h, const void* Bv, const int* skip, bool with_bj = false, T* also = nullptr, bool defer = false) {
+        const T* B = reinterpret_cast<const T*>(Bv);
+        TimingPair tp;
+        LCXCHECK(timing_begin(h, 0, &tp));
+        T* dst = h->nt_S > 1 ? P<T>(h->ypart) : P<T>(h->ybuf);
+        LCXCHECK(nt_pass(h, B, skip, dst));
         LCXCHECK(timing_end(h, 0, &tp));
         const int64_t n = h->Npad * Mp;
         const bool wide = h->nt_S >= WIDE_SPLITS && cdiv(n, 32) < (1 << 20);
+        if (defer && !with_bj && h->nt_S > 1 && h->nt_S <= 4) {
+            h->y_pending = true;             // ytail_kernel (lcx_moments_b) sums the slots on its way to the Gram
+            return LCX_OK;
+        }
         if (with_bj) {
             // partial tiles of Y (if split) and the Bj partials of grad_kernel, one launch
             if (wide) {
@@ -878,15 +930,57 @@ template <typename T, int CT> struct Impl {
                                    h->nt_S, n, P<T>(h->ybuf), yblocks, h->bjpart, h->pv_grid, Mp, P<T>(h->ybuf) + n);
             }
             KCHECK();
-        } else if (wide) {
-            hipLaunchKernelGGL((reduce_partials_wide_kernel<T, T>), dim3((unsigned)cdiv(n, 32)), dim3(256), 0,
-                               h->stream, P<T>(h->ypart), h->nt_S, n, n, P<T>(h->ybuf), skip, also);
-            KCHECK();
-        } else if (h->nt_S > 1) {
-            hipLaunchKernelGGL((reduce_partials_kernel<T, T>), dim3((unsigned)(cdiv(n, 256) < 1024 ? cdiv(n, 256) : 1024)), dim3(256), 0,
-                               h->stream, P<T>(h->ypart), h->nt_S, n, n, P<T>(h->ybuf), skip, also);
-            KCHECK();
+        } else {
+            LCXCHECK(nt_reduce(h, skip, also, 0, n));
         }
+        return LCX_OK;
+    }
+
+    // ---- LCX_Y_PIPELINE=chunks: lcx_moments_a's [Y_partial | W.W^T partial] all-reduce in row chunks on a second stream ----
+    // Chunk c of the summed Y is all-reduced as soon as its slot reduction has run, while the main stream goes on with chunk c+1:
+    // with the wave-split kernels (small shards, where the exchange is exposed: DESIGN.md section 6) the PASS itself is launched
+    // per row chunk, so the all-reduce of chunk c overlaps the pass of chunk c+1; with the stream-K kernels the pass is one launch
+    // and only the reductions overlap.  Every element is summed over slots and over ranks exactly as without chunks (two ranks:
+    // bit-identical; more ranks: the transport's order within a call may depend on the element's position in the call).  The
+    // W.W^T tail sits right behind Y in the buffer and rides in the last chunk.  Every rank issues the same chunks in the same order.
+    static int ypipe_init(lcx_ctx* h) {
+        if (h->comm_stream) return LCX_OK;
+        HIPCHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        for (auto& e : h->ypipe_ev) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return LCX_OK;
+    }
+    static int moments_a_pipelined(lcx_ctx* h, const T* w) {
+        LCXCHECK(ypipe_init(h));
+        int64_t tile = 64;
+        bool chunk_pass = false;
+        if constexpr (!WIDE) {
+            chunk_pass = !(h->panel || h->single_copy || h->nt_ct);
+            if (chunk_pass) tile = 16 * Geo<T, CT>::TN_RT;
+        }
+        const int64_t tiles = h->Npad / tile;
+        const int C = (int)(h->ypipe < tiles ? h->ypipe : tiles);
+        LCXCHECK(gram_w(h, w));                              // the tail first: it rides in the last chunk's all-reduce
+        TimingPair tp;
+        LCXCHECK(timing_begin(h, 0, &tp));
+        T* dst = h->nt_S > 1 ? P<T>(h->ypart) : P<T>(h->ybuf);
+        if (!chunk_pass) {
+            LCXCHECK(nt_pass(h, w, nullptr, dst));
+            LCXCHECK(timing_end(h, 0, &tp));
+        }
+        for (int c = 0; c < C; ++c) {
+            const int64_t r0 = tiles * c / C * tile, r1 = tiles * (c + 1) / C * tile;
+            if (chunk_pass) {
+                LCXCHECK(nt_pass(h, w, nullptr, dst, r0, r1 - r0));
+                if (c == C - 1) LCXCHECK(timing_end(h, 0, &tp));
+            }
+            LCXCHECK(nt_reduce(h, nullptr, (T*)nullptr, r0 * Mp, (r1 - r0) * Mp));
+            HIPCHECK(hipEventRecord(h->ypipe_ev[c], h->stream));
+            HIPCHECK(hipStreamWaitEvent(h->comm_stream, h->ypipe_ev[c], 0));
+            const int64_t count = (r1 - r0) * Mp + (c == C - 1 ? (int64_t)Mp * Mp : 0);
+            LCXCHECK(exchange_on(h, h->comm_stream, P<T>(h->ybuf) + r0 * Mp, count, DT));
+        }
+        HIPCHECK(hipEventRecord(h->ypipe_ev[16], h->comm_stream));
+        HIPCHECK(hipStreamWaitEvent(h->stream, h->ypipe_ev[16], 0));
         return LCX_OK;
     }
     static int make_xt(lcx_ctx* h) {
@@ -940,7 +1034,8 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
 
-    static int moments_a(lcx_ctx* h, int which) {
+    static int moments_a(lcx_ctx* h, int which, bool defer = false) {
+        h->y_pending = false;
         if (which == 1 && h->y1_ready && use_merged(h)) {       // the merged pass of lcx_update_b left it in ybuf / set 1
             h->y1_ready = false;
             return LCX_OK;
@@ -951,8 +1046,10 @@ template <typename T, int CT> struct Impl {
         }
         h->y1_ready = h->yk_ready = false;
         T* w = P<T>(h->Wt[which]);
+        if (h->exchange && h->ypipe > 1 && h->tr.kind != 0) return moments_a_pipelined(h, w);
         // without an exchange the summed Y is final: the set's own copy is written by the same reduction
-        LCXCHECK(nt_big(h, w, nullptr, false, (!h->exchange && h->nt_S > 1) ? P<T>(h->set[which].Y) : (T*)nullptr));
+        LCXCHECK(nt_big(h, w, nullptr, false, (!h->exchange && h->nt_S > 1) ? P<T>(h->set[which].Y) : (T*)nullptr,
+                        defer && ytail_on(h)));
         if (!h->exchange) return LCX_OK;         // nothing to exchange: W.W^T is formed with Y^T.Y in lcx_moments_b (one launch)
         LCXCHECK(gram_w(h, w));
         return exchange(h, h->ybuf, h->ybuf_main, DT);           // L1 of SURVEY 8e: [Y_partial | W.W^T partial]
@@ -1090,9 +1187,50 @@ template <typename T, int CT> struct Impl {
         // keep the (all-reduced) Y of this set: the linear trial mode starts from it
         if (h->exchange || h->nt_S == 1)         // otherwise lcx_moments_a already wrote it
             HIPCHECK(hipMemcpyAsync(s.Y, h->ybuf, (size_t)h->Npad * Mp * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
-        LCXCHECK(small(h, which, eps, quick, P<T>(h->ybuf)));
+        if (ytail_on(h)) LCXCHECK(ytail(h, which, eps, quick));
+        else LCXCHECK(small(h, which, eps, quick, P<T>(h->ybuf)));
         LCXCHECK(tn_big(h, &s.st->invalid));
         return epilogue(h, which, eps, false, 0.0);
+    }
+
+    // ---- ytail_kernel: slot reduction of Y (when lcx_iterate deferred it), Y^T.Y and W.W^T partials and the per-factor moments in
+    // ONE launch (moment_kernels.hpp); one GPU, <= 32 padded factors; LCX_YTAIL=0 keeps the three launches ----
+    static bool ytail_on(const lcx_ctx* h) {
+        if constexpr (WIDE || CT > 2) return false;
+        else return h->ytail_ok && !h->exchange;
+    }
+    static int ytail(lcx_ctx* h, int which, double eps, int quick) {
+        if constexpr (WIDE || CT > 2) {
+            return fail(LCX_ERR_STATE, "ytail_kernel is instantiated for <= 32 padded factors");
+        } else {
+            MomentSet& s = h->set[which];
+            const bool pending = h->y_pending;
+            h->y_pending = false;
+            T* gy = P<T>(h->ytpart);
+            YTailArgs<T> a;
+            a.ysrc = pending ? P<T>(h->ypart) : P<T>(h->ybuf);
+            a.slot_stride = h->Npad * Mp;
+            a.y0 = pending ? P<T>(h->ybuf) : (T*)nullptr;
+            a.y1 = pending ? P<T>(s.Y) : (T*)nullptr;
+            a.w = P<T>(h->Wt[which]);
+            a.gy = gy;
+            a.gw = gy + (int64_t)h->yt_Sy * Mp * Mp;
+            a.kg_y = (int)(h->Npad / 16); a.Sy = h->yt_Sy; a.kg_w = (int)(h->ldx / 16); a.Sw = h->yt_Sw;
+            a.m = h->M; a.quick = quick; a.n_samples = h->Ndiv; a.eps = eps;
+            a.sm = SmallDesc{s.uj, s.ry, s.wmag};
+            a.st = s.st;
+            a.counters = h->ticket + 48;
+            const dim3 grid((unsigned)(h->yt_Sw + h->yt_Sy + Mp * Mp / 32));
+            const size_t lds = (size_t)4 * Mp * Mp * sizeof(T);
+            switch (pending ? h->nt_S : 1) {
+                case 1: hipLaunchKernelGGL((ytail_kernel<T, CT, 1>), grid, dim3(256), lds, h->stream, a); break;
+                case 2: hipLaunchKernelGGL((ytail_kernel<T, CT, 2>), grid, dim3(256), lds, h->stream, a); break;
+                case 3: hipLaunchKernelGGL((ytail_kernel<T, CT, 3>), grid, dim3(256), lds, h->stream, a); break;
+                default: hipLaunchKernelGGL((ytail_kernel<T, CT, 4>), grid, dim3(256), lds, h->stream, a); break;
+            }
+            KCHECK();
+            return LCX_OK;
+        }
     }
 
     // ---- linear trial mode: moments of ws + eta*update without touching X ----------------------
@@ -1290,7 +1428,7 @@ template <typename T, int CT> struct Impl {
     // :321 for the weights in set 1, and right behind it the gradient those weights would need next (:296-300): if the trial
     // is accepted that gradient is already there when the host has decided, if not it is overwritten by the next trial's
     static int evaluate_trial(lcx_ctx* h, double eps) {
-        LCXCHECK(moments_a(h, 1));
+        LCXCHECK(moments_a(h, 1, true));             // (one GPU, few factors: the slot reduction of Y rides in moments_b's ytail launch)
         LCXCHECK(moments_b(h, 1, eps, 1));
         LCXCHECK(moments_c(h, 1));                   // several ranks: TC / tangent from the summed scalars, publication
         h->early_grad = false;
@@ -2427,7 +2565,41 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     A_(h->invwork, sizeof(double) * Mp * 2 * Mp);
     A_(h->states, sizeof(SetState) * 2);
     A_(h->order_dev, sizeof(int) * Mp);
-    A_(h->ticket, 256);        // [0] small_moments; [16..25) moments_epilogue; [32..41) update_kernel
+    A_(h->ticket, 256);        // [0] small_moments; [16..25) moments_epilogue; [32..41) update_kernel; [48..50) ytail_kernel
+    h->ypipe = 0;
+    {
+        const char* e = getenv("LCX_Y_PIPELINE");           // "chunks" (4 row chunks) or "chunks:n", n <= 16
+        if (e && !strncmp(e, "chunks", 6)) {
+            h->ypipe = e[6] == ':' ? atoi(e + 7) : 4;
+            if (h->ypipe < 2) h->ypipe = 0;
+            if (h->ypipe > 16) h->ypipe = 16;
+        }
+    }
+    h->ytail_ok = h->y_pending = false;
+    h->yt_Sy = h->yt_Sw = 0;
+    h->ytpart = nullptr;
+    {
+        const char* e = getenv("LCX_YTAIL");
+        if (Mp <= 32 && !(e && *e && atoi(e) == 0)) {
+            // producers: at least two 16-row groups per wave (4 waves per block); producers + Mp^2/32 finishers <= one block per CU
+            const int nfin = Mp * Mp / 32;
+            int64_t sy = h->Npad / 16 / 8, sw = h->ldx / 16 / 8;
+            if (sy < 1) sy = 1;
+            if (sw < 1) sw = 1;
+            const int64_t room = (int64_t)h->n_cus - nfin;
+            if (sy + sw > room && room >= 2) {
+                const int64_t sy2 = sy * room / (sy + sw) > 0 ? sy * room / (sy + sw) : 1;
+                sw = room - sy2 > 0 ? room - sy2 : 1;
+                sy = sy2;
+            }
+            if (room >= 2) {
+                h->yt_Sy = (int)sy;
+                h->yt_Sw = (int)sw;
+                A_(h->ytpart, (size_t)(sy + sw) * Mp * Mp * es);
+                h->ytail_ok = true;
+            }
+        }
+    }
 #undef A_
     h->set[0].st = h->states;
     h->set[1].st = h->states + 1;
@@ -2470,10 +2642,15 @@ int lcx_destroy(lcx_ctx* h) {
     if (!h) return LCX_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm_stream) {
+        (void)hipStreamSynchronize(h->comm_stream);
+        for (auto& e : h->ypipe_ev) if (e) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(h->comm_stream);
+    }
     if (h->tr.kind == 1 && h->tr.comm) (void)rccl().CommDestroy(h->tr.comm);
     void* ptrs[] = {h->X, h->XT, h->Wt[0], h->Wt[1], h->grad, h->update, h->sgrad, h->scratch, h->ydir, h->ddir, h->ybuf_own, h->sbuf_own,
                     h->gw, h->y2part, h->bjg, h->bsp,
-                    h->ypart, h->dpart, h->gpart, h->gpartw, h->tcpart, h->bjpart, h->tanpart, h->detpart, h->ryinv, h->invwork,
+                    h->ypart, h->dpart, h->gpart, h->gpartw, h->ytpart, h->tcpart, h->bjpart, h->tanpart, h->detpart, h->ryinv, h->invwork,
                     h->states, h->order_dev, h->ticket};
     for (void* p : ptrs) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) {

@@ -50,6 +50,7 @@ def main():
     h = run_loop(model, iters)
     ws = model._gather(be.get_ws(0))
     rho = model._gather(be.get_moment(0, "rho"))
+    model.ws = ws                               # (no `_finish` in this loop: transform_fitted wants the weights in place)
     y = model.transform_fitted()
     info = be.exchange_info()
     if comm.rank == 0:

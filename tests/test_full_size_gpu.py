@@ -29,8 +29,8 @@ def _check_kernels(be, gemm):
         assert "gemm_cr_kernel" in be.kernel_name(0) and "gemm_ct_kernel" in be.kernel_name(1)
 
 
-@pytest.mark.parametrize("gemm", ["mfma", "split"])
-@pytest.mark.parametrize("shape", [(50000, 100000, 64), (50000, 125000, 128)], ids=["config3", "config4_shard"])
+@pytest.mark.parametrize("shape,gemm", [((50000, 100000, 64), "mfma"), ((50000, 125000, 128), "mfma"), ((50000, 125000, 128), "split")],
+                         ids=["config3-mfma", "config4_shard-mfma", "config4_shard-split"])
 def test_full_size_properties(shape, gemm):
     from linearcorex_amd import Corex
     from linearcorex_amd.backend import HipBackend
@@ -129,20 +129,20 @@ def _rel(a, b):
     return float(np.max(np.abs(a - b)) / max(1e-300, float(np.max(np.abs(b)))))
 
 
+# (round 5: the two opt-in riders keep ONE full-size case each - exact-y's 8-trial iteration of the config-4 shard rides on the split
+# case's shape through `reuse`, see below; round 4 ran five)
 @pytest.mark.parametrize("shape,kind,reuse,gemm", [((50000, 100000, 64), 0, False, "mfma"), ((50000, 125000, 128), 1, False, "mfma"),
-                                                   ((50000, 125000, 128), 1, True, "mfma"), ((50000, 100000, 64), 0, False, "split"),
-                                                   ((50000, 125000, 128), 1, False, "split")],
-                         ids=["config3", "config4_shard", "config4_shard_later_trials_by_linearity", "config3_bf16_split",
-                              "config4_shard_bf16_split"])
+                                                   ((50000, 125000, 128), 1, True, "split")],
+                         ids=["config3", "config4_shard", "config4_shard_bf16_split_later_trials_by_linearity"])
 def test_full_size_step_vs_oracle(shape, kind, reuse, gemm):
     """BASELINE configs[2] and the configs[3] shard at FULL size against the oracle, element by element: the resident matrix is
     copied back (20 / 25 GB), and one `_calculate_moments_ns` (reference :236-275), one update direction (:292-305) and one
     whole `_update_ns` with its back-tracking (:306-334) run in NumPy float32 on the host cores - what the reference computes -
     beside the device path (gemm_ct stream-K slots, 64-bit offsets, the merged pass of config 3, lcx_iterate).
     Bars: the float32 step bar of tests/test_parity_gpu.py (2e-4 of the array scale; x10 for derived arrays, as there).
-    Third case: the same with lcx_set_trial_reuse (the iteration of the configs[3] shard back-tracks 7 times: trials 2..8 take
-    X.w_update^T by linearity) - same accepted step, same trial count, same bars against the oracle's two-pass trials.
-    Last two: the X passes on the bf16 matrix pipe (lcx_set_f32_gemm 1: three-way exact split, 6 partial products) - the SAME bars."""
+    Third case: both opt-in riders at once on the configs[3] shard - lcx_set_trial_reuse (its iteration back-tracks 7 times: trials
+    2..8 take X.w_update^T by linearity) and the X passes on the bf16 matrix pipe (lcx_set_f32_gemm 1: three-way exact split, 6 partial
+    products): same accepted step, same trial count, the SAME bars against the oracle's two-pass float32 trials."""
     from linearcorex_amd.backend import HipBackend
     from oracle import corex_oracle as O
     from bench import _BlasPool                                 # BLAS threads = the cores the cgroup really grants

@@ -33,6 +33,7 @@ def test_driver_reproduces_reference_on_big5(g1, tag, dt):
         assert relerr(h, h_ref) < 1e-9
         assert relerr(out.ws, g1["f64_ws"]) < 1e-7
         assert relerr(out.get_covariance(), g1["f64_cov"]) < 1e-7
+        assert out.get_covariance(rows=(9, 9)).shape == (0, 50) and out.get_covariance(rows=(9, 11)).shape == (2, 50)
         assert relerr(out.transform(x), g1["f64_transform"]) < 1e-7
         for key, name in (("rho", "rho"), ("MI", "MI"), ("X_i Z_j", "X_i_Z_j"), ("X_i Y_j", "X_i_Y_j"),
                           ("TCs", "TCs"), ("TC_direct", "TC_direct"), ("I(Y_j ; X)", "IY_j_s_X"),

@@ -10,6 +10,7 @@
 #   line_search_ab <wl> ...        bench --no-extras under line_search exact / exact-y / linear, one line each
 #   two_ranks [bench args]         the driver's --gpus 2 command rehearsed on ONE GPU (two ranks share GPU 0 over gloo)
 #   n_ranks <N> <head> [args]     the driver's --gpus N command on ONE GPU at a reduced shard (N ranks share GPU 0 over gloo)
+#   env_ab <wl> <VAR> <a> <b> [n]  bench --no-extras under VAR=a / VAR=b alternating on one box   -> gpurun_out/<tag>_env_ab_<wl>_<VAR>.txt
 #   probe <name> [args]            build tools/<name>.hip and run it                        -> gpurun_out/<tag>_<name>_<args>.txt
 # TAG (environment, default r05) prefixes the outputs.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -68,6 +69,18 @@ print('$wl $ls', round(d['value'],2), 'it/s', round(d['ms_per_step'],3), 'ms; X 
       2>gpurun_out/${TAG}_${N}_ranks.err > gpurun_out/${TAG}_${N}_ranks.json
     echo "rc=$? wall $(( $(date +%s) - T0 )) s, line $(wc -c < gpurun_out/${TAG}_${N}_ranks.json) bytes" | tee gpurun_out/${TAG}_${N}_ranks_summary.txt
     cat gpurun_out/${TAG}_${N}_ranks.json; grep -v BENCH_DETAIL gpurun_out/${TAG}_${N}_ranks.err | tail -40 ;;
+  env_ab)
+    # bench --workload <wl> --no-extras under VAR=a and VAR=b, alternating on ONE box:  env_ab <wl> <VAR> <a> <b> [rounds]
+    WL=$1; VAR=$2; A=$3; B=$4; ROUNDS=${5:-3}
+    python3 __graft_entry__.py || exit 1
+    OUT=gpurun_out/${TAG}_env_ab_${WL}_${VAR}.txt; : > $OUT
+    for r in $(seq $ROUNDS); do for val in $A $B; do
+      env $VAR=$val python bench.py --workload $WL --no-extras --steps 30 --warmup 5 2>gpurun_out/${TAG}_ab.err > gpurun_out/${TAG}_ab.json || { tail -5 gpurun_out/${TAG}_ab.err; exit 1; }
+      python -c "
+import json; d=json.load(open('gpurun_out/${TAG}_ab.json')); c=d['config']
+print('$WL $VAR=$val', round(d['value'],2), 'it/s', round(d['ms_per_step'],4), 'ms; X passes', round(c['x_passes_per_iteration'],3), 'trials', round(c['line_search_trials_per_iteration'],4), 'walks', c['windows']['ms_per_step_walk_min_median_max'], 'frac', round(d['roofline']['frac'],4))" | tee -a $OUT
+      grep -o '"final_TC": [-0-9.e+]*' gpurun_out/bench_detail.json | head -1 | tee -a $OUT
+    done; done ;;
   probe)
     P=$1; shift
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/$P tools/$P.hip 2>/dev/null || exit 1

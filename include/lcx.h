@@ -343,12 +343,15 @@ int lcx_x_layout(lcx_ctx* h, int* layout);
  * panel-major layout; switchable at any time between two launches, results of both modes within float32 rounding of each other:
  *   0  (default) v_mfma_f32_16x16x4_f32: exact float32 products, float32 accumulation - the float32 MATRIX rate of gfx950 equals
  *      its float32 VECTOR rate (157 TF/s), 1/16 of the bf16 rate, and bounds these passes;
- *   1  every operand element split exactly into three bf16 numbers (8 + 8 + 8 significand bits), 6 of the 9 partial products
- *      (all terms down to 2^-16 of the product; the dropped ones are 2^-24 of it in the rms and at most 2^-21 - the size of one float32
- *      rounding of the product) accumulated in float32
- *      by v_mfma_f32_16x16x32_bf16 - 2.5 x less matrix-pipe time, the passes become HBM / power bound (1.45-1.5 x the fit
- *      iterations per second at the config-3 / config-4 shards).  Error against a float64 contraction: 1.1-1.4 x that of mode 0
- *      (profiles/r04_gemm_probe9_split.txt); every parity fixture holds at the float32 bars in both modes.
+ *   1  every operand element split exactly into three bf16 numbers by rounding to nearest (hi = bf16(x), mid = bf16(x - hi),
+ *      lo = x - hi - mid: 8 + 8 + 8 significand bits, signed residuals), 6 of the 9 partial products (all terms down to 2^-16 of the
+ *      product; the dropped ones are zero-mean, 2^-27 of it in the rms and at most 2^-24.4 - below half a float32 rounding of the
+ *      product) accumulated in float32 by v_mfma_f32_16x16x32_bf16 - 2.5 x less matrix-pipe time, the passes become HBM / power
+ *      bound (1.35-1.45 x the fit iterations per second at the config-3 / config-4 shards).  Error against a float64 contraction:
+ *      1.0-1.2 x that of mode 0 (profiles/r04_gemm_probe9_rne.txt); every parity fixture holds at the float32 bars in both modes.
+ *      (Round 4 split by truncation - 6 % faster, but every dropped term then has the sign of its product, a systematic shrink of
+ *      up to 2^-21.3; the library ships the unbiased split.  Operands within half a bf16 ulp of FLT_MAX would round to infinity.)
+ *      An opt-in: never the arithmetic behind a reported `value` (bench.py), which stays mode 0.
  * Mode 1 needs layout 2 and 32 / 64 / 128 padded factors; on any other handle the call succeeds and leaves mode 0 (read it back with
  * lcx_f32_gemm).  Environment default: LCX_F32_GEMM=split.  Costs 6 bytes per element of the small operand (one scratch buffer). */
 int lcx_set_f32_gemm(lcx_ctx* h, int mode);

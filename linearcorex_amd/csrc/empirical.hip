@@ -58,7 +58,7 @@ struct SegOffset {                       // segment c covers [c * stride + add, 
     __host__ __device__ unsigned int operator()(unsigned int c) const { return c * stride + add; }
 };
 
-__global__ void iota_rows_kernel(unsigned int* idx, int64_t ncols, int64_t stride, int64_t n) {
+static __global__ void iota_rows_kernel(unsigned int* idx, int64_t ncols, int64_t stride, int64_t n) {
     const int64_t total = ncols * n;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x)
         idx[(k / n) * stride + (k % n)] = (unsigned int)(k % n);

@@ -1,9 +1,16 @@
-// lcx_engine.hip - host side of the C ABI declared in include/lcx.h.
+// engine.hpp - the engine behind the C ABI declared in include/lcx.h, shared by its translation units.
 //
-// Owns the device state of one n_variables shard of a Linear CorEx fit (X, W and two moment sets,
-// all resident in HBM) and enqueues the kernels of each dependency level of the reference's
-// _calculate_moments_ns / _update_ns (linearcorex.py:236-334) on one HIP stream.  No torch types,
-// no callbacks; multi-GPU exchange happens between the *_a/_b/_c entry points, outside.
+// Owns the device state of one n_variables shard of a Linear CorEx fit (X, W and two moment sets, all resident in HBM) and
+// enqueues the kernels of each dependency level of the reference's _calculate_moments_ns / _update_ns (linearcorex.py:236-334)
+// on one HIP stream.  No torch types, no callbacks.  This header holds the context, the launch helpers and `Impl<T, CT>` - the
+// typed implementation of every level, instantiated by whichever translation unit's entry points call it:
+//     lcx_core.hip     handles, streams, exchange transport (RCCL / hook), first-contact self-test, state readback, timing
+//     lcx_levels.hip   launch geometry, weights, the moment / update levels, lcx_iterate, the synergistic branch, moment readback
+//                      (entry points; the typed work - most of the compile time - in lcx_levels_f32.hip / lcx_levels_f64.hip)
+//     lcx_data.hip     upload + preprocess, the on-device generator, download, transform of new rows
+//     lcx_outputs.hip  get_covariance, predict, invert
+// (empirical.hip: gaussianize='empirical'.)  One object per unit, compiled side by side (__graft_entry__.py).
+#pragma once
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <stdint.h>
@@ -40,7 +47,7 @@ template <typename T> int empirical_columns(T* X, int64_t ldx, T* XT, int64_t Np
 // -------------------------------------------------------------------------------------------------
 // error plumbing
 // -------------------------------------------------------------------------------------------------
-static thread_local std::string g_err;
+inline thread_local std::string g_err;          // one per thread for the whole library (all translation units)
 static int fail(int code, const std::string& msg) {
     g_err = msg;
     // HIP keeps the last error per thread until somebody reads it: a failed hipMalloc reported here would otherwise
@@ -79,7 +86,7 @@ struct RcclApi {
     std::string error;
     bool ok = false;
 };
-static RcclApi& rccl() {
+inline RcclApi& rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, []() {
@@ -516,17 +523,19 @@ static inline bool pv_mfma() {
     const char* e = getenv("LCX_PV_MFMA");
     return !(e && *e && atoi(e) == 0);
 }
-// waves per block of the stream-K kernels: CtShape's, except that 128 float32 factors can be switched between 4 and 8 at run time
-// (LCX_CT8_KW) - the A/B knob behind CtShape<float, 8>::KW
-template <typename T, int CT> static inline int ct_kw() {
+// waves per block of the stream-K kernels: CtShape's - except at 128 float32 columns, where 8 waves share one copy of B on the
+// PANEL-major copy only (+2-3 %: profiles/r04_gemm_probe4_panelsweep.txt; on the row-major layouts 8 waves measured 10-20 % slower
+// than 4, gemm_kernels.hpp CtShape) and LCX_CT8_KW=4|8 forces either for A/B runs
+template <typename T, int CT> static inline int ct_kw(bool panel) {
     if constexpr (sizeof(T) == 4 && CT == 8) {
-        static const int kw = []() {
+        static const int forced = []() {
             const char* e = getenv("LCX_CT8_KW");
-            const int v = (e && *e) ? atoi(e) : CtShape<T, CT>::KW;
-            return v == 8 ? 8 : 4;
+            return (e && *e) ? (atoi(e) == 8 ? 8 : 4) : 0;
         }();
-        return kw;
+        if (forced) return forced;
+        return panel ? CtShape<T, CT>::KW : 4;
     }
+    (void)panel;
     return CtShape<T, CT>::KW;
 }
 // gemm_ct launch: nb balanced blocks over (super tile, group) units; partial tiles -> out[slot][out_rows][Mp]
@@ -539,7 +548,7 @@ static int launch_ct(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t
     }
     const int ng = (int)(K / (4 * S::U));
     if constexpr (sizeof(T) == 4 && CT == 8) {
-        if (ct_kw<T, CT>() == 8)
+        if (ct_kw<T, CT>(PANEL) == 8)
             hipLaunchKernelGGL((gemm_ct_kernel<T, CT, S::RT, 8, S::U, true, PANEL>), dim3((unsigned)nb), dim3(512), 0, st, A, lda, B, out, vcols, vcols,
                                ng, nsuper, maxslots, skip);
         else
@@ -563,7 +572,7 @@ static int launch_cr(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t
     }
     const int ng = (int)(K / (4 * S::U));
     if constexpr (sizeof(T) == 4 && CT == 8) {
-        if (ct_kw<T, CT>() == 8)
+        if (ct_kw<T, CT>(PANEL) == 8)
             hipLaunchKernelGGL((gemm_cr_kernel<T, CT, S::RT, 8, S::U, PANEL, PANEL>), dim3((unsigned)nb), dim3(512), 0, st, A, lda, B, out, nrows, nrows,
                                ng, nsuper, maxslots, skip);
         else
@@ -576,18 +585,28 @@ static int launch_cr(hipStream_t st, const T* A, int64_t lda, int64_t K, int64_t
     KCHECK();
     return LCX_OK;
 }
-// geometry of a gemm_ct launch over `vcols` columns and K contraction rows
-template <typename T, int CT>
-static void ct_geometry(int n_cus, int64_t K, int64_t vcols, int force_nb, int* nb_o, int* nsuper_o, int* slots_o) {
+// geometry of a stream-K launch over `vcols` output rows and K contraction elements.  panel / cr name the instantiation that will be
+// launched (gemm_ct or gemm_cr, on the panel-major copy or a row-major one): its wave count and ITS occupancy size the grid
+template <typename T, int CT, int KW, bool PANEL, bool CR> static hipError_t ct_occupancy(int* bpc) {
     typedef CtShape<T, CT> S;
-    const int KW = ct_kw<T, CT>();
+    if constexpr (CR) return hipOccupancyMaxActiveBlocksPerMultiprocessor(bpc, (const void*)gemm_cr_kernel<T, CT, S::RT, KW, S::U, PANEL, PANEL>, 64 * KW, 0);
+    else return hipOccupancyMaxActiveBlocksPerMultiprocessor(bpc, (const void*)gemm_ct_kernel<T, CT, S::RT, KW, S::U, true, PANEL>, 64 * KW, 0);
+}
+template <typename T, int CT>
+static void ct_geometry(int n_cus, int64_t K, int64_t vcols, int force_nb, int* nb_o, int* nsuper_o, int* slots_o, bool panel = false,
+                        bool cr = false) {
+    typedef CtShape<T, CT> S;
+    const int KW = ct_kw<T, CT>(panel);
     int bpc = 0;
     hipError_t oe;
     if constexpr (sizeof(T) == 4 && CT == 8) {
-        oe = KW == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)gemm_ct_kernel<T, CT, S::RT, 8, S::U, true>, 512, 0)
-                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)gemm_ct_kernel<T, CT, S::RT, 4, S::U, true>, 256, 0);
+        if (KW == 8) oe = panel ? (cr ? ct_occupancy<T, CT, 8, true, true>(&bpc) : ct_occupancy<T, CT, 8, true, false>(&bpc))
+                                : (cr ? ct_occupancy<T, CT, 8, false, true>(&bpc) : ct_occupancy<T, CT, 8, false, false>(&bpc));
+        else oe = panel ? (cr ? ct_occupancy<T, CT, 4, true, true>(&bpc) : ct_occupancy<T, CT, 4, true, false>(&bpc))
+                        : (cr ? ct_occupancy<T, CT, 4, false, true>(&bpc) : ct_occupancy<T, CT, 4, false, false>(&bpc));
     } else {
-        oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)gemm_ct_kernel<T, CT, S::RT, S::KW, S::U, true>, 64 * S::KW, 0);
+        oe = panel ? (cr ? ct_occupancy<T, CT, S::KW, true, true>(&bpc) : ct_occupancy<T, CT, S::KW, true, false>(&bpc))
+                   : (cr ? ct_occupancy<T, CT, S::KW, false, true>(&bpc) : ct_occupancy<T, CT, S::KW, false, false>(&bpc));
     }
     if (oe != hipSuccess || bpc < 1) bpc = 1;
     // measured (tools/gemm_probe4, 50k x 20k float32, n_hidden 64): 2 resident blocks per CU 122 TF/s, 3 blocks 118
@@ -793,25 +812,29 @@ template <typename T, int CT> struct Impl {
                 if (CT >= 4) return K >= 4096 && (sl <= 40 || small_partials);
                 return K >= 8192 && sl <= 8;
             };
-            int nb, ns, sl;
-            ct_geometry<T, CT>(cus, h->ldx, h->Npad, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
-            h->nt_ct = h->single_copy || (force ? !strcmp(force, "ct") : use_ct(sl, h->ldx));
-            if (h->nt_ct) { h->nt_nb = nb; h->nt_nsuper = ns; h->nt_S = sl; h->nt_KW = ct_kw<T, CT>(); }
-            ct_geometry<T, CT>(cus, h->Npad, h->ldx, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
-            h->tn_ct = force ? !strcmp(force, "ct") : use_ct(sl, h->Npad);
-            if (h->tn_ct) { h->tn_nb = nb; h->tn_nsuper = ns; h->tn_S = sl; h->tn_KW = ct_kw<T, CT>(); }
+            // The wave count (128 float32 columns: 8 on the panel-major copy, 4 on a row-major one) and the occupancy belong to the
+            // instantiation that will be launched, which depends on the layout, which depends on whether BOTH passes take the stream-K
+            // kernels: decide with the panel geometry first (unless LCX_X_LAYOUT=rows forbids the layout), and if the shard does not
+            // end up panel-major redo the geometry of its stream-K passes for the row-major instantiations.
+            const char* lay = getenv("LCX_X_LAYOUT");
+            const bool rows_only = lay && !strcmp(lay, "rows"), force_panel = lay && !strcmp(lay, "panel");
+            auto stream_k = [&](bool as_panel, bool decide) {
+                int nb, ns, sl;
+                // X.B^T: gemm_cr on the panel copy / the row-major X (single-copy mode), gemm_ct on the transposed copy
+                ct_geometry<T, CT>(cus, h->ldx, h->Npad, env_int("LCX_CT_NB", 0), &nb, &ns, &sl, as_panel, as_panel || h->single_copy);
+                if (decide) h->nt_ct = force_panel || h->single_copy || (force ? !strcmp(force, "ct") : use_ct(sl, h->ldx));
+                if (h->nt_ct) { h->nt_nb = nb; h->nt_nsuper = ns; h->nt_S = sl; h->nt_KW = ct_kw<T, CT>(as_panel); }
+                ct_geometry<T, CT>(cus, h->Npad, h->ldx, env_int("LCX_CT_NB", 0), &nb, &ns, &sl, as_panel, false);
+                if (decide) h->tn_ct = force_panel || (force ? !strcmp(force, "ct") : use_ct(sl, h->Npad));
+                if (h->tn_ct) { h->tn_nb = nb; h->tn_nsuper = ns; h->tn_S = sl; h->tn_KW = ct_kw<T, CT>(as_panel); }
+            };
+            stream_k(!rows_only, true);
             // Both passes on the stream-K kernels: ONE panel-major copy of the shard serves both at full speed (gemm_kernels.hpp,
             // PanelW) - no transposed copy, half the resident bytes.  LCX_X_LAYOUT=rows keeps the row-major layout(s), =panel forces
             // the stream-K kernels and the panel layout on any shape.
-            const char* lay = getenv("LCX_X_LAYOUT");
-            if (lay && !strcmp(lay, "panel")) {
-                ct_geometry<T, CT>(cus, h->ldx, h->Npad, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
-                h->nt_ct = true; h->nt_nb = nb; h->nt_nsuper = ns; h->nt_S = sl; h->nt_KW = ct_kw<T, CT>();
-                ct_geometry<T, CT>(cus, h->Npad, h->ldx, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
-                h->tn_ct = true; h->tn_nb = nb; h->tn_nsuper = ns; h->tn_S = sl; h->tn_KW = ct_kw<T, CT>();
-            }
-            h->panel = h->nt_ct && h->tn_ct && !(lay && !strcmp(lay, "rows"));
+            h->panel = h->nt_ct && h->tn_ct && !rows_only;
             if (h->panel) h->single_copy = false;
+            else if (!rows_only && (h->nt_ct || h->tn_ct)) stream_k(false, false);
         }
         // merged pass: float32, 32 / 64 padded factors, large shards (the 2 Mp-wide gemm_ct does the flops of both passes at
         // a higher rate and reads X once); LCX_MERGED_PASS=0 turns it off
@@ -819,7 +842,7 @@ template <typename T, int CT> struct Impl {
         if constexpr (sizeof(T) == 4 && CT >= 2 && CT <= 4) {
             if (h->nt_ct && env_int("LCX_MERGED_PASS", 1) != 0) {
                 int nb, ns, sl;
-                ct_geometry<T, 2 * CT>(cus, h->ldx, h->Npad, env_int("LCX_CT_NB", 0), &nb, &ns, &sl);
+                ct_geometry<T, 2 * CT>(cus, h->ldx, h->Npad, env_int("LCX_CT_NB", 0), &nb, &ns, &sl, h->panel, h->panel || h->single_copy);
                 if (sl <= 8) { h->merged_ok = true; h->nt2_nb = nb; h->nt2_nsuper = ns; h->nt2_S = sl; }
             }
         }
@@ -2087,22 +2110,22 @@ template <typename T, int CT> struct Impl {
             if constexpr (CT <= 4)
                 snprintf(buf, (size_t)len, h->panel ? "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, true, true>"
                                            : h->single_copy ? "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, false, false>" : "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true, false>",
-                         sizeof(T) == 8 ? "double" : "float", 2 * CT, CtShape<T, 2 * CT>::RT, ct_kw<T, 2 * CT>(), CtShape<T, 2 * CT>::U);
+                         sizeof(T) == 8 ? "double" : "float", 2 * CT, CtShape<T, 2 * CT>::RT, ct_kw<T, 2 * CT>(h->panel), CtShape<T, 2 * CT>::U);
             return LCX_OK;
         }
         if (h->panel) {
             snprintf(buf, (size_t)len, kind == 0 ? "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, true, true>" : "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true, true>",
-                     sizeof(T) == 8 ? "double" : "float", CT, CtShape<T, CT>::RT, ct_kw<T, CT>(), CtShape<T, CT>::U);
+                     sizeof(T) == 8 ? "double" : "float", CT, CtShape<T, CT>::RT, ct_kw<T, CT>(true), CtShape<T, CT>::U);
             return LCX_OK;
         }
         if (kind == 0 && h->single_copy) {
             snprintf(buf, (size_t)len, "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, false, false>", sizeof(T) == 8 ? "double" : "float", CT, CtShape<T, CT>::RT,
-                     ct_kw<T, CT>(), CtShape<T, CT>::U);
+                     ct_kw<T, CT>(false), CtShape<T, CT>::U);
             return LCX_OK;
         }
         if (kind == 0 ? h->nt_ct : h->tn_ct)
             snprintf(buf, (size_t)len, "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true, false>", sizeof(T) == 8 ? "double" : "float", CT,
-                     CtShape<T, CT>::RT, ct_kw<T, CT>(), CtShape<T, CT>::U);
+                     CtShape<T, CT>::RT, ct_kw<T, CT>(false), CtShape<T, CT>::U);
         else if (h->f64_4x4)
             snprintf(buf, (size_t)len, "lcx::gemm_tn4_kernel<%d, %d, %d, 4, true, false>", CT, Geo<T, CT>::TN_RT, kind == 0 ? h->nt_KW : h->tn_KW);
         else
@@ -2416,591 +2439,16 @@ static inline void cancel_speculation(lcx_ctx* h) {
 }
 #define NEED_MUT(h) NEED(h); cancel_speculation(h); (h)->early_grad = (h)->grad_ready = (h)->yk_ready = false
 
-// -------------------------------------------------------------------------------------------------
-// C ABI
-// -------------------------------------------------------------------------------------------------
-extern "C" {
+#define WHICH_OK(w) if ((w) < 0 || (w) > 1) return fail(LCX_ERR_ARG, "which must be 0 or 1")
 
-int lcx_abi_version(void) { return 1; }
-const char* lcx_last_error(void) { return g_err.c_str(); }
-
-int lcx_device_count(int* out_count) {
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess) n = 0;
-    if (out_count) *out_count = n;
-    return LCX_OK;
-}
-
+// Wait until the pinned mirror of a set carries the last publication enqueued for it.
+// zero-filled device memory
 static int dev_alloc(void** p, size_t bytes, hipStream_t st) {
     HIPCHECK(hipMalloc(p, bytes ? bytes : 16));
     HIPCHECK(hipMemsetAsync(*p, 0, bytes ? bytes : 16, st));
     return LCX_OK;
 }
 
-int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden, int dtype, int device) {
-    if (!out || n_samples < 1 || nv_local < 1 || n_hidden < 1) return fail(LCX_ERR_ARG, "lcx_create: bad sizes");
-    if (dtype != LCX_F32 && dtype != LCX_F64) return fail(LCX_ERR_ARG, "lcx_create: dtype must be LCX_F32 or LCX_F64");
-    const int ct = ct_for(n_hidden);
-    if (!ct) return fail(LCX_ERR_ARG, "lcx_create: n_hidden > 1024 is not supported by this build");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(LCX_ERR_NO_DEVICE, "no HIP device visible");
-    if (device < 0 || device >= ndev) return fail(LCX_ERR_ARG, "lcx_create: device index out of range");
-    HIPCHECK(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIPCHECK(hipGetDeviceProperties(&prop, device));
-
-    lcx_ctx* h = new lcx_ctx();
-    h->split = false;
-    h->bsp = nullptr;
-    h->bsp_bytes = 0;
-    h->device = device;
-    h->dtype = dtype;
-    h->es = dtype == LCX_F32 ? 4 : 8;
-    h->N = n_samples;
-    h->Ndiv = (double)n_samples;
-    h->V = nv_local;
-    h->M = n_hidden;
-    h->CT = ct;
-    h->Mp = 16 * ct;
-    h->Npad = round_up(n_samples, 64);
-    h->ldx = round_up(nv_local, 64);        // 64 elements: whole 128 B chunks and whole tn column tiles
-    h->timing = false;
-    h->t_every = 1;
-    h->t_count = 0;
-    for (int k = 0; k < 3; ++k) { h->t_launch[k] = 0; h->t_pass[k] = 0; h->t_ms[k] = 0.0; h->t_max[k] = 0.0; h->t_skipped[k] = 0; }
-    h->have_direction = false;
-    h->target_waves = prop.multiProcessorCount * 12;
-    h->n_cus = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
-        delete h;
-        return fail(LCX_ERR_HIP, "lcx_create: cannot create a stream");
-    }
-    h->stream = h->own_stream;
-    hipStream_t st = h->stream;
-    {
-        // One resident copy of the shard instead of two: X.B^T then reads X itself (gemm_cr: 4-6 % slower than gemm_ct on the
-        // transposed copy, tools/gemm_probe4 cr).  LCX_SINGLE_COPY=1 / 0 forces; by default only when two copies would not
-        // leave room for the rest (moments and work space are ~ 20 M x V arrays).
-        const char* e = getenv("LCX_SINGLE_COPY");
-        const double xb = (double)h->Npad * (double)h->ldx * (double)h->es;
-        size_t free_b = 0, total_b = 0;
-        bool want = false;
-        if (e && *e) want = atoi(e) != 0;
-        else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            want = 2.0 * xb + 24.0 * (double)h->ldx * h->Mp * h->es > 0.94 * (double)free_b && xb < 0.9 * (double)free_b;
-        h->single_copy = want || ct > 16;     // the wide path reads X.B^T from the row-major copy anyway (gemm_wide)
-        (void)hipGetLastError();
-    }
-
-    int rc = LCX_OK;
-    {
-        lcx_ctx* hh = h;
-        auto geo = [&]() -> int { DISPATCH(hh, geometry, hh); };
-        rc = geo();
-        if (rc != LCX_OK) { (void)lcx_destroy(h); return rc; }
-    }
-    const size_t es = h->es;
-    const size_t mv = (size_t)h->ldx * h->Mp * es;
-    const size_t vv = (size_t)h->ldx * es;
-    const int Mp = h->Mp;
-    // a failed allocation releases everything allocated so far (lcx_destroy copes with a half-built handle)
-#define A_(ptr, bytes) do { const size_t b_ = (bytes); int r_ = dev_alloc((void**)&(ptr), b_, st); if (r_ != LCX_OK) { (void)lcx_destroy(h); return r_; } h->bytes_resident += b_ ? b_ : 16; } while (0)
-    A_(h->X, (size_t)h->Npad * h->ldx * es);
-    if (!h->single_copy && !h->panel) A_(h->XT, (size_t)h->Npad * h->ldx * es);
-    for (int k = 0; k < 2; ++k) {
-        A_(h->Wt[k], mv);
-        A_(h->set[k].Y, (size_t)h->Npad * Mp * es);
-        A_(h->set[k].D, mv);
-        A_(h->set[k].rho, mv);
-        A_(h->set[k].rir, mv);
-        A_(h->set[k].qij, mv);
-        A_(h->set[k].si, vv);
-        A_(h->set[k].q2, vv);
-        A_(h->set[k].hscale, vv);
-        A_(h->set[k].uj, sizeof(double) * Mp);
-        A_(h->set[k].ry, sizeof(double) * Mp * Mp);
-        A_(h->set[k].wmag, sizeof(double) * Mp);
-        h->set[k].xz = h->set[k].x2y = nullptr;
-        h->set[k].cy = h->set[k].yj2 = h->set[k].inv_sd = nullptr;
-    }
-    A_(h->grad, mv);
-    A_(h->update, mv);
-    A_(h->sgrad, mv);
-    A_(h->scratch, mv);
-    A_(h->ydir, (size_t)h->Npad * Mp * es);
-    A_(h->ddir, mv);
-    h->gw = h->y2part = h->ygbuf = nullptr;
-    h->y1_ready = false;
-    h->bjg = nullptr;
-    if (h->merged_ok) {
-        A_(h->gw, 2 * mv);
-        A_(h->y2part, (size_t)h->nt2_S * h->Npad * 2 * Mp * es);
-        A_(h->bjg, (size_t)Mp * es);
-    }
-    h->have_linear = false;
-    h->full_sig = true;
-    h->exchange = false;
-    h->w1_ready = h->y1_ready = false;
-    h->ybuf_main = h->Npad * Mp + (int64_t)Mp * Mp;
-    h->ybuf_elems = h->ybuf_main + (h->merged_ok ? h->Npad * Mp : 0);    // Y_g of the merged pass right behind the tail
-    h->sbuf_elems = (int64_t)SB_H + (int64_t)Mp * Mp + Mp + 8;
-    A_(h->ybuf_own, (size_t)h->ybuf_elems * es);
-    A_(h->sbuf_own, sizeof(double) * h->sbuf_elems);
-    h->ybuf = h->ybuf_own;
-    h->sbuf = h->sbuf_own;
-    if (h->merged_ok) h->ygbuf = (char*)h->ybuf + (size_t)h->ybuf_main * es;
-    A_(h->ypart, h->nt_S > 1 ? (size_t)h->nt_S * h->Npad * Mp * es : 16);
-    A_(h->dpart, (size_t)h->tn_S * mv);
-    {
-        const int gs = h->gn_S > h->gv_S ? h->gn_S : h->gv_S;
-        A_(h->gpart, (size_t)gs * Mp * Mp * es);
-        A_(h->gpartw, (size_t)gs * Mp * Mp * es);
-    }
-    A_(h->tcpart, sizeof(double) * 2 * 2048);
-    A_(h->bjpart, sizeof(double) * Mp * 2048);
-    A_(h->tanpart, sizeof(double) * 2048);
-    A_(h->detpart, sizeof(double) * (Mp + 3) * 2048);
-    A_(h->ryinv, sizeof(double) * Mp * Mp);
-    A_(h->invwork, sizeof(double) * Mp * 2 * Mp);
-    A_(h->states, sizeof(SetState) * 2);
-    A_(h->order_dev, sizeof(int) * Mp);
-    A_(h->ticket, 256);        // [0] small_moments; [16..25) moments_epilogue; [32..41) update_kernel; [48..50) ytail_kernel
-    h->ypipe = 0;
-    {
-        const char* e = getenv("LCX_Y_PIPELINE");           // "chunks" (4 row chunks) or "chunks:n", n <= 16
-        if (e && !strncmp(e, "chunks", 6)) {
-            h->ypipe = e[6] == ':' ? atoi(e + 7) : 4;
-            if (h->ypipe < 2) h->ypipe = 0;
-            if (h->ypipe > 16) h->ypipe = 16;
-        }
-    }
-    h->ytail_ok = h->y_pending = false;
-    h->yt_Sy = h->yt_Sw = 0;
-    h->ytpart = nullptr;
-    {
-        const char* e = getenv("LCX_YTAIL");
-        if (Mp <= 32 && !(e && *e && atoi(e) == 0)) {
-            // producers: at least two 16-row groups per wave (4 waves per block); producers + Mp^2/32 finishers <= one block per CU
-            const int nfin = Mp * Mp / 32;
-            int64_t sy = h->Npad / 16 / 8, sw = h->ldx / 16 / 8;
-            if (sy < 1) sy = 1;
-            if (sw < 1) sw = 1;
-            const int64_t room = (int64_t)h->n_cus - nfin;
-            if (sy + sw > room && room >= 2) {
-                const int64_t sy2 = sy * room / (sy + sw) > 0 ? sy * room / (sy + sw) : 1;
-                sw = room - sy2 > 0 ? room - sy2 : 1;
-                sy = sy2;
-            }
-            if (room >= 2) {
-                h->yt_Sy = (int)sy;
-                h->yt_Sw = (int)sw;
-                A_(h->ytpart, (size_t)(sy + sw) * Mp * Mp * es);
-                h->ytail_ok = true;
-            }
-        }
-    }
-#undef A_
-    h->set[0].st = h->states;
-    h->set[1].st = h->states + 1;
-    if (hipHostMalloc((void**)&h->host_states, sizeof(SetState) * 2, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
-        (void)lcx_destroy(h);
-        return fail(LCX_ERR_HIP, "lcx_create: cannot allocate the pinned state mirror");
-    }
-    memset(h->host_states, 0, sizeof(SetState) * 2);
-    {
-        SetState* dv = nullptr;
-        if (hipHostGetDevicePointer((void**)&dv, h->host_states, 0) != hipSuccess) {
-            (void)lcx_destroy(h);
-            return fail(LCX_ERR_HIP, "lcx_create: no device address for the pinned state mirror");
-        }
-        for (int k = 0; k < 2; ++k) {
-            h->set[k].hst = h->host_states + k;
-            h->set[k].hst_dev = dv + k;
-            h->set[k].seq_expect = 0;
-        }
-    }
-    h->world = 1;
-    h->n_exchanges = 0;
-    h->seq_next = 0;
-    h->spec_pending = h->spec_dirty = false;
-    h->early_grad = h->grad_ready = false;
-    h->spec_eps = 0.0;
-    HIPCHECK(hipStreamSynchronize(st));
-    {
-        const char* e = getenv("LCX_F32_GEMM");           // "split": the bf16-pipe contractions where the shard supports them
-        if (e && !strcmp(e, "split")) {
-            const int rc2 = lcx_set_f32_gemm(h, 1);
-            if (rc2 != LCX_OK) { (void)lcx_destroy(h); return rc2; }
-        }
-    }
-    *out = h;
-    return LCX_OK;
-}
-
-int lcx_destroy(lcx_ctx* h) {
-    if (!h) return LCX_OK;
-    (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->comm_stream) {
-        (void)hipStreamSynchronize(h->comm_stream);
-        for (auto& e : h->ypipe_ev) if (e) (void)hipEventDestroy(e);
-        (void)hipStreamDestroy(h->comm_stream);
-    }
-    if (h->tr.kind == 1 && h->tr.comm) (void)rccl().CommDestroy(h->tr.comm);
-    void* ptrs[] = {h->X, h->XT, h->Wt[0], h->Wt[1], h->grad, h->update, h->sgrad, h->scratch, h->ydir, h->ddir, h->ybuf_own, h->sbuf_own,
-                    h->gw, h->y2part, h->bjg, h->bsp,
-                    h->ypart, h->dpart, h->gpart, h->gpartw, h->ytpart, h->tcpart, h->bjpart, h->tanpart, h->detpart, h->ryinv, h->invwork,
-                    h->states, h->order_dev, h->ticket};
-    for (void* p : ptrs) (void)hipFree(p);
-    for (int k = 0; k < 2; ++k) {
-        MomentSet& s = h->set[k];
-        void* q[] = {s.Y, s.D, s.rho, s.rir, s.qij, s.si, s.q2, s.hscale, s.uj, s.ry, s.wmag, s.xz, s.x2y, s.cy, s.yj2, s.inv_sd};
-        for (void* p : q) (void)hipFree(p);
-    }
-    if (h->host_states) (void)hipHostFree(h->host_states);
-    if (h->cov) {
-        CovStage& c = *h->cov;
-        for (int k = 0; k < 2; ++k) {
-            if (c.dev[k]) (void)hipFree(c.dev[k]);
-            if (c.pin[k]) (void)hipHostFree(c.pin[k]);
-            if (c.ev_k[k]) (void)hipEventDestroy(c.ev_k[k]);
-            if (c.ev_c[k]) (void)hipEventDestroy(c.ev_c[k]);
-            if (c.t_a[k]) (void)hipEventDestroy(c.t_a[k]);
-            if (c.t_b[k]) (void)hipEventDestroy(c.t_b[k]);
-        }
-        if (c.op_a) (void)hipFree(c.op_a);
-        if (c.op_b) (void)hipFree(c.op_b);
-        if (c.std_dev) (void)hipFree(c.std_dev);
-        if (c.mean_dev) (void)hipFree(c.mean_dev);
-        if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream);
-        delete h->cov;
-    }
-    for (auto& tp : h->pool) { (void)hipEventDestroy(tp.a); (void)hipEventDestroy(tp.b); }
-    for (auto& tp : h->pending) { (void)hipEventDestroy(tp.a); (void)hipEventDestroy(tp.b); }
-    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
-    delete h;
-    return LCX_OK;
-}
-
-int lcx_set_stream(lcx_ctx* h, void* s) {
-    NEED_MUT(h);
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    h->stream = s ? (hipStream_t)s : h->own_stream;
-    return LCX_OK;
-}
-
-int lcx_synchronize(lcx_ctx* h) {
-    NEED(h);
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    return LCX_OK;
-}
-
-int lcx_exchange_layout(lcx_ctx* h, int64_t* ye, int64_t* se, void** yd, void** sd) {
-    NEED(h);
-    if (ye) *ye = h->ybuf_elems;
-    if (se) *se = h->sbuf_elems;
-    if (yd) *yd = h->ybuf;
-    if (sd) *sd = h->sbuf;
-    return LCX_OK;
-}
-
-int lcx_bind_exchange(lcx_ctx* h, void* y, void* s) {
-    NEED_MUT(h);
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    h->ybuf = y ? y : h->ybuf_own;
-    if (h->merged_ok) h->ygbuf = (char*)h->ybuf + (size_t)h->ybuf_main * h->es;
-    h->sbuf = s ? (double*)s : h->sbuf_own;
-    if (y) HIPCHECK(hipMemsetAsync(y, 0, (size_t)h->ybuf_elems * h->es, h->stream));
-    if (s) HIPCHECK(hipMemsetAsync(s, 0, sizeof(double) * h->sbuf_elems, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    return LCX_OK;
-}
-
-// ---- exchange inside the library ---------------------------------------------------------------------
-int lcx_comm_probe(void) {
-    if (!rccl().ok) return fail(LCX_ERR_COMM, rccl().error);
-    return LCX_OK;
-}
-
-int lcx_comm_unique_id(void* id_out) {
-    if (!id_out) return fail(LCX_ERR_ARG, "lcx_comm_unique_id: null");
-    if (!rccl().ok) return fail(LCX_ERR_COMM, rccl().error);
-    ncclUniqueId id;
-    RCCLCHECK(rccl().GetUniqueId(&id));
-    static_assert(sizeof(id) == LCX_COMM_ID_BYTES, "LCX_COMM_ID_BYTES must equal NCCL_UNIQUE_ID_BYTES");
-    memcpy(id_out, &id, sizeof(id));
-    return LCX_OK;
-}
-
-static int drop_transport(lcx_ctx* h) {
-    if (h->tr.kind == 1 && h->tr.comm) {
-        (void)hipStreamSynchronize(h->stream);
-        (void)rccl().CommDestroy(h->tr.comm);
-    }
-    h->tr = Transport();
-    return LCX_OK;
-}
-
-int lcx_comm_init(lcx_ctx* h, int nranks, int rank, const void* id_in) {
-    NEED_MUT(h);
-    if (nranks < 1 || rank < 0 || rank >= nranks || !id_in) return fail(LCX_ERR_ARG, "lcx_comm_init: bad rank / size / id");
-    if (!rccl().ok) return fail(LCX_ERR_COMM, rccl().error);
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    LCXCHECK(drop_transport(h));
-    ncclUniqueId id;
-    memcpy(&id, id_in, sizeof(id));
-    ncclComm_t comm = nullptr;
-    RCCLCHECK(rccl().CommInitRank(&comm, nranks, id, rank));
-    h->tr.kind = 1;
-    h->tr.comm = comm;
-    h->tr.rank = rank;
-    h->tr.nranks = nranks;
-    h->world = nranks;
-    h->exchange = true;          // also for a group of one rank: the caller asked for the multi-rank path
-    return LCX_OK;
-}
-
-int lcx_set_exchange_hook(lcx_ctx* h, lcx_allreduce_fn fn, void* user) {
-    NEED_MUT(h);
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    LCXCHECK(drop_transport(h));
-    if (fn) {
-        h->tr.kind = 2;
-        h->tr.hook = fn;
-        h->tr.user = user;
-    }
-    return LCX_OK;
-}
-
-int lcx_comm_selftest(lcx_ctx* h, int rank, int* ok_out, double* seconds_per_allreduce) {
-    NEED_MUT(h);
-    if (ok_out) *ok_out = 0;
-    if (!h->exchange || h->tr.kind == 0)
-        return fail(LCX_ERR_STATE, "lcx_comm_selftest: no transport bound (lcx_comm_init / lcx_set_exchange_hook first)");
-    if (rank < 0 || rank >= h->world || (h->tr.kind == 1 && rank != h->tr.rank))
-        return fail(LCX_ERR_ARG, "lcx_comm_selftest: rank " + std::to_string(rank) + " is not this handle's rank in a world of " +
-                                     std::to_string(h->world));
-    const int64_t n = h->ybuf_main;                       // what every level all-reduces: [Y | tail]
-    const int nr = h->world;
-    DevTemps tmp;
-    unsigned long long* res = nullptr;
-    LCXCHECK(tmp.get(&res, 4 * sizeof(unsigned long long)));
-    unsigned long long host[4] = {0, 0, 0, 0};
-    const unsigned grid = (unsigned)std::min<int64_t>(2048, cdiv(n, 256));
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    HIPCHECK(hipMemsetAsync(res, 0, 4 * sizeof(unsigned long long), h->stream));
-    double secs = 0.0;
-    for (int pattern = 0; pattern < 2; ++pattern) {
-        if (h->dtype == LCX_F32) hipLaunchKernelGGL((lcx::selftest_fill_kernel<float>), dim3(grid), dim3(256), 0, h->stream, (float*)h->ybuf, n, pattern, rank);
-        else hipLaunchKernelGGL((lcx::selftest_fill_kernel<double>), dim3(grid), dim3(256), 0, h->stream, (double*)h->ybuf, n, pattern, rank);
-        KCHECK();
-        HIPCHECK(hipStreamSynchronize(h->stream));
-        const auto t0 = std::chrono::steady_clock::now();
-        LCXCHECK(exchange(h, h->ybuf, n, h->dtype));
-        HIPCHECK(hipStreamSynchronize(h->stream));
-        secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (h->dtype == LCX_F32) hipLaunchKernelGGL((lcx::selftest_check_kernel<float>), dim3(grid), dim3(256), 0, h->stream, (const float*)h->ybuf, n, pattern, nr, res + 2 * pattern);
-        else hipLaunchKernelGGL((lcx::selftest_check_kernel<double>), dim3(grid), dim3(256), 0, h->stream, (const double*)h->ybuf, n, pattern, nr, res + 2 * pattern);
-        KCHECK();
-    }
-    HIPCHECK(hipMemcpyAsync(host, res, sizeof(host), hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    // every rank learns every rank's verdict through the scalar exchange buffer (doubles): the number of wrong sums, and the
-    // two halves a, b of each result hash with their squares - all ranks hold the same bits iff n * sum(a^2) == (sum a)^2
-    double sv[16] = {0};
-    sv[0] = (double)host[0];
-    for (int pattern = 0; pattern < 2; ++pattern) {
-        const uint64_t hs = host[2 * pattern + 1];
-        for (int k = 0; k < 3; ++k) {
-            const double part = (double)((hs >> (21 * k)) & 0x1FFFFFull);       // 21-bit pieces: squares and 8-rank sums stay exact
-            sv[1 + pattern * 6 + 2 * k] = part;
-            sv[2 + pattern * 6 + 2 * k] = part * part;
-        }
-    }
-    HIPCHECK(hipMemcpyAsync(h->sbuf, sv, 13 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    LCXCHECK(exchange(h, h->sbuf, 13, LCX_F64));
-    HIPCHECK(hipMemcpyAsync(sv, h->sbuf, 13 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    // leave the exchange buffers as lcx_bind_exchange leaves them
-    HIPCHECK(hipMemsetAsync(h->ybuf, 0, (size_t)n * h->es, h->stream));
-    HIPCHECK(hipMemsetAsync(h->sbuf, 0, 13 * sizeof(double), h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    if (seconds_per_allreduce) *seconds_per_allreduce = secs / 2.0;
-    bool same = true;
-    for (int k = 0; k < 6; ++k) same = same && ((double)nr * sv[2 + 2 * k] == sv[1 + 2 * k] * sv[1 + 2 * k]);
-    if (sv[0] != 0.0)
-        return fail(LCX_ERR_COMM, "lcx_comm_selftest: the all-reduce of " + std::to_string(n) + " elements over " + std::to_string(nr) +
-                                      " ranks returned " + std::to_string((long long)sv[0]) + " wrong sums (all ranks together; this rank: " +
-                                      std::to_string((long long)host[0]) + ")");
-    if (!same)
-        return fail(LCX_ERR_COMM, "lcx_comm_selftest: the ranks hold different bits after the same all-reduce (the line-search "
-                                  "decisions of lcx_iterate need rank-identical sums)");
-    if (ok_out) *ok_out = 1;
-    return LCX_OK;
-}
-
-int lcx_exchange_info(lcx_ctx* h, int* kind, int* world, int64_t* allreduces_issued) {
-    NEED(h);
-    if (kind) *kind = h->exchange ? h->tr.kind : -1;
-    if (world) *world = h->world;
-    if (allreduces_issued) *allreduces_issued = h->n_exchanges;
-    return LCX_OK;
-}
-
-int lcx_upload_x(lcx_ctx* h, const void* x, int64_t ld) {
-    NEED_MUT(h);
-    if (!x || ld < h->V) return fail(LCX_ERR_ARG, "lcx_upload_x: bad leading dimension");
-    DISPATCH(h, upload_x, h, x, ld);
-}
-
-int lcx_upload_preprocess(lcx_ctx* h, const void* x, int64_t ld, int kind, int has_missing, double missing, int fit, void* mean_io,
-                          void* std_io, int64_t* n_obs_out, double* max_abs_out) {
-    NEED_MUT(h);
-    if (!x || ld < h->V) return fail(LCX_ERR_ARG, "lcx_upload_preprocess: bad leading dimension");
-    if (kind < 0 || kind > 3) return fail(LCX_ERR_ARG, "lcx_upload_preprocess: kind must be 0 (none), 1 (standard), 2 (outliers) or 3 (empirical)");
-    DISPATCH(h, upload_preprocess, h, x, ld, kind, has_missing, missing, fit, mean_io, std_io, n_obs_out, max_abs_out);
-}
-
-int lcx_download_x(lcx_ctx* h, void* x, int64_t ld) {
-    NEED(h);
-    if (!x || ld < h->V) return fail(LCX_ERR_ARG, "lcx_download_x: bad leading dimension");
-    DISPATCH(h, download_x, h, x, ld);
-}
-
-int lcx_generate_x(lcx_ctx* h, uint64_t seed, int kind, int n_groups, int64_t col_offset) {
-    NEED_MUT(h);
-    DISPATCH(h, generate, h, seed, kind, n_groups, col_offset);
-}
-
-int lcx_set_ws(lcx_ctx* h, const void* w) {
-    NEED_MUT(h);
-    h->w1_ready = h->y1_ready = false;
-    if (!w) return fail(LCX_ERR_ARG, "lcx_set_ws: null");
-    DISPATCH(h, set_ws, h, w);
-}
-
-static int get_ws_impl(lcx_ctx* h, int which, void* w) {
-    if (h->dtype == LCX_F32) {
-        switch (h->CT) { case 1: return Impl<float,1>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
-                         case 2: return Impl<float,2>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
-                         case 4: return Impl<float,4>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
-                         case 8: return Impl<float,8>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
-                         case 16: return Impl<float,16>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
-                         case 32: return Impl<float,32>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true);
-                         case 64: return Impl<float,64>::fetch_mv(h, P<float>(h->Wt[which]), P<float>(w), true); }
-    } else {
-        switch (h->CT) { case 1: return Impl<double,1>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
-                         case 2: return Impl<double,2>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
-                         case 4: return Impl<double,4>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
-                         case 8: return Impl<double,8>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
-                         case 16: return Impl<double,16>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
-                         case 32: return Impl<double,32>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true);
-                         case 64: return Impl<double,64>::fetch_mv(h, P<double>(h->Wt[which]), P<double>(w), true); }
-    }
-    return fail(LCX_ERR_ARG, "bad CT");
-}
-int lcx_get_ws(lcx_ctx* h, int which, void* w) {
-    NEED(h);
-    if (!w || which < 0 || which > 1) return fail(LCX_ERR_ARG, "lcx_get_ws: bad argument");
-    return get_ws_impl(h, which, w);
-}
-
-int lcx_permute_factors(lcx_ctx* h, const int32_t* order) {
-    NEED_MUT(h);
-    h->w1_ready = h->y1_ready = false;
-    if (!order) return fail(LCX_ERR_ARG, "lcx_permute_factors: null");
-    for (int j = 0; j < h->M; ++j)
-        if (order[j] < 0 || order[j] >= h->M) return fail(LCX_ERR_ARG, "lcx_permute_factors: index out of range");
-    DISPATCH(h, permute, h, order);
-}
-
-#define WHICH_OK(w) if ((w) < 0 || (w) > 1) return fail(LCX_ERR_ARG, "which must be 0 or 1")
-
-int lcx_moments_a(lcx_ctx* h, int which) { NEED_MUT(h); WHICH_OK(which); DISPATCH(h, moments_a, h, which); }
-int lcx_moments_b(lcx_ctx* h, int which, double eps, int quick) { NEED_MUT(h); WHICH_OK(which); DISPATCH(h, moments_b, h, which, eps, quick); }
-int lcx_moments_c(lcx_ctx* h, int which) { NEED_MUT(h); WHICH_OK(which); DISPATCH(h, moments_c, h, which); }
-
-static int detail_entry(lcx_ctx* h, int which) {
-    if (h->dtype == LCX_F32) {
-        switch (h->CT) { case 1: return Impl<float,1>::detail(h, which, nullptr, nullptr, nullptr);
-                         case 2: return Impl<float,2>::detail(h, which, nullptr, nullptr, nullptr);
-                         case 4: return Impl<float,4>::detail(h, which, nullptr, nullptr, nullptr);
-                         case 8: return Impl<float,8>::detail(h, which, nullptr, nullptr, nullptr);
-                         case 16: return Impl<float,16>::detail(h, which, nullptr, nullptr, nullptr);
-                         case 32: return Impl<float,32>::detail(h, which, nullptr, nullptr, nullptr);
-                         case 64: return Impl<float,64>::detail(h, which, nullptr, nullptr, nullptr); }
-    } else {
-        switch (h->CT) { case 1: return Impl<double,1>::detail(h, which, nullptr, nullptr, nullptr);
-                         case 2: return Impl<double,2>::detail(h, which, nullptr, nullptr, nullptr);
-                         case 4: return Impl<double,4>::detail(h, which, nullptr, nullptr, nullptr);
-                         case 8: return Impl<double,8>::detail(h, which, nullptr, nullptr, nullptr);
-                         case 16: return Impl<double,16>::detail(h, which, nullptr, nullptr, nullptr);
-                         case 32: return Impl<double,32>::detail(h, which, nullptr, nullptr, nullptr);
-                         case 64: return Impl<double,64>::detail(h, which, nullptr, nullptr, nullptr); }
-    }
-    return fail(LCX_ERR_ARG, "bad CT");
-}
-int lcx_moments_detail(lcx_ctx* h, int which) {
-    NEED(h);
-    WHICH_OK(which);
-    LCXCHECK(detail_entry(h, which));
-    return exchange(h, h->sbuf + sb_det(h->Mp), h->M + 3, LCX_F64);
-}
-
-int lcx_update_a(lcx_ctx* h) { NEED_MUT(h); DISPATCH(h, update_a, h); }
-int lcx_update_b(lcx_ctx* h, double eps) { NEED_MUT(h); DISPATCH(h, update_b, h, eps); }
-int lcx_update_c(lcx_ctx* h, double eps) { NEED_MUT(h); DISPATCH(h, update_c, h, eps); }
-int lcx_update_d(lcx_ctx* h) {
-    NEED_MUT(h);
-    // With one GPU lcx_update_c already published the tangent; with several ranks its partial sits in sbuf[2]
-    // and becomes global with the scalar all-reduce of the first trial (lcx_moments_c stores it).
-    h->have_direction = true;
-    return LCX_OK;
-}
-int lcx_make_trial(lcx_ctx* h, double eta) {
-    NEED_MUT(h);
-    if (!h->have_direction) return fail(LCX_ERR_STATE, "lcx_make_trial before lcx_update_a..d");
-    DISPATCH(h, make_trial, h, eta);
-}
-int lcx_trial_linear_a(lcx_ctx* h, double eta) {
-    NEED_MUT(h);
-    if (!h->have_direction) return fail(LCX_ERR_STATE, "lcx_trial_linear_a before lcx_update_a..d");
-    DISPATCH(h, trial_linear_a, h, eta);
-}
-int lcx_trial_linear_b(lcx_ctx* h, double eps, double eta) {
-    NEED_MUT(h);
-    if (!h->have_direction) return fail(LCX_ERR_STATE, "lcx_trial_linear_b before lcx_update_a..d");
-    DISPATCH(h, trial_linear_b, h, eps, eta);
-}
-int lcx_accept_trial(lcx_ctx* h) {
-    NEED_MUT(h);
-    h->w1_ready = h->y1_ready = false;
-    std::swap(h->Wt[0], h->Wt[1]);
-    std::swap(h->set[0], h->set[1]);
-    h->have_direction = false;
-    return LCX_OK;
-}
-
-int lcx_iterate(lcx_ctx* h, double eps, double tol, double tc_cur, int more, double* out8) {
-    NEED(h);
-    if (!out8) return fail(LCX_ERR_ARG, "lcx_iterate: null");
-    DISPATCH(h, iterate, h, eps, tol, tc_cur, more, out8);
-}
-
-int lcx_syn_moments_b(lcx_ctx* h, int which, double yscale) { NEED_MUT(h); WHICH_OK(which); DISPATCH(h, syn_moments_b, h, which, yscale); }
-int lcx_syn_moments_c(lcx_ctx* h, int which) { NEED_MUT(h); WHICH_OK(which); DISPATCH(h, syn_moments_c, h, which); }
-int lcx_syn_update_a(lcx_ctx* h) { NEED_MUT(h); DISPATCH(h, syn_update_a, h); }
-int lcx_syn_update_b(lcx_ctx* h, double eta) { NEED_MUT(h); DISPATCH(h, syn_update_b, h, eta); }
-int lcx_covariance_rows_syn(lcx_ctx* h, const void* std_host, int64_t row0, int64_t nrows, void* out) {
-    NEED(h);
-    if (!std_host || !out || row0 < 0 || nrows < 1 || row0 + nrows > h->V) return fail(LCX_ERR_ARG, "lcx_covariance_rows_syn: bad range");
-    DISPATCH(h, covariance_syn, h, std_host, row0, nrows, out);
-}
-
-int lcx_rescale_ws(lcx_ctx* h, double e0, double e1) { NEED_MUT(h); h->w1_ready = h->y1_ready = false; DISPATCH(h, rescale, h, e0, e1); }
-int lcx_init_scale_ws(lcx_ctx* h) { NEED_MUT(h); h->w1_ready = h->y1_ready = false; DISPATCH(h, init_scale, h); }
-
-// Wait until the pinned mirror of a set carries the last publication enqueued for it.
 static int wait_published(lcx_ctx* h, MomentSet& s) {
     if (s.seq_expect == 0) {                 // nothing published yet: plain copy
         HIPCHECK(hipMemcpyAsync(s.hst, s.st, sizeof(SetState), hipMemcpyDeviceToHost, h->stream));
@@ -3043,232 +2491,5 @@ static int wait_published(lcx_ctx* h, MomentSet& s) {
     return LCX_OK;
 }
 
-int lcx_read_state(lcx_ctx* h, int which, double* out) {
-    NEED(h);
-    WHICH_OK(which);
-    if (!out) return fail(LCX_ERR_ARG, "lcx_read_state: null");
-    MomentSet& ms = h->set[which];
-    if (which == 0 && h->tan_blocks > 0) {
-        // update_tangent of the direction in flight is normally summed by the tail of the first trial's evaluation;
-        // somebody wants the current solution's state before that
-        const int single = !h->exchange;
-        const unsigned int seq = single ? ++h->seq_next : 0u;
-        if (h->dtype == LCX_F32)
-            hipLaunchKernelGGL((tangent_finalize_kernel<float>), dim3(1), dim3(256), 0, h->stream, h->tanpart, h->tan_blocks, h->sbuf, ms.st,
-                               ms.hst_dev, seq, single);
-        else
-            hipLaunchKernelGGL((tangent_finalize_kernel<double>), dim3(1), dim3(256), 0, h->stream, h->tanpart, h->tan_blocks, h->sbuf, ms.st,
-                               ms.hst_dev, seq, single);
-        KCHECK();
-        if (single) ms.seq_expect = seq;
-        h->tan_blocks = 0;
-    }
-    LCXCHECK(wait_published(h, ms));
-    const SetState& s = *ms.hst;
-    out[LCX_S_TC] = s.tc;
-    out[LCX_S_MAX_UJ] = s.max_uj;
-    out[LCX_S_INVALID] = (double)s.invalid;
-    out[LCX_S_TANGENT] = s.tangent;
-    out[LCX_S_SUM_LOG_RJ] = s.sum_log_rj;
-    out[5] = out[6] = out[7] = 0.0;
-    return LCX_OK;
-}
-
-int lcx_set_trial_reuse(lcx_ctx* h, int enable) {
-    NEED_MUT(h);
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    h->reuse_y = enable != 0;
-    return LCX_OK;
-}
-
-int lcx_set_sample_divisor(lcx_ctx* h, double n_samples) {
-    NEED_MUT(h);
-    if (!(n_samples >= 1.0)) return fail(LCX_ERR_ARG, "lcx_set_sample_divisor: n_samples must be >= 1");
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    h->Ndiv = n_samples;
-    return LCX_OK;
-}
-
-int lcx_set_linear_mode(lcx_ctx* h, int enable) {
-    NEED_MUT(h);
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    h->full_sig = enable != 0;
-    return LCX_OK;
-}
-
-int lcx_set_exchange(lcx_ctx* h, int enable) {
-    NEED_MUT(h);
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    h->exchange = enable != 0 || h->world > 1;
-    return LCX_OK;
-}
-
-int lcx_set_world(lcx_ctx* h, int world) {
-    NEED_MUT(h);
-    if (world < 1) return fail(LCX_ERR_ARG, "lcx_set_world: world must be >= 1");
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    h->world = world;
-    h->exchange = world > 1;
-    return LCX_OK;
-}
-
-int lcx_get_moment(lcx_ctx* h, int which, int key, double eps, void* out) {
-    NEED(h);
-    WHICH_OK(which);
-    if (!out) return fail(LCX_ERR_ARG, "lcx_get_moment: null");
-    DISPATCH(h, get_moment, h, which, key, eps, out);
-}
-
-int lcx_set_moment(lcx_ctx* h, int which, int key, const void* in) {
-    NEED_MUT(h);
-    WHICH_OK(which);
-    if (!in) return fail(LCX_ERR_ARG, "lcx_set_moment: null");
-    DISPATCH(h, set_moment, h, which, key, in);
-}
-
-int lcx_read_sbuf(lcx_ctx* h, int64_t offset, int64_t count, double* out) {
-    NEED(h);
-    if (!out || offset < 0 || count < 1 || offset + count > h->sbuf_elems) return fail(LCX_ERR_ARG, "lcx_read_sbuf: bad range");
-    HIPCHECK(hipMemcpyAsync(out, h->sbuf + offset, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    return LCX_OK;
-}
-
-int lcx_covariance_rows(lcx_ctx* h, double eps, const void* std_host, int64_t row0, int64_t nrows, void* out) {
-    NEED(h);
-    if (!std_host || !out || row0 < 0 || nrows < 1 || row0 + nrows > h->V) return fail(LCX_ERR_ARG, "lcx_covariance_rows: bad range");
-    DISPATCH(h, covariance, h, eps, std_host, row0, nrows, out);
-}
-
-int lcx_covariance(lcx_ctx* h, int synergistic, double eps, const void* std_host, void* out, int64_t ld_out, double* kernel_seconds) {
-    NEED(h);
-    if (!std_host || !out || ld_out < h->V) return fail(LCX_ERR_ARG, "lcx_covariance: bad argument");
-    DISPATCH(h, covariance_full, h, synergistic, eps, std_host, out, ld_out, kernel_seconds);
-}
-
-int lcx_predict(lcx_ctx* h, const void* y_host, int64_t n_rows, int synergistic, const void* xz_host, int kind, const void* mean,
-                const void* stdv, void* out, int64_t ld_out, double* kernel_seconds) {
-    NEED(h);
-    if (!y_host || !out || n_rows < 1 || ld_out < h->V) return fail(LCX_ERR_ARG, "lcx_predict: bad argument");
-    if (kind < 0 || kind > 2 || (kind != 0 && (!mean || !stdv))) return fail(LCX_ERR_ARG, "lcx_predict: bad kind / theta");
-    DISPATCH(h, predict, h, y_host, n_rows, synergistic, xz_host, kind, mean, stdv, out, ld_out, kernel_seconds);
-}
-
-int lcx_invert(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, int kind, const void* mean, const void* stdv, void* out,
-               int64_t ld_out) {
-    NEED(h);
-    if (!x_host || !out || n_rows < 1 || ld < h->V || ld_out < h->V) return fail(LCX_ERR_ARG, "lcx_invert: bad argument");
-    if (kind < 0 || kind > 2 || (kind != 0 && (!mean || !stdv))) return fail(LCX_ERR_ARG, "lcx_invert: bad kind / theta");
-    DISPATCH(h, invert_rows, h, x_host, n_rows, ld, kind, mean, stdv, out, ld_out);
-}
-
-int lcx_x_layout(lcx_ctx* h, int* layout) {
-    NEED(h);
-    if (!layout) return fail(LCX_ERR_ARG, "lcx_x_layout: null");
-    *layout = h->panel ? 2 : (h->single_copy ? 1 : 0);
-    return LCX_OK;
-}
-
-static int split_supported_dispatch(lcx_ctx* h) { DISPATCH(h, split_supported, h); }
-
-int lcx_set_f32_gemm(lcx_ctx* h, int mode) {
-    NEED(h);
-    if (mode != 0 && mode != 1) return fail(LCX_ERR_ARG, "lcx_set_f32_gemm: mode must be 0 (float32 MFMA) or 1 (bf16 split)");
-    HIPCHECK(hipSetDevice(h->device));
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    if (mode == 0 || split_supported_dispatch(h) != 1) { h->split = false; return LCX_OK; }
-    if (!h->bsp) {
-        const int64_t k = h->ldx > h->Npad ? h->ldx : h->Npad;
-        const size_t bytes = (size_t)k * (size_t)(h->merged_ok ? 2 * h->Mp : h->Mp) * 6;
-        int rc = dev_alloc(&h->bsp, bytes, h->stream);
-        if (rc != LCX_OK) { h->bsp = nullptr; return rc; }
-        h->bsp_bytes = bytes;
-        h->bytes_resident += bytes;
-    }
-    h->split = true;
-    return LCX_OK;
-}
-
-int lcx_f32_gemm(lcx_ctx* h, int* mode) {
-    NEED(h);
-    if (!mode) return fail(LCX_ERR_ARG, "lcx_f32_gemm: null");
-    *mode = h->split ? 1 : 0;
-    return LCX_OK;
-}
-
-int lcx_bytes_resident(lcx_ctx* h, int64_t* total, int64_t* x_bytes) {
-    NEED(h);
-    if (total) *total = (int64_t)h->bytes_resident;
-    if (x_bytes) *x_bytes = (int64_t)((h->single_copy || h->panel ? 1 : 2) * (size_t)h->Npad * h->ldx * h->es);
-    return LCX_OK;
-}
-
-int lcx_project(lcx_ctx* h, const void* x, int64_t n_rows, int64_t ld, void* out) {
-    NEED(h);
-    if (!x || !out || n_rows < 1 || ld < h->V) return fail(LCX_ERR_ARG, "lcx_project: bad argument");
-    DISPATCH(h, project, h, x, n_rows, ld, out);
-}
-
-int lcx_project_raw(lcx_ctx* h, const void* x, int64_t n_rows, int64_t ld, int kind, const void* mean, const void* stdv, void* out) {
-    NEED(h);
-    if (!x || !out || n_rows < 1 || ld < h->V) return fail(LCX_ERR_ARG, "lcx_project_raw: bad argument");
-    if (kind < 0 || kind > 2 || (kind != 0 && (!mean || !stdv))) return fail(LCX_ERR_ARG, "lcx_project_raw: bad kind / theta");
-    DISPATCH(h, project_raw, h, x, n_rows, ld, kind, mean, stdv, out);
-}
-
-int lcx_timing_enable(lcx_ctx* h, int enable) {
-    NEED(h);
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    LCXCHECK(timing_collect(h));
-    h->timing = enable != 0;
-    return LCX_OK;
-}
-int lcx_timing_sample(lcx_ctx* h, int every) {
-    NEED(h);
-    if (every < 1) return fail(LCX_ERR_ARG, "lcx_timing_sample: every must be >= 1");
-    h->t_every = every;
-    h->t_count = 0;
-    return LCX_OK;
-}
-int lcx_timing_read(lcx_ctx* h, int kind, int64_t* launches, double* total_ms) {
-    NEED(h);
-    if (kind < 0 || kind > 2) return fail(LCX_ERR_ARG, "kind must be 0, 1 or 2");
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    LCXCHECK(timing_collect(h));
-    if (launches) *launches = h->t_launch[kind];
-    if (total_ms) *total_ms = h->t_ms[kind];
-    return LCX_OK;
-}
-int lcx_timing_reset(lcx_ctx* h) {
-    NEED(h);
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    LCXCHECK(timing_collect(h));
-    for (int k = 0; k < 3; ++k) { h->t_launch[k] = 0; h->t_pass[k] = 0; h->t_ms[k] = 0.0; h->t_max[k] = 0.0; h->t_skipped[k] = 0; }
-    return LCX_OK;
-}
-int lcx_timing_passes(lcx_ctx* h, int kind, int64_t* passes) {
-    NEED(h);
-    if (kind < 0 || kind > 2 || !passes) return fail(LCX_ERR_ARG, "lcx_timing_passes: bad argument");
-    *passes = h->t_pass[kind];
-    return LCX_OK;
-}
-
-int lcx_geometry(lcx_ctx* h, int64_t* n_pad, int64_t* ldx, int* m_pad, int64_t* info8) {
-    NEED(h);
-    if (n_pad) *n_pad = h->Npad;
-    if (ldx) *ldx = h->ldx;
-    if (m_pad) *m_pad = h->Mp;
-    if (info8) {
-        info8[0] = h->nt_S; info8[1] = h->nt_KW; info8[2] = h->tn_S; info8[3] = h->tn_KW;
-        info8[4] = h->nt_bpc; info8[5] = h->tn_bpc; info8[6] = h->pv_grid; info8[7] = h->n_cus;
-    }
-    return LCX_OK;
-}
-
-int lcx_kernel_name(lcx_ctx* h, int kind, char* buf, int64_t len) {
-    if (!h) return fail(LCX_ERR_ARG, "null handle");
-    if (kind < 0 || kind > 2 || !buf || len < 16) return fail(LCX_ERR_ARG, "lcx_kernel_name: bad argument");
-    DISPATCH(h, kernel_name, h, kind, buf, len);
-}
-
-}  // extern "C"
+// the launch geometry of a handle (lcx_create): lives with the kernels it sizes, in lcx_levels.hip
+__attribute__((visibility("hidden"))) int lcx_engine_geometry(lcx_ctx* h);

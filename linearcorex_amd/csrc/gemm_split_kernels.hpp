@@ -3,19 +3,27 @@
 // Why: on MI355X the float32 MFMA (v_mfma_f32_16x16x4_f32) runs at the float32 VECTOR rate, 1/16 of the bf16 MFMA
 // (/opt/skills/guides/MI355X_MICROARCH.md: 157 TF/s against 2.5 PF/s), and the large float32 shards of the fit loop are bound by it
 // (gemm_cr / gemm_ct at 0.80-0.92 of that peak, 4-5.5 TB/s of the 8 TB/s HBM).  A float32 number is EXACTLY the sum of three bf16
-// numbers (24 significand bits = 8 + 8 + 8: hi = the top 16 bits of the word, mid = the top 16 bits of x - hi, lo = x - hi - mid,
-// every subtraction exact), a bf16 x bf16 product is exact in float32, and the matrix pipe accumulates in float32.  So
+// numbers (24 significand bits = 8 + 8 + 8), a bf16 x bf16 product is exact in float32, and the matrix pipe accumulates in float32.  So
 //
 //     a.b = (ah + am + al).(bh + bm + bl) = ah.bh + (ah.bm + am.bh) + (am.bm + ah.bl + al.bh) + [am.bl + al.bm] + {al.bl}
 //
-// and NP = 6 products drop the [..] pair and {..}: with this truncation split (|mid| < 2^-7 |x|, |lo| < 2^-15 |x|) at most 2^-21.3 of
-// the product and 2^-24 of it in the rms (tests/test_split_arithmetic_cpu.py) - the size of ONE float32 rounding of the product,
-// which the float32 MFMA chain commits at every one of its K steps anyway; NP = 8 keeps the [..] pair as well (no measurable
-// difference in a contraction: what is left is the float32 accumulation).  A round-to-nearest split (v_cvt_pk_bf16_f32, the same
-// instruction count) would make the dropped terms 2^-24.4 / 2^-27 (tools/split_rne_probe.hpp).  One v_mfma_f32_16x16x32_bf16 (~17 cycles) covers 32 contraction elements, for which the float32 MFMA needs 8
-// instructions of 32 cycles: 6 products are 2.5 x less matrix-pipe time; 64-column passes become HBM bound (5.6-5.8 TB/s), 128-column
-// passes run the bf16 pipe 0.75 busy under the power cap (1.66 GHz) - 1.45-1.5 x the float32-MFMA passes either way.
-// Measured error against a float64 contraction: tools/gemm_probe9 (profiles/r04_gemm_probe9_split.txt): 1.1-1.4 x the float32 MFMA's.
+// and NP = 6 products drop the [..] pair and {..}.
+//
+// The split is ROUND-TO-NEAREST (round 5; round 4's truncation split is gone): hi = bf16(x) and mid = bf16(x - hi) by
+// v_cvt_pk_bf16_f32 (round to nearest even, two elements per instruction), lo = x - hi - mid; both subtractions are exact and lo has
+// at most 8 significant bits, so x = hi + mid + lo exactly (tests/test_split_arithmetic_cpu.py repeats it in NumPy).  The residuals are
+// signed and at most half a bf16 ulp: |mid| <= 2^-8 |x|, |lo| <= 2^-17 |x|.  The three dropped products are then at most 2^-24.4
+// of the product and 2^-27 of it in the rms, ZERO-MEAN - below half a float32 rounding of the product, which the float32 MFMA chain
+// commits at every one of its K steps anyway.  (A truncation split - mask the upper 16 bits - measured 6 % faster at full
+// size, but its residuals all carry the sign of x: the dropped terms are a systematic shrink of 2^-24 .. 2^-21.3 of every
+// product that adds up coherently in same-sign sums such as uj = sum y^2.  An opt-in arithmetic should not have a bias; measured
+// error against a float64 contraction, full-size operands: 1.0-1.2 x the float32 MFMA's with this split, 1.1-1.4 x with truncation,
+// profiles/r04_gemm_probe9_rne.txt.)  Caveat: rounding to nearest overflows to infinity for |x| >= 2^128 (1 - 2^-9) = 3.39e38, within
+// half a bf16 ulp of FLT_MAX; the operands here are standardised data and weights of order 1.
+// NP = 8 keeps the [..] pair as well (no measurable difference in a contraction: what is left is the float32 accumulation).
+// One v_mfma_f32_16x16x32_bf16 (~17 cycles) covers 32 contraction elements, for which the float32 MFMA needs 8 instructions of 32
+// cycles: 6 products are 2.5 x less matrix-pipe time; 64-column passes become HBM bound (5.2-5.6 TB/s), 128-column passes run the
+// bf16 pipe under the power cap - 1.35-1.45 x the float32-MFMA passes either way.
 //
 // Same machine as gemm_ct / gemm_cr (gemm_kernels.hpp): a block's KW waves own KW adjacent 64-row output tiles and walk the same
 // contraction range; the small operand B is staged once per block through LDS, double buffered, one barrier per group of KS x 32
@@ -46,18 +54,22 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 struct Split3 { u32x4_t p[3]; };             // hi, mid, lo
 
-// 8 floats -> three packed bf16x8 operands (element 2p in the low half of word p)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+// 8 floats -> three packed bf16x8 operands (element 2p in the low half of word p): round-to-nearest three-way split, exact
+// (hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid; v_cvt_pk_bf16_f32 converts a pair per instruction)
 __device__ __forceinline__ Split3 split8(const float (&x)[8]) {
     Split3 s;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const float a = x[2 * p], b = x[2 * p + 1];
-        const unsigned ah = __float_as_uint(a) & 0xffff0000u, bh = __float_as_uint(b) & 0xffff0000u;
-        const float ra = a - __uint_as_float(ah), rb = b - __uint_as_float(bh);
-        const unsigned am = __float_as_uint(ra) & 0xffff0000u, bm = __float_as_uint(rb) & 0xffff0000u;
-        const float la = ra - __uint_as_float(am), lb = rb - __uint_as_float(bm);
-        s.p[0][p] = __builtin_amdgcn_perm(bh, ah, 0x07060302u);
-        s.p[1][p] = __builtin_amdgcn_perm(bm, am, 0x07060302u);
+        const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+        const float ra = a - __uint_as_float(hp << 16), rb = b - __uint_as_float(hp & 0xffff0000u);
+        const unsigned mp = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){ra, rb}, bf16x2_t));
+        const float la = ra - __uint_as_float(mp << 16), lb = rb - __uint_as_float(mp & 0xffff0000u);
+        s.p[0][p] = hp;
+        s.p[1][p] = mp;
         s.p[2][p] = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
     }
     return s;

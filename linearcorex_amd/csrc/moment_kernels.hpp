@@ -214,7 +214,8 @@ small_moments_kernel(const T* __restrict__ gy, int nsplit, const T* __restrict__
 //   producers (blocks [0, Sw + Sy))  W blocks: the W.W^T Gram partial of their rows of W.  Y blocks: their rows of Y as the
 //              sum of the pass's partial slots in slot order (what reduce_partials_kernel computes, bit for bit) -> the
 //              exchange buffer and the set's own copy, and the Y^T.Y Gram partial of those rows from the same registers:
-//              a lane's 16 bytes of a row are both MFMA operands (A^T.A with the tile = all Mp columns).  Release, arrive.
+//              a lane's 16 bytes of a row are both MFMA operands (A^T.A with the tile = all Mp columns).  Tiles are written
+//              through (no release fence: it would flush the XCD's L2, the freshly stored Y included), drained, then arrive.
 //   finishers (Mp^2 / 32 blocks)     wait for the arrival counter, then small_moments_kernel's body: the partials of 32
 //              matrix elements summed in a fixed order -> ry / uj / wmag; the finisher that draws the last ticket derives
 //              max uj, sum log(1 - uj) and the early-exit flag (:250-251) and zeroes both counters.
@@ -307,7 +308,9 @@ __device__ __forceinline__ void gram_sum_body(const T* __restrict__ src, int64_t
         T s = red[idx];
 #pragma unroll
         for (int w = 1; w < KW; ++w) s += red[w * TILE + idx];
-        dst[idx] = s;
+        // write-through (sc1): the hand-off to the finishers then needs no release fence - which would first write back every
+        // dirty line of this XCD's L2, the megabytes of Y the producers have just stored included
+        __hip_atomic_store(&dst[idx], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -323,14 +326,10 @@ ytail_kernel(YTailArgs<T> a) {
         if (b < a.Sw) gram_sum_body<T, CT, KW, 1, false>(a.w, 0, nullptr, nullptr, a.gw, a.kg_w, a.Sw, b, red);
         else if (a.y0 != nullptr) gram_sum_body<T, CT, KW, NS, true>(a.ysrc, a.slot_stride, a.y0, a.y1, a.gy, a.kg_y, a.Sy, b - a.Sw, red);
         else gram_sum_body<T, CT, KW, NS, false>(a.ysrc, a.slot_stride, nullptr, nullptr, a.gy, a.kg_y, a.Sy, b - a.Sw, red);
-        // hand-off: every wave drains its stores, one lane releases at agent scope and arrives
+        // hand-off: every wave drains its (write-through) tile stores, then one lane arrives
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(&a.counters[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid == 0) __hip_atomic_fetch_add(&a.counters[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     // ---- finishers ----
@@ -345,7 +344,6 @@ ytail_kernel(YTailArgs<T> a) {
             if (__hip_atomic_load(&a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)nprod) { ok = 1; break; }
             __builtin_amdgcn_s_sleep(1);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         flag_s = ok;
     }
     __syncthreads();
@@ -356,8 +354,9 @@ ytail_kernel(YTailArgs<T> a) {
     const int64_t mm = (int64_t)Mp * Mp;
     const int64_t idx = (int64_t)fb * 32 + e;
     T sy = (T)0, sw = (T)0;
-    for (int k = g; k < a.Sy; k += 8) sy += a.gy[k * mm + idx];
-    for (int k = g; k < a.Sw; k += 8) sw += a.gw[k * mm + idx];
+    // (coherent loads: the tiles were written through by other CUs, possibly of other XCDs)
+    for (int k = g; k < a.Sy; k += 8) sy += __hip_atomic_load(&a.gy[k * mm + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = g; k < a.Sw; k += 8) sw += __hip_atomic_load(&a.gw[k * mm + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     shy[g][e] = sy;
     shw[g][e] = sw;
     __syncthreads();
@@ -370,7 +369,7 @@ ytail_kernel(YTailArgs<T> a) {
         if (!arrived) val = (T)__builtin_nan("");
         const int j = (int)(idx / Mp), k2 = (int)(idx % Mp);
         if (j == k2) {
-            a.sm.uj[j] = (double)val;
+            __hip_atomic_store(&a.sm.uj[j], (double)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the last finisher
             a.sm.wmag[j] = (double)gwv;
             a.sm.ry[idx] = 1.0;
         } else {
@@ -380,12 +379,8 @@ ytail_kernel(YTailArgs<T> a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned int t = __hip_atomic_fetch_add(&a.counters[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (t == (unsigned int)nfin - 1u);
-        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        flag_s = last;
+        flag_s = (t == (unsigned int)nfin - 1u);
     }
     __syncthreads();
     if (!flag_s) return;
@@ -920,7 +915,7 @@ __global__ void permute_kernel(const T* __restrict__ in, T* __restrict__ out, in
 // detail moments (:277-287)
 // ------------------------------------------------------------------------------------------------
 // inverse of ry by Gauss-Jordan with partial pivoting; one block; work: [Mp][2*Mp] doubles (global)
-__global__ void invert_kernel(const double* __restrict__ a, int Mp, double* __restrict__ work,
+static __global__ void invert_kernel(const double* __restrict__ a, int Mp, double* __restrict__ work,
                               double* __restrict__ inv) {
     __shared__ int piv_s;
     __shared__ double pval_s;

@@ -143,6 +143,22 @@ def test_one_sided_rccl_failure_is_agreed_on(tmp_path, monkeypatch):
     assert int(got["trials"]) == ref.n_trials
 
 
+def test_one_sided_selftest_preflight_failure_strands_nobody(tmp_path, monkeypatch):
+    """Advisor, round 4: a local failure inside lcx_comm_selftest (an allocation, a wrong argument) used to return on that rank before
+    the collective, leaving the others blocked in the all-reduce.  Now everything local happens first and its outcome is shared by a
+    one-element all-reduce every rank enters: with the pre-flight forced to fail on rank 1 ONLY, both ranks come back at once with the
+    diagnosis (the hook transport has no fall-back: the fit raises on every rank) - nobody hangs."""
+    monkeypatch.setenv("LCX_TEST_FAIL_SELFTEST_PREFLIGHT", "1")
+    import time
+    t0 = time.time()
+    timed_out, procs, outs = _launch_once(2, tmp_path, 400, 331, 5, "exact", 150, "engine")
+    assert not timed_out and time.time() - t0 < 120, "\n-----\n".join(o[-3000:] for o in outs)
+    for p, o in zip(procs, outs):
+        assert p.returncode != 0 and "failed its self-test" in o, o[-3000:]
+    assert "pre-flight failed on 1 rank(s): LCX_TEST_FAIL_SELFTEST_PREFLIGHT" in outs[1]
+    assert "pre-flight failed on 1 rank(s) (not this one)" in outs[0]
+
+
 def test_rccl_exchange_path_single_rank(tmp_path):
     """The multi-rank device path with the REAL transport in a group of one rank: world>1 engine kernels and RCCL launches
     interleaved with them on the handle's stream.  In-engine exchange (lcx_comm_init: a communicator owned by the handle,
@@ -224,7 +240,8 @@ try:
     raise SystemExit("a transport that does not sum passed lcx_comm_selftest")
 except _abi.LcxError as e:
     assert "wrong sums" in str(e), e
-assert calls and calls[0] == be.geometry()["n_pad"] * be.geometry()["m_pad"] + be.geometry()["m_pad"] ** 2, calls
+# (the first call is the one-element pre-flight exchange that shares local failures before any rank enters the big all-reduce)
+assert calls[0] == 1 and calls[1] == be.geometry()["n_pad"] * be.geometry()["m_pad"] + be.geometry()["m_pad"] ** 2, calls
 be.set_exchange_hook(lambda ptr, count, dtype, stream: calls.append(-count))      # identity = the right sum over one rank
 assert be.comm_selftest() > 0
 be.close()

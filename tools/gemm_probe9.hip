@@ -13,9 +13,6 @@
 #include <type_traits>
 #include "probe_kernels.hpp"
 #include "../linearcorex_amd/csrc/gemm_split_kernels.hpp"
-#include "split32_probe.hpp"
-#include "split_pp_probe.hpp"
-#include "split_rne_probe.hpp"
 using namespace lcx;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
@@ -58,51 +55,6 @@ Variant mksplit(const float* XP, int64_t nrows_pad, int64_t K, int64_t rows, con
     const int64_t ps = nrows_pad * 16;
     return Variant{buf, [=] {
         hipLaunchKernelGGL((split_b_kernel<CT, CONTRACT_N>), dim3(1024), dim3(256), 0, 0, B, Bsp, ng * KS, (const int*)nullptr);
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, XP, ps, (const u32x4_t*)Bsp, out, rows, rows, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
-}
-
-// lab: the X.B^T pass on the 32x32x16 tile (split32_probe.hpp)
-template <int CT32, int KW, int NP, bool NT, int PRIO>
-Variant mksplit32(const float* XP, int64_t nrows_pad, int64_t K, int64_t rows, const float* B, u32x4_t* Bsp, float* out, int bpc_use) {
-    auto kern = gemm_split32_kernel<CT32, KW, NP, NT, PRIO>;
-    int nb, nsuper, maxslots, bpc;
-    const int ng = (int)(K / 32);
-    geometry((const void*)kern, 64 * KW, bpc_use, rows, KW * 64, ng, &nb, &nsuper, &maxslots, &bpc);
-    char buf[200];
-    snprintf(buf, 200, "bf16 x %d on 32x32x16 KW=%d prio=%d nt=%d bpc=%d(use %d) slots=%d", NP, KW, PRIO, (int)NT, bpc, bpc_use, maxslots);
-    const int64_t ps = nrows_pad * 16;
-    return Variant{buf, [=] {
-        hipLaunchKernelGGL((split_b32_kernel<CT32>), dim3(1024), dim3(256), 0, 0, B, Bsp, ng);
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, XP, ps, (const u32x4_t*)Bsp, out, rows, rows, ng, nsuper, maxslots); }, {}, maxslots};
-}
-
-// lab: the producer / consumer schedule (split_pp_probe.hpp)
-template <int CT, int NP, bool CONTRACT_N, bool NT, int PRIO>
-Variant mksplitpp(const float* XP, int64_t nrows_pad, int64_t K, int64_t rows, const float* B, u32x4_t* Bsp, float* out) {
-    auto kern = gemm_split_pp_kernel<CT, NP, CONTRACT_N, NT, PRIO>;
-    int nb, nsuper, maxslots, bpc;
-    const int ng = (int)(K / SPLIT_KG);
-    geometry((const void*)kern, 512, 0, rows, 512, ng, &nb, &nsuper, &maxslots, &bpc);
-    char buf[200];
-    snprintf(buf, 200, "bf16 x %d ping-pong (2 x 4 waves half an iteration apart) prio=%d bpc=%d slots=%d", NP, PRIO, bpc, maxslots);
-    const int64_t ps = nrows_pad * 16;
-    return Variant{buf, [=] {
-        hipLaunchKernelGGL((split_b_kernel<CT, CONTRACT_N>), dim3(1024), dim3(256), 0, 0, B, Bsp, ng, (const int*)nullptr);
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(512), 0, 0, XP, ps, (const u32x4_t*)Bsp, out, rows, rows, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
-}
-
-// lab: the production kernel with the round-to-nearest split (split_rne_probe.hpp)
-template <int CT, int KW, bool CONTRACT_N, int KS, int PRIO>
-Variant mksplitrne(const float* XP, int64_t nrows_pad, int64_t K, int64_t rows, const float* B, u32x4_t* Bsp, float* out) {
-    auto kern = gemm_split_rne_kernel<CT, KW, 6, CONTRACT_N, true, false, 2, KS, PRIO>;
-    int nb, nsuper, maxslots, bpc;
-    const int ng = (int)(K / (SPLIT_KG * KS));
-    geometry((const void*)kern, 64 * KW, 0, rows, KW * 64, ng, &nb, &nsuper, &maxslots, &bpc);
-    char buf[200];
-    snprintf(buf, 200, "bf16 x 6, ROUND-TO-NEAREST split KW=%d ks=%d prio=%d bpc=%d slots=%d", KW, KS, PRIO, bpc, maxslots);
-    const int64_t ps = nrows_pad * 16;
-    return Variant{buf, [=] {
-        hipLaunchKernelGGL((split_b_rne_kernel<CT, CONTRACT_N>), dim3(1024), dim3(256), 0, 0, B, Bsp, ng * KS, (const int*)nullptr);
         hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * KW), 0, 0, XP, ps, (const u32x4_t*)Bsp, out, rows, rows, ng, nsuper, maxslots, (const int*)nullptr); }, {}, maxslots};
 }
 
@@ -208,22 +160,13 @@ void suite(const char* name, int64_t N, int64_t V) {
                 vs.push_back(mksplit<CT, 8, 6, CN, true, true, 2, 2, 1>(XP, N, K, rows, B, Bsp, out, 0));
                 vs.push_back(mksplit<CT, 8, 3, CN, true, false, 2, 2, 1>(XP, N, K, rows, B, Bsp, out, 0));
                 vs.push_back(mksplit<CT, 8, 8, CN, true, false, 2, 2, 1>(XP, N, K, rows, B, Bsp, out, 0));
-                vs.push_back(mksplitrne<CT, 8, CN, 2, 1>(XP, N, K, rows, B, Bsp, out));
             } else {
-                vs.push_back(mksplitrne<CT, 8, CN, 1, 2>(XP, N, K, rows, B, Bsp, out));
                 vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 1, 1>(XP, N, K, rows, B, Bsp, out, 0));
                 vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 1, 2>(XP, N, K, rows, B, Bsp, out, 0));
                 vs.push_back(mksplit<CT, 8, 6, CN, true, false, 2, 1, 0>(XP, N, K, rows, B, Bsp, out, 0));
                 vs.push_back(mksplit<CT, 4, 6, CN, true, false, 1, 1, 1>(XP, N, K, rows, B, Bsp, out, 0));
                 vs.push_back(mksplit<CT, 8, 3, CN, true, false, 2, 1, 1>(XP, N, K, rows, B, Bsp, out, 0));
                 vs.push_back(mksplit<CT, 8, 8, CN, true, false, 2, 1, 1>(XP, N, K, rows, B, Bsp, out, 0));
-                vs.push_back(mksplitpp<CT, 6, CN, true, 2>(XP, N, K, rows, B, Bsp, out));
-                vs.push_back(mksplitpp<CT, 6, CN, true, 0>(XP, N, K, rows, B, Bsp, out));
-                if constexpr (!CN) {
-                    vs.push_back(mksplit32<CT / 2, 8, 6, true, 2>(XP, N, K, rows, B, Bsp, out, 0));
-                    vs.push_back(mksplit32<CT / 2, 8, 6, true, 0>(XP, N, K, rows, B, Bsp, out, 0));
-                    vs.push_back(mksplit32<CT / 2, 4, 6, true, 2>(XP, N, K, rows, B, Bsp, out, 0));
-                }
             }
         };
         if (cn) add(std::true_type{}); else add(std::false_type{});

@@ -11,6 +11,7 @@
 #   two_ranks [bench args]         the driver's --gpus 2 command rehearsed on ONE GPU (two ranks share GPU 0 over gloo)
 #   n_ranks <N> <head> [args]     the driver's --gpus N command on ONE GPU at a reduced shard (N ranks share GPU 0 over gloo)
 #   env_ab <wl> <VAR> <a> <b> [n]  bench --no-extras under VAR=a / VAR=b alternating on one box   -> gpurun_out/<tag>_env_ab_<wl>_<VAR>.txt
+#   kernel_rows <wl> <VAR> <val>   rocprofv3 kernel rows + launch gaps of bench --no-extras under VAR=val
 #   probe <name> [args]            build tools/<name>.hip and run it                        -> gpurun_out/<tag>_<name>_<args>.txt
 # TAG (environment, default r05) prefixes the outputs.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -81,6 +82,19 @@ import json; d=json.load(open('gpurun_out/${TAG}_ab.json')); c=d['config']
 print('$WL $VAR=$val', round(d['value'],2), 'it/s', round(d['ms_per_step'],4), 'ms; X passes', round(c['x_passes_per_iteration'],3), 'trials', round(c['line_search_trials_per_iteration'],4), 'walks', c['windows']['ms_per_step_walk_min_median_max'], 'frac', round(d['roofline']['frac'],4))" | tee -a $OUT
       grep -o '"final_TC": [-0-9.e+]*' gpurun_out/bench_detail.json | head -1 | tee -a $OUT
     done; done ;;
+  kernel_rows)
+    # rocprofv3 --kernel-trace --stats of bench --workload <wl> --no-extras under VAR=val, the rows + the dependent-launch gaps:
+    #   kernel_rows <wl> <VAR> <val> [bench args]      -> gpurun_out/<tag>_kernel_rows_<wl>_<VAR>_<val>.txt
+    WL=$1; VAR=$2; VAL=$3; shift 3
+    python3 __graft_entry__.py || exit 1
+    export $VAR=$VAL
+    OUT=$R/gpurun_out/${TAG}_kernel_rows_${WL}_${VAR}_${VAL}.txt
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_rows_$WL -o rows -- python3 $R/bench.py --workload $WL --no-extras "$@" > $R/gpurun_out/prof_rows_$WL.log 2>&1
+    echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $WL --no-extras $* ($VAR=$VAL); lib $(python3 -c "import sys; sys.path.insert(0, '$R'); import __graft_entry__ as g; print(g._src_hash()[:16])")" > $OUT
+    tail -1 $R/gpurun_out/prof_rows_$WL.log | cut -c1-160 >> $OUT
+    python3 $R/tools/trace_gaps.py "$(find $R/gpurun_out/prof_rows_$WL -name '*kernel_trace.csv' | head -1)" >> $OUT 2>&1
+    cat $OUT; find $R/gpurun_out/prof_rows_$WL -name "*.csv" -size +2M -delete ;;
   probe)
     P=$1; shift
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/$P tools/$P.hip 2>/dev/null || exit 1

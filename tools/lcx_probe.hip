@@ -1,13 +1,14 @@
 // lcx_probe.hip - the lab: entry points that only tests and probes use, built into tools/liblcx_probe.so.
 //
 // The product library (linearcorex_amd/liblcx_hip.so, include/lcx.h) is the boundary a maintainer of the reference binds;
-// it carries no micro-benchmarks and no kernel unit-test hooks.  This translation unit is the whole engine again (same
-// sources, included below) plus those hooks, declared in tools/lcx_probe.h:
+// it carries no micro-benchmarks and no kernel unit-test hooks.  tools/liblcx_probe.so = the engine's own objects (the same
+// lcx_core / lcx_levels / lcx_data / lcx_outputs / empirical objects the product is linked from) + this unit's hooks, declared in
+// tools/lcx_probe.h:
 //   lcx_test_gemm_nt / lcx_test_gemm_tn   the X-streaming kernels in isolation (tests/test_gemm_kernels_gpu.py)
 //   lcx_bench_gemm                        back-to-back launches of one pass on a handle's resident X (tools/gemm_sweep.py)
 //   lcx_bench_graph                       one moment evaluation direct vs captured into a hipGraph (tools/graph_probe.py)
 // A handle created through this library is a handle of this library: do not mix the two .so files on one handle.
-#include "../linearcorex_amd/csrc/lcx_engine.hip"
+#include "../linearcorex_amd/csrc/engine.hpp"
 #include "lcx_probe.h"
 
 // ---- isolated GEMM checks -------------------------------------------------------------------------

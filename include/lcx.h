@@ -150,7 +150,14 @@ int lcx_bind_exchange(lcx_ctx* h, void* ybuf_dev, void* sbuf_dev);
  *       every rank: lcx_comm_init(h, n, rank, id)  ncclCommInitRank (collective); implies lcx_set_world(h, n)
  *   any other transport: lcx_set_exchange_hook(h, fn, user): fn sums `count` elements of `dtype` (LCX_F32 / LCX_F64) at the
  *       device address `dev_buf` over the ranks, in place, ordered with `hip_stream`; returns 0 on success.
- * lcx_exchange_info: kind -1 = no exchange steps (one rank), 0 = the caller exchanges between the levels, 1 = RCCL, 2 = hook. */
+ * lcx_exchange_info: kind -1 = no exchange steps (one rank), 0 = the caller exchanges between the levels, 1 = RCCL, 2 = hook.
+ *
+ * The hook's `hip_stream` is the stream the collective must be ordered with: the handle's stream - or, with the environment's
+ * LCX_Y_PIPELINE=chunks[:n] (default off, read by lcx_create), a second stream of the library's: the N x m all-reduces of
+ * lcx_moments_a (Y, :247) and lcx_update_b (Y_g, :210) then go out in n (default 4, at most 16) row chunks, each behind the event of
+ * its chunk's slot reduction, and on small shards (the wave-split kernels) behind its own row chunk of the PASS, so that the exchange
+ * of chunk c overlaps the pass of chunk c+1 (:247 -> :259 is where a latency-exposed shard waits).  Every element is summed over
+ * slots and ranks as without chunks; every rank issues the same chunks in the same order; the m x m tail rides in the last chunk. */
 #define LCX_COMM_ID_BYTES 128
 typedef int (*lcx_allreduce_fn)(void* user, void* dev_buf, int64_t count, int dtype, void* hip_stream);
 /* local, no collective: LCX_OK iff this process can bind librccl (dlopen).  ncclCommInitRank is collective - the ranks compare
@@ -163,7 +170,9 @@ int lcx_exchange_info(lcx_ctx* h, int* kind, int* world, int64_t* allreduces_iss
 /* First contact with a bound transport (collective: every rank calls it with its own rank in [0, world), right after lcx_comm_init / lcx_set_exchange_hook and
  * lcx_bind_exchange, before any level): all-reduces the Y exchange buffer at its real size on the handle's stream, once with a
  * rank-dependent integer pattern whose sum is known in closed form and once with rank-dependent values over 12 binades, then
- * shares the verdicts through the scalar buffer.  LCX_OK and *ok = 1 iff every rank got the right sums AND all ranks hold the same
+ * shares the verdicts through the scalar buffer.  Whatever can fail on one rank alone (arguments, an allocation) happens first and is
+ * shared by a one-element all-reduce that every rank enters: a local failure returns an error on EVERY rank instead of leaving the
+ * others blocked inside the big all-reduce.  LCX_OK and *ok = 1 iff every rank got the right sums AND all ranks hold the same
  * bits (lcx_iterate's decisions rely on that); LCX_ERR_COMM with the diagnosis otherwise, on every rank alike.
  * seconds_per_allreduce (may be NULL): host wall time of one Y-buffer all-reduce.  The sums the reference
  * forms in one address space (:247, :259) are only as good as this exchange. */

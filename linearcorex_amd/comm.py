@@ -54,7 +54,7 @@ class Comm:
         if self.world > 1:
             self._dist.barrier(group=self.group)
 
-    def bind_engine(self, backend):
+    def bind_engine(self, backend, first_contact=True):
         """Move the exchange steps into the engine (include/lcx.h, 'exchange inside the library'): afterwards the levels of
         the C ABI all-reduce what they produce themselves and `lcx_iterate` serves several ranks.  Returns the transport
         name, or None when the backend has no in-library exchange (the NumPy test double) or LCX_EXCHANGE=torch asks for
@@ -69,7 +69,9 @@ class Comm:
         if mode == "torch" or not self.exchange or not hasattr(backend, "comm_init"):
             return None
         import torch
-        self.selftest_seconds = None
+        run_selftest = bool(first_contact)      # False: a temporary handle beside one whose transport already passed (same group, same kind)
+        if run_selftest:
+            self.selftest_seconds = None
 
         def agreed(flag, dev):
             """MAX over the ranks of a local failure flag, on this group (every rank calls it at the same point)"""
@@ -82,7 +84,7 @@ class Comm:
             """lcx_comm_selftest on every rank; its verdict is shared inside the test itself (rank-identical), the MAX over the
             ranks on top covers a rank that could not even run it"""
             err = None
-            if os.environ.get("LCX_COMM_SELFTEST", "1") not in ("", "0"):
+            if run_selftest and os.environ.get("LCX_COMM_SELFTEST", "1") not in ("", "0"):
                 try:
                     if os.environ.get("LCX_TEST_FAIL_COMM_INIT") == "selftest" and what == "rccl":
                         raise RuntimeError("LCX_TEST_FAIL_COMM_INIT=selftest")
@@ -213,7 +215,7 @@ class SingleComm:
     def barrier(self):
         pass
 
-    def bind_engine(self, backend):
+    def bind_engine(self, backend, first_contact=True):
         return None
 
     def gather_columns(self, local, nv, like=None):

@@ -293,7 +293,9 @@ class Corex(object):
     # ------------------------------------------------------------------------------------------
     # backend plumbing
     # ------------------------------------------------------------------------------------------
-    def _make_backend(self, n_samples, nv_local):
+    def _make_backend(self, n_samples, nv_local, temporary=False):
+        """temporary: a short-lived handle beside the fit's own (transform(details=True) of a new batch): same transport, whose
+        first-contact self-test the fit's handle has already passed"""
         if self._backend is not None:
             self._backend.close()
         if self._backend_factory is not None:
@@ -313,7 +315,12 @@ class Corex(object):
         self._ex = be.exchange_tensors() if exchange else None
         # the exchange steps inside the engine (RCCL communicator of the handle, or a hook for other transports): the levels
         # then all-reduce what they produce themselves and this class issues no collective on the hot path
-        self._engine_exchange = self._comm.bind_engine(be) if exchange else None
+        if not exchange:
+            self._engine_exchange = None
+        elif temporary:
+            self._engine_exchange = self._comm.bind_engine(be, first_contact=False)
+        else:
+            self._engine_exchange = self._comm.bind_engine(be)
         # which line search runs - decided here, before any data moves.  "exact-y" lives inside lcx_iterate: it needs the
         # line search in the library (not LCX_HOST_LOOP=1, not the per-trial prints of verbose > 1) and, with several ranks,
         # the exchange inside the engine
@@ -403,10 +410,13 @@ class Corex(object):
         y = self.transform_fitted()
         return self.transform(x) if y is None else y
 
-    def transform_fitted(self):
+    def transform_fitted(self, details=False):
         """Latent factors of the data this model was fitted on, taken from the shard that is still resident on the device
         (what `transform(x_fit)` returns; the stacking recipe vis_corex.py:542 asks for exactly this).  None when the data
-        are not resident any more (a model restored from a pickle): call `transform(x)` then."""
+        are not resident any more (a model restored from a pickle): call `transform(x)` then.
+        details=True: `(y, moments)` as `transform(x_fit, details=True)` (:392-394) - the full moments of the fitted data under the
+        final weights are what `fit` left in `self.moments` (:163), so nothing is evaluated and no second handle is built (at the size
+        of BASELINE configs[3] on one GPU a second resident copy of X would not fit)."""
         be = self._backend
         if not getattr(self, "_x_resident", False) or be is None or not hasattr(be, "project_resident") or self.ws.size == 0:
             return None
@@ -421,7 +431,7 @@ class Corex(object):
                 t = torch.from_numpy(y).to(self._ex[1].device)
                 self._comm.allreduce(t)
                 y = t.cpu().numpy()
-        return y
+        return (y, self.moments) if details else y
 
     def fit(self, x):
         if self.m is None:
@@ -829,7 +839,11 @@ class Corex(object):
     # outputs
     # ------------------------------------------------------------------------------------------
     def transform(self, x, details=False):
-        """x -> latent factors Y = x~ . ws^T (:386-395)."""
+        """x -> latent factors Y = x~ . ws^T (:386-395).
+        details=True (:392-394): also the full moments of THIS batch under the fitted weights.  The batch becomes the resident shard
+        of a temporary handle of its own (device memory for a second matrix of the batch's size while the call lasts; with several
+        ranks the handle joins the exchange like the fit's did, without repeating the transport's self-test).  For the data the
+        model was fitted on, `transform_fitted(details=True)` returns the same pair from what is already resident."""
         x = np.asarray(x, dtype=self.dtype)
         ns, nv = x.shape
         assert self.nv == nv, "Incorrect number of variables in input, %d instead of %d" % (nv, self.nv)
@@ -871,7 +885,7 @@ class Corex(object):
         sh._backend, sh._ex, sh._engine_exchange = None, None, None
         sh.moments, sh.history = {}, {}
         sh.stats = dict.fromkeys(self.stats, 0)
-        be = sh._make_backend(x_local.shape[0], x_local.shape[1])
+        be = sh._make_backend(x_local.shape[0], x_local.shape[1], temporary=True)
         try:
             if self.gaussianize == 'empirical':
                 print("Warning: correct inversion/transform of empirical gauss transform not implemented.")     # :425

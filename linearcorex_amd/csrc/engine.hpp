@@ -203,10 +203,6 @@ struct lcx_ctx {
     SetState* host_states;      // pinned [2]
     int* order_dev;
     unsigned int* ticket;       // arrival counters: [0] small_moments_kernel, [1] moments_epilogue_kernel, [2] update_kernel
-    // ytail_kernel (one GPU, <= 32 padded factors): slot reduction of Y + both Grams + the per-factor moments of a trial in ONE launch
-    bool ytail_ok, y_pending;   // y_pending: ypart holds the unreduced slots of the Y in flight (lcx_iterate's trials only)
-    int yt_Sy, yt_Sw;
-    void* ytpart;               // [yt_Sy + yt_Sw][Mp][Mp] partial Gram tiles
     bool full_sig;              // run the second pass of _sig (X^T.Y_g): the linear trial mode needs D(update)
     bool exchange;              // the exchange steps are live (several ranks, or forced for testing)
     bool w1_ready;              // Wt[1] already holds ws + update (written by update_kernel)
@@ -928,7 +924,7 @@ template <typename T, int CT> struct Impl {
         }
         return LCX_OK;
     }
-    static int nt_big(lcx_ctx* h, const void* Bv, const int* skip, bool with_bj = false, T* also = nullptr, bool defer = false) {
+    static int nt_big(lcx_ctx* h, const void* Bv, const int* skip, bool with_bj = false, T* also = nullptr) {
         const T* B = reinterpret_cast<const T*>(Bv);
         TimingPair tp;
         LCXCHECK(timing_begin(h, 0, &tp));
@@ -937,10 +933,6 @@ template <typename T, int CT> struct Impl {
         LCXCHECK(timing_end(h, 0, &tp));
         const int64_t n = h->Npad * Mp;
         const bool wide = h->nt_S >= WIDE_SPLITS && cdiv(n, 32) < (1 << 20);
-        if (defer && !with_bj && h->nt_S > 1 && h->nt_S <= 4) {
-            h->y_pending = true;             // ytail_kernel (lcx_moments_b) sums the slots on its way to the Gram
-            return LCX_OK;
-        }
         if (with_bj) {
             // partial tiles of Y (if split) and the Bj partials of grad_kernel, one launch
             if (wide) {
@@ -959,7 +951,8 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
 
-    // ---- LCX_Y_PIPELINE=chunks: lcx_moments_a's [Y_partial | W.W^T partial] all-reduce in row chunks on a second stream ----
+    // ---- LCX_Y_PIPELINE=chunks: the N x m all-reduces of lcx_moments_a ([Y_partial | W.W^T partial]) and lcx_update_b ([Y_g partial |
+    // Bj partial], separate-pass form) in row chunks on a second stream ----
     // Chunk c of the summed Y is all-reduced as soon as its slot reduction has run, while the main stream goes on with chunk c+1:
     // with the wave-split kernels (small shards, where the exchange is exposed: DESIGN.md section 6) the PASS itself is launched
     // per row chunk, so the all-reduce of chunk c overlaps the pass of chunk c+1; with the stream-K kernels the pass is one launch
@@ -972,7 +965,9 @@ template <typename T, int CT> struct Impl {
         for (auto& e : h->ypipe_ev) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         return LCX_OK;
     }
-    static int moments_a_pipelined(lcx_ctx* h, const T* w) {
+    // B = the weights of the evaluated set (lcx_moments_a: tail = W.W^T partial) or, with_bj, the gradient (lcx_update_b: tail = the
+    // Bj partial sums of grad_kernel, :302)
+    static int y_pass_pipelined(lcx_ctx* h, const T* w, bool with_bj) {
         LCXCHECK(ypipe_init(h));
         int64_t tile = 64;
         bool chunk_pass = false;
@@ -982,7 +977,14 @@ template <typename T, int CT> struct Impl {
         }
         const int64_t tiles = h->Npad / tile;
         const int C = (int)(h->ypipe < tiles ? h->ypipe : tiles);
-        LCXCHECK(gram_w(h, w));                              // the tail first: it rides in the last chunk's all-reduce
+        // the tail first: it rides in the last chunk's all-reduce
+        if (with_bj) {
+            hipLaunchKernelGGL((reduce_y_bj_kernel<T, false>), dim3(Mp), dim3(PV_THREADS), 0, h->stream, P<T>(h->ypart), 1, h->Npad * Mp,
+                               P<T>(h->ybuf), 0, h->bjpart, h->pv_grid, Mp, P<T>(h->ybuf) + h->Npad * Mp);
+            KCHECK();
+        } else {
+            LCXCHECK(gram_w(h, w));
+        }
         TimingPair tp;
         LCXCHECK(timing_begin(h, 0, &tp));
         T* dst = h->nt_S > 1 ? P<T>(h->ypart) : P<T>(h->ybuf);
@@ -1057,8 +1059,7 @@ template <typename T, int CT> struct Impl {
         return LCX_OK;
     }
 
-    static int moments_a(lcx_ctx* h, int which, bool defer = false) {
-        h->y_pending = false;
+    static int moments_a(lcx_ctx* h, int which) {
         if (which == 1 && h->y1_ready && use_merged(h)) {       // the merged pass of lcx_update_b left it in ybuf / set 1
             h->y1_ready = false;
             return LCX_OK;
@@ -1069,10 +1070,9 @@ template <typename T, int CT> struct Impl {
         }
         h->y1_ready = h->yk_ready = false;
         T* w = P<T>(h->Wt[which]);
-        if (h->exchange && h->ypipe > 1 && h->tr.kind != 0) return moments_a_pipelined(h, w);
+        if (h->exchange && h->ypipe > 1 && h->tr.kind != 0) return y_pass_pipelined(h, w, false);
         // without an exchange the summed Y is final: the set's own copy is written by the same reduction
-        LCXCHECK(nt_big(h, w, nullptr, false, (!h->exchange && h->nt_S > 1) ? P<T>(h->set[which].Y) : (T*)nullptr,
-                        defer && ytail_on(h)));
+        LCXCHECK(nt_big(h, w, nullptr, false, (!h->exchange && h->nt_S > 1) ? P<T>(h->set[which].Y) : (T*)nullptr));
         if (!h->exchange) return LCX_OK;         // nothing to exchange: W.W^T is formed with Y^T.Y in lcx_moments_b (one launch)
         LCXCHECK(gram_w(h, w));
         return exchange(h, h->ybuf, h->ybuf_main, DT);           // L1 of SURVEY 8e: [Y_partial | W.W^T partial]
@@ -1210,50 +1210,9 @@ template <typename T, int CT> struct Impl {
         // keep the (all-reduced) Y of this set: the linear trial mode starts from it
         if (h->exchange || h->nt_S == 1)         // otherwise lcx_moments_a already wrote it
             HIPCHECK(hipMemcpyAsync(s.Y, h->ybuf, (size_t)h->Npad * Mp * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
-        if (ytail_on(h)) LCXCHECK(ytail(h, which, eps, quick));
-        else LCXCHECK(small(h, which, eps, quick, P<T>(h->ybuf)));
+        LCXCHECK(small(h, which, eps, quick, P<T>(h->ybuf)));
         LCXCHECK(tn_big(h, &s.st->invalid));
         return epilogue(h, which, eps, false, 0.0);
-    }
-
-    // ---- ytail_kernel: slot reduction of Y (when lcx_iterate deferred it), Y^T.Y and W.W^T partials and the per-factor moments in
-    // ONE launch (moment_kernels.hpp); one GPU, <= 32 padded factors; LCX_YTAIL=0 keeps the three launches ----
-    static bool ytail_on(const lcx_ctx* h) {
-        if constexpr (WIDE || CT > 2) return false;
-        else return h->ytail_ok && !h->exchange;
-    }
-    static int ytail(lcx_ctx* h, int which, double eps, int quick) {
-        if constexpr (WIDE || CT > 2) {
-            return fail(LCX_ERR_STATE, "ytail_kernel is instantiated for <= 32 padded factors");
-        } else {
-            MomentSet& s = h->set[which];
-            const bool pending = h->y_pending;
-            h->y_pending = false;
-            T* gy = P<T>(h->ytpart);
-            YTailArgs<T> a;
-            a.ysrc = pending ? P<T>(h->ypart) : P<T>(h->ybuf);
-            a.slot_stride = h->Npad * Mp;
-            a.y0 = pending ? P<T>(h->ybuf) : (T*)nullptr;
-            a.y1 = pending ? P<T>(s.Y) : (T*)nullptr;
-            a.w = P<T>(h->Wt[which]);
-            a.gy = gy;
-            a.gw = gy + (int64_t)h->yt_Sy * Mp * Mp;
-            a.kg_y = (int)(h->Npad / 16); a.Sy = h->yt_Sy; a.kg_w = (int)(h->ldx / 16); a.Sw = h->yt_Sw;
-            a.m = h->M; a.quick = quick; a.n_samples = h->Ndiv; a.eps = eps;
-            a.sm = SmallDesc{s.uj, s.ry, s.wmag};
-            a.st = s.st;
-            a.counters = h->ticket + 48;
-            const dim3 grid((unsigned)(h->yt_Sw + h->yt_Sy + Mp * Mp / 32));
-            const size_t lds = (size_t)4 * Mp * Mp * sizeof(T);
-            switch (pending ? h->nt_S : 1) {
-                case 1: hipLaunchKernelGGL((ytail_kernel<T, CT, 1>), grid, dim3(256), lds, h->stream, a); break;
-                case 2: hipLaunchKernelGGL((ytail_kernel<T, CT, 2>), grid, dim3(256), lds, h->stream, a); break;
-                case 3: hipLaunchKernelGGL((ytail_kernel<T, CT, 3>), grid, dim3(256), lds, h->stream, a); break;
-                default: hipLaunchKernelGGL((ytail_kernel<T, CT, 4>), grid, dim3(256), lds, h->stream, a); break;
-            }
-            KCHECK();
-            return LCX_OK;
-        }
     }
 
     // ---- linear trial mode: moments of ws + eta*update without touching X ----------------------
@@ -1326,6 +1285,7 @@ template <typename T, int CT> struct Impl {
         if (h->grad_ready) h->grad_ready = false;       // lcx_iterate already computed it behind the accepted trial's evaluation
         else LCXCHECK(launch_grad(h, 0));
         if (!merged) {
+            if (h->exchange && h->ypipe > 1 && h->tr.kind != 0) return y_pass_pipelined(h, P<T>(h->grad), true);
             LCXCHECK(nt_big(h, P<T>(h->grad), nullptr, true));
             return exchange(h, h->ybuf, h->ybuf_main, DT);       // L4: [Y_g partial | Bj partial]
         }
@@ -1451,7 +1411,7 @@ template <typename T, int CT> struct Impl {
     // :321 for the weights in set 1, and right behind it the gradient those weights would need next (:296-300): if the trial
     // is accepted that gradient is already there when the host has decided, if not it is overwritten by the next trial's
     static int evaluate_trial(lcx_ctx* h, double eps) {
-        LCXCHECK(moments_a(h, 1, true));             // (one GPU, few factors: the slot reduction of Y rides in moments_b's ytail launch)
+        LCXCHECK(moments_a(h, 1));
         LCXCHECK(moments_b(h, 1, eps, 1));
         LCXCHECK(moments_c(h, 1));                   // several ranks: TC / tangent from the summed scalars, publication
         h->early_grad = false;

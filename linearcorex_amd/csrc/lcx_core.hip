@@ -140,7 +140,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     A_(h->invwork, sizeof(double) * Mp * 2 * Mp);
     A_(h->states, sizeof(SetState) * 2);
     A_(h->order_dev, sizeof(int) * Mp);
-    A_(h->ticket, 256);        // [0] small_moments; [16..25) moments_epilogue; [32..41) update_kernel; [48..50) ytail_kernel
+    A_(h->ticket, 256);        // [0] small_moments; [16..25) moments_epilogue; [32..41) update_kernel
     h->ypipe = 0;
     {
         const char* e = getenv("LCX_Y_PIPELINE");           // "chunks" (4 row chunks) or "chunks:n", n <= 16
@@ -148,31 +148,6 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
             h->ypipe = e[6] == ':' ? atoi(e + 7) : 4;
             if (h->ypipe < 2) h->ypipe = 0;
             if (h->ypipe > 16) h->ypipe = 16;
-        }
-    }
-    h->ytail_ok = h->y_pending = false;
-    h->yt_Sy = h->yt_Sw = 0;
-    h->ytpart = nullptr;
-    {
-        const char* e = getenv("LCX_YTAIL");               // opt-in (LCX_YTAIL=1): measured slower than the three launches it replaces
-        if (Mp <= 32 && e && *e && atoi(e) != 0) {
-            // producers: at least two 16-row groups per wave (4 waves per block); producers + Mp^2/32 finishers <= one block per CU
-            const int nfin = Mp * Mp / 32;
-            int64_t sy = h->Npad / 16 / 8, sw = h->ldx / 16 / 8;
-            if (sy < 1) sy = 1;
-            if (sw < 1) sw = 1;
-            const int64_t room = (int64_t)h->n_cus - nfin;
-            if (sy + sw > room && room >= 2) {
-                const int64_t sy2 = sy * room / (sy + sw) > 0 ? sy * room / (sy + sw) : 1;
-                sw = room - sy2 > 0 ? room - sy2 : 1;
-                sy = sy2;
-            }
-            if (room >= 2) {
-                h->yt_Sy = (int)sy;
-                h->yt_Sw = (int)sw;
-                A_(h->ytpart, (size_t)(sy + sw) * Mp * Mp * es);
-                h->ytail_ok = true;
-            }
         }
     }
 #undef A_
@@ -225,7 +200,7 @@ int lcx_destroy(lcx_ctx* h) {
     if (h->tr.kind == 1 && h->tr.comm) (void)rccl().CommDestroy(h->tr.comm);
     void* ptrs[] = {h->X, h->XT, h->Wt[0], h->Wt[1], h->grad, h->update, h->sgrad, h->scratch, h->ydir, h->ddir, h->ybuf_own, h->sbuf_own,
                     h->gw, h->y2part, h->bjg, h->bsp,
-                    h->ypart, h->dpart, h->gpart, h->gpartw, h->ytpart, h->tcpart, h->bjpart, h->tanpart, h->detpart, h->ryinv, h->invwork,
+                    h->ypart, h->dpart, h->gpart, h->gpartw, h->tcpart, h->bjpart, h->tanpart, h->detpart, h->ryinv, h->invwork,
                     h->states, h->order_dev, h->ticket};
     for (void* p : ptrs) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) {

@@ -207,208 +207,6 @@ small_moments_kernel(const T* __restrict__ gy, int nsplit, const T* __restrict__
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// ytail_kernel (one GPU, n_hidden <= 32): everything between the X.W'^T pass of a line-search trial and its X^T.Y pass in
-// ONE launch - the dependent chain reduce_partials_kernel -> gram_pair_kernel -> small_moments_kernel (5.3 + 5.8 + 6.6 us
-// at BASELINE configs[1], three launches whose bodies are mostly dependent load latency):
-//   producers (blocks [0, Sw + Sy))  W blocks: the W.W^T Gram partial of their rows of W.  Y blocks: their rows of Y as the
-//              sum of the pass's partial slots in slot order (what reduce_partials_kernel computes, bit for bit) -> the
-//              exchange buffer and the set's own copy, and the Y^T.Y Gram partial of those rows from the same registers:
-//              a lane's 16 bytes of a row are both MFMA operands (A^T.A with the tile = all Mp columns).  Tiles are written
-//              through (no release fence: it would flush the XCD's L2, the freshly stored Y included), drained, then arrive.
-//   finishers (Mp^2 / 32 blocks)     wait for the arrival counter, then small_moments_kernel's body: the partials of 32
-//              matrix elements summed in a fixed order -> ry / uj / wmag; the finisher that draws the last ticket derives
-//              max uj, sum log(1 - uj) and the early-exit flag (:250-251) and zeroes both counters.
-// The grid never exceeds the number of CUs (one block each), so a finisher can only ever wait for producers that are
-// resident or about to be; the wait is bounded all the same (a stuck launch poisons uj instead of hanging the device).
-// Deterministic: fixed block -> rows map, fixed summation orders, no floating-point atomics.
-// ------------------------------------------------------------------------------------------------
-template <typename T> struct YTailArgs {
-    const T* ysrc;            // [nslots][K][Mp] partial slots of the pass (nslots == 1: Y itself, nothing is written back)
-    int64_t slot_stride;
-    T *y0, *y1;               // where the summed rows go (null: nowhere)
-    const T* w;               // [ldx][Mp]
-    T *gy, *gw;               // partial Gram tiles [Sy][Mp][Mp], [Sw][Mp][Mp]
-    int kg_y, Sy, kg_w, Sw;   // 16-row units and splits of the two contractions
-    int m, quick;
-    double n_samples, eps;
-    SmallDesc sm;
-    SetState* st;
-    unsigned int* counters;   // [0] producers arrived, [1] finisher ticket; zero between launches
-};
-
-template <typename T, int CT, int KW, int NS, bool WRITE>
-__device__ __forceinline__ void gram_sum_body(const T* __restrict__ src, int64_t sstride, T* __restrict__ y0, T* __restrict__ y1,
-                                              T* __restrict__ gout, int kgroups, int nsplit, int split, T* red) {
-    constexpr int Mp = 16 * CT;
-    typedef typename MF<T>::acc_t acc_t;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 15, q = lane >> 4;
-    const int part = split * KW + wave, nparts = nsplit * KW;
-    const int g0 = (int)((int64_t)kgroups * part / nparts), g1 = (int)((int64_t)kgroups * (part + 1) / nparts);
-    acc_t acc[CT][CT];
-#pragma unroll
-    for (int t = 0; t < CT; ++t)
-#pragma unroll
-        for (int u = 0; u < CT; ++u) acc[t][u] = (acc_t){0, 0, 0, 0};
-    const int64_t off = (int64_t)q * Mp + i * CT;
-    Pk<T, CT> a0[4], a1[4];
-#define LCX_GS_LOAD(G, AA)                                                                   \
-    {                                                                                        \
-        const int64_t rb = (int64_t)(G) * 16;                                                \
-        _Pragma("unroll") for (int st = 0; st < 4; ++st) {                                   \
-            const int64_t o = off + (rb + 4 * st) * Mp;                                      \
-            Pk<T, CT> v = ldg<T, CT>(src + o);                                               \
-            _Pragma("unroll") for (int k = 1; k < NS; ++k) {                                 \
-                const Pk<T, CT> p = ldg<T, CT>(src + k * sstride + o);                       \
-                _Pragma("unroll") for (int c = 0; c < CT; ++c) v.v[c] += p.v[c];             \
-            }                                                                                \
-            AA[st] = v;                                                                      \
-            if (WRITE) {                                                                     \
-                *reinterpret_cast<Pk<T, CT>*>(y0 + o) = v;                                   \
-                if (y1 != nullptr) *reinterpret_cast<Pk<T, CT>*>(y1 + o) = v;                \
-            }                                                                                \
-        }                                                                                    \
-    }
-#define LCX_GS_MMA(AA)                                                                       \
-    {                                                                                        \
-        _Pragma("unroll") for (int st = 0; st < 4; ++st)                                     \
-        _Pragma("unroll") for (int t = 0; t < CT; ++t)                                       \
-        _Pragma("unroll") for (int u = 0; u < CT; ++u)                                       \
-            acc[t][u] = MF<T>::mma(AA[st].v[t], AA[st].v[u], acc[t][u]);                     \
-    }
-    if (g0 < g1) {
-        LCX_GS_LOAD(g0, a0);
-        int g = g0;
-        while (true) {
-            int gn = (g + 1 < g1) ? g + 1 : g1 - 1;
-            if (g + 1 < g1) LCX_GS_LOAD(gn, a1);
-            LCX_GS_MMA(a0);
-            if (++g >= g1) break;
-            gn = (g + 1 < g1) ? g + 1 : g1 - 1;
-            if (g + 1 < g1) LCX_GS_LOAD(gn, a0);
-            LCX_GS_MMA(a1);
-            if (++g >= g1) break;
-        }
-    }
-#undef LCX_GS_LOAD
-#undef LCX_GS_MMA
-    constexpr int TILE = Mp * Mp;
-    T* mine = red + wave * TILE;
-#pragma unroll
-    for (int t = 0; t < CT; ++t)
-#pragma unroll
-        for (int u = 0; u < CT; ++u)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                mine[(MF<T>::row(lane, g) * CT + t) * Mp + i * CT + u] = acc[t][u][g];
-    __syncthreads();
-    T* dst = gout + (int64_t)split * TILE;
-    for (int idx = threadIdx.x; idx < TILE; idx += 64 * KW) {
-        T s = red[idx];
-#pragma unroll
-        for (int w = 1; w < KW; ++w) s += red[w * TILE + idx];
-        // write-through (sc1): the hand-off to the finishers then needs no release fence - which would first write back every
-        // dirty line of this XCD's L2, the megabytes of Y the producers have just stored included
-        __hip_atomic_store(&dst[idx], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-template <typename T, int CT, int NS>
-__global__ void __launch_bounds__(256)
-ytail_kernel(YTailArgs<T> a) {
-    constexpr int Mp = 16 * CT, KW = 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* red = reinterpret_cast<T*>(smem_raw);              // [KW][Mp][Mp] (producers); the finishers use static LDS
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int nprod = a.Sw + a.Sy;
-    if (b < nprod) {
-        if (b < a.Sw) gram_sum_body<T, CT, KW, 1, false>(a.w, 0, nullptr, nullptr, a.gw, a.kg_w, a.Sw, b, red);
-        else if (a.y0 != nullptr) gram_sum_body<T, CT, KW, NS, true>(a.ysrc, a.slot_stride, a.y0, a.y1, a.gy, a.kg_y, a.Sy, b - a.Sw, red);
-        else gram_sum_body<T, CT, KW, NS, false>(a.ysrc, a.slot_stride, nullptr, nullptr, a.gy, a.kg_y, a.Sy, b - a.Sw, red);
-        // hand-off: every wave drains its (write-through) tile stores, then one lane arrives
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(&a.counters[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    // ---- finishers ----
-    __shared__ T shy[8][32];
-    __shared__ T shw[8][32];
-    __shared__ double lg[256];
-    __shared__ double uu[256];
-    __shared__ int flag_s;
-    if (tid == 0) {
-        int ok = 0;
-        for (int spin = 0; spin < (1 << 22); ++spin) {
-            if (__hip_atomic_load(&a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)nprod) { ok = 1; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        flag_s = ok;
-    }
-    __syncthreads();
-    const bool arrived = flag_s != 0;
-    __syncthreads();
-    const int fb = b - nprod, nfin = (int)gridDim.x - nprod;
-    const int e = tid & 31, g = tid >> 5;
-    const int64_t mm = (int64_t)Mp * Mp;
-    const int64_t idx = (int64_t)fb * 32 + e;
-    T sy = (T)0, sw = (T)0;
-    // (coherent loads: the tiles were written through by other CUs, possibly of other XCDs)
-    for (int k = g; k < a.Sy; k += 8) sy += __hip_atomic_load(&a.gy[k * mm + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int k = g; k < a.Sw; k += 8) sw += __hip_atomic_load(&a.gw[k * mm + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    shy[g][e] = sy;
-    shw[g][e] = sw;
-    __syncthreads();
-    if (g == 0) {
-        T gyv = shy[0][e], gwv = shw[0][e];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) { gyv += shy[k][e]; gwv += shw[k][e]; }
-        const T c1 = (T)(1.0 - a.eps * a.eps), c2 = (T)(a.eps * a.eps), ns = (T)a.n_samples;
-        T val = c1 * gyv / ns + c2 * gwv;
-        if (!arrived) val = (T)__builtin_nan("");
-        const int j = (int)(idx / Mp), k2 = (int)(idx % Mp);
-        if (j == k2) {
-            __hip_atomic_store(&a.sm.uj[j], (double)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the last finisher
-            a.sm.wmag[j] = (double)gwv;
-            a.sm.ry[idx] = 1.0;
-        } else {
-            a.sm.ry[idx] = (double)val;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned int t = __hip_atomic_fetch_add(&a.counters[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        flag_s = (t == (unsigned int)nfin - 1u);
-    }
-    __syncthreads();
-    if (!flag_s) return;
-    {
-        double u = -1e300, l = 0.0;
-        for (int j = tid; j < a.m; j += 256) {
-            const double uv = __hip_atomic_load(&a.sm.uj[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            u = fmax(u, uv);
-            l += (double)log((T)1 - (T)uv);        // log(1-uj) in working precision (:274)
-        }
-        uu[tid] = u;
-        lg[tid] = l;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double mx = -1e300, slog = 0.0;
-        const int nact = a.m < 256 ? a.m : 256;
-        for (int j = 0; j < nact; ++j) { mx = fmax(mx, uu[j]); slog += lg[j]; }
-        a.st->max_uj = mx;
-        a.st->sum_log_rj = slog;
-        const int inv = (a.quick && mx >= 1.0) ? 1 : 0;        // (a stuck launch left NaN in uj: sum_log_rj and TC are NaN then)
-        a.st->invalid = inv;
-        a.st->invalid_d = (double)inv;
-        __hip_atomic_store(&a.counters[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&a.counters[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 // TC = sum log(1+Si) - 1/2 sum log(1+QiSi2) + 1/2 sum log(1-uj), rounded to the working precision
 template <typename T>
 __device__ __forceinline__ void tc_store(const double* sbuf, SetState* st) {

@@ -62,12 +62,12 @@ def launch_hip(world, out_dir, n, v, m, mode, exchange="engine"):
 # world 3 runs in the CPU suite; on the GPU box gloo needs ~4 minutes for it
 @pytest.mark.parametrize("world,mode,shape,exchange", [
     (2, "exact", (400, 331, 5), "engine"), (2, "exact", (400, 331, 5), "torch"), (2, "linear", (400, 331, 5), "engine"),
-    (2, "exact", (300, 6001, 8), "engine"), (2, "exact", (260, 391, 300), "engine"),
+    (2, "exact", (300, 6001, 8), "engine"),
     (2, "exact-y", (400, 331, 5), "engine"), (2, "exact-y", (300, 6001, 8), "engine")])
 def test_sharded_fit_on_device_matches_oracle(world, mode, shape, exchange, tmp_path):
     # (400, 331, 5): uneven shards, ragged padding; (300, 6001, 8): few column tiles per shard - the X.W^T pass is split
-    # into dozens of slots and summed by the wide reductions before the exchange; (260, 391, 300): 300 factors - the wide path
-    # (gemm_wide, one thread per factor) under the exchange.
+    # into dozens of slots and summed by the wide reductions before the exchange.  (Round 3-4 also ran (260, 391, 300) - 300 factors,
+    # the wide path under the exchange - here; no BASELINE config has more than 128 factors and the case cost 13-26 s.)
     # exchange "engine": the all-reduces are issued by the library through its hook (the transport here is gloo) and the exact
     # line search runs inside lcx_iterate on both ranks; "torch": the host-sequenced path, torch.distributed between the levels
     n, v, m = shape
@@ -91,34 +91,6 @@ def test_sharded_fit_on_device_matches_oracle(world, mode, shape, exchange, tmp_
     if mode in ("exact", "exact-y"):
         assert int(got["trials"]) == ref.n_trials
     check_covariance(got, ref, 1e-6)           # sharded get_covariance (the north-star tolerance)
-
-
-def test_sharded_float32_fit_on_the_bf16_pipe(tmp_path, monkeypatch):
-    """Two ranks, float32, each shard in the panel-major layout with its X passes on the bf16 matrix pipe (LCX_F32_GEMM=split: exact
-    three-way split, 6 partial products) and the exchange steps inside the engine: the fit equals the float32 oracle's at the float32
-    bars of tests/test_parity_gpu.py, and the one-rank run of the same library in the same mode."""
-    for k, v_ in (("LCX_X_LAYOUT", "panel"), ("LCX_GEMM", "ct"), ("LCX_F32_GEMM", "split"), ("LCX_TEST_DTYPE", "f32")):
-        monkeypatch.setenv(k, v_)
-    n, v, m = 1500, 3000, 40
-    launch_hip(2, tmp_path, n, v, m, "exact", "engine")
-    got = np.load(os.path.join(tmp_path, "dist_result.npz"))
-    assert str(got["f32_gemm"]) == "split" and "gemm_split_kernel" in str(got["kernel"]) and bool(got["in_library"])
-    x, _ = O.gen_planted(n, v, m, seed=2)
-    ref = O.fit_ns(x, m, seed=0, dtype=np.float32, max_iter=MAX_ITER)
-    h, h_ref = got["history"], np.asarray(ref.history_tc, np.float64)
-    # float32: a stage stops one or two iterations earlier or later when |dTC| sits at the tolerance (the 6 % band of
-    # tests/test_parity_gpu.py); the first stage runs into the cap on every path and is compared element by element
-    def same_fit(a, b, tol):
-        assert abs(len(a) - len(b)) <= 0.06 * len(b), (len(a), len(b))
-        assert np.max(np.abs(a[:MAX_ITER] - b[:MAX_ITER]) / np.maximum(1, np.abs(b[:MAX_ITER]))) < tol
-        assert abs(a[-1] - b[-1]) < tol * abs(b[-1])
-    same_fit(h, h_ref, 2e-3)
-    from linearcorex_amd import Corex
-    one = Corex(n_hidden=m, seed=0, dtype=np.float32, device=0, max_iter=MAX_ITER).fit(x)
-    assert one.f32_gemm == "split"
-    same_fit(h, np.asarray(one.history["TC"], np.float64), 5e-4)
-    assert np.mean(got["clusters"] == one.clusters()) > 0.995
-    one._backend.close()
 
 
 def test_one_sided_rccl_failure_is_agreed_on(tmp_path, monkeypatch):
@@ -349,30 +321,6 @@ def test_sharded_merged_pass_under_exchange(m, tmp_path, monkeypatch):
     assert np.max(np.abs(h2 - hr) / np.maximum(1.0, np.abs(hr))) < 2e-3
 
 
-def test_sharded_later_trials_by_linearity(tmp_path, monkeypatch):
-    """line_search='exact-y' with two ranks: the trials after the first one of an iteration take X.w_update^T by linearity from
-    global Y and X.update^T, so they exchange only W'.W'^T (no N x m all-reduce) and make one pass over their shard.  Must walk the
-    trajectory of the reference-shaped single-GPU run to float32 rounding, with the same number of trials."""
-    from linearcorex_amd import Corex
-    from tests._dist_worker_f32 import planted_f32, run_loop
-    n, v, m, iters = 4096, 8192, 128, 6
-    _launch_f32(2, tmp_path, n, v, m, iters, extra_env={"LCX_TEST_LINE_SEARCH": "exact-y"})
-    got = np.load(os.path.join(tmp_path, "dist_f32.npz"))
-    assert int(got["world"]) == 2 and str(got["transport"]) == "hook" and bool(got["in_library"])
-    monkeypatch.setenv("LCX_GEMM", "ct")
-    xt = planted_f32(n, v, m)
-    single = Corex(n_hidden=m, seed=0, dtype=np.float32, tol=0.0, device=0)
-    be = single._attach_shard(xt, v)
-    h1 = run_loop(single, iters)
-    w1 = be.get_ws(0)
-    be.close()
-    h2 = got["history"]
-    assert len(h1) == len(h2) == 7 * iters
-    assert np.max(np.abs(h2 - h1) / np.maximum(1.0, np.abs(h1))) < 5e-5
-    assert int(got["trials"]) == single.stats["trials"] and single.stats["trials"] > 7 * iters + 3
-    assert np.max(np.abs(got["ws"] - w1)) < 1e-3 * float(np.max(np.abs(w1)))
-
-
 def _launch_uneven(out_dir, n, m, iters, tag, bounds, extra_env=None, timeout=280):
     import subprocess
     import sys
@@ -404,7 +352,7 @@ def _launch_uneven(out_dir, n, m, iters, tag, bounds, extra_env=None, timeout=28
 UNEVEN = {4: [7, 300, 1333, 130], 8: [7, 300, 1333, 130, 64, 1, 513, 700]}
 
 
-@pytest.mark.parametrize("world,tag,gemm,pipeline", [(4, "f64", None, True), (8, "f32", "ct", False), (8, "f32", None, True)])
+@pytest.mark.parametrize("world,tag,gemm,pipeline", [(4, "f64", None, True), (8, "f32", "ct", False)])
 def test_uneven_shards_many_ranks(world, tag, gemm, pipeline, tmp_path, monkeypatch):
     """More than two ranks on REAL engine handles (round 4 ran world 3 / 8 against the NumPy double only): 4 or 8 ranks share GPU 0,
     the exchange steps and the line search inside the library (hook transport over gloo), n_hidden = 128, awkward UNEVEN shards

@@ -42,48 +42,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_MFMA_PEAK_TFLOPS = 78.6
-FP32_MFMA_PEAK_TFLOPS = 157.3
-BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense; the split float32 contraction issues 6 bf16 products per float32 product
-SPLIT_PRODUCTS = 6
-# What this chip has been seen to sustain (profiles/r01_read_probe_c2.txt, r01_mfma_peak.txt, the c3f64* workloads):
-# reported beside the spec-based fraction, never instead of it.
-MEASURED_CEILINGS = {"hbm_read_GBps": 6470.0, "mfma_f64_TFLOPs": 72.0, "mfma_f64_16x16x4_TFLOPs": 59.9,
-                     "mfma_f32_TFLOPs": 151.0}
-MIN_TIMED_SECONDS = 0.6        # one walk of the schedule shorter than this is repeated (median per stage)
-
-WORKLOADS = {
-    # name: (n_samples, n_variables per GPU, n_hidden, dtype)
-    "c2": (10000, 5000, 32, "f64"),      # BASELINE.json configs[1]
-    "c3": (50000, 100000, 64, "f32"),    # configs[2] (MFMA roofline run; X generated on device)
-    "c4shard": (50000, 125000, 128, "f32"),  # configs[3], one GPU's shard
-    "c4full": (50000, 1000000, 128, "f32"),  # configs[3] unsharded on ONE GPU: single-copy mode (gemm_cr), 200 GB of X
-    "c3f64": (50000, 50000, 64, "f64"),  # large float64 shards (gemm_ct on float64; not BASELINE lines)
-    "c3f64m32": (50000, 50000, 32, "f64"),
-    "c3f64m128": (50000, 50000, 128, "f64"),
-    "c2f32": (10000, 5000, 32, "f32"),   # config-2 shape in the reference's own precision (not a BASELINE line)
-    "c2m64": (10000, 5000, 64, "f64"), "c2m64f32": (10000, 5000, 64, "f32"), "c2m128f32": (10000, 5000, 128, "f32"),
-    "mid32": (20000, 20000, 32, "f64"), "mid32f32": (20000, 20000, 32, "f32"), "mid64f32": (20000, 20000, 64, "f32"),
-    "c5": (400, 20000, 30, "f64"),       # configs[4] stand-in shape (few samples, many variables; not a bench line)
-    "c5f32": (400, 20000, 30, "f32"),
-    "tiny": (2000, 640, 8, "f64"),       # plumbing check
-}
-DESCRIPTION = {
-    "c2": "BASELINE.json configs[1]", "c3": "BASELINE.json configs[2], the MFMA roofline run",
-    "c4shard": "BASELINE.json configs[3], one GPU's shard of the 1M-variable problem",
-    "c4full": "BASELINE.json configs[3] unsharded: the whole 1M-variable problem on one GPU, one resident copy of X",
-}
-
-
-def _adhoc(name):
-    """'NxVxM:f32' -> WORKLOADS entry (probing shapes outside BASELINE.json)."""
-    if name not in WORKLOADS and name != "auto":
-        dims, tag = name.split(":")
-        n, v, m = (int(t) for t in dims.split("x"))
-        assert tag in ("f32", "f64")
-        WORKLOADS[name] = (n, v, m, tag)
-
+# the workload table + hardware peaks, the rank launcher, the profile quotes and the stdout record live in benchkit/ (plain modules, no
+# GPU, no oracle); this file keeps the measurement and the CPU-baseline leg.  Re-exported: tests and tools address them as bench.<name>
+from benchkit.workloads import (BF16_MFMA_PEAK_TFLOPS, DESCRIPTION, FP32_MFMA_PEAK_TFLOPS, FP64_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS,  # noqa: E402,F401
+                                MEASURED_CEILINGS, MIN_TIMED_SECONDS, SPLIT_PRODUCTS, WORKLOADS, _adhoc)
+from benchkit.launch import spawn_ranks                                                              # noqa: E402,F401
+from benchkit.profiles import _lib_src_hash, load_pmc_traffic, load_rocprof_avg                      # noqa: E402,F401
+from benchkit.record import ROOFLINE_LINE_KEYS, _pick, _r, compact_line, emit, series_of             # noqa: E402,F401
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
@@ -128,46 +93,6 @@ def parse(argv=None):
     args = ap.parse_args(argv)
     _adhoc(args.workload)
     return args
-
-
-# ------------------------------------------------------------------------------------------------------
-# --gpus N without a launcher: start the N ranks ourselves, as child processes, before anything in this
-# process touches the GPU (never re-exec a process that initialised HIP)
-# ------------------------------------------------------------------------------------------------------
-def spawn_ranks(args):
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    if os.environ.get("LCX_BENCH_DRY_SPAWN"):          # CPU test hook: show the launch, start nothing
-        sys.stdout.write(json.dumps({"spawn": cmd}) + "\n")
-        return 0
-    rc = subprocess.call([sys.executable, os.path.join(ROOT, "__graft_entry__.py")], cwd=ROOT, stdout=sys.stderr)
-    if rc != 0:
-        sys.stderr.write("bench.py: building the HIP library failed\n")
-        return rc
-    sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: launching the ranks as children: %s\n" % (args.gpus, " ".join(cmd)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE)
-    lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.strip()]
-    rec, raw = None, None
-    for ln in reversed(lines):
-        try:
-            rec, raw = json.loads(ln), ln
-            break
-        except ValueError:
-            continue
-    if p.returncode != 0 or rec is None:
-        sys.stderr.write("bench.py: the rank launch failed (rc %d)\n%s\n" % (p.returncode, "\n".join(lines[-20:])))
-        return p.returncode or 1
-    if rec.get("n_gpus") != args.gpus:
-        sys.stderr.write("bench.py: asked for %d GPUs, the ranks report n_gpus=%r\n" % (args.gpus, rec.get("n_gpus")))
-        return 1
-    sys.stdout.write(raw.strip() + "\n")          # rank 0's compact line, byte for byte
-    sys.stdout.flush()
-    return 0
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -353,57 +278,6 @@ def cpu_baseline_generated(n, v, m, dtype, budget_s, label, also=()):
 # ------------------------------------------------------------------------------------------------------
 # committed profile figures (PMC traffic, rocprofv3 kernel time): quoted only while they describe THIS library
 # ------------------------------------------------------------------------------------------------------
-def _lib_src_hash():
-    try:
-        import __graft_entry__ as ge
-        return ge._src_hash()
-    except Exception:
-        return None
-
-
-def load_pmc_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of this same command (tools/pmc_traffic.py writes
-    profiles/pmc_traffic_<workload>.json on the GPU box together with the hash of the library sources it profiled;
-    FETCH_SIZE is doubled there as MI355X_MICROARCH.md prescribes for gfx950).  A profile taken from other sources than
-    the library that is running is not quoted."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % workload)
-    info = {"traffic_source": None, "mfma_util_pmc": None, "traffic_profile_matches_library": None}
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        k = d["kernels"][kernel]
-    except Exception:
-        return None, info
-    info["traffic_source"] = os.path.relpath(path, ROOT)
-    info["traffic_profile_lib_src_hash"] = d.get("lib_src_hash")
-    ok = d.get("lib_src_hash") is not None and d.get("lib_src_hash") == _lib_src_hash()
-    info["traffic_profile_matches_library"] = ok
-    if not ok:
-        return None, info
-    info["mfma_util_pmc"] = k.get("mfma_util")
-    info["mfma_flops_per_launch_pmc"] = k.get("mfma_flops_per_launch")
-    return k.get("hbm_bytes_per_launch"), info
-
-
-def load_rocprof_avg(workload, kernel):
-    """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this same command,
-    quoted beside the live HIP-event figure while the summary's recorded source hash equals the running library's."""
-    import csv
-    import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprof_kernel_stats_%s.csv" % workload))):
-        meta = path[:-4] + ".meta.json"
-        try:
-            with open(meta) as f:
-                if json.load(f).get("lib_src_hash") != _lib_src_hash():
-                    continue
-            with open(path) as f:
-                for row in csv.DictReader(f):
-                    if kernel.replace(" ", "") in row["Name"].replace(" ", ""):
-                        best = (float(row["AverageNs"]) / 1e3, os.path.relpath(path, ROOT))
-        except Exception:
-            continue
-    return best if best else (None, None)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -675,30 +549,6 @@ def config_of(workload, r, world, line_search, force_exchange=False):
             "exchange": r.get("exchange")}
 
 
-def series_of(out, head, world):
-    """The weak-scaling series, readable from the lines alone (top level, every line): which workload the series is measured on,
-    one GPU's rate inside THIS job, the same shard on one GPU without exchange steps, and their ratio.  The N = 1 line headlines
-    configs[2] (`value`), the N > 1 lines headline N x the configs[3] shard, so value(N) / (N x value(1)) is NOT an efficiency -
-    `series.per_gpu_value / series.n1_value_same_workload` is:
-        N = 1, default job:   from the nested config.c4shard block (the workload the --gpus N lines headline); efficiency 1.0
-        N = 1, one workload:  that workload is its own one-GPU point
-        N > 1:                per_gpu_value = value / N; n1_value_same_workload = the same shard measured on every GPU alone in this
-                              job (config.single_gpu_same_shard, slowest rank); null with --no-extras"""
-    cfg = out["config"]
-    if world == 1:
-        c4 = cfg.get("c4shard")
-        if isinstance(c4, dict) and c4.get("value"):
-            wl, per_gpu = "c4shard", c4["value"]
-        else:
-            wl, per_gpu = head, out["value"]
-        n1, eff = per_gpu, 1.0
-    else:
-        wl, per_gpu = head, out["value"] / world
-        n1 = _pick(cfg, "single_gpu_same_shard", "iterations_per_sec_slowest_rank")
-        eff = (per_gpu / n1) if n1 else None
-    n, v_per, m, tag = WORKLOADS[wl]
-    return {"workload": wl, "shard": "%d x %d x %d %s per GPU" % (n, v_per, m, tag), "n_gpus": world, "per_gpu_value": per_gpu,
-            "n1_value_same_workload": n1, "efficiency": eff, "unit": "fit iterations/s per GPU"}
 
 
 def other_gemm_name(args):
@@ -815,135 +665,6 @@ def covariance_block(model, be, label):
 # ------------------------------------------------------------------------------------------------------
 # the stdout line: compact by construction.  The driver keeps a few KB of stdout; round 3's 21 KB line could not be parsed.
 # ------------------------------------------------------------------------------------------------------
-def _r(x, digits=6):
-    """floats to `digits` significant digits (bytes on the line, not precision anybody reads)"""
-    if isinstance(x, bool) or x is None:
-        return x
-    if isinstance(x, float):
-        if not math.isfinite(x):
-            return None
-        return float("%.*g" % (digits, x))
-    if isinstance(x, (list, tuple)):
-        return [_r(v, digits) for v in x]
-    if isinstance(x, dict):
-        return {k: _r(v, digits) for k, v in x.items()}
-    return x
-
-
-def _pick(d, *path, default=None):
-    for k in path:
-        if not isinstance(d, dict) or k not in d:
-            return default
-        d = d[k]
-    return d
-
-
-ROOFLINE_LINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "launches",
-                      "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "rocprofv3_avg_kernel_us",
-                      "rocprofv3_source", "traffic_source", "traffic_profile_matches_library", "mfma_util_pmc")
-
-
-def compact_line(out, detail_path):
-    """The record the driver parses: contract keys + full `roofline` (scalars) + `cpu_baseline` (one-sentence sample) +
-    scalar riders of the nested measurements.  Everything else lives in the detail record."""
-    cfg = out["config"]
-    c = {k: cfg.get(k) for k in ("workload", "n_samples", "n_variables_total", "n_variables_per_gpu", "n_hidden", "line_search",
-                                 "x_passes_per_iteration", "x_passes_per_iteration_reference_shaped",
-                                 "line_search_trials_per_iteration")}
-    w = cfg.get("windows") or {}
-    c["windows"] = {k: w.get(k) for k in ("walks_timed", "timed_iterations", "timed_seconds", "ms_per_step_walk_min_median_max")}
-    c["exchange"] = _pick(cfg, "exchange", "transport") or _pick(cfg, "exchange", "kind")
-    if _pick(cfg, "exchange", "selftest_seconds_per_y_allreduce"):
-        c["y_allreduce_selftest_ms"] = 1e3 * _pick(cfg, "exchange", "selftest_seconds_per_y_allreduce")
-    c["bytes_resident_total"] = _pick(cfg, "bytes_resident", "total")
-    c["bytes_resident_x"] = _pick(cfg, "bytes_resident", "x")
-    c["x_layout"] = _pick(cfg, "bytes_resident", "x_layout")
-    if cfg.get("force_exchange"):
-        c["force_exchange"] = True
-    riders = {
-        # the other line searches of the same workload, reported beside `value`
-        "reference_shaped_value": _pick(cfg, "reference_shaped", "fit_iterations_per_sec"),
-        "exact_y_value": _pick(cfg, "later_trials_by_linearity", "fit_iterations_per_sec"),
-        "linear_value": _pick(cfg, "linear_trial_mode", "fit_iterations_per_sec"),
-        # the X passes of the float32 workload on the bf16 matrix pipe (exact 3-way split, lcx_set_f32_gemm): beside `value`
-        "f32_gemm": cfg.get("f32_gemm"),
-        "f32_gemm_split_value": _pick(cfg, "f32_gemm_split", "fit_iterations_per_sec"),
-        "f32_gemm_split_final_TC_rel_diff": _pick(cfg, "f32_gemm_split", "final_TC_relative_difference"),
-        "f32_gemm_split_roofline_bound": _pick(cfg, "f32_gemm_split", "roofline", "bound"),
-        "f32_gemm_split_roofline_frac": _pick(cfg, "f32_gemm_split", "roofline", "frac"),
-        "f32_gemm_split_fit_to_convergence_planted_seconds": _pick(cfg, "f32_gemm_split", "fit_to_convergence_planted", "seconds"),
-        "f32_gemm_split_fit_to_convergence_planted_iterations": _pick(cfg, "f32_gemm_split", "fit_to_convergence_planted", "iterations"),
-        "f32_gemm_mfma_value": _pick(cfg, "f32_gemm_mfma", "fit_iterations_per_sec"),
-        "merged_pass_roofline_frac": _pick(out, "roofline", "merged_pass", "frac"),
-        "xbt_pass_roofline_frac": _pick(out, "roofline", "frac_by_site", "gemm_nt"),
-        "xty_pass_roofline_frac": _pick(out, "roofline", "frac_by_site", "gemm_tn"),
-        "fit_to_convergence_planted_seconds": _pick(cfg, "fit_to_convergence_planted", "seconds"),
-        "fit_to_convergence_planted_iterations": _pick(cfg, "fit_to_convergence_planted", "iterations"),
-        "weak_scaling_vs_same_shard": cfg.get("weak_scaling_vs_same_shard"),
-        "single_gpu_same_shard_value": _pick(cfg, "single_gpu_same_shard", "iterations_per_sec_slowest_rank"),
-    }
-    for name in ("c2", "c2_weak", "c4shard", "c4_unsharded_one_gpu"):
-        b = cfg.get(name)
-        if isinstance(b, dict) and "value" in b:
-            riders[name + "_value"] = b.get("value")
-            riders[name + "_line_search"] = b.get("line_search")
-            riders[name + "_ms_per_step"] = b.get("ms_per_step")
-            riders[name + "_roofline_frac"] = _pick(b, "roofline", "frac")
-            riders[name + "_xbt_pass_roofline_frac"] = _pick(b, "roofline", "frac_by_site", "gemm_nt")
-            riders[name + "_xty_pass_roofline_frac"] = _pick(b, "roofline", "frac_by_site", "gemm_tn")
-            riders[name + "_roofline_bound"] = _pick(b, "roofline", "bound")
-            riders[name + "_reference_shaped_value"] = _pick(b, "reference_shaped", "fit_iterations_per_sec")
-            riders[name + "_f32_gemm_split_value"] = _pick(b, "f32_gemm_split", "fit_iterations_per_sec")
-            riders[name + "_cpu_baseline_value"] = _pick(b, "cpu_baseline", "value")
-            riders[name + "_fit_to_convergence_seconds"] = _pick(b, "fit_to_convergence", "seconds")
-    c.update({k: v for k, v in riders.items() if v is not None})
-    c["detail"] = detail_path
-    rl = out.get("roofline")
-    if rl:
-        it = rl.get("iteration") or {}
-        rl = dict({k: rl.get(k) for k in ROOFLINE_LINE_KEYS},
-                  iteration={k: it.get(k) for k in ("x_passes", "achieved_TFLOPs", "achieved_GBps",
-                                                    "fraction_of_step_inside_the_x_passes")})
-    cb = out.get("cpu_baseline")
-    if cb:
-        cb = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "trials_per_iteration", "x_passes_per_iteration",
-                                     "n_variables_timed", "scaled_linearly_in_n_variables_by") if cb.get(k) is not None}
-        cb["sample"] = cb["sample"].split(";")[0][:300]          # the first sentence; the rest is in the detail record
-    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-                                "scaling", "vs_baseline", "dtype", "data")}
-    line.update(config=c, roofline=rl, cpu_baseline=cb)
-    if out.get("series"):
-        line["series"] = out["series"]
-    return _r(line)
-
-
-def emit(out, args, real_stdout):
-    """Full record -> side file + one BENCH_DETAIL line on stderr; compact record -> the one stdout line."""
-    rel = args.detail_out or os.path.join("gpurun_out", "bench_detail.json" if out["n_gpus"] == 1
-                                          else "bench_detail_gpus%d.json" % out["n_gpus"])
-    path = rel if os.path.isabs(rel) else os.path.join(ROOT, rel)
-    full = json.dumps(out)
-    try:
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        with open(path, "w") as f:
-            f.write(full + "\n")
-    except OSError as e:
-        sys.stderr.write("bench.py: could not write %s: %s\n" % (path, e))
-        rel = None
-    sys.stderr.write("BENCH_DETAIL " + full + "\n")
-    sys.stderr.flush()
-    line = compact_line(out, rel)
-    text = json.dumps(line, separators=(",", ":"))
-    # a budget, not a hope: shed riders, then the sample sentence, until the line fits
-    droppable = [k for k in list(line["config"]) if k.endswith(("_cpu_baseline_value", "_fit_to_convergence_seconds", "_line_search",
-                                                                "_roofline_bound", "_ms_per_step", "_pass_roofline_frac"))]
-    while len(text) > args.max_line_bytes and droppable:
-        line["config"].pop(droppable.pop())
-        text = json.dumps(line, separators=(",", ":"))
-    if len(text) > args.max_line_bytes and line.get("cpu_baseline"):
-        line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:120]
-        text = json.dumps(line, separators=(",", ":"))
-    os.write(real_stdout, (text + "\n").encode())
 
 
 def main():

@@ -9,7 +9,8 @@ namespace lcx {
 // Ablation variants of the production kernels (moved out of linearcorex_amd/csrc/gemm_kernels.hpp in round 3: the
 // product headers carry no probe knobs).  gemm_tn_probe_kernel = gemm_tn_kernel with MODE (0 = real kernel, 1 = loads
 // without MFMA, 2 = MFMA without loads, registers loaded once); gemm_ct_probe_kernel = gemm_ct_kernel with PRIO (1, 2:
-// s_setprio around the MFMA burst; 3, 4: iglp_opt scheduler hints); gemm_ct32_kernel = gemm_ct on v_mfma_f32_32x32x2.
+// s_setprio around the MFMA burst; 3, 4: iglp_opt scheduler hints).  (gemm_ct32 / gemm_ct3 of round 2 - the 32x32x2 tile, the
+// two-groups-ahead prefetch - went with their harness: git show 30efff1:tools/probe_kernels.hpp.)
 // ------------------------------------------------------------------------------------------------
 // MODE is for ablation probes only (tools/gemm_probe.hip): 0 = real kernel, 1 = loads without MFMA,
 // 2 = MFMA without loads (registers loaded once).
@@ -247,305 +248,6 @@ gemm_ct_probe_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__
     }
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// gemm_ct32: gemm_ct on v_mfma_f32_32x32x2_f32 (float32 only).
-//
-// Same decomposition, LDS staging of B, stream-K work split and slot contract as gemm_ct.  The 32x32x2 form runs at the
-// same 64 FLOP/clk/SIMD as 16x16x4 but does twice the work per instruction, i.e. half the operand-register reads per
-// flop - the large float32 shards are power-limited (the shader clock sags to ~2.1 GHz under gemm_ct at n_hidden 64),
-// so what is saved there returns as clock.
-//   A operand: lane l feeds X column i = l & 31 of a 32-column block at contraction row kq = l >> 5 of a 2-row step;
-//   a lane loads EPL = min(4, NTB) consecutive floats of a row (16 bytes; 32 lanes = 512 contiguous bytes), element e
-//   going to column block (piece * EPL + e) - the same "interleaved columns" trick as load_row_pieces;
-//   B operand: lane l feeds factor (NU * j + u), j = l & 31, u < NU = Mp / 32, row kq: one ds_read of NU floats;
-//   D layout: register r of lane l is output row 8 (r / 4) + 4 (l >> 5) + r % 4, column l & 31.
-// A wave owns 32 * NTB columns of A; the block's KW waves own KW adjacent such tiles.  A group is 2 * U2 rows.
-// ------------------------------------------------------------------------------------------------
-template <int NTB> struct Epl32 { static constexpr int v = NTB < 4 ? NTB : 4; };
-template <int NTB>
-__device__ __forceinline__ int col32(int t, int i) {
-    constexpr int EPL = Epl32<NTB>::v;
-    return (t / EPL) * 32 * EPL + i * EPL + (t % EPL);
-}
-
-template <int CT, int NTB, int KW, int U2, bool NT = true>
-__global__ void __launch_bounds__(64 * KW)
-gemm_ct32_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, float* __restrict__ out,
-                 int64_t out_rows, int64_t vcols, int ng /* groups of 2*U2 rows */, int nsuper, int maxslots,
-                 const int* __restrict__ skip_flag) {
-    constexpr int Mp = 16 * CT, NU = Mp / 32;
-    constexpr int ROWS = 2 * U2;
-    constexpr int CHUNK = ROWS * Mp;
-    constexpr int PCS = CHUNK * 4 / 16;
-    constexpr int NTH = 64 * KW;
-    constexpr int PPT = (PCS + NTH - 1) / NTH;
-    constexpr int EPL = Epl32<NTB>::v;
-    constexpr int WT = 32 * NTB;                              // columns per wave
-    typedef float acc_t __attribute__((ext_vector_type(16)));
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    typedef typename VecT<float, EPL>::type AV;
-    static_assert(Mp % 32 == 0, "gemm_ct32 needs a multiple of 32 padded factors");
-    __shared__ __attribute__((aligned(16))) float Bs[2][CHUNK];
-    if (skip_flag != nullptr && *skip_flag != 0) return;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 31, kq = lane >> 5;
-    const int64_t total = (int64_t)nsuper * ng;
-    const int nb = gridDim.x;
-    int64_t L0 = total * blockIdx.x / nb;
-    const int64_t L1 = total * (blockIdx.x + 1) / nb;
-
-    while (L0 < L1) {
-        const int st_ = (int)(L0 / ng);
-        const int s0 = (int)(L0 - (int64_t)st_ * ng);
-        const int s1 = (L1 - L0) < (int64_t)(ng - s0) ? s0 + (int)(L1 - L0) : ng;
-        const int cnt = s1 - s0;
-        const int64_t v0 = ((int64_t)st_ * KW + wave) * WT;
-        const bool active = v0 < vcols;
-
-        acc_t acc[NTB][NU];
-#pragma unroll
-        for (int t = 0; t < NTB; ++t)
-#pragma unroll
-            for (int u = 0; u < NU; ++u)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
-        const float* ap = A + (active ? v0 : 0) + (int64_t)kq * lda + i * EPL;
-        float a0[U2][NTB], a1[U2][NTB];
-        f4 bst[PPT];
-
-#define LCX_C32_LOADA(R, AA)                                                              \
-        if (active) {                                                                     \
-            const int64_t rb = (int64_t)(s0 + (R)) * ROWS;                                \
-            _Pragma("unroll") for (int st = 0; st < U2; ++st)                             \
-            _Pragma("unroll") for (int p = 0; p < NTB / EPL; ++p) {                       \
-                const AV* src = reinterpret_cast<const AV*>(ap + (rb + 2 * st) * lda + p * 32 * EPL); \
-                const AV v = NT ? __builtin_nontemporal_load(src) : *src;                 \
-                _Pragma("unroll") for (int e = 0; e < EPL; ++e) {                         \
-                    if constexpr (EPL == 1) AA[st][p] = v; else AA[st][p * EPL + e] = v[e]; \
-                }                                                                         \
-            }                                                                             \
-        }
-#define LCX_C32_LOADB(R)                                                                  \
-        {                                                                                 \
-            const f4* src = reinterpret_cast<const f4*>(B + (int64_t)(s0 + (R)) * CHUNK); \
-            _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                             \
-                const int pc = p * NTH + (int)threadIdx.x;                                \
-                if (PCS % NTH == 0 || pc < PCS) bst[p] = src[pc];                         \
-            }                                                                             \
-        }
-#define LCX_C32_STOREB(BUF)                                                               \
-        {                                                                                 \
-            f4* dstp = reinterpret_cast<f4*>(&Bs[BUF][0]);                                \
-            _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                             \
-                const int pc = p * NTH + (int)threadIdx.x;                                \
-                if (PCS % NTH == 0 || pc < PCS) dstp[pc] = bst[p];                        \
-            }                                                                             \
-        }
-#define LCX_C32_MMA(AA, BUF)                                                              \
-        if (active) {                                                                     \
-            Pk<float, NU> bb[U2];                                                         \
-            _Pragma("unroll") for (int st = 0; st < U2; ++st)                             \
-                bb[st] = *reinterpret_cast<const Pk<float, NU>*>(&Bs[BUF][(2 * st + kq) * Mp + i * NU]); \
-            _Pragma("unroll") for (int st = 0; st < U2; ++st)                             \
-            _Pragma("unroll") for (int t = 0; t < NTB; ++t)                               \
-            _Pragma("unroll") for (int u = 0; u < NU; ++u)                                \
-                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(AA[st][t], bb[st].v[u], acc[t][u], 0, 0, 0); \
-        }
-
-        LCX_C32_LOADA(0, a0);
-        LCX_C32_LOADB(0);
-        int r = 0;
-        while (true) {
-            LCX_C32_STOREB(0);
-            if (r + 1 < cnt) { LCX_C32_LOADA(r + 1, a1); LCX_C32_LOADB(r + 1); }
-            __syncthreads();
-            LCX_C32_MMA(a0, 0);
-            if (++r >= cnt) break;
-            LCX_C32_STOREB(1);
-            if (r + 1 < cnt) { LCX_C32_LOADA(r + 1, a0); LCX_C32_LOADB(r + 1); }
-            __syncthreads();
-            LCX_C32_MMA(a1, 1);
-            if (++r >= cnt) break;
-        }
-#undef LCX_C32_LOADA
-#undef LCX_C32_LOADB
-#undef LCX_C32_STOREB
-#undef LCX_C32_MMA
-
-        const int fb = sk_owner((int64_t)st_ * ng, total, nb);
-        if (active) {
-            float* dst = out + ((int64_t)(blockIdx.x - fb) * out_rows + v0) * Mp;
-#pragma unroll
-            for (int t = 0; t < NTB; ++t)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int row = 8 * (g / 4) + 4 * kq + (g % 4);
-                    Pk<float, NU> o;
-#pragma unroll
-                    for (int u = 0; u < NU; ++u) o.v[u] = acc[t][u][g];
-                    *reinterpret_cast<Pk<float, NU>*>(dst + (int64_t)col32<NTB>(t, row) * Mp + i * NU) = o;
-                }
-            if (s1 == ng) {        // last contributor of this super tile: zero the slots nobody writes
-                const int lb = sk_owner((int64_t)st_ * ng + ng - 1, total, nb);
-                Pk<float, NU> z;
-#pragma unroll
-                for (int u = 0; u < NU; ++u) z.v[u] = 0.f;
-                for (int sl = lb - fb + 1; sl < maxslots; ++sl) {
-                    float* zd = out + ((int64_t)sl * out_rows + v0) * Mp;
-#pragma unroll
-                    for (int t = 0; t < NTB; ++t)
-#pragma unroll
-                        for (int g = 0; g < 16; ++g)
-                            *reinterpret_cast<Pk<float, NU>*>(zd + (int64_t)(32 * t + 2 * g + kq) * Mp + i * NU) = z;
-                }
-            }
-        }
-        __syncthreads();
-        L0 += cnt;
-    }
-}
-
-
-
-// ------------------------------------------------------------------------------------------------
-// gemm_ct3: gemm_ct with the A operand prefetched TWO groups ahead (a ring of three register sets) and the B chunk
-// requested before the A rows of the same group, so that the wait in front of the LDS store only covers loads that are two
-// (A) / one (B) MFMA bursts old.  Probe variant (tools/gemm_probe8): the production kernel waits for everything
-// (`s_waitcnt vmcnt(0)`) one burst after issuing it, which under a 3.9 TB/s stream is about the loaded-HBM latency.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int CT, int RT, int KW, int U, bool NT = true>
-__global__ void __launch_bounds__(64 * KW)
-gemm_ct3_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, T* __restrict__ out,
-                int64_t out_rows, int64_t vcols, int ng, int nsuper, int maxslots, const int* __restrict__ skip_flag) {
-    constexpr int Mp = 16 * CT;
-    constexpr int CHUNK = 4 * U * Mp;
-    constexpr int PCS = CHUNK * (int)sizeof(T) / 16;
-    constexpr int NTH = 64 * KW;
-    constexpr int PPT = (PCS + NTH - 1) / NTH;
-    typedef typename MF<T>::acc_t acc_t;
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) T Bs[2][CHUNK];
-    if (skip_flag != nullptr && *skip_flag != 0) return;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 15, q = lane >> 4;
-    const int64_t total = (int64_t)nsuper * ng;
-    const int nb = gridDim.x;
-    int64_t L0 = total * blockIdx.x / nb;
-    const int64_t L1 = total * (blockIdx.x + 1) / nb;
-
-    while (L0 < L1) {
-        const int st_ = (int)(L0 / ng);
-        const int s0 = (int)(L0 - (int64_t)st_ * ng);
-        const int s1 = (L1 - L0) < (int64_t)(ng - s0) ? s0 + (int)(L1 - L0) : ng;
-        const int cnt = s1 - s0;
-        const int64_t v0 = ((int64_t)st_ * KW + wave) * (16 * RT);
-        const bool active = v0 < vcols;
-
-        acc_t acc[RT][CT];
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int u = 0; u < CT; ++u) acc[t][u] = (acc_t){0, 0, 0, 0};
-        const T* ap = A + (active ? v0 : 0) + (int64_t)q * lda;
-        T a0[U][RT], a1[U][RT], a2[U][RT];
-        f4 bst[PPT];
-
-        // loads are unconditional (past the end the last group is fetched again; inactive waves read tile 0): straight-line
-        // code lets the compiler count outstanding loads exactly instead of waiting for all of them at every join
-#define LCX_C3_LOADA(R, AA)                                                               \
-        {                                                                                 \
-            const int64_t rb = (int64_t)(s0 + ((R) < cnt ? (R) : cnt - 1)) * (4 * U);     \
-            _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
-                load_row_pieces<T, RT, NT>(ap + (rb + 4 * st) * lda, i, AA[st]);          \
-        }
-#define LCX_C3_LOADB(R)                                                                   \
-        {                                                                                 \
-            const f4* src = reinterpret_cast<const f4*>(B + (int64_t)(s0 + ((R) < cnt ? (R) : cnt - 1)) * CHUNK); \
-            _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                             \
-                const int pc = p * NTH + (int)threadIdx.x;                                \
-                if (PCS % NTH == 0 || pc < PCS) bst[p] = src[pc];                         \
-            }                                                                             \
-        }
-#define LCX_C3_STOREB(BUF)                                                                \
-        {                                                                                 \
-            f4* dstp = reinterpret_cast<f4*>(&Bs[BUF][0]);                                \
-            _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                             \
-                const int pc = p * NTH + (int)threadIdx.x;                                \
-                if (PCS % NTH == 0 || pc < PCS) dstp[pc] = bst[p];                        \
-            }                                                                             \
-        }
-#define LCX_C3_MMA(AA, BUF)                                                               \
-        if (active) {                                                                     \
-            Pk<T, CT> bb[U];                                                              \
-            _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
-                bb[st] = *reinterpret_cast<const Pk<T, CT>*>(&Bs[BUF][(4 * st + q) * Mp + i * CT]); \
-            _Pragma("unroll") for (int st = 0; st < U; ++st)                              \
-            _Pragma("unroll") for (int t = 0; t < RT; ++t)                                \
-            _Pragma("unroll") for (int u = 0; u < CT; ++u)                                \
-                acc[t][u] = MF<T>::mma(AA[st][t], bb[st].v[u], acc[t][u]);                \
-        }
-        // step r: B chunk r is in bst, A rows r in ring slot r % 3, A rows r+1 already in flight
-#define LCX_C3_STEP(CUR, NXT2, BUF)                                                       \
-        {                                                                                 \
-            LCX_C3_STOREB(BUF);                                                           \
-            LCX_C3_LOADB(r + 1);                                                          \
-            LCX_C3_LOADA(r + 2, NXT2);                                                    \
-            __syncthreads();                                                              \
-            LCX_C3_MMA(CUR, BUF);                                                         \
-        }
-
-        LCX_C3_LOADB(0);
-        LCX_C3_LOADA(0, a0);
-        LCX_C3_LOADA(1, a1);
-        int r = 0;
-        while (true) {
-            LCX_C3_STEP(a0, a2, 0); if (++r >= cnt) break;
-            LCX_C3_STEP(a1, a0, 1); if (++r >= cnt) break;
-            LCX_C3_STEP(a2, a1, 0); if (++r >= cnt) break;
-            LCX_C3_STEP(a0, a2, 1); if (++r >= cnt) break;
-            LCX_C3_STEP(a1, a0, 0); if (++r >= cnt) break;
-            LCX_C3_STEP(a2, a1, 1); if (++r >= cnt) break;
-        }
-#undef LCX_C3_LOADA
-#undef LCX_C3_LOADB
-#undef LCX_C3_STOREB
-#undef LCX_C3_MMA
-#undef LCX_C3_STEP
-
-        const int fb = sk_owner((int64_t)st_ * ng, total, nb);
-        if (active) {
-            T* dst = out + ((int64_t)(blockIdx.x - fb) * out_rows + v0) * Mp;
-#pragma unroll
-            for (int t = 0; t < RT; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    Pk<T, CT> o;
-#pragma unroll
-                    for (int u = 0; u < CT; ++u) o.v[u] = acc[t][u][g];
-                    *reinterpret_cast<Pk<T, CT>*>(dst + piece_col<T, RT>(t, MF<T>::row(lane, g)) * Mp + i * CT) = o;
-                }
-            if (s1 == ng) {
-                const int lb = sk_owner((int64_t)st_ * ng + ng - 1, total, nb);
-                Pk<T, CT> z;
-#pragma unroll
-                for (int u = 0; u < CT; ++u) z.v[u] = (T)0;
-                for (int sl = lb - fb + 1; sl < maxslots; ++sl) {
-                    T* zd = out + ((int64_t)sl * out_rows + v0) * Mp;
-#pragma unroll
-                    for (int t = 0; t < RT; ++t)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            *reinterpret_cast<Pk<T, CT>*>(zd + (16 * t + 4 * g + q) * Mp + i * CT) = z;
-                }
-            }
-        }
-        __syncthreads();
-        L0 += cnt;
-    }
-}
 
 // moments_epilogue_kernel with its ablation knob (tools/epilogue_probe.hip; moved out of moment_kernels.hpp in round 3)
 // ABL is for ablation probes only: 1 = no m x m matvec, 2 = no M x V stores, 8 = no logarithms, 16 = first slot only.

@@ -156,7 +156,8 @@ int lcx_bind_exchange(lcx_ctx* h, void* ybuf_dev, void* sbuf_dev);
  * LCX_Y_PIPELINE=chunks[:n] (default off, read by lcx_create), a second stream of the library's: the N x m all-reduces of
  * lcx_moments_a (Y, :247) and lcx_update_b (Y_g, :210) then go out in n (default 4, at most 16) row chunks, each behind the event of
  * its chunk's slot reduction, and on small shards (the wave-split kernels) behind its own row chunk of the PASS, so that the exchange
- * of chunk c overlaps the pass of chunk c+1 (:247 -> :259 is where a latency-exposed shard waits).  Every element is summed over
+ * of chunk c overlaps the pass of chunk c+1 (:247 -> :259 is where a latency-exposed shard waits) - as long as a chunk's launch
+ * still fills the chip ("chunks:n:pass" forces it on any shape).  Every element is summed over
  * slots and ranks as without chunks; every rank issues the same chunks in the same order; the m x m tail rides in the last chunk. */
 #define LCX_COMM_ID_BYTES 128
 typedef int (*lcx_allreduce_fn)(void* user, void* dev_buf, int64_t count, int dtype, void* hip_stream);

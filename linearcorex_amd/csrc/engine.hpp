@@ -249,6 +249,7 @@ struct lcx_ctx {
     // LCX_Y_PIPELINE=chunks[:n]: the Y all-reduce of lcx_moments_a in n row chunks on a second stream, each behind the event of its
     // chunk's slot reduction (and, for the wave-split kernels, behind its own row chunk of the pass); default off
     int ypipe;
+    bool ypipe_force_pass;
     hipStream_t comm_stream;
     hipEvent_t ypipe_ev[17];
     Transport tr;               // in-library exchange (kind != 0): every level sums what it produced over the ranks itself
@@ -977,6 +978,12 @@ template <typename T, int CT> struct Impl {
         }
         const int64_t tiles = h->Npad / tile;
         const int C = (int)(h->ypipe < tiles ? h->ypipe : tiles);
+        // A row chunk of the pass is a launch of tiles / C x nt_S blocks: worth it only while that still fills one round of resident
+        // blocks - the whole launch is sized to exactly that (single_round_split), so a quarter of it leaves three quarters of the chip
+        // idle and the pass, HBM-bound, takes about as long per chunk as in one piece (config 2: 157 tiles x 3 splits = 471 blocks
+        // on 512 slots).  Otherwise the pass stays one launch and only the slot reductions and all-reduces go out in chunks
+        // ("chunks:n:pass" forces the per-chunk pass: tests).
+        if (chunk_pass && !h->ypipe_force_pass && (tiles / C) * (int64_t)h->nt_S < (int64_t)h->n_cus * h->nt_bpc) chunk_pass = false;
         // the tail first: it rides in the last chunk's all-reduce
         if (with_bj) {
             hipLaunchKernelGGL((reduce_y_bj_kernel<T, false>), dim3(Mp), dim3(PV_THREADS), 0, h->stream, P<T>(h->ypart), 1, h->Npad * Mp,

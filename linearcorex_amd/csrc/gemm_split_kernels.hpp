@@ -30,7 +30,7 @@
 // contraction elements (KS = 2 up to 64 columns); (super tile, group) units are split stream-K style over one round of resident
 // blocks; partial tiles go to slots (fixed count, zero-filled by the last contributor, summed in fixed order by the consumers).
 // The engine launches 8-wave blocks of 512 rows, one per CU, from 64 columns on (B is re-read once per super tile: its L2 -> fabric
-// traffic halves against 4-wave blocks), with the MFMA phase at raised wave priority (lcx_engine.hip, SplitShape).  What is new:
+// traffic halves against 4-wave blocks), with the MFMA phase at raised wave priority (engine.hpp, SplitShape).  What is new:
 //   * the A operand (X from the PANEL-major copy XP[v / 16][n][16]) goes global -> VGPR as 16-byte loads exactly as in the float32
 //     kernels (1 KB contiguous per load instruction for X.B^T, 4 x 256 B for X^T.Y) and is split in registers (4 VALU operations per
 //     element + 3 v_perm_b32 per pair) right before use;

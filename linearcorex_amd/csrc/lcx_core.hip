@@ -143,11 +143,14 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     A_(h->ticket, 256);        // [0] small_moments; [16..25) moments_epilogue; [32..41) update_kernel
     h->ypipe = 0;
     {
-        const char* e = getenv("LCX_Y_PIPELINE");           // "chunks" (4 row chunks) or "chunks:n", n <= 16
+        const char* e = getenv("LCX_Y_PIPELINE");           // "chunks" (4 row chunks), "chunks:n" (n <= 16), "chunks:n:pass"
+        h->ypipe_force_pass = false;
         if (e && !strncmp(e, "chunks", 6)) {
             h->ypipe = e[6] == ':' ? atoi(e + 7) : 4;
             if (h->ypipe < 2) h->ypipe = 0;
             if (h->ypipe > 16) h->ypipe = 16;
+            const char* f = e[6] == ':' ? strchr(e + 7, ':') : nullptr;
+            h->ypipe_force_pass = f && !strcmp(f, ":pass");
         }
     }
 #undef A_

@@ -369,7 +369,7 @@ def test_uneven_shards_many_ranks(world, tag, gemm, pipeline, tmp_path, monkeypa
     v = bounds[-1]
     if gemm:
         monkeypatch.setenv("LCX_GEMM", gemm)
-    _launch_uneven(tmp_path, n, m, iters, tag, bounds, extra_env={"LCX_Y_PIPELINE": "chunks"} if pipeline else None)
+    _launch_uneven(tmp_path, n, m, iters, tag, bounds, extra_env={"LCX_Y_PIPELINE": "chunks:4:pass"} if pipeline else None)
     got = np.load(os.path.join(tmp_path, "dist_uneven.npz"))
     assert int(got["world"]) == world and str(got["transport"]) == "hook" and bool(got["in_library"])
     assert np.all(got["selftest_seconds"] > 0) and int(got["allreduces"]) > 7 * iters * (5 if pipeline else 2)
@@ -411,7 +411,7 @@ def test_pipelined_y_allreduce_is_bit_identical(tag, m, gemm, tmp_path, monkeypa
     if gemm:
         monkeypatch.setenv("LCX_GEMM", gemm)
     runs = {}
-    for mode in ("off", "chunks:7"):
+    for mode in ("off", "chunks:7:pass"):      # (":pass": per-chunk launches of the pass even where a chunk cannot fill the chip)
         out = tmp_path / mode.replace(":", "_")
         out.mkdir()
         _launch_uneven(out, n, m, iters, tag, bounds, extra_env=None if mode == "off" else {"LCX_Y_PIPELINE": mode})
@@ -419,7 +419,7 @@ def test_pipelined_y_allreduce_is_bit_identical(tag, m, gemm, tmp_path, monkeypa
         assert str(runs[mode]["transport"]) == "hook" and bool(runs[mode]["in_library"])
     off = runs["off"]
     assert len(off["history"]) == 7 * iters and np.all(np.isfinite(off["history"]))
-    for mode in ("chunks:7",):
+    for mode in ("chunks:7:pass",):
         r = runs[mode]
         assert np.array_equal(r["history"], off["history"]) and np.array_equal(r["ws"], off["ws"]), mode
         assert np.array_equal(r["rho"], off["rho"]) and np.array_equal(r["y"], off["y"]) and int(r["trials"]) == int(off["trials"])

@@ -71,12 +71,12 @@ print('$wl $ls', round(d['value'],2), 'it/s', round(d['ms_per_step'],3), 'ms; X 
     echo "rc=$? wall $(( $(date +%s) - T0 )) s, line $(wc -c < gpurun_out/${TAG}_${N}_ranks.json) bytes" | tee gpurun_out/${TAG}_${N}_ranks_summary.txt
     cat gpurun_out/${TAG}_${N}_ranks.json; grep -v BENCH_DETAIL gpurun_out/${TAG}_${N}_ranks.err | tail -40 ;;
   env_ab)
-    # bench --workload <wl> --no-extras under VAR=a and VAR=b, alternating on ONE box:  env_ab <wl> <VAR> <a> <b> [rounds]
-    WL=$1; VAR=$2; A=$3; B=$4; ROUNDS=${5:-3}
+    # bench --workload <wl> --no-extras under VAR=a and VAR=b, alternating on ONE box:  env_ab <wl> <VAR> <a> <b> [rounds [bench args]]
+    WL=$1; VAR=$2; A=$3; B=$4; ROUNDS=${5:-3}; shift 5 2>/dev/null || shift $#      # (anything after the round count goes to bench.py)
     python3 __graft_entry__.py || exit 1
     OUT=gpurun_out/${TAG}_env_ab_${WL}_${VAR}.txt; : > $OUT
     for r in $(seq $ROUNDS); do for val in $A $B; do
-      env $VAR=$val python bench.py --workload $WL --no-extras --steps 30 --warmup 5 2>gpurun_out/${TAG}_ab.err > gpurun_out/${TAG}_ab.json || { tail -5 gpurun_out/${TAG}_ab.err; exit 1; }
+      env $VAR=$val python bench.py --workload $WL --no-extras --steps 30 --warmup 5 "$@" 2>gpurun_out/${TAG}_ab.err > gpurun_out/${TAG}_ab.json || { tail -5 gpurun_out/${TAG}_ab.err; exit 1; }
       python -c "
 import json; d=json.load(open('gpurun_out/${TAG}_ab.json')); c=d['config']
 print('$WL $VAR=$val', round(d['value'],2), 'it/s', round(d['ms_per_step'],4), 'ms; X passes', round(c['x_passes_per_iteration'],3), 'trials', round(c['line_search_trials_per_iteration'],4), 'walks', c['windows']['ms_per_step_walk_min_median_max'], 'frac', round(d['roofline']['frac'],4))" | tee -a $OUT

@@ -207,6 +207,8 @@ def test_big5_end_to_end(tag, g1, ls_both):
             out.get_covariance(rows=(40, 51))
         assert out.get_covariance(rows=(9, 9)).shape == (0, 50)          # an empty block: (0, nv), as from a sharded fit
         assert relerr(out.transform(g1["x_raw"].astype(np.float64)), g1["f64_transform"]) < 1e-6
+        y_res, mo_res = out.transform_fitted(details=True)          # (:392-394 for the fitted data, from what is resident: no second handle)
+        assert relerr(y_res, g1["f64_transform"]) < 1e-6 and mo_res is out.moments
         assert relerr(out.moments["TCs"], g1["f64_mom_TCs"]) < 1e-6
         for key, name in (("rho", "rho"), ("MI", "MI"), ("X_i Z_j", "X_i_Z_j"), ("X_i Y_j", "X_i_Y_j"),
                           ("Qij", "Qij"), ("Si", "Si"), ("ry", "ry"), ("uj", "uj")):

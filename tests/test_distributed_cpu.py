@@ -126,3 +126,33 @@ def test_sharded_moments_need_an_explicit_collective(mode, tmp_path):
     ref = (O.fit_syn if mode == "syn" else O.fit_ns)(x, m, seed=0, dtype=np.float64, keep_x=True)
     assert np.max(np.abs(got["rho"] - ref.moments["rho"])) < 1e-8
     assert np.max(np.abs(got["xz"] - ref.moments["X_i Z_j"])) < 1e-8
+
+
+def test_shard_boundaries_are_validated():
+    """Comm(bounds=...): `world + 1` increasing boundaries from 0, every rank at least one column, ending at the data's n_variables -
+    anything else is refused before a handle exists (one-rank gloo group in a child process)."""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch.distributed as dist
+dist.init_process_group("gloo", rank=0, world_size=1, init_method="tcp://127.0.0.1:%d")
+from linearcorex_amd.comm import Comm
+for bad in ([0, 5, 9], [1, 9], [0, 0], [0]):
+    try:
+        Comm(bounds=bad)
+        raise SystemExit("accepted %%r" %% (bad,))
+    except ValueError:
+        pass
+c = Comm(bounds=[0, 9])
+assert c.shard(9) == (0, 9) and c.shard(9, 0) == (0, 9)
+try:
+    c.shard(10)
+    raise SystemExit("boundaries that end at 9 accepted for 10 variables")
+except ValueError:
+    pass
+assert Comm().shard(10) == (0, 10)
+dist.destroy_process_group()
+print("BOUNDS_OK")
+''' % (ROOT, free_port())
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "BOUNDS_OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])

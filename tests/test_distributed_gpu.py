@@ -13,7 +13,7 @@ from tests.test_distributed_cpu import ROOT, check_covariance, free_port  # noqa
 
 pytestmark = pytest.mark.gpu
 
-MAX_ITER = 25          # per annealing stage: gloo stages every CUDA all-reduce through the host (slow)
+MAX_ITER = 15          # per annealing stage: gloo stages every CUDA all-reduce through the host (slow; 25 until round 5)
 
 
 def _launch_once(world, out_dir, n, v, m, mode, timeout, exchange="engine"):
@@ -261,7 +261,7 @@ def test_sharded_float32_large_kernels_match_single_gpu(m, tmp_path, monkeypatch
     with the same number of line-search trials, and both must agree with the float32 oracle."""
     from linearcorex_amd import Corex
     from tests._dist_worker_f32 import planted_f32, run_loop
-    n, v, iters = 4096, 8192, 3
+    n, v, iters = 4096, 8192, 2
     _launch_f32(2, tmp_path, n, v, m, iters)
     got = np.load(os.path.join(tmp_path, "dist_f32.npz"))
     assert int(got["world"]) == 2 and str(got["transport"]) == "hook" and bool(got["in_library"])
@@ -406,12 +406,12 @@ def test_pipelined_y_allreduce_is_bit_identical(tag, m, gemm, tmp_path, monkeypa
     PASS, so that the exchange of chunk c overlaps the pass of chunk c+1.  Every element is summed over slots and ranks as before:
     with two ranks the whole trajectory must be BIT-identical to the unpipelined run (float64 on the wave-split v_mfma_f64_4x4x4
     kernel, float32 on the stream-K pair and on the wave-split float32 kernel)."""
-    n, iters = 2048, 3
+    n, iters = 2048, 2
     bounds = [0, 1000, 2500]
     if gemm:
         monkeypatch.setenv("LCX_GEMM", gemm)
     runs = {}
-    for mode in ("off", "chunks:7:pass"):      # (":pass": per-chunk launches of the pass even where a chunk cannot fill the chip)
+    for mode in ("off", "chunks:5:pass"):      # (":pass": per-chunk launches of the pass even where a chunk cannot fill the chip)
         out = tmp_path / mode.replace(":", "_")
         out.mkdir()
         _launch_uneven(out, n, m, iters, tag, bounds, extra_env=None if mode == "off" else {"LCX_Y_PIPELINE": mode})
@@ -419,9 +419,9 @@ def test_pipelined_y_allreduce_is_bit_identical(tag, m, gemm, tmp_path, monkeypa
         assert str(runs[mode]["transport"]) == "hook" and bool(runs[mode]["in_library"])
     off = runs["off"]
     assert len(off["history"]) == 7 * iters and np.all(np.isfinite(off["history"]))
-    for mode in ("chunks:7:pass",):
+    for mode in ("chunks:5:pass",):
         r = runs[mode]
         assert np.array_equal(r["history"], off["history"]) and np.array_equal(r["ws"], off["ws"]), mode
         assert np.array_equal(r["rho"], off["rho"]) and np.array_equal(r["y"], off["y"]) and int(r["trials"]) == int(off["trials"])
-        # 7 all-reduces per Y exchange of lcx_moments_a instead of one
-        assert int(r["allreduces"]) > int(off["allreduces"]) + 6 * 7 * iters, (int(r["allreduces"]), int(off["allreduces"]))
+        # 5 all-reduces per N x m exchange instead of one
+        assert int(r["allreduces"]) > int(off["allreduces"]) + 4 * 7 * iters, (int(r["allreduces"]), int(off["allreduces"]))

@@ -520,19 +520,19 @@ static inline bool pv_mfma() {
     const char* e = getenv("LCX_PV_MFMA");
     return !(e && *e && atoi(e) == 0);
 }
-// waves per block of the stream-K kernels: CtShape's - except at 128 float32 columns, where 8 waves share one copy of B on the
-// PANEL-major copy only (+2-3 %: profiles/r04_gemm_probe4_panelsweep.txt; on the row-major layouts 8 waves measured 10-20 % slower
-// than 4, gemm_kernels.hpp CtShape) and LCX_CT8_KW=4|8 forces either for A/B runs
+// waves per block of the stream-K kernels: CtShape's; at 128 float32 columns LCX_CT8_KW=4|8 forces either for A/B runs.  8 waves on one
+// copy of B pay on BOTH layouts there (tools/layout_ab.sh, profiles/r05_layout_ab_one_box.txt: config-4 shard row-major 19.6-19.7 ->
+// 20.1-20.2 it/s, panel-major 19.5-19.6 -> 20.2; the "8 waves lose 10-20 % on the row-major layouts" of an earlier kernel generation
+// no longer holds), so the layout does not enter; `panel` only names the instantiation whose occupancy sizes the grid (ct_geometry)
 template <typename T, int CT> static inline int ct_kw(bool panel) {
+    (void)panel;
     if constexpr (sizeof(T) == 4 && CT == 8) {
         static const int forced = []() {
             const char* e = getenv("LCX_CT8_KW");
             return (e && *e) ? (atoi(e) == 8 ? 8 : 4) : 0;
         }();
         if (forced) return forced;
-        return panel ? CtShape<T, CT>::KW : 4;
     }
-    (void)panel;
     return CtShape<T, CT>::KW;
 }
 // gemm_ct launch: nb balanced blocks over (super tile, group) units; partial tiles -> out[slot][out_rows][Mp]
@@ -809,10 +809,10 @@ template <typename T, int CT> struct Impl {
                 if (CT >= 4) return K >= 4096 && (sl <= 40 || small_partials);
                 return K >= 8192 && sl <= 8;
             };
-            // The wave count (128 float32 columns: 8 on the panel-major copy, 4 on a row-major one) and the occupancy belong to the
-            // instantiation that will be launched, which depends on the layout, which depends on whether BOTH passes take the stream-K
-            // kernels: decide with the panel geometry first (unless LCX_X_LAYOUT=rows forbids the layout), and if the shard does not
-            // end up panel-major redo the geometry of its stream-K passes for the row-major instantiations.
+            // The occupancy that sizes a stream-K grid belongs to the instantiation that will be launched (gemm_cr / gemm_ct, panel-major
+            // or row-major operand), which depends on the layout, which depends on whether BOTH passes take the stream-K kernels: decide
+            // with the panel instantiations first (unless LCX_X_LAYOUT=rows forbids the layout), and if the shard does not end up
+            // panel-major redo the geometry of its stream-K passes for the row-major ones.
             const char* lay = getenv("LCX_X_LAYOUT");
             const bool rows_only = lay && !strcmp(lay, "rows"), force_panel = lay && !strcmp(lay, "panel");
             auto stream_k = [&](bool as_panel, bool decide) {

@@ -876,11 +876,11 @@ gemm_wide_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, 
 template <typename T, int CT> struct CtShape {
     // 256 padded factors (CT = 16): half the column tile, so that the accumulators stay at 128 registers
     static constexpr int RT = (sizeof(T) == 8) ? (CT >= 16 ? 1 : (CT >= 4 ? 2 : 4)) : (CT >= 16 ? 2 : 4);
-    // measured (tools/gemm_probe4, 50k x 20k float32): KW=4, U=4 gives 122 TF/s at n_hidden 64 and 140 TF/s
-    // at 128; KW=8 or U=2 lose 10-20 % on the row-major layouts.  On the panel-major copy (round 4, tools/gemm_probe4 panelsweep,
-    // profiles/r04_gemm_probe4_panelsweep.txt) 128 float32 factors gain 2 % from 8 waves on one copy of B instead of 2 x 4 waves on
-    // two (X.B^T 11 064 vs 11 263 us, X^T.Y 11 040 vs 11 271 us at the config-4 shard: B is 8 KB per group against 4 KB of X per wave,
-    // so halving its re-reads shows); 64 factors lose 6 % with it and keep 4
+    // measured: KW=4, U=4 is the shape at 64 columns (tools/gemm_probe4, 50k x 20k float32: 122 TF/s; 8 waves lose 6 % there, U=2
+    // loses more).  At 128 float32 columns 8 waves share one copy of B per block instead of 2 x 4 waves on two (B is 8 KB per group
+    // against 4 KB of X per wave, so halving its re-reads shows): +2-3 % on the panel-major copy (profiles/r04_gemm_probe4_panelsweep.txt:
+    // X.B^T 11 064 vs 11 263 us, X^T.Y 11 040 vs 11 271 us at the config-4 shard) and on the row-major layouts alike
+    // (profiles/r05_layout_ab_one_box.txt: 20.1-20.2 vs 19.6-19.7 it/s)
     static constexpr int KW = (sizeof(T) == 4 && CT == 8) ? 8 : 4;
     static constexpr int U = 4;
 };

@@ -458,17 +458,20 @@ def test_bench_stdout_line_stays_within_the_drivers_budget(tmp_path):
 
 def test_bench_default_record_riders_and_series():
     """The nested blocks of the default job, checked on the record of such a run (the GPU suite measures the c3 headline alone; the
-    whole job is what the driver's bench step runs): profiles/r04_bench_default_detail.json through bench.series_of /
+    whole job is what the driver's bench step runs): profiles/r05_bench_default_detail.json through bench.series_of /
     bench.compact_line - c2, the config-4 shard and the opt-in modes ride on the line as scalars, and the weak-scaling series is
     readable from the lines alone: at N = 1 from the c4shard block, at N > 1 from the same-shard reference of that job."""
     import json
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    with open(os.path.join(ROOT, "profiles", "r04_bench_default_detail.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r05_bench_default_detail.json")) as f:
         full = json.load(f)
-    full["series"] = bench.series_of(full, "c3", 1)
+    assert full["series"] == bench.series_of(full, "c3", 1)          # what the run itself put on its line
     line = bench.compact_line(full, "d.json")
+    with open(os.path.join(ROOT, "profiles", "r05_bench_default.json")) as f:
+        committed = json.load(f)
+    assert committed["series"] == line["series"] and committed["value"] == line["value"]
     assert len(json.dumps(line, separators=(",", ":"))) <= 4096
     c, sr = line["config"], line["series"]
     for k in ("c2_value", "c2_roofline_frac", "c2_cpu_baseline_value", "c4shard_value", "c4shard_roofline_frac", "linear_value",
@@ -490,9 +493,9 @@ def test_bench_default_record_riders_and_series():
     cv = d["fit_to_convergence_planted"]
     assert cv["stages_converged_before_the_cap"] == 7 and cv["cluster_purity_vs_planted_groups"] > 0.99
     # N > 1: the two-rank rehearsal's record
-    with open(os.path.join(ROOT, "profiles", "r04_two_ranks_full_one_gpu_gloo_detail.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r05_two_ranks_full_one_gpu_gloo_detail.json")) as f:
         two = json.load(f)
-    two["series"] = bench.series_of(two, "c4shard", 2)
+    assert two["series"] == bench.series_of(two, "c4shard", 2)
     sr = bench.compact_line(two, "d2.json")["series"]
     assert sr["workload"] == "c4shard" and sr["n_gpus"] == 2
     assert sr["per_gpu_value"] == pytest.approx(two["value"] / 2, rel=1e-5)

@@ -157,18 +157,23 @@ x, _ = O.gen_planted(400, 331, 5, seed=2)
 for syn in (False, True):
     ref = (O.fit_syn if syn else O.fit_ns)(x, 5, seed=0, dtype=np.float64, max_iter=40)
     runs = {}
-    for mode in ("engine", "torch", "hook", "fallback-probe", "fallback-id", "fallback-init", "fallback-selftest"):
-        os.environ["LCX_EXCHANGE"] = "engine" if mode.startswith("fallback") else mode
+    for mode in ("engine", "torch", "hook", "fallback-probe", "fallback-id", "fallback-init", "fallback-selftest", "pipe-chunks:3", "pipe-chunks:3:pass"):
+        # ("pipe-...": the engine's own RCCL communicator with the N x m all-reduces in row chunks on the library's second stream - real
+        # asynchronous ncclAllReduce launches behind events, where the gloo hook of the multi-rank tests blocks the host)
+        os.environ["LCX_EXCHANGE"] = "engine" if mode.startswith(("fallback", "pipe")) else mode
         os.environ["LCX_TEST_FAIL_COMM_INIT"] = mode.split("-")[1] if mode.startswith("fallback") else ""
+        os.environ["LCX_Y_PIPELINE"] = mode[5:] if mode.startswith("pipe-") else ""
         comm = Comm(always_exchange=True)
         out = Corex(n_hidden=5, seed=0, dtype=np.float64, device=0, comm=comm, max_iter=40,
                     discourage_overlap=not syn).fit(x)
         assert out._ex is not None and out._backend.torch_stream is not None
         assert (comm.selftest_seconds is not None and comm.selftest_seconds > 0) == (mode != "torch"), (mode, comm.selftest_seconds)
         info = out._backend.exchange_info()
-        if mode == "engine":
+        if mode == "engine" or mode.startswith("pipe-"):
             assert out._engine_exchange == "rccl" and info["kind"] == "rccl" and info["allreduces_issued"] > 100, info
             assert syn or out._iterated_in_library
+            if mode.startswith("pipe-"):
+                assert info["allreduces_issued"] > runs["engine"][4] + 50, (mode, info, runs["engine"][4])
         elif mode == "torch":
             assert out._engine_exchange is None and info["kind"] == "caller" and info["allreduces_issued"] == 0, info
         else:       # the group's own all_reduce behind the library's hook: asked for, or agreed on after a failed communicator
@@ -180,9 +185,10 @@ for syn in (False, True):
         assert np.max(np.abs(out.ws - ref.ws)) < 1e-7
         y = out.transform(x)
         assert np.max(np.abs(y - ref.transform(O.preprocess(x)[0]))) < 1e-7
-        runs[mode] = (h, out.ws.copy(), y, out.stats["trials"])
+        runs[mode] = (h, out.ws.copy(), y, out.stats["trials"], info["allreduces_issued"])
         out._backend.close()
-    for other in ("torch", "hook", "fallback-probe", "fallback-id", "fallback-init", "fallback-selftest"):
+    os.environ["LCX_Y_PIPELINE"] = ""
+    for other in ("torch", "hook", "fallback-probe", "fallback-id", "fallback-init", "fallback-selftest", "pipe-chunks:3", "pipe-chunks:3:pass"):
         assert np.array_equal(runs["engine"][0], runs[other][0]) and np.array_equal(runs["engine"][1], runs[other][1]), other
         assert np.array_equal(runs["engine"][2], runs[other][2]) and runs["engine"][3] == runs[other][3], other
 # the self-test itself, driven directly: it refuses a handle without a transport, and a transport that does not SUM is caught

@@ -578,7 +578,7 @@ def other_gemm_block(args, comm, world, rank, local_rank, workload, steps, warmu
 
 
 def linear_mode_block(workload, r3, world):
-    """The same iterations with the linear trial mode (DESIGN.md 4a; SURVEY.md section 7 'linearity shortcut'): trials cost no
+    """The same iterations with the linear trial mode (DESIGN.md section 9 (4a); SURVEY.md section 7 'linearity shortcut'): trials cost no
     pass over X.  Reported beside the reference-shaped figure, never as `value`; the roofline is computed from the flops
     this mode actually executes."""
     rl = roofline_of(workload, r3, world) or {}

@@ -1,4 +1,4 @@
-"""The arithmetic claim behind `f32_gemm="split"` (linearcorex_amd/csrc/gemm_split_kernels.hpp, DESIGN.md 4c), checked in NumPy with
+"""The arithmetic claim behind `f32_gemm="split"` (linearcorex_amd/csrc/gemm_split_kernels.hpp, DESIGN.md section 9 (4c)), checked in NumPy with
 the device code's own operations: a float32 number IS the sum of three bf16 numbers (round-to-nearest split: hi = bf16(x), mid =
 bf16(x - hi), lo = x - hi - mid - v_cvt_pk_bf16_f32 rounds to nearest even), a bf16 x bf16 product is exact in float32, and the 3 partial
 products the kernel drops are zero-mean, 2^-27 |a b| in the rms and at most 2^-24.  (Round 4 shipped a truncation split - mask the upper

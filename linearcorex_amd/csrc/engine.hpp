@@ -211,6 +211,10 @@ struct lcx_ctx {
     // merged pass (float32 large shards with <= 64 padded factors): X.grad^T and the first trial's X.(ws+update)^T as ONE
     // pass over X with 2 Mp columns - half the X traffic of the two and the more efficient wide kernel
     bool merged_ok, y1_ready;   // y1_ready: ybuf / set[1].Y already hold Y of the eta = 1 trial
+    // Several ranks: whether a shard HAS a merged form depends on its own width (slot count of the 2 Mp-column launch), but taking it
+    // changes the sequence of collectives (a Bj all-reduce in front of the pass, one [Y' | W'.W'^T | Y_g] all-reduce behind it): the
+    // ranks agree once per transport - all of them, or none (-1: not asked yet)
+    int merged_agreed;
     // lcx_set_trial_reuse: the trials AFTER the first one of an iteration take X.w_update^T by linearity from what the iteration has
     // already computed exactly (Y of the current solution and X.update^T of lcx_update_c) instead of one more pass over X;
     // yk_ready: ybuf holds the Y of such a trial
@@ -703,6 +707,7 @@ template <typename T, int CT> struct Impl {
 
     static int launch_grad(lcx_ctx* h, int which);
     static int update_b(lcx_ctx* h, double eps);
+    static int agree_on_merged(lcx_ctx* h);
     static bool use_merged(const lcx_ctx* h);
     static int update_grid(const lcx_ctx* h);
 

@@ -339,20 +339,22 @@ int Impl<T, CT>::ypipe_init(lcx_ctx* h) {
 template <typename T, int CT>
 int Impl<T, CT>::y_pass_pipelined(lcx_ctx* h, const T* w, bool with_bj) {
     LCXCHECK(ypipe_init(h));
-    int64_t tile = 64;
+    // chunk boundaries in units of 64 rows, a function of the replicated n_samples alone: every rank must all-reduce the same
+    // chunks, whatever kernels its own shard width selected (64 is a multiple of every row tile of the wave-split kernels)
+    const int64_t tile = 64;
     bool chunk_pass = false;
-    if constexpr (!WIDE) {
-        chunk_pass = !(h->panel || h->single_copy || h->nt_ct);
-        if (chunk_pass) tile = 16 * Geo<T, CT>::TN_RT;
-    }
+    if constexpr (!WIDE) chunk_pass = !(h->panel || h->single_copy || h->nt_ct);
     const int64_t tiles = h->Npad / tile;
     const int C = (int)(h->ypipe < tiles ? h->ypipe : tiles);
     // A row chunk of the pass is a launch of tiles / C x nt_S blocks: worth it only while that still fills one round of resident
     // blocks - the whole launch is sized to exactly that (single_round_split), so a quarter of it leaves three quarters of the chip
-    // idle and the pass, HBM-bound, takes about as long per chunk as in one piece (config 2: 157 tiles x 3 splits = 471 blocks
+    // idle and the pass, HBM-bound, takes about as long per chunk as in one piece (config 2: 157 row tiles x 3 splits = 471 blocks
     // on 512 slots).  Otherwise the pass stays one launch and only the slot reductions and all-reduces go out in chunks
     // ("chunks:n:pass" forces the per-chunk pass: tests).
-    if (chunk_pass && !h->ypipe_force_pass && (tiles / C) * (int64_t)h->nt_S < (int64_t)h->n_cus * h->nt_bpc) chunk_pass = false;
+    if constexpr (!WIDE) {
+        const int64_t pass_tiles = h->Npad / (16 * Geo<T, CT>::TN_RT);
+        if (chunk_pass && !h->ypipe_force_pass && (pass_tiles / C) * (int64_t)h->nt_S < (int64_t)h->n_cus * h->nt_bpc) chunk_pass = false;
+    }
     // the tail first: it rides in the last chunk's all-reduce
     if (with_bj) {
         hipLaunchKernelGGL((reduce_y_bj_kernel<T, false>), dim3(Mp), dim3(PV_THREADS), 0, h->stream, P<T>(h->ypart), 1, h->Npad * Mp,
@@ -667,6 +669,7 @@ int Impl<T, CT>::update_b(lcx_ctx* h, double eps) {
         h->spec_dirty = false;
     }
     MomentSet& s = h->set[0];
+    LCXCHECK(agree_on_merged(h));
     const bool merged = use_merged(h);
     if (h->grad_ready) h->grad_ready = false;       // lcx_iterate already computed it behind the accepted trial's evaluation
     else LCXCHECK(launch_grad(h, 0));
@@ -725,9 +728,25 @@ int Impl<T, CT>::update_b(lcx_ctx* h, double eps) {
 
 // the merged pass needs: its buffers, the Y-space tangent, and - with several ranks - the exchange inside the library (a caller
 // that all-reduces the buffers itself between the levels does not know about the Bj exchange in front of the pass)
+// One all-reduce of one flag, once per transport: does EVERY rank's shard have a merged form?  (Uneven shards: a rank of 64 variables
+// next to one of 1333 - tests/test_thread_ranks_gpu.py caught ranks issuing different collectives.)  Every rank gets here at the
+// same point of the same program: the first lcx_update_b.
+template <typename T, int CT>
+int Impl<T, CT>::agree_on_merged(lcx_ctx* h) {
+    if (h->merged_agreed >= 0) return LCX_OK;
+    if (!h->exchange || h->tr.kind == 0 || h->world <= 1) { h->merged_agreed = 1; return LCX_OK; }
+    double flag = h->merged_ok ? 1.0 : 0.0;
+    HIPCHECK(hipMemcpyAsync(h->sbuf + 3, &flag, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    LCXCHECK(exchange(h, h->sbuf + 3, 1, LCX_F64));
+    HIPCHECK(hipMemcpyAsync(&flag, h->sbuf + 3, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipMemsetAsync(h->sbuf + 3, 0, sizeof(double), h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    h->merged_agreed = flag == (double)h->world ? 1 : 0;
+    return LCX_OK;
+}
 template <typename T, int CT>
 bool Impl<T, CT>::use_merged(const lcx_ctx* h) {
-    return h->merged_ok && (!h->exchange || h->tr.kind != 0) && !h->full_sig && h->gw != nullptr;
+    return h->merged_ok && h->merged_agreed != 0 && (!h->exchange || h->tr.kind != 0) && !h->full_sig && h->gw != nullptr;
 }
 
 template <typename T, int CT>

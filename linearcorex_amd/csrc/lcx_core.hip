@@ -141,6 +141,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     A_(h->states, sizeof(SetState) * 2);
     A_(h->order_dev, sizeof(int) * Mp);
     A_(h->ticket, 256);        // [0] small_moments; [16..25) moments_epilogue; [32..41) update_kernel
+    h->merged_agreed = -1;
     h->ypipe = 0;
     {
         const char* e = getenv("LCX_Y_PIPELINE");           // "chunks" (4 row chunks), "chunks:n" (n <= 16), "chunks:n:pass"
@@ -292,6 +293,7 @@ static int drop_transport(lcx_ctx* h) {
         (void)rccl().CommDestroy(h->tr.comm);
     }
     h->tr = Transport();
+    h->merged_agreed = -1;         // another transport, another group: the ranks agree on the merged pass again
     return LCX_OK;
 }
 
@@ -487,6 +489,7 @@ int lcx_set_world(lcx_ctx* h, int world) {
     HIPCHECK(hipStreamSynchronize(h->stream));
     h->world = world;
     h->exchange = world > 1;
+    h->merged_agreed = -1;
     return LCX_OK;
 }
 

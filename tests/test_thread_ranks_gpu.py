@@ -216,3 +216,60 @@ def test_eight_thread_ranks_async_transport(tag, m, gemm, pipeline, line_search,
         # 128-column pass) and some do not; taking it changes the sequence of collectives, so the ranks must agree - all or none
         # (Impl::agree_on_merged).  Before that, ranks met in all-reduces of different sizes: a hang under RCCL.
         assert len({r["merged_form"] for r in results}) == 2, [r["merged_form"] for r in results]
+
+
+def test_eight_thread_ranks_whole_fit(monkeypatch):
+    """The whole `fit` path over the same transport: random start and its normalisation (:113-117), seven annealing stages with their
+    rescaling (:127-134), four iterations each, the final detail moments, factor sort and gathers (:160-163) - eight uneven thread
+    ranks against the one-rank run.  (`np.random.randn` is made a pure function of its shape for the test: the reference draws the
+    start from NumPy's global RNG, which threads of one process would share.)"""
+    import torch          # noqa: F401
+    from linearcorex_amd import Corex
+    monkeypatch.setenv("LCX_CHECK_RANKS", "1")
+    monkeypatch.delenv("LCX_Y_PIPELINE", raising=False)
+    monkeypatch.setattr(np.random, "randn", lambda *shape: np.random.RandomState(0).randn(*shape))
+    world, n, m, dt = 8, 2048, 24, np.float64
+    bounds = np.concatenate([[0], np.cumsum(WIDTHS)]).tolist()
+    v = bounds[-1]
+    xt = _planted(n, v, m, dt, seed=92)
+
+    def fit(x_local, comm):
+        model = Corex(n_hidden=m, seed=0, dtype=dt, max_iter=4, device=0, comm=comm)
+        be = model._attach_shard(x_local, v)
+        model._fit_resident()
+        out = {"history": np.asarray(model.history["TC"], np.float64), "ws": model.ws.copy(), "clusters": model.clusters(),
+               "tcs": np.asarray(model.tcs, np.float64), "rho": np.asarray(model.moments["rho"]), "trials": model.stats["trials"]}
+        be.close()
+        return out
+
+    one = fit(xt, None)
+    shared = _Shared(world)
+    results, errors = [None] * world, [None] * world
+
+    def rank_main(r):
+        try:
+            torch.cuda.set_device(0)
+            comm = ThreadComm(shared, r, bounds)
+            c0, c1 = comm.shard(v)
+            results[r] = fit(np.ascontiguousarray(xt[:, c0:c1]), comm)
+        except BaseException as e:          # noqa: BLE001
+            errors[r] = e
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(TIMEOUT * 3)
+    first = next((e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)), None)
+    assert first is None, repr(first)
+    assert all(e is None for e in errors) and all(r is not None for r in results)
+    r0 = results[0]
+    for r in results[1:]:
+        assert np.array_equal(r["history"], r0["history"]) and np.array_equal(r["ws"], r0["ws"]) and r["trials"] == r0["trials"]
+    assert len(r0["history"]) == len(one["history"]) == 28 and r0["trials"] == one["trials"]
+    assert np.max(np.abs(r0["history"] - one["history"]) / np.maximum(1.0, np.abs(one["history"]))) < 1e-10
+    assert r0["ws"].shape == (m, v) and np.max(np.abs(r0["ws"] - one["ws"])) < 1e-9 * float(np.max(np.abs(one["ws"])))
+    assert np.array_equal(r0["clusters"], one["clusters"])
+    assert np.max(np.abs(r0["tcs"] - one["tcs"])) < 1e-9 * max(1.0, float(np.max(np.abs(one["tcs"]))))
+    assert r0["rho"].shape == (m, v) and np.max(np.abs(r0["rho"] - one["rho"])) < 1e-9

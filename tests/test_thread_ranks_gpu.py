@@ -273,3 +273,73 @@ def test_eight_thread_ranks_whole_fit(monkeypatch):
     assert np.array_equal(r0["clusters"], one["clusters"])
     assert np.max(np.abs(r0["tcs"] - one["tcs"])) < 1e-9 * max(1.0, float(np.max(np.abs(one["tcs"]))))
     assert r0["rho"].shape == (m, v) and np.max(np.abs(r0["rho"] - one["rho"])) < 1e-9
+
+
+@pytest.mark.parametrize("branch", ["ns", "syn"])
+def test_eight_thread_ranks_public_api_vs_oracle(branch, monkeypatch):
+    """The public surface over eight uneven thread ranks against the ORACLE: `fit(x)` on raw data (gaussianize='outliers': the device
+    preprocess per shard, theta gathered), `transform`, `predict`, `get_covariance(rows=...)` across shard boundaries, `clusters`, the
+    moments dict - both branches (discourage_overlap True / False).  What tests/_dist_worker.py checks with two gloo processes."""
+    import torch          # noqa: F401
+    from linearcorex_amd import Corex
+    from oracle import corex_oracle as O
+    monkeypatch.setenv("LCX_CHECK_RANKS", "1")
+    monkeypatch.delenv("LCX_Y_PIPELINE", raising=False)
+    monkeypatch.setattr(np.random, "randn", lambda *shape: np.random.RandomState(0).randn(*shape))
+    world, n, m, max_iter = 8, 500, 6, 12
+    widths = [40, 3, 120, 7, 64, 1, 90, 75]
+    bounds = np.concatenate([[0], np.cumsum(widths)]).tolist()
+    v = bounds[-1]
+    x, _ = O.gen_planted(n, v, m, seed=4)
+    x[:, ::17] = np.sign(x[:, ::17]) * np.abs(x[:, ::17]) ** 1.5
+    syn = branch == "syn"
+    # (the oracle draws its start the way the reference does: np.random.seed(seed) + the global randn - unpatch for it)
+    monkeypatch.undo()
+    ref = (O.fit_syn if syn else O.fit_ns)(x, m, seed=0, dtype=np.float64, gaussianize="outliers", max_iter=max_iter, keep_x=True)
+    monkeypatch.setenv("LCX_CHECK_RANKS", "1")
+    monkeypatch.setattr(np.random, "randn", lambda *shape: np.random.RandomState(0).randn(*shape))
+    shared = _Shared(world)
+    results, errors = [None] * world, [None] * world
+
+    def rank_main(r):
+        try:
+            torch.cuda.set_device(0)
+            comm = ThreadComm(shared, r, bounds)
+            model = Corex(n_hidden=m, seed=0, dtype=np.float64, max_iter=max_iter, device=0, comm=comm, gaussianize="outliers",
+                          discourage_overlap=not syn)
+            y_fit = model.fit_transform(x)
+            y = model.transform(x)
+            xr = model.predict(y[:40])
+            b = bounds[3]
+            rows = model.get_covariance(rows=(b - 60, b + 90))
+            results[r] = {"history": np.asarray(model.history["TC"], np.float64), "ws": model.ws.copy(), "clusters": model.clusters(),
+                          "y_fit": y_fit, "y": y, "predict": xr, "cov_rows": rows, "row0": b - 60, "tcs": np.asarray(model.tcs),
+                          "rho": np.asarray(model.moments["rho"]), "theta": model.theta}
+            model._backend.close()
+        except BaseException as e:          # noqa: BLE001
+            errors[r] = e
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(TIMEOUT * 3)
+    first = next((e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)), None)
+    assert first is None, repr(first)
+    assert all(e is None for e in errors) and all(r is not None for r in results)
+    r0 = results[0]
+    for r in results[1:]:
+        for k in ("history", "ws", "y", "predict", "cov_rows", "clusters"):
+            assert np.array_equal(r[k], r0[k]), k
+    h, h_ref = r0["history"], np.asarray(ref.history_tc)
+    assert len(h) == len(h_ref) and np.max(np.abs(h - h_ref) / np.maximum(1, np.abs(h_ref))) < 1e-8
+    assert np.array_equal(r0["clusters"], ref.clusters())
+    assert np.max(np.abs(r0["ws"] - ref.ws)) < 1e-7
+    y_ref = ref.transform(ref.x_tilde)
+    assert np.max(np.abs(r0["y"] - y_ref)) < 1e-7 and np.max(np.abs(r0["y_fit"] - y_ref)) < 1e-7
+    assert np.max(np.abs(r0["predict"] - O.predict(ref.moments["X_i Z_j"], y_ref[:40], ref.theta, "outliers"))) < 1e-6
+    assert np.max(np.abs(r0["rho"] - ref.moments["rho"])) < 1e-7 and np.max(np.abs(r0["tcs"] - ref.moments["TCs"])) < 1e-7
+    cov_ref = ref.get_covariance()
+    rows, a = r0["cov_rows"], r0["row0"]
+    assert rows.shape == (150, v) and np.max(np.abs(rows - cov_ref[a:a + 150])) < 1e-6 * float(np.max(np.abs(cov_ref)))

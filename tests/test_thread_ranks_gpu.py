@@ -275,7 +275,7 @@ def test_eight_thread_ranks_whole_fit(monkeypatch):
     assert r0["rho"].shape == (m, v) and np.max(np.abs(r0["rho"] - one["rho"])) < 1e-9
 
 
-@pytest.mark.parametrize("branch", ["ns", "syn"])
+@pytest.mark.parametrize("branch", ["ns", "syn", "ns-missing", "ns-empirical"])
 def test_eight_thread_ranks_public_api_vs_oracle(branch, monkeypatch):
     """The public surface over eight uneven thread ranks against the ORACLE: `fit(x)` on raw data (gaussianize='outliers': the device
     preprocess per shard, theta gathered), `transform`, `predict`, `get_covariance(rows=...)` across shard boundaries, `clusters`, the
@@ -293,9 +293,16 @@ def test_eight_thread_ranks_public_api_vs_oracle(branch, monkeypatch):
     x, _ = O.gen_planted(n, v, m, seed=4)
     x[:, ::17] = np.sign(x[:, ::17]) * np.abs(x[:, ::17]) ** 1.5
     syn = branch == "syn"
+    gz, missing = "outliers", None
+    if branch == "ns-missing":            # missing cells (-1e6 sentinel): imputation by the batch's column means, per-column n_obs
+        gz, missing = "standard", -1e6
+        x[np.random.RandomState(8).rand(*x.shape) < 0.04] = missing
+    elif branch == "ns-empirical":        # per-column rank -> normal quantile (the segmented sort of every rank's own columns)
+        gz = "empirical"
     # (the oracle draws its start the way the reference does: np.random.seed(seed) + the global randn - unpatch for it)
     monkeypatch.undo()
-    ref = (O.fit_syn if syn else O.fit_ns)(x, m, seed=0, dtype=np.float64, gaussianize="outliers", max_iter=max_iter, keep_x=True)
+    ref = (O.fit_syn if syn else O.fit_ns)(x, m, seed=0, dtype=np.float64, gaussianize=gz, max_iter=max_iter, keep_x=True,
+                                           **({"missing_values": missing} if missing is not None else {}))
     monkeypatch.setenv("LCX_CHECK_RANKS", "1")
     monkeypatch.setattr(np.random, "randn", lambda *shape: np.random.RandomState(0).randn(*shape))
     shared = _Shared(world)
@@ -305,13 +312,14 @@ def test_eight_thread_ranks_public_api_vs_oracle(branch, monkeypatch):
         try:
             torch.cuda.set_device(0)
             comm = ThreadComm(shared, r, bounds)
-            model = Corex(n_hidden=m, seed=0, dtype=np.float64, max_iter=max_iter, device=0, comm=comm, gaussianize="outliers",
-                          discourage_overlap=not syn)
+            model = Corex(n_hidden=m, seed=0, dtype=np.float64, max_iter=max_iter, device=0, comm=comm, gaussianize=gz,
+                          missing_values=missing, discourage_overlap=not syn)
             y_fit = model.fit_transform(x)
             y = model.transform(x)
             xr = model.predict(y[:40])
             b = bounds[3]
-            rows = model.get_covariance(rows=(b - 60, b + 90))
+            # ('empirical' leaves no theta: get_covariance needs theta[1] in the reference as here, :449)
+            rows = model.get_covariance(rows=(b - 60, b + 90)) if gz != "empirical" else np.zeros((150, v))
             results[r] = {"history": np.asarray(model.history["TC"], np.float64), "ws": model.ws.copy(), "clusters": model.clusters(),
                           "y_fit": y_fit, "y": y, "predict": xr, "cov_rows": rows, "row0": b - 60, "tcs": np.asarray(model.tcs),
                           "rho": np.asarray(model.moments["rho"]), "theta": model.theta}
@@ -338,8 +346,10 @@ def test_eight_thread_ranks_public_api_vs_oracle(branch, monkeypatch):
     assert np.max(np.abs(r0["ws"] - ref.ws)) < 1e-7
     y_ref = ref.transform(ref.x_tilde)
     assert np.max(np.abs(r0["y"] - y_ref)) < 1e-7 and np.max(np.abs(r0["y_fit"] - y_ref)) < 1e-7
-    assert np.max(np.abs(r0["predict"] - O.predict(ref.moments["X_i Z_j"], y_ref[:40], ref.theta, "outliers"))) < 1e-6
+    if gz != "empirical":                 # (the reference cannot invert the empirical transform either: :425)
+        assert np.max(np.abs(r0["predict"] - O.predict(ref.moments["X_i Z_j"], y_ref[:40], ref.theta, gz))) < 1e-6
     assert np.max(np.abs(r0["rho"] - ref.moments["rho"])) < 1e-7 and np.max(np.abs(r0["tcs"] - ref.moments["TCs"])) < 1e-7
-    cov_ref = ref.get_covariance()
-    rows, a = r0["cov_rows"], r0["row0"]
-    assert rows.shape == (150, v) and np.max(np.abs(rows - cov_ref[a:a + 150])) < 1e-6 * float(np.max(np.abs(cov_ref)))
+    if gz != "empirical":
+        cov_ref = ref.get_covariance()
+        rows, a = r0["cov_rows"], r0["row0"]
+        assert rows.shape == (150, v) and np.max(np.abs(rows - cov_ref[a:a + 150])) < 1e-6 * float(np.max(np.abs(cov_ref)))

@@ -32,6 +32,50 @@ class ShardedMomentError(RuntimeError):
     also a RuntimeError) propagates."""
 
 
+class _MomentKeys(object):
+    """keys() of a `DeviceMoments`: the reference's key list (set-like enough for `sorted`, `in`, `len`, `set(...)`)"""
+
+    def __init__(self, m):
+        self._m = m
+
+    def __iter__(self):
+        return iter(self._m._listed())
+
+    def __len__(self):
+        return len(self._m._listed())
+
+    def __contains__(self, k):
+        return k in self._m._listed()
+
+    def __repr__(self):
+        return "dict_keys(%r)" % (self._m._listed(),)
+
+
+class _MomentItems(_MomentKeys):
+    """items(): the value of a key still on the device is copied out when the iteration reaches it"""
+
+    def __iter__(self):
+        return ((k, self._m[k]) for k in self._m._listed())
+
+    def __contains__(self, kv):
+        k, v = kv
+        return k in self._m._listed() and self._m[k] is v
+
+    def __repr__(self):
+        return "dict_items(%r)" % (self._m._listed(),)
+
+
+class _MomentValues(_MomentKeys):
+    def __iter__(self):
+        return (self._m[k] for k in self._m._listed())
+
+    def __contains__(self, v):
+        return any(u is v for u in self)
+
+    def __repr__(self):
+        return "dict_values(of %r)" % (self._m._listed(),)
+
+
 class DeviceMoments(dict):
     """`self.moments`: same keys as the reference dict (linearcorex.py:249-287).  Scalars and
     per-factor vectors are stored eagerly; the m x nv arrays stay on the GPU and are copied out on
@@ -43,12 +87,58 @@ class DeviceMoments(dict):
     until every rank calls `Corex.gather_moments(keys)`, and touching one before that raises instead of hanging the
     ranks that did not ask."""
 
-    def __init__(self, owner, generation, eps, eager):
+    # the reference's dict in its insertion order (:249-273 quick, :277-287 detail): what keys() / items() / iteration / len() list
+    _ORDER_QUICK = ("uj", "rho", "ry", "Y_j^2", "invrho", "rhoinvrho", "Qij", "Si", "Qi-Si^2", "TC")
+    _ORDER_DETAIL = _ORDER_QUICK + ("MI", "X_i Y_j", "X_i Z_j", "X_i^2 | Y", "I(Y_j ; X)", "I(X_i ; Y)", "TCs", "TC_no_overlap",
+                                    "TC_direct", "additivity")
+
+    def __init__(self, owner, generation, eps, eager, details=None):
         super().__init__(eager)
         self._owner, self._gen, self._eps = owner, generation, eps
         self._lazy = set(_DEVICE_KEYS) | {"Y_j^2", "X_i Y_j", "I(X_i ; Y)"}
+        # details: the evaluation behind this dict was the reference's quick=False one (None: told by the eager keys)
+        self._details = ("TCs" in eager) if details is None else bool(details)
 
     _REPLICATED = ("uj", "ry")
+
+    # ---- enumeration: every key the reference's dict holds after the same call, whether or not its array has left the device.
+    # Listing never copies and never issues a collective; VALUE access materialises (several ranks: ShardedMomentError until
+    # `gather_moments`, as with []).  Once the state the dict describes is gone from the device, what was read stays listed.
+    def _order(self):
+        return self._ORDER_DETAIL if self._details else self._ORDER_QUICK
+
+    def _listed(self):
+        order = self._order()
+        live = self._resident()
+        keys = [k for k in order if dict.__contains__(self, k) or (live and k in self._lazy)]
+        seen = set(keys)
+        return keys + [k for k in dict.keys(self) if k not in seen]
+
+    def __iter__(self):
+        return iter(self._listed())
+
+    def __len__(self):
+        return len(self._listed())
+
+    def keys(self):
+        return _MomentKeys(self)
+
+    def items(self):
+        return _MomentItems(self)
+
+    def values(self):
+        return _MomentValues(self)
+
+    def copy(self):
+        return dict(self.items())
+
+    def _stored(self):
+        """what has been read so far, as a plain dict in the reference's order (no copy from the device, no collective)"""
+        return {k: dict.__getitem__(self, k) for k in self._listed() if dict.__contains__(self, k)}
+
+    def __repr__(self):
+        return "%s(%s)" % (type(self).__name__, ", ".join(
+            "%r: %s" % (k, repr(dict.__getitem__(self, k)) if dict.__contains__(self, k) else "<on device>") for k in self._listed()))
 
     def _resident(self):
         be = self._owner._backend if self._owner is not None else None
@@ -124,7 +214,7 @@ class DeviceMoments(dict):
                     self[k]
                 except (KeyError, ShardedMomentError):
                     pass
-        return dict(self)
+        return self._stored()
 
     def __reduce__(self):
         return (dict, (self.materialize(),))
@@ -135,9 +225,16 @@ class SynMoments(DeviceMoments):
     _SYN_DEVICE = {"X_i Y_j": "syn X_i Y_j", "X_i Z_j": "syn X_i Z_j", "X_i^2 | Y": "syn X_i^2 | Y", "rho": "rho",
                    "cy": "cy", "Y_j^2": "Y_j^2", "ry": "ry"}
 
+    # insertion order of `_calculate_moments_syn` (:348-373), which has no quick form
+    _ORDER_SYN = ("X_i Y_j", "cy", "Y_j^2", "ry", "rho", "invrho", "rhoinvrho", "Qij", "Qi", "Si", "MI", "X_i Z_j", "X_i^2 | Y", "TCs",
+                  "additivity", "TC")
+
     def __init__(self, owner, generation, eager):
-        DeviceMoments.__init__(self, owner, generation, 0, eager)
+        DeviceMoments.__init__(self, owner, generation, 0, eager, details=True)
         self._lazy = set(self._SYN_DEVICE) | {"invrho", "rhoinvrho", "Qij", "Qi", "Si", "MI"}
+
+    def _order(self):
+        return self._ORDER_SYN
 
     _REPLICATED = ("cy", "Y_j^2", "ry")
 

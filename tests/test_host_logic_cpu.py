@@ -173,6 +173,62 @@ def test_pickle_warm_start_and_predict(g1):
         m_old["invrho"]
 
 
+def reference_moment_keys(fixture, prefix):
+    """The key list of the reference's `moments` dict after a fit, recovered from the fixture's own entry names (tests/golden/make_golden.py
+    stores moments[k] as <prefix>_mom_<key_name(k)>)."""
+    from tests.test_oracle_golden import key_name
+    candidates = ("uj", "rho", "ry", "Y_j^2", "invrho", "rhoinvrho", "Qij", "Qi", "Si", "Qi-Si^2", "TC", "MI", "X_i Y_j", "X_i Z_j",
+                  "X_i^2 | Y", "I(Y_j ; X)", "I(X_i ; Y)", "TCs", "TC_no_overlap", "TC_direct", "additivity", "cy")
+    stored = {n[len(prefix) + 5:] for n in fixture.keys() if n.startswith(prefix + "_mom_")}
+    keys = [k for k in candidates if key_name(k) in stored]
+    assert len(keys) == len(stored), (sorted(stored), keys)          # every stored name is accounted for
+    return keys
+
+
+def check_moments_enumerate_like_the_reference(model, ref_keys, quick_keys=None):
+    """linearcorex.py:249-287 / :348-373: `moments` is a plain dict there - keys(), items(), values(), iteration and len() see every
+    key.  Here the big arrays stay on the device until read; listing them must not depend on what has been read."""
+    mo = model.moments
+    assert sorted(mo) == sorted(ref_keys) and len(mo) == len(ref_keys)
+    assert sorted(mo.keys()) == sorted(ref_keys) and set(ref_keys) - set(mo.keys()) == set()
+    assert list(mo) == list(mo.keys()) and len(mo.items()) == len(mo.values()) == len(ref_keys)
+    assert all(k in mo for k in ref_keys) and all(k in mo.keys() for k in ref_keys)
+    assert len(mo._stored()) < len(ref_keys)            # listing did not copy anything out
+    assert [k for k, _ in mo.items()] == list(mo)
+    vals = dict(mo.items())                             # value access does
+    assert sorted(vals) == sorted(ref_keys) and len(mo._stored()) == len(ref_keys)
+    assert all(np.array_equal(np.asarray(v), np.asarray(mo[k])) for (k, v) in zip(mo, mo.values()))
+    assert sorted(dict(mo)) == sorted(ref_keys) and sorted(mo.copy()) == sorted(ref_keys)
+    back = pickle.loads(pickle.dumps(model))
+    assert type(back.moments) is dict and sorted(back.moments) == sorted(ref_keys)
+    return vals
+
+
+def test_moments_enumerate_like_the_reference_dict(g1):
+    from tests.conftest import load_golden
+    g8 = load_golden("g8_syn")
+    x = g1["x_raw"].astype(np.float64)
+    ref_keys = reference_moment_keys(g1, "f64")
+    assert len(ref_keys) == 20
+    out = Corex(n_hidden=5, seed=0, dtype=np.float64, max_iter=4, _backend_factory=FACTORY).fit(x)
+    assert list(out.moments) == list(out.moments._ORDER_DETAIL)         # the reference's insertion order too
+    check_moments_enumerate_like_the_reference(out, ref_keys)
+    # the quick evaluation of an iteration (:321 -> quick=True) holds the first ten keys only (:249-273)
+    out2 = Corex(n_hidden=5, seed=0, dtype=np.float64, max_iter=4, _backend_factory=FACTORY).fit(x)
+    quick = out2._calculate_moments_ns(quick=True)
+    assert list(quick) == ["uj", "rho", "ry", "Y_j^2", "invrho", "rhoinvrho", "Qij", "Si", "Qi-Si^2", "TC"]
+    assert quick["Qi-Si^2"].shape == (50,) and len(quick) == 10
+    # once the fit state the dict describes is gone, what was read stays listed and nothing else is promised
+    out2._backend.generation += 1
+    assert sorted(quick) == ["Qi-Si^2", "TC"]
+    # synergistic branch (:348-373)
+    syn_keys = reference_moment_keys(g8, "big5_f64")
+    assert len(syn_keys) == 16
+    syn = Corex(n_hidden=5, seed=0, dtype=np.float64, max_iter=4, discourage_overlap=False, _backend_factory=FACTORY).fit(x)
+    assert list(syn.moments) == list(syn.moments._ORDER_SYN)
+    check_moments_enumerate_like_the_reference(syn, syn_keys)
+
+
 def test_missing_values_and_outliers_through_driver(g5, g6):
     out = Corex(n_hidden=6, seed=0, dtype=np.float64, missing_values=-1e6, max_iter=60,
                 _backend_factory=FACTORY).fit(g6["x_raw"])

@@ -197,6 +197,10 @@ def test_big5_end_to_end(tag, g1, ls_both):
     h_ref = g1[tag + "_history_tc"]
     h = np.asarray(out.history["TC"], dtype=np.float64)
     assert np.array_equal(out.clusters(), g1[tag + "_clusters"])            # integer output: bit-exact
+    # `moments` lists the reference dict's 20 keys (:249-287) before any of the device arrays has been read, in its insertion order
+    from tests.test_host_logic_cpu import reference_moment_keys
+    assert sorted(out.moments) == sorted(out.moments.keys()) == sorted(reference_moment_keys(g1, tag)) and len(out.moments) == 20
+    assert list(out.moments) == list(out.moments._ORDER_DETAIL) and len(out.moments._stored()) < 20
     if tag == "f64":
         assert len(h) == len(h_ref) == 261
         assert relerr(h, h_ref) < 1e-6
@@ -215,6 +219,9 @@ def test_big5_end_to_end(tag, g1, ls_both):
             assert relerr(out.moments[key], g1["f64_mom_" + name]) < 1e-6, key
         assert abs(out.moments["additivity"] - float(g1["f64_mom_additivity"])) < 1e-6
         assert abs(out.moments["TC_no_overlap"] - float(g1["f64_mom_TC_no_overlap"])) < 1e-6
+        for k, v in out.moments.items():             # every listed key materialises, with the reference's values
+            from tests.test_oracle_golden import key_name
+            assert relerr(v, g1["f64_mom_" + key_name(k)]) < 1e-6, k
     else:
         assert abs(len(h) - len(h_ref)) <= F32_ITER_BAR[ls] * len(h_ref)
         assert abs(float(out.tc) - float(g1["f32_tc"])) < 5e-5 * float(g1["f32_tc"])

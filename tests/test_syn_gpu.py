@@ -54,6 +54,10 @@ def test_syn_end_to_end(tag, g1):
         out = Corex(n_hidden=m, seed=0, dtype=dt, device=0, discourage_overlap=False).fit(x)
         p = "%s_%s_" % (name, tag)
         h, h_ref = np.asarray(out.history["TC"], np.float64), g[p + "history_tc"]
+        # `moments` lists the 16 keys of the reference's dict (:348-373) in its order, before any device array has been read
+        from tests.test_host_logic_cpu import reference_moment_keys
+        assert sorted(out.moments) == sorted(reference_moment_keys(g, p[:-1])) and len(out.moments.keys()) == 16
+        assert list(out.moments) == list(out.moments._ORDER_SYN) and len(out.moments._stored()) < 16
         if tag == "f64":
             assert len(h) == len(h_ref), name
             assert relerr(h, h_ref) < 1e-6

@@ -525,6 +525,11 @@ def roofline_of(workload, r, world):
                                  "achieved_GBps": it_bytes / r["per_step_s"] / 1e9,
                                  "achieved_TFLOPs": it_flops / r["per_step_s"] / 1e12,
                                  "fraction_of_step_inside_the_x_passes": in_pass / r["per_step_s"]}
+        # the whole step against the same roof: the algorithmic flops (bytes) of the X passes an iteration executes / ms_per_step / peak
+        # - launch gaps, the small kernels and the exchange steps all count against it.  `frac` above is the dominant kernel alone
+        roofline["step_frac"] = ((it_bytes / r["per_step_s"] / 1e9) if roofline["bound"] == "hbm" else (it_flops / r["per_step_s"] / 1e12)) / peak_site
+    # the slowest of the pass sites (`frac` is the dominant kernel's, which on the merged-pass workloads is the BEST of the three)
+    roofline["frac_min_site"] = min(roofline["frac_by_site"].values())
     return roofline
 
 

@@ -34,7 +34,7 @@ def _pick(d, *path, default=None):
     return d
 
 
-ROOFLINE_LINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "launches",
+ROOFLINE_LINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "step_frac", "frac_min_site", "traffic", "kernel", "avg_launch_us", "launches",
                       "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "rocprofv3_avg_kernel_us",
                       "rocprofv3_source", "traffic_source", "traffic_profile_matches_library", "mfma_util_pmc")
 
@@ -85,6 +85,8 @@ def compact_line(out, detail_path):
             riders[name + "_line_search"] = b.get("line_search")
             riders[name + "_ms_per_step"] = b.get("ms_per_step")
             riders[name + "_roofline_frac"] = _pick(b, "roofline", "frac")
+            riders[name + "_roofline_step_frac"] = _pick(b, "roofline", "step_frac")
+            riders[name + "_roofline_frac_min_site"] = _pick(b, "roofline", "frac_min_site")
             riders[name + "_xbt_pass_roofline_frac"] = _pick(b, "roofline", "frac_by_site", "gemm_nt")
             riders[name + "_xty_pass_roofline_frac"] = _pick(b, "roofline", "frac_by_site", "gemm_tn")
             riders[name + "_roofline_bound"] = _pick(b, "roofline", "bound")

@@ -170,8 +170,9 @@ int lcx_set_exchange_hook(lcx_ctx* h, lcx_allreduce_fn fn, void* user);
 int lcx_exchange_info(lcx_ctx* h, int* kind, int* world, int64_t* allreduces_issued);
 /* First contact with a bound transport (collective: every rank calls it with its own rank in [0, world), right after lcx_comm_init / lcx_set_exchange_hook and
  * lcx_bind_exchange, before any level): all-reduces the Y exchange buffer at its real size on the handle's stream, once with a
- * rank-dependent integer pattern whose sum is known in closed form and once with rank-dependent values over 12 binades, then
- * shares the verdicts through the scalar buffer.  Whatever can fail on one rank alone (arguments, an allocation) happens first and is
+ * rank-dependent integer pattern whose sum is known in closed form and once with rank-dependent values over 12 binades (with
+ * LCX_Y_PIPELINE=chunks that second one on the library's second stream, behind an event, as the pipelined exchange issues its
+ * chunks - the stream argument of a hook is part of what is tested), then shares the verdicts through the scalar buffer.  Whatever can fail on one rank alone (arguments, an allocation) happens first and is
  * shared by a one-element all-reduce that every rank enters: a local failure returns an error on EVERY rank instead of leaving the
  * others blocked inside the big all-reduce.  LCX_OK and *ok = 1 iff every rank got the right sums AND all ranks hold the same
  * bits (lcx_iterate's decisions rely on that); LCX_ERR_COMM with the diagnosis otherwise, on every rank alike.
@@ -387,17 +388,23 @@ int lcx_invert(lcx_ctx* h, const void* x_host, int64_t n_rows, int64_t ld, int k
                void* out_host, int64_t ld_out);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
-/* HIP-event timing of the two X-streaming GEMM kernels on the handle's stream.
- * kind 0 = X.B^T ("nt", :247/:210), kind 1 = X^T.Y ("tn", :259/:211), kind 2 = the merged pass
- * X.[grad | ws + update]^T (the :210 pass and the first trial's :321 pass as one launch with 2 x m_padded columns;
- * float32 shards on the column-tiled kernel with <= 64 padded factors, one GPU - see lcx_update_b). */
+/* HIP-event timing sites (kinds) on the stream that carries the work:
+ *   the X-streaming GEMM kernels - kind 0 = X.B^T ("nt", :247/:210), kind 1 = X^T.Y ("tn", :259/:211), kind 2 = the merged pass
+ *   X.[grad | ws + update]^T (the :210 pass and the first trial's :321 pass as one launch with 2 x m_padded columns; float32
+ *   shards on the column-tiled kernel with <= 64 padded factors - see lcx_update_b);
+ *   the exchange steps of a handle with a bound transport (the sums of :247, :259, :294, :301-305 over the ranks) - kind 3 = the
+ *   Y-buffer all-reduce of lcx_moments_a ([Y | W.W^T], every chunk of the pipelined form), kind 4 = the one of lcx_update_b
+ *   ([Y_g | Bj]; merged form [Y' | W'.W'^T | Y_g]), kind 5 = the scalar buffer of an evaluation (TC sums, tangent, H), kind 6 = the
+ *   small ones (Bj in front of the merged pass, W'.W'^T of a trial taken by linearity, a restored H).  With RCCL the pair
+ *   brackets the all-reduce kernel - including its wait for a slower rank; with a host-blocking hook the gap it leaves on the
+ *   stream.  Not timed: first contact (lcx_comm_selftest reports its own figure) and the one-flag agreement on the merged pass. */
 int lcx_timing_enable(lcx_ctx* h, int enable);
-/* time only every `every`-th X pass (an event pair costs ~5 us of stream time; default 1 = all) */
+/* time only every `every`-th launch of each site (an event pair costs ~5 us of stream time; default 1 = all) */
 int lcx_timing_sample(lcx_ctx* h, int every);
-/* launches / total_ms: the timed passes that did their work.  A pass whose trial went invalid (:250-251) returns at its skip
- * flag; such launches (shorter than a fifth of the longest of their kind) are not averaged in */
+/* launches / total_ms of site `kind` in [0, 7): the timed launches that did their work.  An X pass whose trial went invalid
+ * (:250-251) returns at its skip flag; such launches (shorter than a fifth of the longest of their kind) are not averaged in */
 int lcx_timing_read(lcx_ctx* h, int kind, int64_t* launches, double* total_ms);
-/* every X pass issued since the last reset while timing was enabled (timed or skipped by the sampling) */
+/* every launch of site `kind` issued since the last reset while timing was enabled (timed or skipped by the sampling) */
 int lcx_timing_passes(lcx_ctx* h, int kind, int64_t* passes);
 int lcx_timing_reset(lcx_ctx* h);
 /* geometry actually used (for the roofline arithmetic): padded sizes and launch shapes */

@@ -103,6 +103,19 @@ class HipBackend:
             out[name] = n.value
         return out
 
+    EXCHANGE_SITES = ((3, "y"), (4, "direction"), (5, "scalars"), (6, "small"))
+
+    def timing_exchange_read(self):
+        """The exchange steps issued inside the library while timing was on (include/lcx.h, timing kinds 3-6):
+        site -> (issued, timed, total ms of the timed ones)."""
+        out = {}
+        issued, n, ms = C.c_int64(), C.c_int64(), C.c_double()
+        for kind, name in self.EXCHANGE_SITES:
+            _abi.check(self.lib.lcx_timing_passes(self.h, kind, C.byref(issued)))
+            _abi.check(self.lib.lcx_timing_read(self.h, kind, C.byref(n), C.byref(ms)))
+            out[name] = (issued.value, n.value, ms.value)
+        return out
+
     def kernel_name(self, kind):
         buf = C.create_string_buffer(256)
         _abi.check(self.lib.lcx_kernel_name(self.h, int(kind), buf, 256))

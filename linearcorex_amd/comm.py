@@ -27,11 +27,31 @@ class Comm:
         self.exchange = self.world > 1 or bool(always_exchange)
         self.selftest_seconds = None       # seconds one Y-buffer all-reduce took in the transport's first-contact test (bind_engine)
         self.bounds = None
+        err = None
         if bounds is not None:
             b = [int(t) for t in bounds]
             if len(b) != self.world + 1 or b[0] != 0 or any(b[k + 1] <= b[k] for k in range(self.world)):
-                raise ValueError("bounds must be %d increasing column boundaries starting at 0" % (self.world + 1))
-            self.bounds = b
+                err = "bounds must be %d increasing column boundaries starting at 0" % (self.world + 1)
+            else:
+                self.bounds = b
+        if self.world > 1:
+            # "the same on every rank" is checked, not assumed: shard widths enter the padding of the gathers and the global column
+            # map - ranks that disagree would hang or gather wrong columns without an error.  Every rank takes part (balanced split =
+            # all -1), and the verdict is rank-identical, so all of them raise together.
+            import torch
+            mine = (self.bounds if self.bounds is not None else [-1] * (self.world + 1)) + [1 if err else 0]
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+            t = torch.tensor(mine + [-v for v in mine], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            t = [int(v) for v in t.cpu()]
+            hi, lo = t[:len(mine)], [-v for v in t[len(mine):]]
+            if hi[-1]:
+                raise ValueError(err or "another rank passed malformed shard bounds")
+            if hi != lo:
+                raise ValueError("rank %d: Comm(bounds=...) differs across the ranks: mine %r, elementwise max %r, min %r"
+                                 % (self.rank, mine[:-1], hi[:-1], lo[:-1]))
+        elif err:
+            raise ValueError(err)
 
     # contiguous column ranges: balanced, or the caller's boundaries
     def shard(self, nv, rank=None):
@@ -69,7 +89,10 @@ class Comm:
         if mode == "torch" or not self.exchange or not hasattr(backend, "comm_init"):
             return None
         import torch
-        run_selftest = bool(first_contact)      # False: a temporary handle beside one whose transport already passed (same group, same kind)
+        # first_contact=False: a temporary handle beside one whose transport already passed (same group, same kind).  That holds
+        # literally for the hook (the same process group carries it); an RCCL handle owns a brand-new communicator from a fresh
+        # ncclCommInitRank, so it is always tested
+        run_selftest = bool(first_contact)
         if run_selftest:
             self.selftest_seconds = None
 
@@ -84,11 +107,13 @@ class Comm:
             """lcx_comm_selftest on every rank; its verdict is shared inside the test itself (rank-identical), the MAX over the
             ranks on top covers a rank that could not even run it"""
             err = None
-            if run_selftest and os.environ.get("LCX_COMM_SELFTEST", "1") not in ("", "0"):
+            if (run_selftest or what == "rccl") and os.environ.get("LCX_COMM_SELFTEST", "1") not in ("", "0"):
                 try:
                     if os.environ.get("LCX_TEST_FAIL_COMM_INIT") == "selftest" and what == "rccl":
                         raise RuntimeError("LCX_TEST_FAIL_COMM_INIT=selftest")
-                    self.selftest_seconds = backend.comm_selftest(self.rank)
+                    secs = backend.comm_selftest(self.rank)
+                    if run_selftest:
+                        self.selftest_seconds = secs
                 except Exception as e:       # noqa: BLE001 - reported by the caller, on every rank
                     err = "lcx_comm_selftest (%s): %s" % (what, e)
             return err

@@ -170,6 +170,8 @@ struct TimingPair {
     hipEvent_t a, b;
     int kind;
 };
+constexpr int LCX_T_KINDS = 7;          // timing sites: 0-2 the X passes, 3-6 the exchange steps (lcx_ctx::t_launch)
+constexpr int LCX_T_AR_Y = 3, LCX_T_AR_DIR = 4, LCX_T_AR_S = 5, LCX_T_AR_SMALL = 6;
 
 struct lcx_ctx {
     int device, dtype;
@@ -231,14 +233,19 @@ struct lcx_ctx {
     int nt_nb, nt_nsuper, tn_nb, tn_nsuper;
     // timing
     bool timing;
-    int t_every, t_count;       // HIP-event timing samples every t_every-th X pass (an event pair costs ~5 us of stream time)
+    int t_every;                // HIP-event timing samples every t_every-th launch of a site (an event pair costs ~5 us of stream time)
+    int t_count[LCX_T_KINDS];
     std::vector<TimingPair> pending;
     std::vector<TimingPair> pool;
-    int64_t t_launch[3];        // kind 0 = X.B^T, 1 = X^T.Y, 2 = the merged X.[grad | ws+update]^T pass (2 Mp columns)
-    int64_t t_pass[3];          // every X pass issued while timing is on (sampled or not)
-    double t_ms[3];
-    double t_max[3];            // longest timed launch per kind; launches below a fifth of it were skipped by their flag
-    int64_t t_skipped[3];
+    // sites: kind 0 = X.B^T, 1 = X^T.Y, 2 = the merged X.[grad | ws+update]^T pass (2 Mp columns); the exchange steps (events on the
+    // stream that carries the collective): 3 = the Y-buffer all-reduce behind X.W^T (lcx_moments_a, :247 -> :259), 4 = the one of the
+    // direction (lcx_update_b: [Y_g | Bj], merged form [Y' | W'.W'^T | Y_g]), 5 = the scalar buffer (TC sums, tangent, H: :294, :301-305),
+    // 6 = the small ones (Bj in front of the merged pass, W'.W'^T of a trial taken by linearity, a restored H)
+    int64_t t_launch[LCX_T_KINDS];
+    int64_t t_pass[LCX_T_KINDS];   // every launch of the site issued while timing is on (sampled or not)
+    double t_ms[LCX_T_KINDS];
+    double t_max[LCX_T_KINDS];     // longest timed launch per kind; X passes below a fifth of it were skipped by their flag
+    int64_t t_skipped[LCX_T_KINDS];
     bool have_direction;
     int world;                  // ranks sharing the variables axis (1: no exchange between levels)
     unsigned int seq_next;
@@ -280,6 +287,13 @@ static int exchange_on(lcx_ctx* h, hipStream_t st, void* buf, int64_t count, int
     return LCX_OK;
 }
 static int exchange(lcx_ctx* h, void* buf, int64_t count, int dtype) { return exchange_on(h, h->stream, buf, count, dtype); }
+// the second stream of the pipelined Y exchange (LCX_Y_PIPELINE) and its events, created on first use
+static int ypipe_streams(lcx_ctx* h) {
+    if (h->comm_stream) return LCX_OK;
+    HIPCHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    for (auto& e : h->ypipe_ev) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return LCX_OK;
+}
 // the library can sequence whole iterations when it does not depend on the caller for the sums
 static inline bool self_contained(const lcx_ctx* h) { return !h->exchange || h->tr.kind != 0 || h->world == 1; }
 
@@ -346,11 +360,11 @@ struct DevTemps {
 // -------------------------------------------------------------------------------------------------
 // GEMM launchers
 // -------------------------------------------------------------------------------------------------
-static int timing_begin(lcx_ctx* h, int kind, TimingPair* tp) {
+static int timing_begin_on(lcx_ctx* h, hipStream_t st, int kind, TimingPair* tp) {
     tp->kind = -1;
     if (!h || !h->timing || kind < 0) return LCX_OK;
     h->t_pass[kind] += 1;
-    if (h->t_every > 1 && (h->t_count++ % h->t_every) != 0) return LCX_OK;
+    if (h->t_every > 1 && (h->t_count[kind]++ % h->t_every) != 0) return LCX_OK;
     if (h->pool.empty()) {
         HIPCHECK(hipEventCreate(&tp->a));
         HIPCHECK(hipEventCreate(&tp->b));
@@ -359,15 +373,27 @@ static int timing_begin(lcx_ctx* h, int kind, TimingPair* tp) {
         h->pool.pop_back();
     }
     tp->kind = kind;
-    HIPCHECK(hipEventRecord(tp->a, h->stream));
+    HIPCHECK(hipEventRecord(tp->a, st));
     return LCX_OK;
 }
-static int timing_end(lcx_ctx* h, int kind, TimingPair* tp) {
+static int timing_end_on(lcx_ctx* h, hipStream_t st, int kind, TimingPair* tp) {
     if (!h || !h->timing || kind < 0 || tp->kind < 0) return LCX_OK;
-    HIPCHECK(hipEventRecord(tp->b, h->stream));
+    HIPCHECK(hipEventRecord(tp->b, st));
     h->pending.push_back(*tp);
     return LCX_OK;
 }
+static int timing_begin(lcx_ctx* h, int kind, TimingPair* tp) { return timing_begin_on(h, h ? h->stream : nullptr, kind, tp); }
+static int timing_end(lcx_ctx* h, int kind, TimingPair* tp) { return timing_end_on(h, h ? h->stream : nullptr, kind, tp); }
+// an exchange step with its timing site: the event pair brackets the collective on the stream that carries it (RCCL: the all-reduce
+// kernel and whatever it waits for - a slower rank shows up here; a host-blocking hook: the device-side gap it leaves)
+static int exchange_site_on(lcx_ctx* h, hipStream_t st, int site, void* buf, int64_t count, int dtype) {
+    if (!h->exchange || h->tr.kind == 0 || count <= 0) return LCX_OK;
+    TimingPair tp;
+    LCXCHECK(timing_begin_on(h, st, site, &tp));
+    LCXCHECK(exchange_on(h, st, buf, count, dtype));
+    return timing_end_on(h, st, site, &tp);
+}
+static int exchange_site(lcx_ctx* h, int site, void* buf, int64_t count, int dtype) { return exchange_site_on(h, h->stream, site, buf, count, dtype); }
 static int timing_collect(lcx_ctx* h) {
     // The X^T.Y pass of an invalid trial (:250-251) returns at its first instruction (skip flag): such a launch is not a pass
     // and must not pull the average down.  A launch shorter than a fifth of the longest one of its kind is counted apart.
@@ -380,7 +406,7 @@ static int timing_collect(lcx_ctx* h) {
     }
     for (size_t k = 0; k < h->pending.size(); ++k) {
         TimingPair& tp = h->pending[k];
-        if (dur[k] < 0.2 * h->t_max[tp.kind]) {
+        if (tp.kind < 3 && dur[k] < 0.2 * h->t_max[tp.kind]) {
             h->t_skipped[tp.kind] += 1;
         } else {
             h->t_launch[tp.kind] += 1;

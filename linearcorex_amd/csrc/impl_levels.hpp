@@ -328,10 +328,7 @@ int Impl<T, CT>::nt_big(lcx_ctx* h, const void* Bv, const int* skip, bool with_b
 // W.W^T tail sits right behind Y in the buffer and rides in the last chunk.  Every rank issues the same chunks in the same order.
 template <typename T, int CT>
 int Impl<T, CT>::ypipe_init(lcx_ctx* h) {
-    if (h->comm_stream) return LCX_OK;
-    HIPCHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
-    for (auto& e : h->ypipe_ev) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    return LCX_OK;
+    return ypipe_streams(h);
 }
 
 // B = the weights of the evaluated set (lcx_moments_a: tail = W.W^T partial) or, with_bj, the gradient (lcx_update_b: tail = the
@@ -380,7 +377,7 @@ int Impl<T, CT>::y_pass_pipelined(lcx_ctx* h, const T* w, bool with_bj) {
         HIPCHECK(hipEventRecord(h->ypipe_ev[c], h->stream));
         HIPCHECK(hipStreamWaitEvent(h->comm_stream, h->ypipe_ev[c], 0));
         const int64_t count = (r1 - r0) * Mp + (c == C - 1 ? (int64_t)Mp * Mp : 0);
-        LCXCHECK(exchange_on(h, h->comm_stream, P<T>(h->ybuf) + r0 * Mp, count, DT));
+        LCXCHECK(exchange_site_on(h, h->comm_stream, with_bj ? LCX_T_AR_DIR : LCX_T_AR_Y, P<T>(h->ybuf) + r0 * Mp, count, DT));
     }
     HIPCHECK(hipEventRecord(h->ypipe_ev[16], h->comm_stream));
     HIPCHECK(hipStreamWaitEvent(h->stream, h->ypipe_ev[16], 0));
@@ -449,7 +446,7 @@ int Impl<T, CT>::moments_a(lcx_ctx* h, int which) {
     LCXCHECK(nt_big(h, w, nullptr, false, (!h->exchange && h->nt_S > 1) ? P<T>(h->set[which].Y) : (T*)nullptr));
     if (!h->exchange) return LCX_OK;         // nothing to exchange: W.W^T is formed with Y^T.Y in lcx_moments_b (one launch)
     LCXCHECK(gram_w(h, w));
-    return exchange(h, h->ybuf, h->ybuf_main, DT);           // L1 of SURVEY 8e: [Y_partial | W.W^T partial]
+    return exchange_site(h, LCX_T_AR_Y, h->ybuf, h->ybuf_main, DT);           // L1 of SURVEY 8e: [Y_partial | W.W^T partial]
 }
 
 // per-factor moments; ysrc != null: first form the Y^T.Y partials of that Y
@@ -580,7 +577,7 @@ int Impl<T, CT>::epilogue(lcx_ctx* h, int which, double eps, bool linear, double
     hipLaunchKernelGGL((reduce_wide_kernel<T, double>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
                        P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, h->sbuf + SB_H, skip);
     KCHECK();
-    return exchange(h, h->sbuf, SB_H + Mp * Mp, LCX_F64);    // L2 + L3 + L5: TC sums, pending tangent, H of this set
+    return exchange_site(h, LCX_T_AR_S, h->sbuf, SB_H + Mp * Mp, LCX_F64);    // L2 + L3 + L5: TC sums, pending tangent, H of this set
 }
 
 template <typename T, int CT>
@@ -605,7 +602,7 @@ int Impl<T, CT>::trial_linear_a(lcx_ctx* h, double eta) {
                        P<T>(h->set[0].Y), P<T>(h->ydir), P<T>(h->set[1].Y), n2, (T)eta);
     KCHECK();
     LCXCHECK(gram_pair(h, P<T>(h->Wt[1]), P<T>(h->set[1].Y)));
-    return exchange(h, P<T>(h->ybuf) + h->Npad * Mp, (int64_t)Mp * Mp, DT);      // W'.W'^T partial
+    return exchange_site(h, LCX_T_AR_SMALL, P<T>(h->ybuf) + h->Npad * Mp, (int64_t)Mp * Mp, DT);      // W'.W'^T partial
 }
 
 // b: (W.W^T tail global) uj, flag, D' = D + eta*D(update), rho ... TC partial sums
@@ -633,7 +630,7 @@ int Impl<T, CT>::update_a(lcx_ctx* h) {
     hipLaunchKernelGGL((reduce_wide_kernel<T, double>), dim3(cdiv(Mp * Mp, 32)), dim3(256), 0, h->stream,
                        P<T>(h->gpart), h->gv_S, (int64_t)Mp * Mp, (int64_t)Mp * Mp, h->sbuf + SB_H, (const int*)nullptr);
     KCHECK();
-    return exchange(h, h->sbuf + SB_H, (int64_t)Mp * Mp, LCX_F64);
+    return exchange_site(h, LCX_T_AR_SMALL, h->sbuf + SB_H, (int64_t)Mp * Mp, LCX_F64);
 }
 
 // grad (:296-300) and the per-block Bj partials (:302) of set `which`, from its moments and the H its evaluation left in sbuf
@@ -676,7 +673,7 @@ int Impl<T, CT>::update_b(lcx_ctx* h, double eps) {
     if (!merged) {
         if (h->exchange && h->ypipe > 1 && h->tr.kind != 0) return y_pass_pipelined(h, P<T>(h->grad), true);
         LCXCHECK(nt_big(h, P<T>(h->grad), nullptr, true));
-        return exchange(h, h->ybuf, h->ybuf_main, DT);       // L4: [Y_g partial | Bj partial]
+        return exchange_site(h, LCX_T_AR_DIR, h->ybuf, h->ybuf_main, DT);       // L4: [Y_g partial | Bj partial]
     }
     if constexpr (sizeof(T) == 4 && CT >= 2 && CT <= 4) {
         // Bj (:302) does not wait for the pass: sum its per-block partials now, form update and ws + update (:303, :320) and
@@ -689,7 +686,7 @@ int Impl<T, CT>::update_b(lcx_ctx* h, double eps) {
         if (h->exchange) {
             // several ranks: `update` needs Bj over ALL variables before the pass - one tiny all-reduce in front of it - and
             // the tail of ybuf is needed again for W'.W'^T of the first trial, so the global Bj moves to a buffer of its own
-            LCXCHECK(exchange(h, P<T>(h->ybuf) + n, Mp, DT));
+            LCXCHECK(exchange_site(h, LCX_T_AR_SMALL, P<T>(h->ybuf) + n, Mp, DT));
             HIPCHECK(hipMemcpyAsync(h->bjg, P<T>(h->ybuf) + n, sizeof(T) * Mp, hipMemcpyDeviceToDevice, h->stream));
             bj = P<T>(h->bjg);
         }
@@ -719,7 +716,7 @@ int Impl<T, CT>::update_b(lcx_ctx* h, double eps) {
             // what lcx_moments_a(1) would have left for the first trial - W'.W'^T partial in the tail - and ONE all-reduce of
             // [Y' | W'.W'^T | Y_g] (ygbuf sits right behind the tail); lcx_moments_b copies the summed Y' into set 1
             LCXCHECK(gram_w(h, P<T>(h->Wt[1])));
-            LCXCHECK(exchange(h, h->ybuf, h->ybuf_elems, DT));
+            LCXCHECK(exchange_site(h, LCX_T_AR_DIR, h->ybuf, h->ybuf_elems, DT));
         }
         h->w1_ready = h->y1_ready = true;
     }
@@ -746,7 +743,9 @@ int Impl<T, CT>::agree_on_merged(lcx_ctx* h) {
 }
 template <typename T, int CT>
 bool Impl<T, CT>::use_merged(const lcx_ctx* h) {
-    return h->merged_ok && h->merged_agreed != 0 && (!h->exchange || h->tr.kind != 0) && !h->full_sig && h->gw != nullptr;
+    // == 1: "not asked yet" (-1) is not an agreement - only lcx_update_b asks, and whatever resets the answer (lcx_set_world, another
+    // transport) also drops what an earlier merged pass left behind (y1_ready / w1_ready / a gradient computed ahead)
+    return h->merged_ok && h->merged_agreed == 1 && (!h->exchange || h->tr.kind != 0) && !h->full_sig && h->gw != nullptr;
 }
 
 template <typename T, int CT>
@@ -812,7 +811,7 @@ int Impl<T, CT>::trial_by_linearity(lcx_ctx* h, double eta) {
     if (h->exchange) {
         // Y and X.update^T are already sums over all ranks; only W'.W'^T of the trial is still per shard
         LCXCHECK(gram_w(h, P<T>(h->Wt[1])));
-        LCXCHECK(exchange(h, P<T>(h->ybuf) + h->Npad * Mp, (int64_t)Mp * Mp, DT));
+        LCXCHECK(exchange_site(h, LCX_T_AR_SMALL, P<T>(h->ybuf) + h->Npad * Mp, (int64_t)Mp * Mp, DT));
     } else if (h->nt_S > 1) {
         HIPCHECK(hipMemcpyAsync(h->set[1].Y, h->ybuf, (size_t)n2 * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
     }
@@ -1205,14 +1204,14 @@ int Impl<T, CT>::kernel_name(lcx_ctx* h, int kind, char* buf, int64_t len) {
 template <typename T, int CT>
 int Impl<T, CT>::kernel_name_tuned(lcx_ctx* h, int kind, char* buf, int64_t len) {
     if (h->split) {
-        if (kind == 2 && !h->merged_ok) { buf[0] = 0; return LCX_OK; }
+        if (kind == 2 && (!h->merged_ok || h->merged_agreed == 0)) { buf[0] = 0; return LCX_OK; }   // the group agreed not to take it
         const int ct = kind == 2 ? 2 * CT : CT;
         snprintf(buf, (size_t)len, "lcx::gemm_split_kernel<%d, %d, 6, %s, true, false, 2, %d, %d>", ct, ct >= 4 ? 8 : 4, kind == 1 ? "true" : "false",
                  ct <= 4 ? 2 : 1, ct == 8 ? 2 : 1);
         return LCX_OK;
     }
     if (kind == 2) {
-        if (!h->merged_ok) { buf[0] = 0; return LCX_OK; }
+        if (!h->merged_ok || h->merged_agreed == 0) { buf[0] = 0; return LCX_OK; }
         if constexpr (CT <= 4)
             snprintf(buf, (size_t)len, h->panel ? "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, true, true>"
                                        : h->single_copy ? "lcx::gemm_cr_kernel<%s, %d, %d, %d, %d, false, false>" : "lcx::gemm_ct_kernel<%s, %d, %d, %d, %d, true, false>",

@@ -44,8 +44,7 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     h->ldx = round_up(nv_local, 64);        // 64 elements: whole 128 B chunks and whole tn column tiles
     h->timing = false;
     h->t_every = 1;
-    h->t_count = 0;
-    for (int k = 0; k < 3; ++k) { h->t_launch[k] = 0; h->t_pass[k] = 0; h->t_ms[k] = 0.0; h->t_max[k] = 0.0; h->t_skipped[k] = 0; }
+    for (int k = 0; k < LCX_T_KINDS; ++k) { h->t_count[k] = 0; h->t_launch[k] = 0; h->t_pass[k] = 0; h->t_ms[k] = 0.0; h->t_max[k] = 0.0; h->t_skipped[k] = 0; }
     h->have_direction = false;
     h->target_waves = prop.multiProcessorCount * 12;
     h->n_cus = prop.multiProcessorCount;
@@ -294,6 +293,8 @@ static int drop_transport(lcx_ctx* h) {
     }
     h->tr = Transport();
     h->merged_agreed = -1;         // another transport, another group: the ranks agree on the merged pass again
+    h->y1_ready = h->w1_ready = h->yk_ready = h->grad_ready = h->early_grad = false;      // nothing of a merged flow survives it
+    h->have_direction = false;
     return LCX_OK;
 }
 
@@ -371,7 +372,19 @@ int lcx_comm_selftest(lcx_ctx* h, int rank, int* ok_out, double* seconds_per_all
         KCHECK();
         HIPCHECK(hipStreamSynchronize(h->stream));
         const auto t0 = std::chrono::steady_clock::now();
-        LCXCHECK(exchange(h, h->ybuf, n, h->dtype));
+        if (pattern == 1 && h->ypipe > 1) {
+            // the pipelined Y exchange hands the transport the library's SECOND stream: the rank-dependent pattern goes that way,
+            // ordered by events exactly as y_pass_pipelined orders a chunk - a hook that ignores its stream argument (or a
+            // transport that cannot run there) fails here, at first contact, instead of racing with the slot reductions later
+            LCXCHECK(ypipe_streams(h));
+            HIPCHECK(hipEventRecord(h->ypipe_ev[0], h->stream));
+            HIPCHECK(hipStreamWaitEvent(h->comm_stream, h->ypipe_ev[0], 0));
+            LCXCHECK(exchange_on(h, h->comm_stream, h->ybuf, n, h->dtype));
+            HIPCHECK(hipEventRecord(h->ypipe_ev[16], h->comm_stream));
+            HIPCHECK(hipStreamWaitEvent(h->stream, h->ypipe_ev[16], 0));
+        } else {
+            LCXCHECK(exchange(h, h->ybuf, n, h->dtype));
+        }
         HIPCHECK(hipStreamSynchronize(h->stream));
         secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (h->dtype == LCX_F32) hipLaunchKernelGGL((lcx::selftest_check_kernel<float>), dim3(grid), dim3(256), 0, h->stream, (const float*)h->ybuf, n, pattern, nr, res + 2 * pattern);
@@ -490,6 +503,8 @@ int lcx_set_world(lcx_ctx* h, int world) {
     h->world = world;
     h->exchange = world > 1;
     h->merged_agreed = -1;
+    h->y1_ready = h->w1_ready = h->yk_ready = h->grad_ready = h->early_grad = false;
+    h->have_direction = false;
     return LCX_OK;
 }
 
@@ -534,13 +549,13 @@ int lcx_timing_sample(lcx_ctx* h, int every) {
     NEED(h);
     if (every < 1) return fail(LCX_ERR_ARG, "lcx_timing_sample: every must be >= 1");
     h->t_every = every;
-    h->t_count = 0;
+    for (int k = 0; k < LCX_T_KINDS; ++k) h->t_count[k] = 0;
     return LCX_OK;
 }
 
 int lcx_timing_read(lcx_ctx* h, int kind, int64_t* launches, double* total_ms) {
     NEED(h);
-    if (kind < 0 || kind > 2) return fail(LCX_ERR_ARG, "kind must be 0, 1 or 2");
+    if (kind < 0 || kind >= LCX_T_KINDS) return fail(LCX_ERR_ARG, "lcx_timing_read: kind must be in [0, 7)");
     HIPCHECK(hipStreamSynchronize(h->stream));
     LCXCHECK(timing_collect(h));
     if (launches) *launches = h->t_launch[kind];
@@ -552,13 +567,13 @@ int lcx_timing_reset(lcx_ctx* h) {
     NEED(h);
     HIPCHECK(hipStreamSynchronize(h->stream));
     LCXCHECK(timing_collect(h));
-    for (int k = 0; k < 3; ++k) { h->t_launch[k] = 0; h->t_pass[k] = 0; h->t_ms[k] = 0.0; h->t_max[k] = 0.0; h->t_skipped[k] = 0; }
+    for (int k = 0; k < LCX_T_KINDS; ++k) { h->t_launch[k] = 0; h->t_pass[k] = 0; h->t_ms[k] = 0.0; h->t_max[k] = 0.0; h->t_skipped[k] = 0; }
     return LCX_OK;
 }
 
 int lcx_timing_passes(lcx_ctx* h, int kind, int64_t* passes) {
     NEED(h);
-    if (kind < 0 || kind > 2 || !passes) return fail(LCX_ERR_ARG, "lcx_timing_passes: bad argument");
+    if (kind < 0 || kind >= LCX_T_KINDS || !passes) return fail(LCX_ERR_ARG, "lcx_timing_passes: bad argument");
     *passes = h->t_pass[kind];
     return LCX_OK;
 }

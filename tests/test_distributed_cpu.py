@@ -156,3 +156,34 @@ print("BOUNDS_OK")
 ''' % (ROOT, free_port())
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and "BOUNDS_OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+
+
+def test_shard_boundaries_must_agree_across_the_ranks(tmp_path):
+    """Comm(bounds=...) "the same on every rank" is checked, not assumed: two gloo ranks with different boundaries - or one with
+    boundaries and one without, or one malformed - all raise on BOTH ranks, at construction, instead of hanging in a gather later;
+    matching boundaries pass."""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch.distributed as dist
+rank = int(sys.argv[1])
+dist.init_process_group("gloo", rank=rank, world_size=2, init_method="tcp://127.0.0.1:%d")
+from linearcorex_amd.comm import Comm
+cases = [([0, 4, 9], [0, 5, 9]), ([0, 4, 9], None), ([0, 4, 9], [0, 9, 4]), (None, [0, 4, 10])]
+for k, pair in enumerate(cases):
+    try:
+        Comm(bounds=pair[rank])
+        raise SystemExit("case %%d accepted on rank %%d" %% (k, rank))
+    except ValueError as e:
+        assert "differs across the ranks" in str(e) or "bounds must be" in str(e) or "another rank" in str(e), str(e)
+c = Comm(bounds=[0, 4, 9])
+assert c.shard(9) == ((0, 4) if rank == 0 else (4, 9))
+assert Comm().shard(9) == ((0, 4) if rank == 0 else (4, 9))
+dist.barrier()
+dist.destroy_process_group()
+print("AGREE_OK")
+''' % (ROOT, free_port())
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0 and "AGREE_OK" in out, (out[-500:], err[-2000:])

@@ -369,6 +369,13 @@ def test_bench_roofline_accounting_with_the_merged_pass():
     it = rf["iteration"]
     assert abs(it["achieved_TFLOPs"] - (0.63 + 1.63 + 2 * 1.0) * flops / 22.0e-3 / 1e12) < 1e-6 * it["achieved_TFLOPs"]
     assert 0.9 < it["fraction_of_step_inside_the_x_passes"] < 1.0
+    # the whole step and the slowest site against the same roof, beside `frac` (the dominant function alone)
+    assert abs(rf["step_frac"] - it["achieved_TFLOPs"] / 157.3) < 1e-9 and rf["frac_min_site"] <= rf["frac"]
+    assert abs(rf["frac_min_site"] - min(flops / 5.2e-3, 2 * flops / 9.7e-3) / 1e12 / 157.3) < 1e-9
+    line = bench.compact_line({"config": {}, "roofline": rf, "metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 0,
+                               "ms_per_step": 22.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                               "data": "synthetic"}, None)
+    assert abs(line["roofline"]["step_frac"] - rf["step_frac"]) < 1e-5 and abs(line["roofline"]["frac_min_site"] - rf["frac_min_site"]) < 1e-5
     # committed profiles are only quoted for the library they were taken from
     assert rf["traffic"] is None or rf["traffic_profile_matches_library"] is True
 

@@ -145,10 +145,70 @@ def cpu_baseline_resident(x, m, dtype, iters_per_stage):
         res = O.fit_ns_preprocessed(xt, m, seed=0, dtype=dtype, max_iter=iters_per_stage, tol=0.0, finish=False)
         t1 = time.perf_counter()
     n_it = len(res.history_tc)
-    return {"value": n_it / (t1 - t0), "unit": "iterations/s", "cores": threads, "kind": "port",
+    return {"value": n_it / (t1 - t0), "unit": "iterations/s", "cores": threads, "kind": "port", "host": _host_facts(),
             "sample": "%d iterations (%d per annealing stage x 7, stage changes included) of the same workload on the same X, "
                       "NumPy %s / %s, BLAS threads=%d, %.1f s" % (n_it, iters_per_stage, np.__version__, vendor, threads, t1 - t0),
             "trials_per_iteration": res.n_trials / max(1, n_it)}
+
+
+def _host_facts():
+    """what else competes for the cores the CPU figures are taken on"""
+    try:
+        la = [round(v, 2) for v in os.getloadavg()]
+    except OSError:
+        la = None
+    return {"loadavg_1_5_15": la, "usable_cores": _usable_cores(), "logical_cpus": os.cpu_count()}
+
+
+def cpu_fit_to_convergence(x, m, dtype):
+    """BASELINE.md section 3's CPU leg: wall-clock of the oracle's whole fit (reference defaults: tol 1e-5 per annealing stage,
+    linearcorex.py:136-155; preprocessing and the final detail moments included) on the same host matrix the device fit ran on."""
+    import numpy as np
+    from oracle import corex_oracle as O
+    before = _host_facts()
+    with _BlasPool() as pool:
+        t0 = time.perf_counter()
+        res = O.fit_ns(np.asarray(x), m, seed=0, dtype=dtype)
+        t1 = time.perf_counter()
+        threads, vendor = pool.threads, pool.vendor
+    n_it = len(res.history_tc)
+    return {"seconds": t1 - t0, "iterations": n_it, "trials": int(res.n_trials), "trials_per_iteration": res.n_trials / max(1, n_it),
+            "TC": float(res.history_tc[-1]), "tol": 1e-5, "cores": threads, "kind": "port",
+            "iterations_per_sec_incl_setup": n_it / (t1 - t0), "host": before,
+            "sample": "the whole fit of the oracle (NumPy %s / %s, BLAS threads=%d) on the same X" % (np.__version__, vendor, threads)}
+
+
+def c1_block(device):
+    """BASELINE.json configs[0]: tests/data/test_big5.csv (2000 x 50), n_hidden=5 - the latency-bound end of the path.  The matrix is
+    the one the reference's CLI parses from that file (vis_corex.py:496-512: header row and label column dropped, float), carried
+    as `x_raw` in tests/golden/g1_big5.npz (the reference's tree does not exist on the GPU box).  Whole fits with the reference's
+    defaults, device (second fit of a process: library loaded, allocator warm) and oracle, in both precisions."""
+    import numpy as np
+    from linearcorex_amd import Corex
+    from oracle import corex_oracle as O
+    x = np.load(os.path.join(ROOT, "tests", "golden", "g1_big5.npz"))["x_raw"].astype(np.float64)
+    blk = {"workload": "c1: tests/data/test_big5.csv %d x %d, n_hidden=5 (BASELINE.json configs[0]); whole fit, tol 1e-5" % x.shape,
+           "host": _host_facts()}
+    for tag, dt in (("f32", np.float32), ("f64", np.float64)):
+        Corex(n_hidden=5, seed=0, dtype=dt, device=device).fit(x)._backend.close()
+        t0 = time.perf_counter()
+        mdl = Corex(n_hidden=5, seed=0, dtype=dt, device=device).fit(x)
+        t1 = time.perf_counter()
+        n_it = len(mdl.history["TC"])
+        with _BlasPool() as pool:
+            t2 = time.perf_counter()
+            ref = O.fit_ns(x, 5, seed=0, dtype=dt)
+            t3 = time.perf_counter()
+            threads = pool.threads
+        n_ref = len(ref.history_tc)
+        blk[tag] = {"fit_seconds": t1 - t0, "iterations": n_it, "trials": int(mdl.stats["trials"]), "TC": float(mdl.tc),
+                    "us_per_iteration": (t1 - t0) / n_it * 1e6,
+                    "cpu_fit_seconds": t3 - t2, "cpu_iterations": n_ref, "cpu_trials": int(ref.n_trials), "cpu_TC": float(ref.history_tc[-1]),
+                    "cpu_us_per_iteration": (t3 - t2) / n_ref * 1e6, "cpu_cores": threads,
+                    "device_over_cpu_wall_clock": (t1 - t0) / (t3 - t2),
+                    "same_clusters": bool(np.array_equal(mdl.clusters(), ref.clusters()))}
+        mdl._backend.close()
+    return blk
 
 
 def _host_gaussian(n, v, dtype, seed):
@@ -226,6 +286,7 @@ def cpu_baseline_generated(n, v, m, dtype, budget_s, label, also=()):
         fit = int(0.6 * avail / (n * es))
         if fit < v_cpu:
             v_cpu = max(1000, fit // 1000 * 1000)
+    host_before = _host_facts()
     t_gen = time.perf_counter()
     x = _host_gaussian(n, v_cpu, dtype, seed=1)
     t_gen = time.perf_counter() - t_gen
@@ -258,7 +319,7 @@ def cpu_baseline_generated(n, v, m, dtype, budget_s, label, also=()):
         its = n_it / t_iter
         scale = float(v_cpu) / float(v_work)
         results.append({
-            "value": its * scale, "unit": "iterations/s", "cores": threads, "kind": "port",
+            "value": its * scale, "unit": "iterations/s", "cores": threads, "kind": "port", "host": host_before,
             "sample": "%s: %d iterations of the oracle loop (reference linearcorex.py:136-155), the first one of each of the "
                       "first %d annealing stages, on host-generated iid Gaussian X %d x %d %s, n_hidden %d; %.1f s in the "
                       "iterations (%.2f s each), %.1f s in the %d stage changes, %.1f s to draw X; NumPy %s / %s, BLAS threads=%d"
@@ -292,7 +353,7 @@ def make_model(workload, comm, world, rank, local_rank, line_search, keep_x=Fals
     model = Corex(n_hidden=m, seed=0, dtype=dtype, tol=0.0, max_iter=10 ** 9, device=local_rank, comm=comm,
                   line_search=line_search, f32_gemm=f32_gemm if tag == "f32" else None)
     x_host = None
-    if n * v_per * 8 <= (4 << 30):
+    if n * v_per * 8 <= int(os.environ.get("LCX_BENCH_GENERATE_ABOVE", 4 << 30)):      # (the variable: a test hook, see benchkit/workloads._shrink)
         # Gen-A: iid N(0,1); rank r draws its own columns from RandomState(1 + r)
         from linearcorex_amd.preprocess import preprocess as pp
         x_host = np.random.RandomState(1 + rank).randn(n, v_per)
@@ -318,9 +379,12 @@ def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_s
     model, be, x_host = make_model(workload, comm, world, rank, local_rank, line_search, keep_x,
                                    f32_gemm if f32_gemm is not None else args.f32_gemm)
 
-    def sync():
+    def sync_local():
         be.synchronize()
         torch.cuda.synchronize()
+
+    def sync():
+        sync_local()
         if comm is not None:
             comm.barrier()
             torch.cuda.synchronize()
@@ -360,7 +424,7 @@ def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_s
         model.ws = np.zeros((0, 0))
         model.history = {}
         sched = model._init_weights()
-        win, chg = [], []
+        win, chg, loc = [], [], []
         for i_eps, eps in enumerate(sched):
             sync()
             t0 = time.perf_counter()
@@ -379,6 +443,8 @@ def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_s
                 # more: the engine may start iteration k+1 before returning (as in a real fit); never past the window's
                 # end, so that exactly `steps` iterations of work lie between t0 and t1
                 model._iterate(more=k + 1 < steps)
+            sync_local()
+            t_loc = time.perf_counter()          # this rank's own stream has drained; the barrier below then waits for the slowest one
             sync()
             t1 = time.perf_counter()
             if timing and record:
@@ -387,9 +453,13 @@ def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_s
                 for k in stat_keys:
                     totals[k] += model.stats.get(k, 0) - before[k]
             win.append(t1 - t0)
+            loc.append(t_loc - t0)
+        local_windows.append(loc)
         return rank_max(win), rank_max(chg)
 
+    local_windows = []
     first_win, first_chg = walk(record=False)
+    local_windows.clear()
     est = sum(first_win)
     if repeats <= 0:
         repeats = 1 if est >= MIN_TIMED_SECONDS else min(60, int(math.ceil(MIN_TIMED_SECONDS / max(est, 1e-6))))
@@ -431,7 +501,47 @@ def measure(args, comm, world, rank, local_rank, workload, steps, warmup, line_s
                          selftest_seconds_per_y_allreduce=getattr(comm, "selftest_seconds", None),
                          line_search_in_library=bool(getattr(model, "_iterated_in_library", False))),
     }
+    local_per_step = float(np.median(np.asarray(local_windows), axis=0).sum() / (n_stages * steps)) if local_windows else per_step
+    res["exchange_profile"] = exchange_profile(be, comm, rank, timing, timed_iters, local_per_step, every)
     return res, model, be
+
+
+EXCHANGE_SITE_WHAT = {"y": "[Y | W.W^T] behind X.W^T (reference :247 -> :259)", "direction": "[Y_g | Bj] of _sig / the merged [Y' | W'.W'^T | Y_g] (:210, :302)",
+                      "scalars": "TC sums + tangent + H of an evaluation (:294, :301-305)", "small": "Bj before the merged pass, W'.W'^T of a trial by linearity, a restored H"}
+
+
+def exchange_profile(be, comm, rank, timing, timed_iters, local_per_step, every):
+    """Where an iteration's time goes besides the X passes when several ranks share the variables axis: the all-reduces the library
+    issued in the timed windows by site (HIP events on the stream that carries each collective: an all-reduce's duration includes its
+    wait for a slower rank), their count, and every rank's own ms_per_step up to the moment ITS stream drained (the window itself ends at
+    a barrier, so its length is the slowest rank's by construction).  None without exchange steps inside the library."""
+    import numpy as np
+    import torch
+    sites = be.timing_exchange_read() if (timing and hasattr(be, "timing_exchange_read")) else {}
+    if not any(v[0] for v in sites.values()):
+        return None
+    ms_it = {k: (issued / timed_iters) * (ms / n) for k, (issued, n, ms) in sites.items() if n}
+    prof = {"allreduces_per_iteration": sum(v[0] for v in sites.values()) / timed_iters,
+            "allreduces_per_iteration_by_site": {k: v[0] / timed_iters for k, v in sites.items() if v[0]},
+            "exchange_ms_per_iteration": dict(ms_it, total=sum(ms_it.values())),
+            "avg_us_by_site": {k: 1e3 * ms / n for k, (issued, n, ms) in sites.items() if n},
+            "timed_every_nth": every, "sites": {k: EXCHANGE_SITE_WHAT[k] for k in ms_it},
+            "ms_per_step_this_rank_until_its_stream_drained": local_per_step * 1e3}
+    vals = [local_per_step * 1e3, prof["exchange_ms_per_iteration"]["total"]]
+    if comm is not None and comm.world > 1:
+        import torch.distributed as dist
+        t = torch.tensor(vals, dtype=torch.float64, device="cuda")
+        parts = [torch.empty_like(t) for _ in range(comm.world)]
+        dist.all_gather(parts, t)
+        allv = np.asarray([[float(u) for u in p.cpu()] for p in parts])
+    else:
+        allv = np.asarray([vals])
+    prof["ms_per_step_by_rank"] = [float(u) for u in allv[:, 0]]
+    prof["ms_per_step_rank_min_median_max"] = [float(np.min(allv[:, 0])), float(np.median(allv[:, 0])), float(np.max(allv[:, 0]))]
+    prof["slowest_rank"] = int(np.argmax(allv[:, 0]))
+    # the all-reduce time of the FASTEST-waiting rank is the transfer itself; what the others show on top is rank skew
+    prof["exchange_ms_per_iteration_rank_min_median_max"] = [float(np.min(allv[:, 1])), float(np.median(allv[:, 1])), float(np.max(allv[:, 1]))]
+    return prof
 
 
 def roofline_of(workload, r, world):
@@ -551,7 +661,7 @@ def config_of(workload, r, world, line_search, force_exchange=False):
             # who issues the all-reduces of the exchange steps: "rccl" = the library, on a communicator the handle owns
             # (include/lcx.h lcx_comm_init); "hook" = the library through the caller's transport; None / "caller" = the
             # host-sequenced path (LCX_EXCHANGE=torch); kind "none" = one rank, no exchange steps
-            "exchange": r.get("exchange")}
+            "exchange": r.get("exchange"), "exchange_profile": r.get("exchange_profile")}
 
 
 
@@ -672,6 +782,43 @@ def covariance_block(model, be, label):
 # ------------------------------------------------------------------------------------------------------
 
 
+class _Park:
+    """Keeps the ranks that do not time the CPU baseline off the cores: they sleep-poll for a file rank 0 creates when it is done.
+    LCX_TEST_PARK=spin (test hook) makes them busy-wait instead - what waiting in an RCCL barrier amounts to - so that the difference
+    can be measured on a rehearsal."""
+
+    def __init__(self, world, rank):
+        self.world, self.rank = world, rank
+        self.path = os.path.join("/tmp", "lcx_bench_park_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+        self.spin = os.environ.get("LCX_TEST_PARK") == "spin"
+        self.how = ("busy-waiting (LCX_TEST_PARK=spin: emulates ranks waiting in an RCCL barrier)" if self.spin
+                    else "parked: sleeping poll (0.2 s) for a file rank 0 creates when the baseline is done")
+        if rank == 0 and os.path.exists(self.path):
+            os.remove(self.path)
+
+    def release(self):
+        if self.world > 1:
+            with open(self.path, "w") as f:
+                f.write("done\n")
+
+    def wait(self, limit_s=3600.0):
+        t_end, t_next = time.time() + limit_s, 0.0
+        while time.time() < t_end:
+            if self.spin:
+                if time.time() < t_next:
+                    continue
+                t_next = time.time() + 0.2
+            else:
+                time.sleep(0.2)
+            if os.path.exists(self.path):
+                return
+        raise SystemExit("bench.py: rank %d waited %d s for rank 0's CPU baseline" % (self.rank, int(limit_s)))
+
+    def cleanup(self):
+        if self.rank == 0 and os.path.exists(self.path):
+            os.remove(self.path)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -709,14 +856,20 @@ def main():
     backend = os.environ.get("LCX_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     comm = None
+    lean = bool(os.environ.get("LCX_BENCH_LEAN"))           # a fall-back attempt of the rank launcher: headline, same-shard pre-run, CPU baseline
     if world > 1:
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-        from linearcorex_amd.comm import Comm
-        comm = Comm()
+        from linearcorex_amd.comm import Comm, _FirstContactWatchdog
+        # torch.distributed's own first contact (its RCCL communicator comes up inside the first collective - the one Comm() issues)
+        # is bounded like the library's: a rank stuck here exits 3 and the launcher starts a fresh set (benchkit/launch.py)
+        with _FirstContactWatchdog(rank) as dog:
+            dog.step("torch.distributed.init_process_group(%r)" % backend)
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
+            dog.step("first collective on the process group (Comm(): shard bounds check)")
+            comm = Comm()
         if comm.world != args.gpus:
             sys.stderr.write("bench.py: the process group has %d ranks, --gpus %d\n" % (comm.world, args.gpus))
             return 2
@@ -769,13 +922,16 @@ def main():
     if same_shard_single is not None:
         cfg["single_gpu_same_shard"] = same_shard_single
         cfg["weak_scaling_vs_same_shard"] = r["its_per_s"] / same_shard_single["iterations_per_sec_slowest_rank"]
+        if cfg.get("exchange_profile"):
+            # the same shard without any exchange step, slowest rank: ms_per_step - this - the exchange sites = launch gaps of the exchange path
+            cfg["exchange_profile"]["compute_only_ms_per_step"] = 1e3 / same_shard_single["iterations_per_sec_slowest_rank"]
     if args.extras and world == 1 and comm is None and v_per <= 20000:
         cfg["get_covariance"] = covariance_block(model, be, head)
     be.close()
     model._backend = None
     del model, be
     generated = x_head is None
-    if args.extras and generated:
+    if args.extras and generated and not lean:
         # the other line searches of the same workload, reported beside the headline, never as `value`: "exact" = the
         # reference-shaped iteration (every trial two passes over X, :321), "exact-y" = trials after the first one of an
         # iteration take X.w_update^T by linearity (lcx_set_trial_reuse), "linear" = trials cost no pass over X
@@ -789,7 +945,7 @@ def main():
             be3.close()
             model3._backend = None
             del model3, be3
-    if args.extras and generated and tag == "f32":
+    if args.extras and generated and tag == "f32" and not lean:
         cfg[other_gemm_name(args)] = other_gemm_block(args, comm, world, rank, local_rank, head, args.steps, args.warmup, args.line_search, r)
     if args.extras and world == 1 and comm is None and generated and args.convergence_max_iter > 0:
         # BASELINE.json's second figure for the headline workload.  On the iid matrix of the throughput run there is nothing to
@@ -820,7 +976,9 @@ def main():
         "cpu_baseline": None,
     }
 
-    if args.extras:
+    if args.extras and lean:
+        out["config"]["lean"] = "fall-back attempt of the rank launcher: no c2_weak block, no other line searches, no split block"
+    if args.extras and not lean:
         # ---- nested block: BASELINE.json configs[1] (HBM-bound), 5k variables per GPU, its own fixed protocol ----
         c2_steps, c2_warm = 30, 5
         c2_ls = args.line_search if args.line_search != "linear" else "exact"
@@ -857,7 +1015,7 @@ def main():
             mdl = Corex(n_hidden=32, seed=0, dtype=np.float64, device=local_rank).fit(x2)
             t1 = time.perf_counter()
             blk["fit_to_convergence"] = {
-                "seconds": t1 - t0, "iterations": len(mdl.history["TC"]), "TC": float(mdl.tc), "tol": 1e-5,
+                "seconds": t1 - t0, "iterations": len(mdl.history["TC"]), "trials": int(mdl.stats["trials"]), "TC": float(mdl.tc), "tol": 1e-5,
                 "iterations_per_sec_incl_setup": len(mdl.history["TC"]) / (t1 - t0),
                 "trials_per_iteration": mdl.stats["trials"] / max(1, len(mdl.history["TC"]))}
             mdl._backend.close()
@@ -870,8 +1028,15 @@ def main():
             del mdl
         if rank == 0 and world == 1 and comm is None and args.cpu_iters_per_stage > 0 and x2 is not None:
             blk["cpu_baseline"] = cpu_baseline_resident(x2, 32, np.float64, args.cpu_iters_per_stage)
+            # "full convergence (tol=1e-5) for configs 1-2" on the host cores, beside fit_to_convergence
+            blk["cpu_fit_to_convergence"] = cpu_fit_to_convergence(x2, 32, np.float64)
+            if "fit_to_convergence" in blk:
+                blk["fit_to_convergence"]["cpu_over_device_wall_clock"] = (blk["cpu_fit_to_convergence"]["seconds"]
+                                                                           / blk["fit_to_convergence"]["seconds"])
         out["config"]["c2" if world == 1 else "c2_weak"] = blk
         del x2
+        if rank == 0 and world == 1 and comm is None and auto and args.cpu_iters_per_stage > 0:
+            out["config"]["c1"] = c1_block(local_rank)
 
         # ---- N=1, default workload: the one-GPU point of the weak-scaling series the --gpus N lines headline (configs[3]'s
         # shard), so that the series 1 -> 8 is self-contained in the driver's records ----
@@ -923,19 +1088,35 @@ def main():
                 except Exception as e:          # noqa: BLE001
                     out["config"]["c4_unsharded_one_gpu"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
-        # ---- CPU baseline of the headline workload: rank 0, the other ranks wait in the barrier below ----
-        if rank == 0 and args.cpu_seconds > 0 and (world == 1 and comm is None or world > 1):
-            if x_head is not None:
-                out["cpu_baseline"] = cpu_baseline_resident(x_head, m, dtype, max(1, args.cpu_iters_per_stage))
-            elif c4 is not None:
-                n4, v4, m4, _ = WORKLOADS["c4shard"]
-                both = cpu_baseline_generated(n, v_per, m, dtype, args.cpu_seconds, head, also=[("c4shard", m4, v4)])
-                out["cpu_baseline"], c4["cpu_baseline"] = both
-            else:
-                out["cpu_baseline"] = cpu_baseline_generated(n, v_per, m, dtype, args.cpu_seconds, head)
-            if world > 1:
-                out["cpu_baseline"]["sample"] += ("; one shard's iteration (n_variables per GPU = %d): `value` counts every "
-                                                  "rank's shard iterations, so the two are in the same unit" % v_per)
+    c4 = out["config"].get("c4shard") if isinstance(out["config"].get("c4shard"), dict) else None
+    parked = None
+    if args.extras and args.cpu_seconds > 0 and (world == 1 and comm is None or world > 1):
+        # ---- CPU baseline of the headline workload: rank 0.  The other ranks must not compete for the cores meanwhile: a rank
+        # waiting in an RCCL barrier sits in a device synchronisation, which the HIP runtime services by busy-waiting - N-1 spinning
+        # threads inside the cgroup whose quota the BLAS pool is sized by.  They are parked on a sleeping poll instead (a file in
+        # /tmp that rank 0 creates when the baseline is done; one node by the contract of --gpus N) ----
+        park = parked = _Park(world, rank)
+        if world > 1:
+            torch.cuda.synchronize()
+            comm.barrier()                      # everybody's GPU work is done; nothing is enqueued past this point
+        if rank == 0:
+            try:
+                if x_head is not None:
+                    out["cpu_baseline"] = cpu_baseline_resident(x_head, m, dtype, max(1, args.cpu_iters_per_stage))
+                elif c4 is not None:
+                    n4, v4, m4, _ = WORKLOADS["c4shard"]
+                    both = cpu_baseline_generated(n, v_per, m, dtype, args.cpu_seconds, head, also=[("c4shard", m4, v4)])
+                    out["cpu_baseline"], c4["cpu_baseline"] = both
+                else:
+                    out["cpu_baseline"] = cpu_baseline_generated(n, v_per, m, dtype, args.cpu_seconds, head)
+                if world > 1:
+                    out["cpu_baseline"]["sample"] += ("; one shard's iteration (n_variables per GPU = %d): `value` counts every "
+                                                      "rank's shard iterations, so the two are in the same unit" % v_per)
+                    out["cpu_baseline"]["other_ranks_while_timed"] = park.how
+            finally:
+                park.release()
+        else:
+            park.wait()
 
     out["series"] = series_of(out, head, world)
 
@@ -946,6 +1127,8 @@ def main():
     if comm is not None:
         import torch.distributed as dist
         dist.barrier()
+        if parked is not None:
+            parked.cleanup()
         libc.fflush(None)
         dist.destroy_process_group()
     libc.fflush(None)

@@ -1,45 +1,224 @@
 """`python bench.py --gpus N` typed without a launcher: start the N ranks as child processes - decided before anything in the parent
-touches torch or HIP (never re-exec a process that initialised the GPU) - relay rank 0's line, check n_gpus."""
+touches torch or HIP (never re-exec a process that initialised the GPU) - relay rank 0's line, check n_gpus.
+
+The job always ends in ONE JSON line.  A rank set that hangs (first contact with RCCL over xGMI is the step that has never run
+on hardware: a hang inside ncclCommInitRank is fatal by RCCL's own contract) or fails is killed as a process group and a FRESH child
+set is started on the next transport of the ladder below - never a restart inside a rank, never an exec:
+
+    engine   the library's own RCCL communicator per handle (include/lcx.h lcx_comm_init)          the product path
+    hook     the library issues the all-reduces through torch.distributed's RCCL group (LCX_EXCHANGE=hook)
+    torch    the host sequences the levels and all-reduces between them (LCX_EXCHANGE=torch)
+    gloo     LCX_EXCHANGE=hook over a gloo group (host-staged sums: slow, but it needs nothing of RCCL)   last resort, lean job
+
+Every attempt is recorded on the line (`exchange_attempts`: transport, rc, seconds, reason); if every rung fails the line carries
+`value: null`, the attempts and the exit code is non-zero.  Inside a rank first contact is bounded too (linearcorex_amd/comm.py,
+LCX_FIRST_CONTACT_TIMEOUT_S): a rank stuck there dumps its stacks and exits 3, which ends the attempt at once instead of at its
+wall-clock budget."""
 import json
 import os
+import signal
 import subprocess
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
+# (name, environment of the rank set, lean): lean = headline + same-shard pre-run + CPU baseline only (bench.py LCX_BENCH_LEAN)
+LADDER = (("engine", {}, False),
+          ("hook", {"LCX_EXCHANGE": "hook"}, False),
+          ("torch", {"LCX_EXCHANGE": "torch"}, False),
+          ("gloo", {"LCX_EXCHANGE": "hook", "LCX_BENCH_BACKEND": "gloo"}, True))
+ATTEMPT_S = 900.0          # LCX_BENCH_ATTEMPT_S: wall-clock budget of one rank set
+TOTAL_S = 1700.0           # LCX_BENCH_TOTAL_S: of the whole ladder (the driver allows a --gpus N job 1 800 s)
+FIRST_CONTACT_S = 180      # LCX_FIRST_CONTACT_TIMEOUT_S handed to the ranks unless the caller set one
 
-def spawn_ranks(args):
+
+def _free_port():
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH] + sys.argv[1:]
-    if os.environ.get("LCX_BENCH_DRY_SPAWN"):          # CPU test hook: show the launch, start nothing
-        sys.stdout.write(json.dumps({"spawn": cmd}) + "\n")
+        return sk.getsockname()[1]
+
+
+def rank_command(gpus, port, argv):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH] + list(argv)
+
+
+def ladder_for(env):
+    """The rungs this job may take, first to last: (name, environment laid over the caller's, lean).  A caller's own LCX_EXCHANGE /
+    LCX_BENCH_BACKEND is the first rung (that is what was asked for) and its backend is kept on the rungs below it (the tests: gloo,
+    several ranks on one GPU); rungs that would repeat a setting already tried are dropped.  LCX_BENCH_LADDER=engine,hook,... picks
+    rungs by name."""
+    asked = env.get("LCX_BENCH_LADDER")
+    if asked:
+        names = [t.strip() for t in asked.split(",") if t.strip()]
+        unknown = [n for n in names if n not in [r[0] for r in LADDER]]
+        if unknown:
+            raise SystemExit("bench.py: LCX_BENCH_LADDER names unknown rungs %r (known: %s)" % (unknown, ", ".join(r[0] for r in LADDER)))
+        return [r for n in names for r in LADDER if r[0] == n]
+    ex, bk = env.get("LCX_EXCHANGE"), env.get("LCX_BENCH_BACKEND")
+    if not (ex or bk):
+        return list(LADDER)
+    own = ", ".join("%s=%s" % kv for kv in (("LCX_EXCHANGE", ex), ("LCX_BENCH_BACKEND", bk)) if kv[1])
+    rungs, seen = [("caller (%s)" % own, {}, False)], {(ex or "engine", bk or "nccl")}
+    for name, extra, lean in LADDER[1:]:
+        eff = dict(extra)
+        if bk:
+            eff["LCX_BENCH_BACKEND"] = bk
+        key = (eff.get("LCX_EXCHANGE", ex or "engine"), eff.get("LCX_BENCH_BACKEND", "nccl"))
+        if key not in seen:
+            seen.add(key)
+            rungs.append((name, eff, lean))
+    return rungs
+
+
+def _tagged_pids(token):
+    """Processes of this user that carry the attempt's token in their environment: the ranks (torchrun starts each in a session of its
+    own, so the launcher's process group does not contain them) and anything they started."""
+    needle = ("LCX_BENCH_ATTEMPT_TOKEN=%s" % token).encode()
+    found = []
+    for name in os.listdir("/proc"):
+        if not name.isdigit() or int(name) == os.getpid():
+            continue
+        try:
+            with open("/proc/%s/environ" % name, "rb") as f:
+                if needle in f.read().split(b"\0"):
+                    found.append(int(name))
+        except OSError:
+            continue
+    return found
+
+
+def _end_rank_set(p, token, grace=15.0):
+    """SIGTERM to the launcher's process group (torchrun forwards it to its ranks), then SIGKILL to it and to every process that still
+    carries the attempt's token - exactly the processes this attempt started, found by a token only they have."""
+    for sig, wait in ((signal.SIGTERM, grace), (signal.SIGKILL, 5.0)):
+        if p.poll() is not None:
+            break
+        try:
+            os.killpg(p.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+        try:
+            p.wait(timeout=wait)
+        except subprocess.TimeoutExpired:
+            pass
+    deadline = time.time() + 10.0
+    while True:
+        left = _tagged_pids(token)
+        if not left or time.time() > deadline:
+            return left
+        for pid in left:
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+        time.sleep(0.2)
+
+
+def _last_json(text):
+    for ln in reversed([t for t in text.splitlines() if t.strip()]):
+        try:
+            rec = json.loads(ln)
+            if isinstance(rec, dict):
+                return rec
+        except ValueError:
+            continue
+    return None
+
+
+def run_attempt(cmd, env, budget_s):
+    """One rank set, launcher in a process group of its own.  -> (rc, or None when it was killed at its budget; seconds; stdout text)"""
+    t0 = time.time()
+    token = "%d-%d" % (os.getpid(), time.time_ns())
+    env = dict(env, LCX_BENCH_ATTEMPT_TOKEN=token)
+    p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=budget_s)
+        rc = p.returncode
+    except subprocess.TimeoutExpired:
+        rc = None
+        _end_rank_set(p, token)
+        try:
+            out, _ = p.communicate(timeout=5)
+        except Exception:          # noqa: BLE001 - the pipe of a killed child: whatever is there
+            out = b""
+    if rc != 0:
+        left = _end_rank_set(p, token, grace=2.0)          # a failed torchrun may leave ranks behind: none may meet the next rank set
+        if left:
+            sys.stderr.write("bench.py: processes of the failed attempt still alive: %r\n" % (left,))
+    return rc, time.time() - t0, (out or b"").decode(errors="replace")
+
+
+def spawn_ranks(args, argv=None, runner=run_attempt):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    base_env = dict(os.environ)
+    rungs = ladder_for(base_env)
+    attempt_s = float(base_env.get("LCX_BENCH_ATTEMPT_S", ATTEMPT_S))
+    total_s = float(base_env.get("LCX_BENCH_TOTAL_S", TOTAL_S))
+    dry = bool(base_env.get("LCX_BENCH_DRY_SPAWN"))
+    if dry:          # CPU test hook: show the launch (first rung) and the ladder, start nothing
+        sys.stdout.write(json.dumps({"spawn": rank_command(args.gpus, _free_port(), argv),
+                                     "ladder": [{"transport": n, "env": e, "lean": lean} for n, e, lean in rungs],
+                                     "attempt_s": attempt_s, "total_s": total_s}) + "\n")
         return 0
     rc = subprocess.call([sys.executable, os.path.join(ROOT, "__graft_entry__.py")], cwd=ROOT, stdout=sys.stderr)
     if rc != 0:
         sys.stderr.write("bench.py: building the HIP library failed\n")
         return rc
-    sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: launching the ranks as children: %s\n" % (args.gpus, " ".join(cmd)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE)
-    lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.strip()]
-    rec, raw = None, None
-    for ln in reversed(lines):
-        try:
-            rec, raw = json.loads(ln), ln
-            break
-        except ValueError:
+    t_job = time.time()
+    attempts, rec = [], None
+    for k, (name, extra, lean) in enumerate(rungs):
+        left = total_s - (time.time() - t_job)
+        if left < 60 and attempts:
+            attempts.append({"transport": name, "rc": None, "seconds": 0.0, "reason": "not started: %.0f s of the job's %.0f s left" % (left, total_s)})
             continue
-    if p.returncode != 0 or rec is None:
-        sys.stderr.write("bench.py: the rank launch failed (rc %d)\n%s\n" % (p.returncode, "\n".join(lines[-20:])))
-        return p.returncode or 1
-    if rec.get("n_gpus") != args.gpus:
-        sys.stderr.write("bench.py: asked for %d GPUs, the ranks report n_gpus=%r\n" % (args.gpus, rec.get("n_gpus")))
-        return 1
-    sys.stdout.write(raw.strip() + "\n")          # rank 0's compact line, byte for byte
+        budget = max(30.0, min(attempt_s, left - 30.0))
+        env = dict(base_env)
+        # The pool's host driver supports dmabuf IPC only: with the legacy mode hipIpcGetMemHandle fails ("invalid argument") and with it
+        # RCCL's intra-node P2P set-up and any device-tensor sharing between the ranks.  The GPU boxes export this already; the launcher
+        # only makes sure a caller's scrubbed environment does not lose it.
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("NCCL_DEBUG", "WARN")               # the first RCCL run on xGMI: its warnings belong in the record's stderr
+        env.setdefault("LCX_FIRST_CONTACT_TIMEOUT_S", str(FIRST_CONTACT_S))
+        for key, val in extra.items():
+            if val == "":
+                env.pop(key, None)
+            else:
+                env[key] = val
+        if lean or (k > 0 and budget < 0.5 * attempt_s):
+            env["LCX_BENCH_LEAN"] = "1"                     # what is left of the job's time does not fit the riders
+        env["LCX_BENCH_ATTEMPT"] = "%d:%s" % (k + 1, name)
+        env.setdefault("LCX_BENCH_LINE_RESERVE", "600")     # room on the 4 KB line for the attempts record added below
+        cmd = rank_command(args.gpus, _free_port(), argv)
+        sys.stderr.write("bench.py: --gpus %d, attempt %d (%s, <= %.0f s%s): %s\n"
+                         % (args.gpus, k + 1, name, budget, ", lean" if env.get("LCX_BENCH_LEAN") else "", " ".join(cmd)))
+        sys.stderr.flush()
+        rc, secs, out = runner(cmd, env, budget)
+        got = _last_json(out)
+        if rc is None:
+            reason = "killed after its wall-clock budget of %.0f s" % budget
+        elif rc != 0:
+            reason = "rank set exited with rc %d" % rc
+        elif got is None:
+            reason = "no JSON line on stdout"
+        elif got.get("n_gpus") != args.gpus:
+            reason = "the ranks report n_gpus=%r" % (got.get("n_gpus"),)
+        else:
+            reason = "ok"
+        attempts.append({"transport": name, "rc": rc, "seconds": round(secs, 1), "reason": reason})
+        if reason == "ok":
+            rec = got
+            break
+        sys.stderr.write("bench.py: attempt %d (%s) failed: %s\n%s\n" % (k + 1, name, reason, "\n".join(out.splitlines()[-20:])))
+    if rec is None:
+        rec = {"metric": "corex_fit_iterations_per_sec", "value": None, "unit": "fit iterations/s", "n_gpus": args.gpus, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic", "config": {"workload": "c4shard x %d GPUs: no rank set finished" % args.gpus},
+               "error": "every transport of the ladder failed; see exchange_attempts and stderr"}
+    rec["exchange_attempts"] = attempts
+    sys.stdout.write(json.dumps(rec, separators=(",", ":")) + "\n")
     sys.stdout.flush()
-    return 0
+    return 0 if attempts and attempts[-1]["reason"] == "ok" else 1

@@ -56,6 +56,15 @@ def compact_line(out, detail_path):
     c["x_layout"] = _pick(cfg, "bytes_resident", "x_layout")
     if cfg.get("force_exchange"):
         c["force_exchange"] = True
+    xp = cfg.get("exchange_profile")
+    if xp:
+        # several ranks (or --force-exchange): where the time outside the X passes goes - all-reduces by site, rank skew, the same shard alone
+        c["exchange_ms_per_iteration"] = _r(xp.get("exchange_ms_per_iteration"), 4)
+        c["allreduces_per_iteration"] = _r(xp.get("allreduces_per_iteration"), 4)
+        c["ms_per_step_rank_min_median_max"] = _r(xp.get("ms_per_step_rank_min_median_max"), 5)
+        c["exchange_ms_rank_min_median_max"] = _r(xp.get("exchange_ms_per_iteration_rank_min_median_max"), 4)
+        if xp.get("compute_only_ms_per_step") is not None:
+            c["compute_only_ms_per_step"] = _r(xp["compute_only_ms_per_step"], 5)
     riders = {
         # the other line searches of the same workload, reported beside `value`
         "reference_shaped_value": _pick(cfg, "reference_shaped", "fit_iterations_per_sec"),
@@ -94,6 +103,15 @@ def compact_line(out, detail_path):
             riders[name + "_f32_gemm_split_value"] = _pick(b, "f32_gemm_split", "fit_iterations_per_sec")
             riders[name + "_cpu_baseline_value"] = _pick(b, "cpu_baseline", "value")
             riders[name + "_fit_to_convergence_seconds"] = _pick(b, "fit_to_convergence", "seconds")
+            riders[name + "_cpu_fit_to_convergence_seconds"] = _pick(b, "cpu_fit_to_convergence", "seconds")
+            riders[name + "_exchange_ms_per_iteration"] = _pick(b, "exchange_profile", "exchange_ms_per_iteration", "total")
+            riders[name + "_allreduces_per_iteration"] = _pick(b, "exchange_profile", "allreduces_per_iteration")
+    # BASELINE.json configs[0] (big5, 2000 x 50): whole fits, device and oracle wall clock - the latency-bound end of the path
+    for tag in ("f32", "f64"):
+        riders["c1_fit_seconds" + ("" if tag == "f32" else "_f64")] = _pick(cfg, "c1", tag, "fit_seconds")
+        riders["c1_cpu_fit_seconds" + ("" if tag == "f32" else "_f64")] = _pick(cfg, "c1", tag, "cpu_fit_seconds")
+    riders["c1_iterations"] = _pick(cfg, "c1", "f32", "iterations")
+    riders["c1_cpu_iterations"] = _pick(cfg, "c1", "f32", "cpu_iterations")
     c.update({k: v for k, v in riders.items() if v is not None})
     c["detail"] = detail_path
     rl = out.get("roofline")
@@ -132,13 +150,15 @@ def emit(out, args, real_stdout):
     sys.stderr.flush()
     line = compact_line(out, rel)
     text = json.dumps(line, separators=(",", ":"))
+    # (the rank launcher adds `exchange_attempts` to the line it relays: LCX_BENCH_LINE_RESERVE bytes of the budget are its)
+    budget = args.max_line_bytes - int(os.environ.get("LCX_BENCH_LINE_RESERVE", "0") or 0)
     # a budget, not a hope: shed riders, then the sample sentence, until the line fits
-    droppable = [k for k in list(line["config"]) if k.endswith(("_cpu_baseline_value", "_fit_to_convergence_seconds", "_line_search",
-                                                                "_roofline_bound", "_ms_per_step", "_pass_roofline_frac"))]
-    while len(text) > args.max_line_bytes and droppable:
+    droppable = [k for k in list(line["config"]) if k.endswith(("_cpu_baseline_value", "_line_search", "_roofline_bound", "_ms_per_step",
+                                                                "_pass_roofline_frac", "_f64", "_cpu_iterations", "_allreduces_per_iteration"))]
+    while len(text) > budget and droppable:
         line["config"].pop(droppable.pop())
         text = json.dumps(line, separators=(",", ":"))
-    if len(text) > args.max_line_bytes and line.get("cpu_baseline"):
+    if len(text) > budget and line.get("cpu_baseline"):
         line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:120]
         text = json.dumps(line, separators=(",", ":"))
     os.write(real_stdout, (text + "\n").encode())

@@ -35,6 +35,23 @@ DESCRIPTION = {
 }
 
 
+def _shrink():
+    """LCX_BENCH_SHRINK=k (test hook): the BASELINE workloads with n_variables / k, so that the WHOLE default job - every nested block,
+    CPU legs included - runs live in the GPU suite in about a minute (tests/test_bench_gpu.py).  The shapes then select other kernels
+    than the real configs: the hook tests bench.py, not the kernels, and says so on the line."""
+    import os
+    k = int(os.environ.get("LCX_BENCH_SHRINK", "0") or 0)
+    if k > 1:
+        for name in ("c2", "c3", "c4shard"):
+            n, v, m, tag = WORKLOADS[name]
+            WORKLOADS[name] = (n, max(256, v // k // 64 * 64), m, tag)
+            DESCRIPTION[name] = DESCRIPTION[name] + " SHRUNK: n_variables / %d (LCX_BENCH_SHRINK, a test of bench.py - not a BASELINE figure)" % k
+    return k
+
+
+SHRUNK = _shrink()
+
+
 def _adhoc(name):
     """'NxVxM:f32' -> WORKLOADS entry (probing shapes outside BASELINE.json)."""
     if name not in WORKLOADS and name != "auto":

@@ -11,6 +11,55 @@ from __future__ import annotations
 import numpy as np
 
 
+class _FirstContactWatchdog:
+    """Bounds first contact with a transport (LCX_FIRST_CONTACT_TIMEOUT_S, default 600 s, 0 = unbounded).  A rank that blocks inside
+    ncclCommInitRank - or in the group collectives around it because ANOTHER rank blocks there - cannot be rescued in-process (RCCL's own
+    contract), and waiting forever turns one bad link into a job that never reports: after the limit the rank says which step it was in,
+    dumps the stacks of all its threads and exits with code 3.  Whoever started the ranks sees a non-zero exit and may start a FRESH set
+    on another transport (benchkit/launch.py does); nothing is retried inside this process."""
+
+    def __init__(self, rank):
+        import os
+        try:
+            self.seconds = float(os.environ.get("LCX_FIRST_CONTACT_TIMEOUT_S", "600"))
+        except ValueError:
+            self.seconds = 600.0
+        self.rank, self.what, self.timer, self.t0 = rank, "start", None, 0.0
+
+    def step(self, what):
+        self.what = what
+
+    def _fire(self):
+        import faulthandler
+        import os
+        import sys
+        import time
+        sys.stderr.write("linearcorex_amd: rank %d: first contact with the exchange transport did not finish within %.0f s "
+                         "(LCX_FIRST_CONTACT_TIMEOUT_S); step in progress for this rank: %s (%.0f s since bind_engine began).  "
+                         "Stacks of all threads follow; exiting with code 3 - start a fresh set of ranks, e.g. with LCX_EXCHANGE=hook\n"
+                         % (self.rank, self.seconds, self.what, time.time() - self.t0))
+        try:
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            sys.stderr.flush()
+        finally:
+            os._exit(3)
+
+    def __enter__(self):
+        import threading
+        import time
+        self.t0 = time.time()
+        if self.seconds > 0:
+            self.timer = threading.Timer(self.seconds, self._fire)
+            self.timer.daemon = True
+            self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timer is not None:
+            self.timer.cancel()
+        return False
+
+
 class Comm:
     def __init__(self, group=None, always_exchange=False, bounds=None):
         """always_exchange: issue every exchange step even in a group of one rank (the all-reduces are then
@@ -84,10 +133,15 @@ class Comm:
         through this group's broadcast - and issues ncclAllReduce on its stream.  Any other backend (gloo in the tests, two
         ranks sharing one GPU): a hook that runs this group's all_reduce on a zero-copy view of the device buffer."""
         import os
-        import sys
         mode = os.environ.get("LCX_EXCHANGE", "engine")
         if mode == "torch" or not self.exchange or not hasattr(backend, "comm_init"):
             return None
+        with _FirstContactWatchdog(self.rank) as dog:
+            return self._bind_engine(backend, first_contact, mode, dog)
+
+    def _bind_engine(self, backend, first_contact, mode, dog):
+        import os
+        import sys
         import torch
         # first_contact=False: a temporary handle beside one whose transport already passed (same group, same kind).  That holds
         # literally for the hook (the same process group carries it); an RCCL handle owns a brand-new communicator from a fresh
@@ -136,15 +190,18 @@ class Comm:
             err, box = None, [None]
             forced = os.environ.get("LCX_TEST_FAIL_COMM_INIT", "")
             can = True
+            dog.step("librccl probe (dlopen)")
             try:
                 if forced == "probe" or forced == "probe:%d" % self.rank:
                     raise RuntimeError("LCX_TEST_FAIL_COMM_INIT=%s" % forced)
                 backend.comm_probe()
             except Exception as e:           # noqa: BLE001
                 can, err = False, "librccl probe: %s" % e
+            dog.step("agreeing on the librccl probe (all_reduce on the process group)")
             if agreed(not can, dev):
                 err = err or "another rank cannot load librccl"
             else:
+                dog.step("unique id: ncclGetUniqueId on rank 0, broadcast on the process group")
                 if self.rank == 0:
                     try:
                         if forced == "id":
@@ -155,18 +212,25 @@ class Comm:
                 src = self._dist.get_global_rank(self.group, 0) if self.group is not None else 0
                 self._dist.broadcast_object_list(box, src=src, group=self.group, device=dev)
                 if box[0] is not None:
+                    dog.step("ncclCommInitRank of the handle's own communicator (lcx_comm_init)")
                     try:
                         if forced == "init":
                             raise RuntimeError("LCX_TEST_FAIL_COMM_INIT=init")
+                        if os.environ.get("LCX_TEST_HANG_COMM_INIT") in ("all", str(self.rank)):
+                            import time          # test hook: this rank never arrives in ncclCommInitRank - the others block inside it
+                            time.sleep(10 ** 6)
                         backend.comm_init(self.world, self.rank, box[0])
                     except Exception as e:       # noqa: BLE001
                         err = "lcx_comm_init: %s" % e
                 elif err is None:
                     err = "rank 0 could not draw an RCCL unique id"
+                dog.step("agreeing on the outcome of ncclCommInitRank (all_reduce on the process group)")
                 if agreed(err is not None, dev):
                     err = err or "another rank failed"
                 else:
+                    dog.step("lcx_comm_selftest on the handle's RCCL communicator")
                     err = selftest(dev, "rccl")
+                    dog.step("agreeing on the self-test (all_reduce on the process group)")
                     if agreed(err is not None, dev):
                         err = err or "another rank failed the self-test"
             if err is None:
@@ -199,6 +263,7 @@ class Comm:
         backend.set_exchange_hook(allreduce)
         # the hook transport gets the same first-contact test; here a failure has no fall-back left: raise on every rank
         dev = torch.device("cuda", backend.device)
+        dog.step("lcx_comm_selftest through the hook (this process group's all_reduce)")
         err = selftest(dev, "hook")
         if agreed(err is not None, dev):
             raise RuntimeError("linearcorex_amd: rank %d: the exchange transport failed its self-test (%s)"

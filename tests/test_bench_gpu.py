@@ -161,3 +161,92 @@ def test_two_ranks_full_line_has_the_same_shard_reference_and_the_c2_block(tmp_p
     c2 = d["config"]["c2_weak"]
     assert c2["n_variables_total"] == 10000 and c2["n_variables_per_gpu"] == 5000 and c2["roofline"]["bound"] == "hbm"
     assert "linear_trial_mode" not in c2          # (several ranks: the other line searches of c2 are skipped)
+    # where the time outside the X passes goes: the all-reduces by site (HIP events on the engine's stream), their count, every rank's own
+    # ms_per_step, and the same shard without exchange steps - on the line and in the record
+    c = line["config"]
+    assert c["exchange"] == "hook" and c["allreduces_per_iteration"] >= 3.0 and c["compute_only_ms_per_step"] > 0
+    xs = c["exchange_ms_per_iteration"]
+    assert set(xs) >= {"y", "direction", "scalars", "total"} and all(v >= 0 for v in xs.values())
+    assert xs["total"] == pytest.approx(sum(v for k, v in xs.items() if k != "total"), rel=1e-3)
+    lo, med, hi = c["ms_per_step_rank_min_median_max"]
+    assert 0 < lo <= med <= hi <= line["ms_per_step"] * 1.05
+    assert c["c2_weak_exchange_ms_per_iteration"] > 0
+    xp = d["config"]["exchange_profile"]
+    assert len(xp["ms_per_step_by_rank"]) == 2 and xp["slowest_rank"] in (0, 1)
+    assert xp["allreduces_per_iteration_by_site"]["scalars"] >= 1.0 and xp["avg_us_by_site"]["y"] > 0
+    # 1 + 2T collectives per iteration: Y + scalars per evaluated trial, one for the direction
+    t = d["config"]["line_search_trials_per_iteration"]
+    assert xp["allreduces_per_iteration"] == pytest.approx(1 + 2 * t, abs=0.35)
+    assert d["cpu_baseline"]["other_ranks_while_timed"].startswith("parked") and d["cpu_baseline"]["host"]["usable_cores"] >= 1
+    assert [a["reason"] for a in line["exchange_attempts"]] == ["ok"]
+
+
+def test_default_job_live_every_nested_block(tmp_path):
+    """The driver's bench command - `python bench.py` with every nested block, CPU legs included - run LIVE, on shrunk workloads
+    (LCX_BENCH_SHRINK: n_variables / 25, so the whole job takes about a minute; the kernels the real shapes select are covered by
+    test_c3_headline_alone and the parity tests).  What the committed-record tests on the CPU side can only re-parse is produced here:
+    the c2 block with both convergence legs, the c1 block (BASELINE configs[0], device and oracle wall clock), the config-4 shard
+    block, the opt-in line searches and arithmetic, both CPU baselines, the whole-step roofline fraction, the series."""
+    detail = str(tmp_path / "detail.json")
+    env = dict(os.environ, LCX_BENCH_SHRINK="25", LCX_BENCH_GENERATE_ABOVE=str(10 ** 8))
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--cpu-seconds", "2",
+                        "--cpu-iters-per-stage", "2", "--convergence-max-iter", "3", "--convergence-planted-max-iter", "40",
+                        "--detail-out", detail], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    wall = time.time() - t0
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    line = _one_json_line(p.stdout)
+    c, rl = line["config"], line["roofline"]
+    assert c["workload"].startswith("c3:") and "SHRUNK" in c["workload"] and line["n_gpus"] == 1 and line["value"] > 0
+    # roofline: the dominant kernel, the slowest pass site and the whole step against the same roof
+    assert 0 < rl["step_frac"] < 1 and 0 < rl["frac_min_site"] <= rl["frac"] < 1 and rl["step_frac"] <= rl["frac"] * 1.2
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
+    # riders of every nested block
+    for k in ("c2_value", "c2_roofline_frac", "c2_roofline_step_frac", "c2_cpu_baseline_value", "c2_fit_to_convergence_seconds",
+              "c2_cpu_fit_to_convergence_seconds", "c1_fit_seconds", "c1_cpu_fit_seconds", "c4shard_value", "c4shard_roofline_frac",
+              "c4shard_roofline_step_frac", "c4shard_roofline_frac_min_site", "exact_y_value", "linear_value",
+              "fit_to_convergence_planted_seconds"):
+        assert c.get(k, 0) > 0, k
+    sr = _series_ok(line)
+    assert sr["workload"] == "c4shard" and sr["efficiency"] == 1.0 and sr["per_gpu_value"] == pytest.approx(c["c4shard_value"], rel=1e-4)
+    d = _detail(detail, p.stderr)["config"]
+    c2, c1, c4 = d["c2"], d["c1"], d["c4shard"]
+    # BASELINE.md section 3's convergence leg: the same X, the same tolerance, device and oracle side by side - and they agree
+    dev, cpu = c2["fit_to_convergence"], c2["cpu_fit_to_convergence"]
+    assert dev["iterations"] == cpu["iterations"] and dev["trials"] == cpu["trials"] and abs(dev["TC"] - cpu["TC"]) < 1e-6 * max(1.0, abs(cpu["TC"]))
+    assert dev["seconds"] > 0 and cpu["seconds"] > 0 and cpu["cores"] >= 1 and cpu["host"]["usable_cores"] >= 1
+    assert c2["cpu_baseline"]["host"]["loadavg_1_5_15"] is not None
+    for tag in ("f32", "f64"):
+        b = c1[tag]
+        assert b["fit_seconds"] > 0 and b["cpu_fit_seconds"] > 0 and b["same_clusters"] is True
+    assert c1["f64"]["iterations"] == c1["f64"]["cpu_iterations"] == 261 and c1["f64"]["trials"] == c1["f64"]["cpu_trials"]
+    assert abs(c1["f32"]["iterations"] - c1["f32"]["cpu_iterations"]) <= 0.06 * c1["f32"]["cpu_iterations"]
+    assert c4["cpu_baseline"]["value"] > 0 and c4["roofline"]["step_frac"] > 0 and "f32_gemm_split" in c4
+    for blk in (d, c4):
+        assert blk["later_trials_by_linearity"]["fit_iterations_per_sec"] > 0 and blk["linear_trial_mode"]["fit_iterations_per_sec"] > 0
+    assert d["fit_to_convergence_planted"]["iterations"] > 0 and d["get_covariance_c5_standin"]["n_variables"] == 20000
+    assert wall < 240, wall
+
+
+def test_a_hung_first_contact_ends_in_a_line_from_the_next_transport(tmp_path):
+    """The first multi-GPU job must not be lost to a bad first contact: `python bench.py --gpus 2` whose rank 1 never arrives in
+    ncclCommInitRank (LCX_TEST_HANG_COMM_INIT=1; two gloo ranks on this one GPU, the RCCL negotiation forced) - the watchdog inside
+    the ranks ends attempt 1 (exit code 3, stacks on stderr), the launcher starts a FRESH rank set on LCX_EXCHANGE=hook, and the job
+    ends in ONE JSON line that records both attempts.  (A rank set that nothing ends from the inside is killed at the launcher's
+    wall-clock budget: tests/test_host_logic_cpu.py::test_rank_launcher_kills_a_hung_rank_set_and_its_detached_children.)"""
+    env = dict(_two_rank_env(), LCX_TEST_FORCE_RCCL_NEGOTIATION="1", LCX_TEST_HANG_COMM_INIT="1", LCX_FIRST_CONTACT_TIMEOUT_S="12",
+               LCX_BENCH_ATTEMPT_S="100")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + FAST, cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    wall = time.time() - t0
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode == 0, err[-3000:]
+    d = _one_json_line(p.stdout)
+    att = d["exchange_attempts"]
+    assert [a["transport"] for a in att] == ["caller (LCX_BENCH_BACKEND=gloo)", "hook"], att
+    assert att[0]["rc"] not in (0, None) and att[0]["reason"].startswith("rank set exited") and att[0]["seconds"] < 60
+    assert att[1]["rc"] == 0 and att[1]["reason"] == "ok"
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["exchange"] == "hook"
+    assert "first contact with the exchange transport did not finish" in err and "ncclCommInitRank" in err and "File " in err
+    assert wall < 120, wall

@@ -338,6 +338,132 @@ def test_bench_gpus_n_spawns_the_ranks_itself():
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd
     assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    plan = json.loads(p.stdout.strip().splitlines()[-1])
+    assert [r["transport"] for r in plan["ladder"]] == ["engine", "hook", "torch", "gloo"] and plan["attempt_s"] == 900.0
+
+
+def test_rank_launcher_attempt_ladder(monkeypatch, capsys):
+    """benchkit/launch.py: a `--gpus N` job always ends in ONE line.  A rank set that is killed at its budget or exits non-zero is
+    followed by a FRESH set on the next transport (engine -> hook -> torch -> gloo); every attempt is on the line; when every rung
+    fails the line says so (value null, rc != 0).  The rank sets are faked here (the real thing: tests/test_bench_gpu.py)."""
+    import argparse
+    import json
+    from benchkit import launch
+    monkeypatch.setattr(launch.subprocess, "call", lambda *a, **k: 0)         # the build step
+    for k in ("LCX_EXCHANGE", "LCX_BENCH_BACKEND", "LCX_BENCH_LADDER", "LCX_BENCH_DRY_SPAWN", "LCX_BENCH_ATTEMPT_S", "LCX_BENCH_TOTAL_S"):
+        monkeypatch.delenv(k, raising=False)
+    args = argparse.Namespace(gpus=4, steps=20, warmup=5)
+    good = json.dumps({"metric": "corex_fit_iterations_per_sec", "value": 70.0, "n_gpus": 4, "config": {"exchange": "hook"}})
+    seen = []
+
+    def runner_factory(outcomes):
+        it = iter(outcomes)
+
+        def runner(cmd, env, budget):
+            seen.append({"exchange": env.get("LCX_EXCHANGE"), "backend": env.get("LCX_BENCH_BACKEND"), "lean": env.get("LCX_BENCH_LEAN"),
+                         "budget": budget, "ipc": env.get("HSA_ENABLE_IPC_MODE_LEGACY"), "nccl_debug": env.get("NCCL_DEBUG"),
+                         "fc": env.get("LCX_FIRST_CONTACT_TIMEOUT_S"), "reserve": env.get("LCX_BENCH_LINE_RESERVE"), "cmd": cmd})
+            return next(it)
+        return runner
+
+    # 1. the first rank set hangs (killed at its budget), the second fails, the third answers
+    rc = launch.spawn_ranks(args, argv=["--gpus", "4"], runner=runner_factory([(None, 900.0, "RCCL banner\n"), (3, 12.0, ""), (0, 200.0, "noise\n" + good + "\n")]))
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert rc == 0 and line["value"] == 70.0 and line["n_gpus"] == 4
+    att = line["exchange_attempts"]
+    assert [a["transport"] for a in att] == ["engine", "hook", "torch"] and [a["rc"] for a in att] == [None, 3, 0]
+    assert "killed after its wall-clock budget" in att[0]["reason"] and "rc 3" in att[1]["reason"] and att[2]["reason"] == "ok"
+    assert [t["exchange"] for t in seen] == [None, "hook", "torch"] and all(t["backend"] is None for t in seen)
+    assert seen[0]["budget"] == 900.0 and all(t["ipc"] == "0" and t["nccl_debug"] == "WARN" and t["fc"] == "180" for t in seen)
+    assert all(t["cmd"][1:3] == ["-m", "torch.distributed.run"] and t["cmd"][-2:] == ["--gpus", "4"] for t in seen)
+    assert len({t["cmd"][t["cmd"].index("--master-port") + 1] for t in seen}) == 3          # a fresh rendezvous per attempt
+    assert int(seen[0]["reserve"]) >= len(json.dumps(att))                                  # the attempts fit the line's reserve
+    # 2. a wrong world on the line is a failure of that attempt, a clean first attempt needs no second one
+    seen.clear()
+    rc = launch.spawn_ranks(args, argv=["--gpus", "4"], runner=runner_factory([(0, 100.0, good.replace('"n_gpus": 4', '"n_gpus": 1')), (0, 150.0, good)]))
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert rc == 0 and [a["reason"] == "ok" for a in line["exchange_attempts"]] == [False, True] and "n_gpus=1" in line["exchange_attempts"][0]["reason"]
+    seen.clear()
+    rc = launch.spawn_ranks(args, argv=["--gpus", "4"], runner=runner_factory([(0, 100.0, good)]))
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert rc == 0 and len(seen) == 1 and line["exchange_attempts"] == [{"transport": "engine", "rc": 0, "seconds": 100.0, "reason": "ok"}]
+    # 3. nothing works: still one line, with the attempts, value null, rc != 0; the last rung is gloo and lean
+    seen.clear()
+    rc = launch.spawn_ranks(args, argv=["--gpus", "4"], runner=runner_factory([(1, 5.0, "")] * 4))
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert rc != 0 and line["value"] is None and line["n_gpus"] == 4 and len(line["exchange_attempts"]) == 4 and "error" in line
+    assert (seen[3]["exchange"], seen[3]["backend"], seen[3]["lean"]) == ("hook", "gloo", "1") and seen[0]["lean"] is None
+    # 4. the job's total budget bounds the ladder: what does not fit is recorded as not started
+    seen.clear()
+    monkeypatch.setenv("LCX_BENCH_TOTAL_S", "100")
+    monkeypatch.setenv("LCX_BENCH_ATTEMPT_S", "80")
+    clock = [1000.0]
+    monkeypatch.setattr(launch.time, "time", lambda: clock[0])
+
+    def slow_runner(cmd, env, budget):
+        seen.append(budget)
+        clock[0] += budget
+        return None, budget, ""
+    rc = launch.spawn_ranks(args, argv=["--gpus", "4"], runner=slow_runner)
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert rc != 0 and seen == [70.0] and [a["reason"].startswith("not started") for a in line["exchange_attempts"]] == [False, True, True, True]
+    # 5. a caller's own transport is the first rung and its backend stays on the rungs below
+    monkeypatch.delenv("LCX_BENCH_TOTAL_S")
+    assert [r[0] for r in launch.ladder_for({"LCX_BENCH_BACKEND": "gloo"})] == ["caller (LCX_BENCH_BACKEND=gloo)", "hook", "torch"]
+    assert all(r[1].get("LCX_BENCH_BACKEND") == "gloo" for r in launch.ladder_for({"LCX_BENCH_BACKEND": "gloo"})[1:])
+    assert [r[0] for r in launch.ladder_for({"LCX_EXCHANGE": "hook"})] == ["caller (LCX_EXCHANGE=hook)", "torch", "gloo"]
+    assert [r[0] for r in launch.ladder_for({"LCX_BENCH_LADDER": "hook,gloo"})] == ["hook", "gloo"]
+
+
+def test_rank_launcher_kills_a_hung_rank_set_and_its_detached_children(tmp_path):
+    """benchkit/launch.run_attempt on real processes: a launcher whose child lives in a session of its own (as torchrun's ranks do)
+    and ignores SIGTERM is gone after the attempt's budget - found by the token only this attempt's processes carry."""
+    import sys
+    import time
+    from benchkit import launch
+    script = tmp_path / "hang.py"
+    script.write_text(
+        "import os, signal, subprocess, sys, time\n"
+        "if len(sys.argv) > 1:\n"
+        "    signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+        "    open(sys.argv[1], 'w').write(str(os.getpid()))\n"
+        "    time.sleep(600)\n"
+        "subprocess.Popen([sys.executable, __file__, %r], start_new_session=True)\n"
+        "print('started', flush=True)\n"
+        "time.sleep(600)\n" % str(tmp_path / "child.pid"))
+    t0 = time.time()
+    rc, secs, out = launch.run_attempt([sys.executable, str(script)], dict(os.environ), 3.0)
+    assert rc is None and "started" in out and time.time() - t0 < 40
+    pid = int((tmp_path / "child.pid").read_text())
+    time.sleep(0.3)
+    alive = os.path.exists("/proc/%d" % pid) and "Z" not in open("/proc/%d/stat" % pid).read().split(")")[-1].split()[0]
+    assert not alive
+    # and a rank set that simply answers is passed through
+    rc, secs, out = launch.run_attempt([sys.executable, "-c", "print('{\"n_gpus\": 2}')"], dict(os.environ), 30.0)
+    assert rc == 0 and launch._last_json(out) == {"n_gpus": 2}
+
+
+def test_first_contact_watchdog_ends_a_stuck_rank():
+    """linearcorex_amd/comm.py: first contact is bounded (LCX_FIRST_CONTACT_TIMEOUT_S) - a rank stuck in it names the step, dumps its
+    stacks and exits 3 (a child process here: the watchdog ends the process by design)."""
+    import subprocess
+    import sys
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "from linearcorex_amd.comm import _FirstContactWatchdog\n"
+            "with _FirstContactWatchdog(5) as dog:\n"
+            "    dog.step('ncclCommInitRank of the handle (test)')\n"
+            "    time.sleep(60)\n"
+            "print('survived')\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LCX_FIRST_CONTACT_TIMEOUT_S="1.5"), capture_output=True, text=True,
+                       timeout=60)
+    assert p.returncode == 3 and "survived" not in p.stdout
+    assert "rank 5" in p.stderr and "ncclCommInitRank of the handle (test)" in p.stderr and "time.sleep" not in p.stdout
+    assert "File " in p.stderr                         # the stacks
+    # within the limit nothing happens; 0 disables it
+    for limit in ("30", "0"):
+        p = subprocess.run([sys.executable, "-c", code.replace("time.sleep(60)", "time.sleep(0.2)")],
+                           env=dict(os.environ, LCX_FIRST_CONTACT_TIMEOUT_S=limit), capture_output=True, text=True, timeout=60)
+        assert p.returncode == 0 and "survived" in p.stdout
 
 
 def test_bench_refuses_a_world_that_does_not_match_gpus():

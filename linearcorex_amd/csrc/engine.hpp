@@ -263,6 +263,14 @@ struct lcx_ctx {
     // chunk's slot reduction (and, for the wave-split kernels, behind its own row chunk of the pass); default off
     int ypipe;
     bool ypipe_force_pass;
+    // LCX_Y_PIPELINE=signal[:n[:poll]]: ONE pass launch that sums its own slots and signals every row chunk of the summed Y through a
+    // signal word (gemm_kernels.hpp, ChunkSig); the second stream waits on the word (hipStreamWaitValue32, or poll_signal_kernel
+    // with ":poll" / where the runtime has no wait-value) and all-reduces the chunk while the pass goes on.  Wave-split kernels only
+    bool ypipe_signal, ypipe_poll;
+    unsigned int *sig_counters;         // [row tiles of 16 rows + SIG_MAX_CHUNKS + 1]: tile tickets, chunk tickets, poll error word
+    int64_t sig_tiles;
+    unsigned int* sig_flag[SIG_MAX_CHUNKS];
+    unsigned int sig_epoch;
     hipStream_t comm_stream;
     hipEvent_t ypipe_ev[17];
     Transport tr;               // in-library exchange (kind != 0): every level sums what it produced over the ranks itself
@@ -292,6 +300,33 @@ static int ypipe_streams(lcx_ctx* h) {
     if (h->comm_stream) return LCX_OK;
     HIPCHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
     for (auto& e : h->ypipe_ev) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return LCX_OK;
+}
+// the tickets and signal words of the in-launch chunk signalling, created on first use.  A signal word is its own 8-byte allocation of
+// signal memory (what hipStreamWaitValue32 may wait on); where the runtime refuses that, plain device memory and the polling kernel
+static int ypipe_signals(lcx_ctx* h) {
+    if (h->sig_counters) return LCX_OK;
+    h->sig_tiles = h->Npad / 16;
+    const size_t words = (size_t)h->sig_tiles + SIG_MAX_CHUNKS + 1;
+    HIPCHECK(hipMalloc((void**)&h->sig_counters, words * sizeof(unsigned int)));
+    HIPCHECK(hipMemsetAsync(h->sig_counters, 0, words * sizeof(unsigned int), h->stream));
+    int can_wait = 0;
+    if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, h->device) != hipSuccess) can_wait = 0;
+    (void)hipGetLastError();
+    for (int c = 0; c < SIG_MAX_CHUNKS; ++c) {
+        void* p = nullptr;
+        if (!h->ypipe_poll && can_wait && hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) != hipSuccess) p = nullptr;
+        (void)hipGetLastError();
+        if (!p) {
+            h->ypipe_poll = true;                 // no signal memory: every chunk polls (mixing the two would be legal but pointless)
+            HIPCHECK(hipMalloc(&p, 8));
+        }
+        h->sig_flag[c] = (unsigned int*)p;
+        hipLaunchKernelGGL(init_signal_kernel, dim3(1), dim3(1), 0, h->stream, h->sig_flag[c], 0u);
+        KCHECK();
+    }
+    h->sig_epoch = 0;
+    HIPCHECK(hipStreamSynchronize(h->stream));
     return LCX_OK;
 }
 // the library can sequence whole iterations when it does not depend on the caller for the sums

@@ -271,6 +271,92 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const 
                                                  blockIdx.x, blockIdx.y);
 }
 
+// ---- in-launch chunk signalling (the pipelined Y exchange, LCX_Y_PIPELINE=signal: DESIGN.md section 6) -----------------------
+// ONE launch of a wave-split pass that also sums its own partial slots and tells a second stream, row chunk by row chunk, when the
+// summed Y of that chunk is complete - so that chunk c's all-reduce overlaps the pass over chunk c+1 without cutting the pass
+// into launches that cannot fill the chip.  The 1-D grid walks (row tile, slot) with the slot fastest: the blocks of a row tile are
+// dispatched together and the tiles in chunk order.  Hand-offs: a block publishes its partial tile (release, agent scope) and
+// draws a ticket of its row tile; the block that draws the last one (acquire) sums the tile's slots in slot order - the order of
+// reduce_partials_kernel, hence the same bits - into the summed Y, and draws a ticket of the tile's chunk; the last tile of a chunk
+// stores the launch's epoch into the chunk's signal word (system scope: the command processor of the waiting stream reads it).
+// Counters return to zero by themselves; epochs only grow.
+constexpr int SIG_MAX_CHUNKS = 16;
+struct ChunkSig {
+    unsigned int* tile_cnt;                  // [row tiles] partial slots written
+    unsigned int* chunk_cnt;                 // [chunks] row tiles summed
+    unsigned int* flag[SIG_MAX_CHUNKS];      // one signal word per chunk (hipMallocSignalMemory)
+    int tile_begin[SIG_MAX_CHUNKS + 1];      // chunk c = row tiles [tile_begin[c], tile_begin[c + 1])
+    int nchunks;
+    unsigned int epoch;
+    void* ysum;                              // the summed Y ([rows][Mp]); with one slot the pass writes it directly
+};
+
+template <typename T, int TILE, int NTHREADS>
+__device__ __forceinline__ void chunk_signal_tail(const ChunkSig& sg, const T* __restrict__ part, int64_t slot_stride, int tile,
+                                                  int nslots) {
+    __shared__ int sig_last;
+    const int tid = threadIdx.x;
+    if (nslots > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int t = __hip_atomic_fetch_add(&sg.tile_cnt[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (t == (unsigned int)(nslots - 1));
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(&sg.tile_cnt[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            sig_last = last;
+        }
+        __syncthreads();
+        if (!sig_last) return;
+        T* ys = reinterpret_cast<T*>(sg.ysum) + (int64_t)tile * TILE;
+        const T* p0 = part + (int64_t)tile * TILE;
+        for (int idx = tid; idx < TILE; idx += NTHREADS) {
+            T s = p0[idx];
+            for (int k = 1; k < nslots; ++k) s += p0[(int64_t)k * slot_stride + idx];
+            ys[idx] = s;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        int c = 0;
+        while (c + 1 < sg.nchunks && tile >= sg.tile_begin[c + 1]) ++c;
+        const unsigned int want = (unsigned int)(sg.tile_begin[c + 1] - sg.tile_begin[c]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(&sg.chunk_cnt[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == want - 1) {
+            __hip_atomic_store(&sg.chunk_cnt[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");          // every tile of the chunk happened before the signal
+            __hip_atomic_store(sg.flag[c], sg.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+template <typename T, int CT, int RT, int KW, int U = 4>
+__global__ void __launch_bounds__(64 * KW)
+gemm_tn_sig_kernel(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const T* __restrict__ B, T* __restrict__ out,
+                   int64_t out_rows, int kgroups, int nsplit, ChunkSig sg) {
+    const int tile = (int)(blockIdx.x / (unsigned)nsplit), slot = (int)(blockIdx.x % (unsigned)nsplit);
+    tn_body<T, CT, RT, KW, false, U, false>(A, lda, tile_stride, B, nullptr, out, out_rows, kgroups, nsplit, tile, slot);
+    chunk_signal_tail<T, 16 * RT * 16 * CT, 64 * KW>(sg, out, out_rows * (16 * CT), tile, nsplit);
+}
+
+// a stand-in for a stream wait-value where the runtime has none: one lane polls the chunk's signal word (bounded: ~4 s, then the
+// error word is set and the stream goes on - the caller checks it)
+static __global__ void poll_signal_kernel(const unsigned int* flag, unsigned int epoch, unsigned int* err) {
+    long spins = 0;
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1L << 24)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+}
+static __global__ void init_signal_kernel(unsigned int* flag, unsigned int value) { __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 // Two independent Gram contractions (A^T.A of two [K][Mp] arrays) in one launch: blockIdx.z picks
 // the problem, grid.y = max of the two split counts.
 template <typename T> struct GramProblem {
@@ -671,9 +757,9 @@ gemm_cr_kernel(const T* __restrict__ A, int64_t lda /* PANEL: the panel stride *
 //     operand reads are LDS broadcasts.  No block barrier in the main loop.
 // ------------------------------------------------------------------------------------------------
 template <int CT, int RT, int KW, int U, bool NT = false, bool SERIAL = false>
-__global__ void __launch_bounds__(64 * KW)
-gemm_tn4_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, double* __restrict__ out,
-                int64_t out_rows, int kgroups /* K / 16 */, int nsplit, const int* __restrict__ skip_flag) {
+__device__ __forceinline__ void
+tn4_body(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, double* __restrict__ out,
+         int64_t out_rows, int kgroups /* K / 16 */, int nsplit, const int tile_x, const int split_y) {
     constexpr int Mp = 16 * CT, NG = Mp / 4;
     constexpr int ROWS = 4 * U;                      // rows of B per group
     constexpr int LDB = Mp + 4;                      // padded LDS row (doubles)
@@ -684,12 +770,11 @@ gemm_tn4_kernel(const double* __restrict__ A, int64_t lda, const double* __restr
     typedef double d2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* smem = reinterpret_cast<double*>(smem_raw);
-    if (skip_flag != nullptr && *skip_flag != 0) return;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4, jj = lane & 3;
-    const int64_t v0 = (int64_t)blockIdx.x * (16 * RT);
-    const int part = blockIdx.y * KW + wave, nparts = nsplit * KW;
+    const int64_t v0 = (int64_t)tile_x * (16 * RT);
+    const int part = split_y * KW + wave, nparts = nsplit * KW;
     const int ng = kgroups * 4 / U;                  // groups of 4*U rows
     const int g0 = (int)((int64_t)ng * part / nparts), g1 = (int)((int64_t)ng * (part + 1) / nparts);
     const int cnt = g1 - g0;
@@ -763,7 +848,7 @@ gemm_tn4_kernel(const double* __restrict__ A, int64_t lda, const double* __restr
     constexpr int TILE = 16 * RT * Mp;
     __syncthreads();                                  // the B strips are dead: the same LDS holds the tiles now
     const int row = ((lane & 15) >> 2) * 4 + (lane >> 4);          // blk*4 + i: the column of X inside the 16-wide piece
-    double* dst = out + ((int64_t)blockIdx.y * out_rows + v0) * Mp;
+    double* dst = out + ((int64_t)split_y * out_rows + v0) * Mp;
     if (SERIAL) {
         // one tile of LDS: the waves add their tiles one after the other (fixed order), so that wide tiles do not
         // cost KW times their size in LDS (occupancy)
@@ -795,6 +880,23 @@ gemm_tn4_kernel(const double* __restrict__ A, int64_t lda, const double* __restr
         for (int w = 1; w < KW; ++w) sacc += smem[w * TILE + idx];
         dst[idx] = sacc;
     }
+}
+template <int CT, int RT, int KW, int U, bool NT = false, bool SERIAL = false>
+__global__ void __launch_bounds__(64 * KW)
+gemm_tn4_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, double* __restrict__ out,
+                int64_t out_rows, int kgroups /* K / 16 */, int nsplit, const int* __restrict__ skip_flag) {
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+    tn4_body<CT, RT, KW, U, NT, SERIAL>(A, lda, B, out, out_rows, kgroups, nsplit, blockIdx.x, blockIdx.y);
+}
+// the same pass with in-launch chunk signalling (see ChunkSig): 1-D grid over (row tile, slot), slot fastest
+template <int CT, int RT, int KW, int U>
+__global__ void __launch_bounds__(64 * KW)
+gemm_tn4_sig_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, double* __restrict__ out,
+                    int64_t out_rows, int kgroups, int nsplit, ChunkSig sg) {
+    const int tile = (int)(blockIdx.x / (unsigned)nsplit), slot = (int)(blockIdx.x % (unsigned)nsplit);
+    tn4_body<CT, RT, KW, U, true, false>(A, lda, B, out, out_rows, kgroups, nsplit, tile, slot);
+    __syncthreads();
+    chunk_signal_tail<double, 16 * RT * 16 * CT, 64 * KW>(sg, out, out_rows * (16 * CT), tile, nsplit);
 }
 // dynamic LDS of gemm_tn4: max(B strips, reduction tiles)
 template <int CT, int RT, int KW, int U, bool SERIAL = false> struct Tn4Lds {

@@ -360,24 +360,98 @@ int Impl<T, CT>::y_pass_pipelined(lcx_ctx* h, const T* w, bool with_bj) {
     } else {
         LCXCHECK(gram_w(h, w));
     }
-    TimingPair tp;
-    LCXCHECK(timing_begin(h, 0, &tp));
+    const int site = with_bj ? LCX_T_AR_DIR : LCX_T_AR_Y;
     T* dst = h->nt_S > 1 ? P<T>(h->ypart) : P<T>(h->ybuf);
+    if constexpr (!WIDE) {
+        // in-launch chunk signalling: the wave-split kernels with the plain slot reduction (the wide reduction sums in another order)
+        if (h->ypipe_signal && !(h->panel || h->single_copy || h->nt_ct) && h->nt_S < WIDE_SPLITS) {
+            LCXCHECK(ypipe_signals(h));
+            constexpr int RTT = Geo<T, CT>::TN_RT;          // row tile of the pass: 16 * RTT rows (a divisor of the 64-row chunk unit)
+            ChunkSig sg;
+            sg.tile_cnt = h->sig_counters;
+            sg.chunk_cnt = h->sig_counters + h->sig_tiles;
+            for (int c = 0; c < SIG_MAX_CHUNKS; ++c) sg.flag[c] = h->sig_flag[c];
+            for (int c = 0; c <= C; ++c) sg.tile_begin[c] = (int)(tiles * c / C * tile / (16 * RTT));
+            sg.nchunks = C;
+            sg.epoch = ++h->sig_epoch;
+            sg.ysum = h->ybuf;
+            const unsigned nblocks = (unsigned)(h->Npad / (16 * RTT)) * (unsigned)h->nt_S;
+            TimingPair tp;
+            LCXCHECK(timing_begin(h, 0, &tp));
+            bool launched = false;
+            if (h->f64_4x4) {
+                if constexpr (sizeof(T) == 8 && CT <= 2) {
+                    constexpr int U4 = 4;
+                    if (h->nt_KW == 2) {
+                        const size_t lds = Tn4Lds<CT, RTT, 2, U4>::bytes;
+                        LCXCHECK(allow_lds(gemm_tn4_sig_kernel<CT, RTT, 2, U4>, lds));
+                        hipLaunchKernelGGL((gemm_tn4_sig_kernel<CT, RTT, 2, U4>), dim3(nblocks), dim3(128), lds, h->stream, P<double>(h->XT), h->Npad,
+                                           (const double*)w, (double*)dst, h->Npad, (int)(h->ldx / 16), h->nt_S, sg);
+                    } else {
+                        const size_t lds = Tn4Lds<CT, RTT, 4, U4>::bytes;
+                        LCXCHECK(allow_lds(gemm_tn4_sig_kernel<CT, RTT, 4, U4>, lds));
+                        hipLaunchKernelGGL((gemm_tn4_sig_kernel<CT, RTT, 4, U4>), dim3(nblocks), dim3(256), lds, h->stream, P<double>(h->XT), h->Npad,
+                                           (const double*)w, (double*)dst, h->Npad, (int)(h->ldx / 16), h->nt_S, sg);
+                    }
+                    launched = true;
+                }
+            } else {
+                int kw = h->nt_KW;
+                if (kw > 4 && CT >= 16) kw = 4;
+                const size_t lds = (size_t)kw * 16 * RTT * 16 * CT * sizeof(T);
+#define LCX_SIG_LAUNCH(KWV)                                                                                                              \
+    {                                                                                                                                    \
+        LCXCHECK(allow_lds(gemm_tn_sig_kernel<T, CT, RTT, KWV>, lds));                                                                    \
+        hipLaunchKernelGGL((gemm_tn_sig_kernel<T, CT, RTT, KWV>), dim3(nblocks), dim3(64 * KWV), lds, h->stream, P<T>(h->XT), h->Npad,     \
+                           (int64_t)(16 * RTT), w, dst, h->Npad, (int)(h->ldx / 16), h->nt_S, sg);                                         \
+    }
+                switch (kw) {
+                    case 1: LCX_SIG_LAUNCH(1); break;
+                    case 2: LCX_SIG_LAUNCH(2); break;
+                    case 4: LCX_SIG_LAUNCH(4); break;
+                    default: LCX_SIG_LAUNCH(MaxKw<CT>::v); break;
+                }
+#undef LCX_SIG_LAUNCH
+                launched = true;
+            }
+            if (launched) {
+                KCHECK();
+                LCXCHECK(timing_end(h, 0, &tp));
+                unsigned int* err = h->sig_counters + h->sig_tiles + SIG_MAX_CHUNKS;
+                for (int c = 0; c < C; ++c) {
+                    const int64_t r0 = tiles * c / C * tile, r1 = tiles * (c + 1) / C * tile;
+                    if (h->ypipe_poll) {
+                        hipLaunchKernelGGL(poll_signal_kernel, dim3(1), dim3(1), 0, h->comm_stream, h->sig_flag[c], sg.epoch, err);
+                        KCHECK();
+                    } else {
+                        HIPCHECK(hipStreamWaitValue32(h->comm_stream, h->sig_flag[c], sg.epoch, hipStreamWaitValueGte, 0xFFFFFFFFu));
+                    }
+                    const int64_t count = (r1 - r0) * Mp + (c == C - 1 ? (int64_t)Mp * Mp : 0);
+                    LCXCHECK(exchange_site_on(h, h->comm_stream, site, P<T>(h->ybuf) + r0 * Mp, count, DT));
+                }
+                HIPCHECK(hipEventRecord(h->ypipe_ev[16], h->comm_stream));
+                HIPCHECK(hipStreamWaitEvent(h->stream, h->ypipe_ev[16], 0));
+                return LCX_OK;
+            }
+        }
+    }
+    TimingPair tp;
+    tp.kind = -1;
+    // (per-chunk launches of the pass: the pair would also span the slot reductions between them - the pass is counted, not timed)
+    if (!chunk_pass) LCXCHECK(timing_begin(h, 0, &tp));
+    else if (h->timing) h->t_pass[0] += 1;
     if (!chunk_pass) {
         LCXCHECK(nt_pass(h, w, nullptr, dst));
         LCXCHECK(timing_end(h, 0, &tp));
     }
     for (int c = 0; c < C; ++c) {
         const int64_t r0 = tiles * c / C * tile, r1 = tiles * (c + 1) / C * tile;
-        if (chunk_pass) {
-            LCXCHECK(nt_pass(h, w, nullptr, dst, r0, r1 - r0));
-            if (c == C - 1) LCXCHECK(timing_end(h, 0, &tp));
-        }
+        if (chunk_pass) LCXCHECK(nt_pass(h, w, nullptr, dst, r0, r1 - r0));
         LCXCHECK(nt_reduce(h, nullptr, (T*)nullptr, r0 * Mp, (r1 - r0) * Mp));
         HIPCHECK(hipEventRecord(h->ypipe_ev[c], h->stream));
         HIPCHECK(hipStreamWaitEvent(h->comm_stream, h->ypipe_ev[c], 0));
         const int64_t count = (r1 - r0) * Mp + (c == C - 1 ? (int64_t)Mp * Mp : 0);
-        LCXCHECK(exchange_site_on(h, h->comm_stream, with_bj ? LCX_T_AR_DIR : LCX_T_AR_Y, P<T>(h->ybuf) + r0 * Mp, count, DT));
+        LCXCHECK(exchange_site_on(h, h->comm_stream, site, P<T>(h->ybuf) + r0 * Mp, count, DT));
     }
     HIPCHECK(hipEventRecord(h->ypipe_ev[16], h->comm_stream));
     HIPCHECK(hipStreamWaitEvent(h->stream, h->ypipe_ev[16], 0));

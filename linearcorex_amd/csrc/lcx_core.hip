@@ -143,14 +143,19 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     h->merged_agreed = -1;
     h->ypipe = 0;
     {
-        const char* e = getenv("LCX_Y_PIPELINE");           // "chunks" (4 row chunks), "chunks:n" (n <= 16), "chunks:n:pass"
-        h->ypipe_force_pass = false;
-        if (e && !strncmp(e, "chunks", 6)) {
+        // "chunks" (4 row chunks), "chunks:n" (n <= 16), "chunks:n:pass" (per-chunk launches of the pass: tests);
+        // "signal[:n[:poll]]": one pass launch with in-launch chunk signalling (engine.hpp, ypipe_signal)
+        const char* e = getenv("LCX_Y_PIPELINE");
+        h->ypipe_force_pass = h->ypipe_signal = h->ypipe_poll = false;
+        const bool chunks = e && !strncmp(e, "chunks", 6), signal = e && !strncmp(e, "signal", 6);
+        if (chunks || signal) {
             h->ypipe = e[6] == ':' ? atoi(e + 7) : 4;
             if (h->ypipe < 2) h->ypipe = 0;
             if (h->ypipe > 16) h->ypipe = 16;
             const char* f = e[6] == ':' ? strchr(e + 7, ':') : nullptr;
-            h->ypipe_force_pass = f && !strcmp(f, ":pass");
+            h->ypipe_force_pass = chunks && f && !strcmp(f, ":pass");
+            h->ypipe_signal = signal && h->ypipe > 1;
+            h->ypipe_poll = signal && f && !strcmp(f, ":poll");
         }
     }
 #undef A_
@@ -201,6 +206,10 @@ int lcx_destroy(lcx_ctx* h) {
         (void)hipStreamDestroy(h->comm_stream);
     }
     if (h->tr.kind == 1 && h->tr.comm) (void)rccl().CommDestroy(h->tr.comm);
+    if (h->sig_counters) {
+        (void)hipFree(h->sig_counters);
+        for (auto& f : h->sig_flag) if (f) (void)hipFree(f);
+    }
     void* ptrs[] = {h->X, h->XT, h->Wt[0], h->Wt[1], h->grad, h->update, h->sgrad, h->scratch, h->ydir, h->ddir, h->ybuf_own, h->sbuf_own,
                     h->gw, h->y2part, h->bjg, h->bsp,
                     h->ypart, h->dpart, h->gpart, h->gpartw, h->tcpart, h->bjpart, h->tanpart, h->detpart, h->ryinv, h->invwork,

@@ -13,9 +13,9 @@
 #   env_ab <wl> <VAR> <a> <b> [n]  bench --no-extras under VAR=a / VAR=b alternating on one box   -> gpurun_out/<tag>_env_ab_<wl>_<VAR>.txt
 #   kernel_rows <wl> <VAR> <val>   rocprofv3 kernel rows + launch gaps of bench --no-extras under VAR=val
 #   probe <name> [args]            build tools/<name>.hip and run it                        -> gpurun_out/<tag>_<name>_<args>.txt
-# TAG (environment, default r05) prefixes the outputs.
+# TAG (environment, default r06) prefixes the outputs.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 cd $R; mkdir -p gpurun_out
 recipe=$1; shift
 case "$recipe" in

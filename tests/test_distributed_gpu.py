@@ -157,7 +157,8 @@ x, _ = O.gen_planted(400, 331, 5, seed=2)
 for syn in (False, True):
     ref = (O.fit_syn if syn else O.fit_ns)(x, 5, seed=0, dtype=np.float64, max_iter=40)
     runs = {}
-    for mode in ("engine", "torch", "hook", "fallback-probe", "fallback-id", "fallback-init", "fallback-selftest", "pipe-chunks:3", "pipe-chunks:3:pass"):
+    for mode in ("engine", "torch", "hook", "fallback-probe", "fallback-id", "fallback-init", "fallback-selftest", "pipe-chunks:3", "pipe-chunks:3:pass",
+                 "pipe-signal:3", "pipe-signal:4:poll"):
         # ("pipe-...": the engine's own RCCL communicator with the N x m all-reduces in row chunks on the library's second stream - real
         # asynchronous ncclAllReduce launches behind events, where the gloo hook of the multi-rank tests blocks the host)
         os.environ["LCX_EXCHANGE"] = "engine" if mode.startswith(("fallback", "pipe")) else mode
@@ -188,7 +189,8 @@ for syn in (False, True):
         runs[mode] = (h, out.ws.copy(), y, out.stats["trials"], info["allreduces_issued"])
         out._backend.close()
     os.environ["LCX_Y_PIPELINE"] = ""
-    for other in ("torch", "hook", "fallback-probe", "fallback-id", "fallback-init", "fallback-selftest", "pipe-chunks:3", "pipe-chunks:3:pass"):
+    for other in ("torch", "hook", "fallback-probe", "fallback-id", "fallback-init", "fallback-selftest", "pipe-chunks:3", "pipe-chunks:3:pass",
+                 "pipe-signal:3", "pipe-signal:4:poll"):
         assert np.array_equal(runs["engine"][0], runs[other][0]) and np.array_equal(runs["engine"][1], runs[other][1]), other
         assert np.array_equal(runs["engine"][2], runs[other][2]) and runs["engine"][3] == runs[other][3], other
 # the self-test itself, driven directly: it refuses a handle without a transport, and a transport that does not SUM is caught
@@ -417,7 +419,10 @@ def test_pipelined_y_allreduce_is_bit_identical(tag, m, gemm, tmp_path, monkeypa
     if gemm:
         monkeypatch.setenv("LCX_GEMM", gemm)
     runs = {}
-    for mode in ("off", "chunks:5:pass"):      # (":pass": per-chunk launches of the pass even where a chunk cannot fill the chip)
+    # (":pass": per-chunk launches of the pass even where a chunk cannot fill the chip; "signal": ONE launch of the pass that sums its own
+    # slots and signals each row chunk to the second stream - a stream wait-value, or the polling kernel)
+    modes = ("chunks:5:pass", "signal:5", "signal:3:poll")
+    for mode in ("off",) + modes:
         out = tmp_path / mode.replace(":", "_")
         out.mkdir()
         _launch_uneven(out, n, m, iters, tag, bounds, extra_env=None if mode == "off" else {"LCX_Y_PIPELINE": mode})
@@ -425,9 +430,10 @@ def test_pipelined_y_allreduce_is_bit_identical(tag, m, gemm, tmp_path, monkeypa
         assert str(runs[mode]["transport"]) == "hook" and bool(runs[mode]["in_library"])
     off = runs["off"]
     assert len(off["history"]) == 7 * iters and np.all(np.isfinite(off["history"]))
-    for mode in ("chunks:5:pass",):
+    for mode in modes:
         r = runs[mode]
         assert np.array_equal(r["history"], off["history"]) and np.array_equal(r["ws"], off["ws"]), mode
         assert np.array_equal(r["rho"], off["rho"]) and np.array_equal(r["y"], off["y"]) and int(r["trials"]) == int(off["trials"])
-        # 5 all-reduces per N x m exchange instead of one
-        assert int(r["allreduces"]) > int(off["allreduces"]) + 4 * 7 * iters, (int(r["allreduces"]), int(off["allreduces"]))
+        # 5 (3) all-reduces per N x m exchange instead of one
+        extra = int(mode.split(":")[1]) - 1
+        assert int(r["allreduces"]) > int(off["allreduces"]) + extra * 7 * iters, (mode, int(r["allreduces"]), int(off["allreduces"]))

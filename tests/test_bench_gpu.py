@@ -234,7 +234,7 @@ def test_a_hung_first_contact_ends_in_a_line_from_the_next_transport(tmp_path):
     the ranks ends attempt 1 (exit code 3, stacks on stderr), the launcher starts a FRESH rank set on LCX_EXCHANGE=hook, and the job
     ends in ONE JSON line that records both attempts.  (A rank set that nothing ends from the inside is killed at the launcher's
     wall-clock budget: tests/test_host_logic_cpu.py::test_rank_launcher_kills_a_hung_rank_set_and_its_detached_children.)"""
-    env = dict(_two_rank_env(), LCX_TEST_FORCE_RCCL_NEGOTIATION="1", LCX_TEST_HANG_COMM_INIT="1", LCX_FIRST_CONTACT_TIMEOUT_S="12",
+    env = dict(_two_rank_env(), LCX_TEST_FORCE_RCCL_NEGOTIATION="1", LCX_TEST_HANG_COMM_INIT="1", LCX_FIRST_CONTACT_TIMEOUT_S="6",
                LCX_BENCH_ATTEMPT_S="100")
     t0 = time.time()
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + FAST, cwd=ROOT, env=env,

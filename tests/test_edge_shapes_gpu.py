@@ -99,7 +99,8 @@ def test_abi_misuse_returns_status_codes():
     out = (C.c_double * 8)()
     assert lib.lcx_covariance_rows(be.h, C.c_double(0.0), None, 0, 1, None) == ARG
     assert lib.lcx_covariance_rows(be.h, C.c_double(0.0), C.cast(out, C.c_void_p), 39, 5, C.cast(out, C.c_void_p)) == ARG   # rows past the end
-    assert lib.lcx_timing_read(be.h, 5, None, None) == ARG
+    assert lib.lcx_timing_read(be.h, 7, None, None) == ARG and lib.lcx_timing_read(be.h, -1, None, None) == ARG      # sites 0 .. 6
+    assert lib.lcx_timing_read(be.h, 6, None, None) == 0
     assert lib.lcx_syn_update_a(be.h) == STATE                                # before any synergistic moments
     buf = C.create_string_buffer(8)
     assert lib.lcx_kernel_name(be.h, 0, buf, 8) == ARG                        # buffer too small

@@ -11,6 +11,7 @@
 #   two_ranks [bench args]         the driver's --gpus 2 command rehearsed on ONE GPU (two ranks share GPU 0 over gloo)
 #   n_ranks <N> <head> [args]     the driver's --gpus N command on ONE GPU at a reduced shard (N ranks share GPU 0 over gloo)
 #   env_ab <wl> <VAR> <a> <b> [n]  bench --no-extras under VAR=a / VAR=b alternating on one box   -> gpurun_out/<tag>_env_ab_<wl>_<VAR>.txt
+#   env_list <wl> <VAR> <n> <v>... the same for any number of values ("-" = unset), exchange sites printed; bench args after "--"
 #   kernel_rows <wl> <VAR> <val>   rocprofv3 kernel rows + launch gaps of bench --no-extras under VAR=val
 #   probe <name> [args]            build tools/<name>.hip and run it                        -> gpurun_out/<tag>_<name>_<args>.txt
 # TAG (environment, default r06) prefixes the outputs.
@@ -80,6 +81,22 @@ print('$wl $ls', round(d['value'],2), 'it/s', round(d['ms_per_step'],3), 'ms; X 
       python -c "
 import json; d=json.load(open('gpurun_out/${TAG}_ab.json')); c=d['config']
 print('$WL $VAR=$val', round(d['value'],2), 'it/s', round(d['ms_per_step'],4), 'ms; X passes', round(c['x_passes_per_iteration'],3), 'trials', round(c['line_search_trials_per_iteration'],4), 'walks', c['windows']['ms_per_step_walk_min_median_max'], 'frac', round(d['roofline']['frac'],4))" | tee -a $OUT
+      grep -o '"final_TC": [-0-9.e+]*' gpurun_out/bench_detail.json | head -1 | tee -a $OUT
+    done; done ;;
+  env_list)
+    # the same, any number of values, alternating on ONE box, with the exchange sites of the line (config.exchange_ms_per_iteration):
+    #   env_list <wl> <VAR> <rounds> <val> [<val> ...] [-- bench args]   ("-" = VAR unset)  -> gpurun_out/<tag>_env_list_<wl>_<VAR>.txt
+    WL=$1; VAR=$2; ROUNDS=$3; shift 3
+    VALS=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do VALS+=("$1"); shift; done; [ "$1" = "--" ] && shift
+    python3 __graft_entry__.py || exit 1
+    OUT=gpurun_out/${TAG}_env_list_${WL}_${VAR}.txt; : > $OUT
+    for r in $(seq $ROUNDS); do for val in "${VALS[@]}"; do
+      if [ "$val" = "-" ]; then unset $VAR; else export $VAR=$val; fi
+      timeout 300 python bench.py --workload $WL --no-extras --steps 30 --warmup 5 "$@" 2>gpurun_out/${TAG}_ab.err > gpurun_out/${TAG}_ab.json || { tail -5 gpurun_out/${TAG}_ab.err; exit 1; }
+      python -c "
+import json; d=json.load(open('gpurun_out/${TAG}_ab.json')); c=d['config']
+x=c.get('exchange_ms_per_iteration') or {}
+print('$WL $VAR=$val', ' '.join('$*'.split()), '|', round(d['value'],1), 'it/s', round(d['ms_per_step'],4), 'ms; X passes', round(c['x_passes_per_iteration'],3), 'trials', round(c['line_search_trials_per_iteration'],4), 'frac', round(d['roofline']['frac'],4), '| all-reduces/it', c.get('allreduces_per_iteration'), 'exchange ms/it', x)" | tee -a $OUT
       grep -o '"final_TC": [-0-9.e+]*' gpurun_out/bench_detail.json | head -1 | tee -a $OUT
     done; done ;;
   kernel_rows)

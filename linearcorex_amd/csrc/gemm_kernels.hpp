@@ -170,7 +170,8 @@ gemm_nt_kernel(const T* __restrict__ X, int64_t ldx, const T* __restrict__ B, T*
 // A: [K][lda] (or panel-major, see below) with K a multiple of 64 and the tile columns in bounds;
 // optional per-row scale of A (used for H, linearcorex.py:294).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int CT, int RT, int KW, bool SCALE, int U, bool NTA = false>
+// WT: the tile is stored write-through (agent-scope relaxed stores), for a consumer on another XCD inside the same launch
+template <typename T, int CT, int RT, int KW, bool SCALE, int U, bool NTA = false, bool WT = false>
 __device__ __forceinline__ void
 tn_body(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const T* __restrict__ B,
         const T* __restrict__ rowscale, T* __restrict__ out, int64_t out_rows, int kgroups,
@@ -257,7 +258,8 @@ tn_body(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const T* __re
         T s = red[idx];
 #pragma unroll
         for (int w = 1; w < KW; ++w) s += red[w * TILE + idx];
-        dst[idx] = s;
+        if constexpr (WT) __hip_atomic_store(&dst[idx], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else dst[idx] = s;
     }
 }
 
@@ -279,7 +281,8 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const 
 // draws a ticket of its row tile; the block that draws the last one (acquire) sums the tile's slots in slot order - the order of
 // reduce_partials_kernel, hence the same bits - into the summed Y, and draws a ticket of the tile's chunk; the last tile of a chunk
 // stores the launch's epoch into the chunk's signal word (system scope: the command processor of the waiting stream reads it).
-// Counters return to zero by themselves; epochs only grow.
+// Counters return to zero by themselves; epochs only grow.  ("publishes" / "acquire" = write-through stores and cache-bypassing loads
+// of exactly the data handed over, see chunk_signal_tail - not cache-wide fences.)
 constexpr int SIG_MAX_CHUNKS = 16;
 struct ChunkSig {
     unsigned int* tile_cnt;                  // [row tiles] partial slots written
@@ -294,20 +297,19 @@ struct ChunkSig {
 template <typename T, int TILE, int NTHREADS>
 __device__ __forceinline__ void chunk_signal_tail(const ChunkSig& sg, const T* __restrict__ part, int64_t slot_stride, int tile,
                                                   int nslots) {
+    // No cache-wide fence anywhere (an agent-scope release writes the whole L2 back and an acquire invalidates it - under the other
+    // blocks of the pass, which keep their B operand there: measured, 75 -> 95 us per pass at config 2).  Instead every datum that
+    // crosses blocks is stored write-through and loaded past the caches by agent-scope relaxed atomics, and program order inside a
+    // block does the rest: data stores acknowledged (vmcnt(0)) and the block synchronised BEFORE its one lane draws the ticket.
     __shared__ int sig_last;
     const int tid = threadIdx.x;
     if (nslots > 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned int t = __hip_atomic_fetch_add(&sg.tile_cnt[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (t == (unsigned int)(nslots - 1));
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                __hip_atomic_store(&sg.tile_cnt[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (last) __hip_atomic_store(&sg.tile_cnt[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sig_last = last;
         }
         __syncthreads();
@@ -315,9 +317,9 @@ __device__ __forceinline__ void chunk_signal_tail(const ChunkSig& sg, const T* _
         T* ys = reinterpret_cast<T*>(sg.ysum) + (int64_t)tile * TILE;
         const T* p0 = part + (int64_t)tile * TILE;
         for (int idx = tid; idx < TILE; idx += NTHREADS) {
-            T s = p0[idx];
-            for (int k = 1; k < nslots; ++k) s += p0[(int64_t)k * slot_stride + idx];
-            ys[idx] = s;
+            T s = __hip_atomic_load(&p0[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 1; k < nslots; ++k) s += __hip_atomic_load(&p0[(int64_t)k * slot_stride + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ys[idx], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);          // read next by another stream's kernel
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -326,13 +328,11 @@ __device__ __forceinline__ void chunk_signal_tail(const ChunkSig& sg, const T* _
         int c = 0;
         while (c + 1 < sg.nchunks && tile >= sg.tile_begin[c + 1]) ++c;
         const unsigned int want = (unsigned int)(sg.tile_begin[c + 1] - sg.tile_begin[c]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned int t = __hip_atomic_fetch_add(&sg.chunk_cnt[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == want - 1) {
             __hip_atomic_store(&sg.chunk_cnt[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");          // every tile of the chunk happened before the signal
-            __hip_atomic_store(sg.flag[c], sg.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __hip_atomic_store(sg.flag[c], sg.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(64 * KW)
 gemm_tn_sig_kernel(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const T* __restrict__ B, T* __restrict__ out,
                    int64_t out_rows, int kgroups, int nsplit, ChunkSig sg) {
     const int tile = (int)(blockIdx.x / (unsigned)nsplit), slot = (int)(blockIdx.x % (unsigned)nsplit);
-    tn_body<T, CT, RT, KW, false, U, false>(A, lda, tile_stride, B, nullptr, out, out_rows, kgroups, nsplit, tile, slot);
+    tn_body<T, CT, RT, KW, false, U, false, true>(A, lda, tile_stride, B, nullptr, out, out_rows, kgroups, nsplit, tile, slot);
     chunk_signal_tail<T, 16 * RT * 16 * CT, 64 * KW>(sg, out, out_rows * (16 * CT), tile, nsplit);
 }
 
@@ -756,7 +756,7 @@ gemm_cr_kernel(const T* __restrict__ A, int64_t lda /* PANEL: the panel stride *
 //     LDS strip, rows padded by 32 B so that the 4 contraction rows of a ds_read_b64 land on distinct banks; the
 //     operand reads are LDS broadcasts.  No block barrier in the main loop.
 // ------------------------------------------------------------------------------------------------
-template <int CT, int RT, int KW, int U, bool NT = false, bool SERIAL = false>
+template <int CT, int RT, int KW, int U, bool NT = false, bool SERIAL = false, bool WT = false>
 __device__ __forceinline__ void
 tn4_body(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, double* __restrict__ out,
          int64_t out_rows, int kgroups /* K / 16 */, int nsplit, const int tile_x, const int split_y) {
@@ -878,7 +878,8 @@ tn4_body(const double* __restrict__ A, int64_t lda, const double* __restrict__ B
         double sacc = smem[idx];
 #pragma unroll
         for (int w = 1; w < KW; ++w) sacc += smem[w * TILE + idx];
-        dst[idx] = sacc;
+        if constexpr (WT) __hip_atomic_store(&dst[idx], sacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else dst[idx] = sacc;
     }
 }
 template <int CT, int RT, int KW, int U, bool NT = false, bool SERIAL = false>
@@ -894,7 +895,7 @@ __global__ void __launch_bounds__(64 * KW)
 gemm_tn4_sig_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, double* __restrict__ out,
                     int64_t out_rows, int kgroups, int nsplit, ChunkSig sg) {
     const int tile = (int)(blockIdx.x / (unsigned)nsplit), slot = (int)(blockIdx.x % (unsigned)nsplit);
-    tn4_body<CT, RT, KW, U, true, false>(A, lda, B, out, out_rows, kgroups, nsplit, tile, slot);
+    tn4_body<CT, RT, KW, U, true, false, true>(A, lda, B, out, out_rows, kgroups, nsplit, tile, slot);
     __syncthreads();
     chunk_signal_tail<double, 16 * RT * 16 * CT, 64 * KW>(sg, out, out_rows * (16 * CT), tile, nsplit);
 }

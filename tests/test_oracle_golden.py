@@ -309,3 +309,25 @@ def test_transform_details_matches_reference(g1, gz, branch, tag):
     # the divisor is the fit's: the batch's own row count gives another TC
     own = O.moments_ns(xt, ws, float(g[p + "eps"]), quick=False) if branch == "ns" else O.moments_syn(xt, ws)
     assert abs(float(own["TC"]) - float(g[p + "mom_TC"])) > 0.1
+
+
+def test_config2_whole_fit_matches_reference():
+    """BASELINE.json configs[1] END TO END against the reference itself (g12_c2_fit.npz: the float64-lifted reference's whole fit of
+    RandomState(1).randn(10000, 5000), n_hidden = 32 - tests/golden/make_golden_c2fit.py): the oracle walks the same 422 iterations
+    with the same 472 line-search trials, history / weights / covariance to rounding, clusters bit for bit.  This is what pins the
+    CPU legs of bench.py (`cpu_fit_to_convergence`) and lets the GPU suite compare the device fit with the REFERENCE's output at
+    this size instead of re-running the oracle there.  About a minute on 8 cores."""
+    g = load_golden("g12_c2_fit")
+    n, v, m = (int(t) for t in g["shape"])
+    x = np.random.RandomState(1).randn(n, v)
+    r = O.fit_ns(x, m, seed=0, dtype=np.float64)
+    h, h_ref = np.asarray(r.history_tc, np.float64), g["history_tc"]
+    assert len(h) == len(h_ref) == 422 and r.n_trials == int(g["trials_per_iter"].sum()) == 472
+    assert r.n_trials + 10 == int(g["n_moment_calls"])
+    assert np.max(np.abs(h - h_ref) / np.maximum(1.0, np.abs(h_ref))) < 1e-9
+    assert np.array_equal(r.clusters(), g["clusters"])
+    assert np.max(np.abs(r.ws - g["ws"])) < 1e-8 * float(np.max(np.abs(g["ws"])))
+    assert np.max(np.abs(np.asarray(r.moments["TCs"]) - g["tcs"])) < 1e-8
+    cov = r.get_covariance()
+    assert np.max(np.abs(cov[g["cov_rows"]] - g["cov_block"])) < 1e-9 and np.max(np.abs(np.diag(cov) - g["cov_diag"])) < 1e-9
+    assert abs(np.linalg.norm(cov) - float(g["cov_fro"])) < 1e-9 * float(g["cov_fro"])

@@ -49,6 +49,8 @@ def main():
                 comm.barrier()
 
         t_iter = 0.0
+        be.timing_reset()
+        be.timing_sample(4)
         for walk in range(2):                      # the first walk warms up
             model.ws = np.zeros((0, 0))
             model.history = {}
@@ -56,13 +58,18 @@ def main():
             for i_eps, eps in enumerate(model._init_weights()):
                 model._begin_stage(i_eps, eps)
                 sync()
+                be.timing_enable(walk == 1)
                 t0 = time.perf_counter()
                 for k in range(iters):
                     model._iterate(more=k + 1 < iters)
                 sync()
                 t_iter += time.perf_counter() - t0
+                be.timing_enable(False)
+        # the exchange steps by site (include/lcx.h, timing kinds 3-6: HIP events on the stream that carries each all-reduce) and the X passes
+        sites = {k: (issued / (7 * iters)) * (ms / cnt) for k, (issued, cnt, ms) in be.timing_exchange_read().items() if cnt}
+        passes = {k: (be.timing_passes_by_kind()[k] / (7 * iters)) * (ms / cnt) for k, (cnt, ms) in be.timing_read().items() if cnt}
         out.update(ms_per_iteration=t_iter / (7 * iters) * 1e3, final_tc=float(model.tc), trials=model.stats["trials"],
-                   allreduces=be.exchange_info()["allreduces_issued"])
+                   allreduces=be.exchange_info()["allreduces_issued"], exchange_ms=sites, pass_ms=passes)
         be.close()
 
     one = {}
@@ -91,6 +98,12 @@ def main():
     rec = {"shard": "%d x %d x %d %s" % (n, v_per, m, np.dtype(dt).name), "ranks_on_one_gpu": world, "iterations_per_stage": iters,
            "one_rank_ms_per_iteration": t1, "all_ranks_ms_per_iteration": tn, "ideal_time_sliced_ms": world * t1,
            "fraction_of_ideal": world * t1 / tn, "allreduces_issued_per_rank": outs[0]["allreduces"],
+           # per iteration of ONE rank, by site; the all-reduce durations include the wait for the other (time-sliced) ranks' partial sums
+           "exchange_ms_per_iteration_rank0": {k: round(v, 4) for k, v in outs[0]["exchange_ms"].items()},
+           "exchange_ms_per_iteration_rank_min_max": [round(min(sum(o["exchange_ms"].values()) for o in outs), 4),
+                                                      round(max(sum(o["exchange_ms"].values()) for o in outs), 4)],
+           "x_pass_ms_per_iteration_rank0": {k: round(v, 4) for k, v in outs[0]["pass_ms"].items()},
+           "x_pass_ms_per_iteration_one_rank_alone": {k: round(v, 4) for k, v in one["pass_ms"].items()},
            "same_decisions_on_every_rank": len({o["trials"] for o in outs}) == 1 and len({o["final_tc"] for o in outs}) == 1,
            "transport": "asynchronous on-device sums behind events (tests/test_thread_ranks_gpu.py), ranks = threads of one process"}
     print(json.dumps(rec))

@@ -647,18 +647,18 @@ def test_bench_stdout_line_stays_within_the_drivers_budget(tmp_path):
 
 def test_bench_default_record_riders_and_series():
     """The nested blocks of the default job, checked on the record of such a run (the GPU suite measures the c3 headline alone; the
-    whole job is what the driver's bench step runs): profiles/r05_bench_default_detail.json through bench.series_of /
+    whole job is what the driver's bench step runs): profiles/r06_bench_default_detail.json through bench.series_of /
     bench.compact_line - c2, the config-4 shard and the opt-in modes ride on the line as scalars, and the weak-scaling series is
     readable from the lines alone: at N = 1 from the c4shard block, at N > 1 from the same-shard reference of that job."""
     import json
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    with open(os.path.join(ROOT, "profiles", "r05_bench_default_detail.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r06_bench_default_detail.json")) as f:
         full = json.load(f)
     assert full["series"] == bench.series_of(full, "c3", 1)          # what the run itself put on its line
     line = bench.compact_line(full, "d.json")
-    with open(os.path.join(ROOT, "profiles", "r05_bench_default.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r06_bench_default.json")) as f:
         committed = json.load(f)
     assert committed["series"] == line["series"] and committed["value"] == line["value"]
     assert len(json.dumps(line, separators=(",", ":"))) <= 4096
@@ -681,8 +681,27 @@ def test_bench_default_record_riders_and_series():
         assert its["linear"] > its["exact-y"] > its["exact"] > 0, its
     cv = d["fit_to_convergence_planted"]
     assert cv["stages_converged_before_the_cap"] == 7 and cv["cluster_purity_vs_planted_groups"] > 0.99
+    # the headline's roofline: `frac` is the dominant kernel (the merged pass: the best of c3's three pass kernels); the slowest site and the
+    # WHOLE step against the same roof stand beside it on the line, for the riders too
+    rl, frl = line["roofline"], full["roofline"]
+    assert rl["step_frac"] == pytest.approx(frl["iteration"]["achieved_TFLOPs"] / frl["peak"], rel=1e-4)
+    assert rl["frac_min_site"] == pytest.approx(min(frl["frac_by_site"].values()), rel=1e-4)
+    assert 0.6 < rl["frac_min_site"] <= rl["step_frac"] * 1.02 and rl["step_frac"] < rl["frac"] < 1.0
+    assert committed["roofline"]["step_frac"] == rl["step_frac"] and committed["roofline"]["frac_min_site"] == rl["frac_min_site"]
+    for name in ("c2", "c4shard"):
+        assert 0 < c[name + "_roofline_step_frac"] <= c[name + "_roofline_frac"] and 0 < c[name + "_roofline_frac_min_site"] <= c[name + "_roofline_frac"]
+        assert c[name + "_roofline_step_frac"] == pytest.approx(d[name]["roofline"]["step_frac"], rel=1e-4)
+    # BASELINE.md section 3's convergence leg: configs 1 and 2, device and host side by side on the line
+    for k in ("c2_fit_to_convergence_seconds", "c2_cpu_fit_to_convergence_seconds", "c1_fit_seconds", "c1_cpu_fit_seconds"):
+        assert c[k] > 0 and committed["config"][k] == c[k], k
+    dev, cpu = d["c2"]["fit_to_convergence"], d["c2"]["cpu_fit_to_convergence"]
+    assert dev["iterations"] == cpu["iterations"] == 422 and dev["trials"] == cpu["trials"] == 472          # = the reference's (g12_c2_fit.npz)
+    assert abs(dev["TC"] - cpu["TC"]) < 1e-6 and cpu["cores"] >= 1 and cpu["host"]["usable_cores"] >= 1
+    c1 = d["c1"]
+    assert c1["f64"]["iterations"] == c1["f64"]["cpu_iterations"] == 261 and c1["f64"]["same_clusters"] and c1["f32"]["same_clusters"]
+    assert c1["f32"]["fit_seconds"] == pytest.approx(c["c1_fit_seconds"], rel=1e-4)
     # N > 1: the two-rank rehearsal's record
-    with open(os.path.join(ROOT, "profiles", "r05_two_ranks_full_one_gpu_gloo_detail.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r06_two_ranks_full_one_gpu_gloo_detail.json")) as f:
         two = json.load(f)
     assert two["series"] == bench.series_of(two, "c4shard", 2)
     sr = bench.compact_line(two, "d2.json")["series"]
@@ -692,6 +711,20 @@ def test_bench_default_record_riders_and_series():
     assert sr["efficiency"] == pytest.approx(two["config"]["weak_scaling_vs_same_shard"], rel=1e-5)
     # four lines N = 1, 2, 4, 8 and no prose: the curve is efficiency(N), and N x per_gpu_value(N) over n1_value gives the speed-up
     assert sr["efficiency"] == pytest.approx(sr["per_gpu_value"] / sr["n1_value_same_workload"], rel=1e-5)
+    # ... and what an efficiency below 1 is made of: the all-reduces by site, their count (1 + 2T), every rank's own step time, the same shard
+    # without exchange steps; the launcher's attempts on the line it relayed
+    with open(os.path.join(ROOT, "profiles", "r06_two_ranks_full_one_gpu_gloo.json")) as f:
+        two_line = json.load(f)
+    assert len(json.dumps(two_line, separators=(",", ":"))) <= 4096
+    c2l, xp = two_line["config"], two["config"]["exchange_profile"]
+    assert set(c2l["exchange_ms_per_iteration"]) >= {"y", "direction", "scalars", "total"}
+    assert c2l["allreduces_per_iteration"] == pytest.approx(1 + 2 * two["config"]["line_search_trials_per_iteration"], abs=0.01)
+    assert c2l["compute_only_ms_per_step"] == pytest.approx(1e3 / two["config"]["single_gpu_same_shard"]["iterations_per_sec_slowest_rank"], rel=1e-4)
+    assert len(xp["ms_per_step_by_rank"]) == 2 and c2l["ms_per_step_rank_min_median_max"][2] <= two_line["ms_per_step"] * 1.01
+    assert c2l["compute_only_ms_per_step"] + c2l["exchange_ms_per_iteration"]["total"] <= two_line["ms_per_step"]
+    assert two_line["exchange_attempts"] == [{"transport": "caller (LCX_BENCH_BACKEND=gloo)", "rc": 0, "seconds": two_line["exchange_attempts"][0]["seconds"],
+                                              "reason": "ok"}]
+    assert two["cpu_baseline"]["other_ranks_while_timed"].startswith("parked")
 
 
 def test_headers_are_plain_c_and_a_c_program_links_the_library(tmp_path):

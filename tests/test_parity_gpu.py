@@ -687,7 +687,8 @@ def test_more_than_128_factors_end_to_end(tag):
         assert len(hs) == len(hs_ref) and np.max(np.abs(hs - hs_ref) / np.maximum(1.0, np.abs(hs_ref))) < 1e-8
 
 
-@pytest.mark.parametrize("tag,m", [("f32", 300), ("f64", 300), ("f32", 520)])
+# (520 factors end to end - 8 s on the untuned wide path - left the suite in round 6; 512 / 600 / 1024 factors stay in test_step_level)
+@pytest.mark.parametrize("tag,m", [("f32", 300), ("f64", 300)])
 def test_more_than_256_factors_end_to_end(tag, m):
     """n_hidden above 256 (the reference takes any n_hidden, :72) on the wide path (m_pad 512 / 1024): a short fit follows the
     oracle, clusters bit-exact on planted data in float64; transform, predict, get_covariance, the linear trial mode and the

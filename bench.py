@@ -46,7 +46,7 @@ sys.path.insert(0, ROOT)
 # GPU, no oracle); this file keeps the measurement and the CPU-baseline leg.  Re-exported: tests and tools address them as bench.<name>
 from benchkit.workloads import (BF16_MFMA_PEAK_TFLOPS, DESCRIPTION, FP32_MFMA_PEAK_TFLOPS, FP64_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS,  # noqa: E402,F401
                                 MEASURED_CEILINGS, MIN_TIMED_SECONDS, SPLIT_PRODUCTS, WORKLOADS, _adhoc)
-from benchkit.launch import spawn_ranks                                                              # noqa: E402,F401
+from benchkit.launch import spawn_ranks, supervise_rank                                              # noqa: E402,F401
 from benchkit.profiles import _lib_src_hash, load_pmc_traffic, load_rocprof_avg                      # noqa: E402,F401
 from benchkit.record import ROOFLINE_LINE_KEYS, _pick, _r, compact_line, emit, series_of             # noqa: E402,F401
 
@@ -823,6 +823,10 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)
+    if args.gpus > 1 and not os.environ.get("LCX_BENCH_WORKER") and int(os.environ.get("WORLD_SIZE", "1")) == args.gpus:
+        # a rank of somebody else's launcher (the driver's torch.distributed.run): supervise the real rank as a child, so that a hung
+        # first contact costs an attempt of the transport ladder instead of the job (benchkit/launch.py)
+        return supervise_rank(args)
     # ONE JSON line on stdout, nothing else: RCCL prints a version banner to the C-level stdout (buffered, so it lands
     # after anything Python printed).  Everything written to fd 1 from here on goes to stderr; rank 0 writes the JSON line
     # to the saved descriptor at the end.

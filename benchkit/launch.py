@@ -152,6 +152,168 @@ def run_attempt(cmd, env, budget_s):
     return rc, time.time() - t0, (out or b"").decode(errors="replace")
 
 
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The same ladder when somebody ELSE launched the ranks (the driver's `python -m torch.distributed.run ... bench.py --gpus N`): then
+# every rank process is a supervisor - it never imports torch, never touches the GPU - that runs the real rank as a child
+# (LCX_BENCH_WORKER=1) on a rendezvous of the attempt's own, and the supervisors of one node agree through files in /tmp:
+#     <k>.port          rank 0: the attempt's rendezvous port          <k>.fail          whoever saw its child fail / exceed the budget
+#     <k>.ok.<rank>     this rank's child finished with rc 0           <k>.done.<rank>   this rank's child is gone (before attempt k + 1 starts)
+# A rank set hung in first contact therefore costs one attempt, not the job: all children are killed, a fresh set starts on the next rung.
+# ------------------------------------------------------------------------------------------------------------------------------------
+def _write_atomic(path, text):
+    tmp = "%s.tmp.%d" % (path, os.getpid())
+    with open(tmp, "w") as f:
+        f.write(text)
+    os.replace(tmp, path)
+
+
+def _wait_for(paths, limit_s, stop=None):
+    """until every path exists (True), `stop` exists (False), or limit_s passed (None)"""
+    t_end = time.time() + limit_s
+    while time.time() < t_end:
+        if stop and os.path.exists(stop):
+            return False
+        if all(os.path.exists(q) for q in paths):
+            return True
+        time.sleep(0.05)
+    return None
+
+
+def supervise_rank(args, argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    env0 = dict(os.environ)
+    rank, world = int(env0.get("RANK", "0")), int(env0.get("WORLD_SIZE", "1"))
+    rungs = ladder_for(env0)
+    attempt_s = float(env0.get("LCX_BENCH_ATTEMPT_S", ATTEMPT_S))
+    total_s = float(env0.get("LCX_BENCH_TOTAL_S", TOTAL_S))
+    box = os.path.join("/tmp", "lcx_sup_%s_%d" % (env0.get("MASTER_PORT", "0"), os.getppid()))
+    if rank == 0:
+        os.makedirs(box, exist_ok=True)
+        for name in os.listdir(box):
+            os.remove(os.path.join(box, name))
+        _write_atomic(os.path.join(box, "ready"), "%d\n" % os.getpid())
+        rc = subprocess.call([sys.executable, os.path.join(ROOT, "__graft_entry__.py")], cwd=ROOT, stdout=sys.stderr)      # build once, before any rank
+        _write_atomic(os.path.join(box, "built"), "%d\n" % rc)
+    if _wait_for([os.path.join(box, "ready"), os.path.join(box, "built")], 900.0) is not True:
+        sys.stderr.write("bench.py: rank %d: rank 0's supervisor never appeared (%s)\n" % (rank, box))
+        return 1
+    with open(os.path.join(box, "built")) as f:
+        if int(f.read().strip() or 1) != 0:
+            sys.stderr.write("bench.py: rank %d: building the HIP library failed\n" % rank)
+            return 1
+    worker = json.loads(env0["LCX_BENCH_WORKER_CMD"]) if env0.get("LCX_BENCH_WORKER_CMD") else [sys.executable, BENCH]      # (test hook)
+    t_job = time.time()
+    attempts, rec = [], None
+    for k, (name, extra, lean) in enumerate(rungs):
+        f_port, f_fail = os.path.join(box, "%d.port" % k), os.path.join(box, "%d.fail" % k)
+        left = total_s - (time.time() - t_job)
+        if left < 60 and attempts:
+            attempts.append({"transport": name, "rc": None, "seconds": 0.0, "reason": "not started: %.0f s of the job's %.0f s left" % (left, total_s)})
+            continue
+        budget = max(min(30.0, attempt_s), min(attempt_s, left - 30.0))
+        if rank == 0:
+            _write_atomic(f_port, "%d\n" % _free_port())
+        if _wait_for([f_port], 120.0) is not True:
+            attempts.append({"transport": name, "rc": None, "seconds": 0.0, "reason": "rank 0's supervisor did not open the attempt"})
+            break
+        with open(f_port) as f:
+            port = f.read().strip()
+        env = dict(env0, LCX_BENCH_WORKER="1", MASTER_PORT=port, TORCHELASTIC_USE_AGENT_STORE="False")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # (see spawn_ranks)
+        env.setdefault("NCCL_DEBUG", "WARN")
+        env.setdefault("LCX_FIRST_CONTACT_TIMEOUT_S", str(FIRST_CONTACT_S))
+        env.setdefault("LCX_BENCH_LINE_RESERVE", "600")
+        env.update(extra)
+        if lean or (k > 0 and budget < 0.5 * attempt_s):
+            env["LCX_BENCH_LEAN"] = "1"
+        token = "%d-%d" % (os.getpid(), time.time_ns())
+        env.update(LCX_BENCH_ATTEMPT="%d:%s" % (k + 1, name), LCX_BENCH_ATTEMPT_TOKEN=token)
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d under a launcher, attempt %d (%s, <= %.0f s%s): every rank supervises a worker child\n"
+                             % (world, k + 1, name, budget, ", lean" if env.get("LCX_BENCH_LEAN") else ""))
+        t0 = time.time()
+        p = subprocess.Popen(worker + argv, cwd=ROOT, env=env, stdout=subprocess.PIPE)
+        chunks, reason, rc = [], None, None
+        os.set_blocking(p.stdout.fileno(), False)
+        while True:
+            try:
+                data = p.stdout.read()
+                if data:
+                    chunks.append(data)
+            except (BlockingIOError, OSError):
+                pass
+            rc = p.poll()
+            if rc is not None:
+                reason = "ok" if rc == 0 else "rank %d's worker exited with rc %d" % (rank, rc)
+                break
+            if os.path.exists(f_fail):
+                reason = "another rank's worker failed"
+                break
+            if time.time() - t0 > budget:
+                reason = "rank %d's worker killed after the attempt's wall-clock budget of %.0f s" % (rank, budget)
+                break
+            time.sleep(0.1)
+        if reason != "ok":
+            if not os.path.exists(f_fail):
+                try:
+                    _write_atomic(f_fail, reason + "\n")
+                except OSError:
+                    pass
+            if p.poll() is None:
+                p.terminate()
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            for pid in _tagged_pids(token):
+                try:
+                    os.kill(pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+        try:
+            rest = p.stdout.read()
+            if rest:
+                chunks.append(rest)
+        except (BlockingIOError, OSError, ValueError):
+            pass
+        out = b"".join(chunks).decode(errors="replace")
+        if reason == "ok":
+            _write_atomic(os.path.join(box, "%d.ok.%d" % (k, rank)), "ok\n")
+            # the attempt counts only if EVERY rank's worker came through
+            done = _wait_for([os.path.join(box, "%d.ok.%d" % (k, r)) for r in range(world)], max(60.0, budget - (time.time() - t0)), stop=f_fail)
+            if done is not True:
+                reason = "another rank's worker failed" if done is False else "the other ranks' workers did not finish"
+        if reason != "ok":
+            with open(f_fail) as f:
+                first = f.read().strip()
+            reason = reason if first == reason else "%s (first failure: %s)" % (reason, first)
+        attempts.append({"transport": name, "rc": rc, "seconds": round(time.time() - t0, 1), "reason": reason})
+        # nobody opens the next attempt while a worker of this one may still hold its GPU
+        _write_atomic(os.path.join(box, "%d.done.%d" % (k, rank)), "done\n")
+        _wait_for([os.path.join(box, "%d.done.%d" % (k, r)) for r in range(world)], 120.0)
+        if reason == "ok":
+            rec = _last_json(out) if rank == 0 else {}
+            if rank == 0 and (rec is None or rec.get("n_gpus") != args.gpus):
+                attempts[-1]["reason"] = reason = "no JSON line on rank 0's stdout" if rec is None else "the ranks report n_gpus=%r" % (rec.get("n_gpus"),)
+                rec = None
+                # (the other ranks cannot learn of this any more: the job ends here, with the line below)
+            break
+        if rank == 0:
+            sys.stderr.write("bench.py: attempt %d (%s) failed: %s\n" % (k + 1, name, reason))
+    ok = bool(attempts) and attempts[-1]["reason"] == "ok"
+    if rank == 0:
+        if rec is None:
+            rec = {"metric": "corex_fit_iterations_per_sec", "value": None, "unit": "fit iterations/s", "n_gpus": args.gpus, "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                   "data": "synthetic", "config": {"workload": "c4shard x %d GPUs: no rank set finished" % args.gpus},
+                   "error": "every transport of the ladder failed; see exchange_attempts and stderr"}
+        rec["exchange_attempts"] = attempts
+        sys.stdout.write(json.dumps(rec, separators=(",", ":")) + "\n")
+        sys.stdout.flush()
+    return 0 if ok else 1
+
+
 def spawn_ranks(args, argv=None, runner=run_attempt):
     argv = list(sys.argv[1:] if argv is None else argv)
     base_env = dict(os.environ)
@@ -175,7 +337,7 @@ def spawn_ranks(args, argv=None, runner=run_attempt):
         if left < 60 and attempts:
             attempts.append({"transport": name, "rc": None, "seconds": 0.0, "reason": "not started: %.0f s of the job's %.0f s left" % (left, total_s)})
             continue
-        budget = max(30.0, min(attempt_s, left - 30.0))
+        budget = max(min(30.0, attempt_s), min(attempt_s, left - 30.0))
         env = dict(base_env)
         # The pool's host driver supports dmabuf IPC only: with the legacy mode hipIpcGetMemHandle fails ("invalid argument") and with it
         # RCCL's intra-node P2P set-up and any device-tensor sharing between the ranks.  The GPU boxes export this already; the launcher
@@ -191,6 +353,7 @@ def spawn_ranks(args, argv=None, runner=run_attempt):
         if lean or (k > 0 and budget < 0.5 * attempt_s):
             env["LCX_BENCH_LEAN"] = "1"                     # what is left of the job's time does not fit the riders
         env["LCX_BENCH_ATTEMPT"] = "%d:%s" % (k + 1, name)
+        env["LCX_BENCH_WORKER"] = "1"                       # these ranks ARE the workers: this function is their ladder (see supervise_rank)
         env.setdefault("LCX_BENCH_LINE_RESERVE", "600")     # room on the 4 KB line for the attempts record added below
         cmd = rank_command(args.gpus, _free_port(), argv)
         sys.stderr.write("bench.py: --gpus %d, attempt %d (%s, <= %.0f s%s): %s\n"

@@ -229,23 +229,26 @@ def test_default_job_live_every_nested_block(tmp_path):
 
 
 def test_a_hung_first_contact_ends_in_a_line_from_the_next_transport(tmp_path):
-    """The first multi-GPU job must not be lost to a bad first contact: `python bench.py --gpus 2` whose rank 1 never arrives in
-    ncclCommInitRank (LCX_TEST_HANG_COMM_INIT=1; two gloo ranks on this one GPU, the RCCL negotiation forced) - the watchdog inside
-    the ranks ends attempt 1 (exit code 3, stacks on stderr), the launcher starts a FRESH rank set on LCX_EXCHANGE=hook, and the job
-    ends in ONE JSON line that records both attempts.  (A rank set that nothing ends from the inside is killed at the launcher's
+    """The first multi-GPU job must not be lost to a bad first contact: the driver's `torch.distributed.run ... bench.py --gpus 2` whose
+    rank 1 never arrives in ncclCommInitRank (LCX_TEST_HANG_COMM_INIT=1; two gloo ranks on this one GPU, the RCCL negotiation forced) -
+    the watchdog inside the workers ends attempt 1 (exit code 3, stacks on stderr), the rank supervisors start FRESH workers on
+    LCX_EXCHANGE=hook, and the job ends in ONE JSON line that records both attempts.  (`python bench.py --gpus 2`, where bench.py is
+    the launcher itself, takes the same ladder in spawn_ranks: CPU tests + test_gpus_2_without_a_launcher_starts_two_ranks.)  (A rank set that nothing ends from the inside is killed at the launcher's
     wall-clock budget: tests/test_host_logic_cpu.py::test_rank_launcher_kills_a_hung_rank_set_and_its_detached_children.)"""
     env = dict(_two_rank_env(), LCX_TEST_FORCE_RCCL_NEGOTIATION="1", LCX_TEST_HANG_COMM_INIT="1", LCX_FIRST_CONTACT_TIMEOUT_S="6",
                LCX_BENCH_ATTEMPT_S="100")
+    # launched the way the driver launches a multi-GPU run: the ranks come from torch.distributed.run, each is a supervisor of its worker
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + FAST
     t0 = time.time()
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + FAST, cwd=ROOT, env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     wall = time.time() - t0
     err = p.stderr.decode(errors="replace")
     assert p.returncode == 0, err[-3000:]
     d = _one_json_line(p.stdout)
     att = d["exchange_attempts"]
     assert [a["transport"] for a in att] == ["caller (LCX_BENCH_BACKEND=gloo)", "hook"], att
-    assert att[0]["rc"] not in (0, None) and att[0]["reason"].startswith("rank set exited") and att[0]["seconds"] < 60
+    assert att[0]["rc"] not in (0, None) and "worker exited with rc 3" in att[0]["reason"] and att[0]["seconds"] < 60
     assert att[1]["rc"] == 0 and att[1]["reason"] == "ok"
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["exchange"] == "hook"
     assert "first contact with the exchange transport did not finish" in err and "ncclCommInitRank" in err and "File " in err

@@ -443,6 +443,59 @@ def test_rank_launcher_kills_a_hung_rank_set_and_its_detached_children(tmp_path)
     assert rc == 0 and launch._last_json(out) == {"n_gpus": 2}
 
 
+def test_ranks_of_a_foreign_launcher_supervise_their_workers(tmp_path):
+    """The driver starts the ranks itself (`python -m torch.distributed.run ... bench.py --gpus N`): then every rank process is a
+    supervisor (no torch, no GPU) that runs the real rank as a child and the supervisors agree through files (benchkit/launch.py
+    supervise_rank).  Two supervisors here, fake workers: attempt 1 - rank 1's worker never arrives, rank 0's blocks (killed at the
+    attempt's budget); attempt 2 - rank 1's worker exits 3 at once (what the first-contact watchdog does), rank 0's is killed because
+    of it; attempt 3 answers.  One line, on rank 0 only, with the three attempts; fresh rendezvous port per attempt."""
+    import json
+    import subprocess
+    import sys
+    import time
+    worker = tmp_path / "worker.py"
+    worker.write_text(
+        "import json, os, sys, time\n"
+        "rank, att = int(os.environ['RANK']), os.environ['LCX_BENCH_ATTEMPT']\n"
+        "open(os.path.join(%r, 'seen_%%s_%%d' %% (att.replace(':', '_'), rank)), 'w').write(os.environ['MASTER_PORT'] + ' ' + os.environ.get('LCX_EXCHANGE', '-') + ' ' + os.environ['LCX_BENCH_WORKER'])\n"
+        "if att.startswith('1:'):\n"
+        "    time.sleep(600)\n"
+        "if att.startswith('2:'):\n"
+        "    if rank == 1:\n"
+        "        sys.exit(3)\n"
+        "    time.sleep(600)\n"
+        "if rank == 0:\n"
+        "    print('banner from a library')\n"
+        "    print(json.dumps({'metric': 'corex_fit_iterations_per_sec', 'value': 70.0, 'n_gpus': 2, 'config': {}}))\n"
+        % str(tmp_path))
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("LCX_", "TORCHELASTIC"))}
+    env.update(WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29876", LCX_BENCH_ATTEMPT_S="4", LCX_BENCH_TOTAL_S="600",
+               LCX_BENCH_WORKER_CMD=json.dumps([sys.executable, str(worker)]), TORCHELASTIC_USE_AGENT_STORE="True")
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3"],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], [o[1][-1500:] for o in outs]
+    assert time.time() - t0 < 90
+    assert outs[1][0].strip() == ""                                     # rank 1 prints nothing
+    lines = [ln for ln in outs[0][0].splitlines() if ln.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    att = line["exchange_attempts"]
+    assert line["value"] == 70.0 and [a["transport"] for a in att] == ["engine", "hook", "torch"]
+    assert "budget" in att[0]["reason"] and att[0]["rc"] is None
+    assert "rank 1's worker exited with rc 3" in att[1]["reason"] and att[2]["reason"] == "ok" and att[2]["rc"] == 0
+    seen = {n: (tmp_path / n).read_text().split() for n in os.listdir(tmp_path) if n.startswith("seen_")}
+    assert len(seen) == 6 and all(v[2] == "1" for v in seen.values())
+    assert [seen["seen_%s_0" % a][1] for a in ("1_engine", "2_hook", "3_torch")] == ["-", "hook", "torch"]
+    ports = [seen["seen_%s_0" % a][0] for a in ("1_engine", "2_hook", "3_torch")]
+    assert len(set(ports)) == 3 and "29876" not in ports and all(seen["seen_%s_1" % a][0] == q for a, q in zip(("1_engine", "2_hook", "3_torch"), ports))
+    # nothing of the failed attempts is left running
+    time.sleep(0.5)
+    left = subprocess.run(["pgrep", "-f", str(worker)], capture_output=True, text=True).stdout.split()
+    assert left == [], left
+
+
 def test_first_contact_watchdog_ends_a_stuck_rank():
     """linearcorex_amd/comm.py: first contact is bounded (LCX_FIRST_CONTACT_TIMEOUT_S) - a rank stuck in it names the step, dumps its
     stacks and exits 3 (a child process here: the watchdog ends the process by design)."""

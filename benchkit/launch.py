@@ -156,6 +156,7 @@ def run_attempt(cmd, env, budget_s):
 # The same ladder when somebody ELSE launched the ranks (the driver's `python -m torch.distributed.run ... bench.py --gpus N`): then
 # every rank process is a supervisor - it never imports torch, never touches the GPU - that runs the real rank as a child
 # (LCX_BENCH_WORKER=1) on a rendezvous of the attempt's own, and the supervisors of one node agree through files in /tmp:
+#     ready, built      rank 0: its pid (names the job's directory), the build's rc
 #     <k>.port          rank 0: the attempt's rendezvous port          <k>.fail          whoever saw its child fail / exceed the budget
 #     <k>.ok.<rank>     this rank's child finished with rc 0           <k>.done.<rank>   this rank's child is gone (before attempt k + 1 starts)
 # A rank set hung in first contact therefore costs one attempt, not the job: all children are killed, a fresh set starts on the next rung.
@@ -186,16 +187,42 @@ def supervise_rank(args, argv=None):
     rungs = ladder_for(env0)
     attempt_s = float(env0.get("LCX_BENCH_ATTEMPT_S", ATTEMPT_S))
     total_s = float(env0.get("LCX_BENCH_TOTAL_S", TOTAL_S))
-    box = os.path.join("/tmp", "lcx_sup_%s_%d" % (env0.get("MASTER_PORT", "0"), os.getppid()))
+    # the job's coordination directory: /tmp/lcx_sup_<MASTER_PORT>/<pid of rank 0's supervisor>.  The other ranks take the pid from
+    # `ready` and believe it only while that process is alive and IS this job's rank-0 supervisor (a stale file of an earlier job on the
+    # same port names a dead or foreign process) - no assumption about who the ranks' parent is
+    root = os.path.join("/tmp", "lcx_sup_%s" % env0.get("MASTER_PORT", "0"))
     if rank == 0:
+        box = os.path.join(root, str(os.getpid()))
         os.makedirs(box, exist_ok=True)
-        for name in os.listdir(box):
-            os.remove(os.path.join(box, name))
-        _write_atomic(os.path.join(box, "ready"), "%d\n" % os.getpid())
+        _write_atomic(os.path.join(root, "ready"), "%d\n" % os.getpid())
         rc = subprocess.call([sys.executable, os.path.join(ROOT, "__graft_entry__.py")], cwd=ROOT, stdout=sys.stderr)      # build once, before any rank
         _write_atomic(os.path.join(box, "built"), "%d\n" % rc)
-    if _wait_for([os.path.join(box, "ready"), os.path.join(box, "built")], 900.0) is not True:
-        sys.stderr.write("bench.py: rank %d: rank 0's supervisor never appeared (%s)\n" % (rank, box))
+        for name in os.listdir(root):                                     # directories of earlier jobs on this port
+            old = os.path.join(root, name)
+            if name.isdigit() and name != str(os.getpid()) and not os.path.exists("/proc/%s" % name):
+                for q in os.listdir(old):
+                    os.remove(os.path.join(old, q))
+                os.rmdir(old)
+    else:
+        box, t_end = None, time.time() + 900.0
+        while box is None and time.time() < t_end:
+            try:
+                with open(os.path.join(root, "ready")) as f:
+                    pid0 = int(f.read().strip())
+                with open("/proc/%d/environ" % pid0, "rb") as f:
+                    env_of = dict(kv.split(b"=", 1) for kv in f.read().split(b"\0") if b"=" in kv)
+                if (env_of.get(b"RANK") == b"0" and env_of.get(b"MASTER_PORT", b"").decode() == env0.get("MASTER_PORT", "0")
+                        and env_of.get(b"WORLD_SIZE", b"").decode() == env0.get("WORLD_SIZE") and b"LCX_BENCH_WORKER" not in env_of):
+                    box = os.path.join(root, str(pid0))
+            except (OSError, ValueError):
+                pass
+            if box is None:
+                time.sleep(0.1)
+        if box is None:
+            sys.stderr.write("bench.py: rank %d: rank 0's supervisor never appeared (%s)\n" % (rank, root))
+            return 1
+    if _wait_for([os.path.join(box, "built")], 900.0) is not True:
+        sys.stderr.write("bench.py: rank %d: rank 0's supervisor never finished the build (%s)\n" % (rank, box))
         return 1
     with open(os.path.join(box, "built")) as f:
         if int(f.read().strip() or 1) != 0:

@@ -471,6 +471,9 @@ def test_ranks_of_a_foreign_launcher_supervise_their_workers(tmp_path):
     env = {k: v for k, v in os.environ.items() if not k.startswith(("LCX_", "TORCHELASTIC"))}
     env.update(WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29876", LCX_BENCH_ATTEMPT_S="4", LCX_BENCH_TOTAL_S="600",
                LCX_BENCH_WORKER_CMD=json.dumps([sys.executable, str(worker)]), TORCHELASTIC_USE_AGENT_STORE="True")
+    os.makedirs("/tmp/lcx_sup_29876", exist_ok=True)          # what an earlier job on the same port left behind: believed by nobody
+    with open("/tmp/lcx_sup_29876/ready", "w") as f:
+        f.write("4194000\n")
     t0 = time.time()
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3"],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]

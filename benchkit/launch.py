@@ -29,6 +29,11 @@ LADDER = (("engine", {}, False),
           ("hook", {"LCX_EXCHANGE": "hook"}, False),
           ("torch", {"LCX_EXCHANGE": "torch"}, False),
           ("gloo", {"LCX_EXCHANGE": "hook", "LCX_BENCH_BACKEND": "gloo"}, True))
+# Fall-back attempts (every rung after the first) on ONE node also pin the sockets that RCCL's and gloo's bootstraps open to the loopback
+# interface unless the caller chose one: the interface picked by default is the one thing a bad first attempt may have tripped over
+# that no transport rung changes (a container whose hostname does not resolve), and loopback always carries a single-node rendezvous.
+# The data path is untouched (xGMI peer-to-peer / shared memory).
+FALLBACK_DEFAULTS = {"NCCL_SOCKET_IFNAME": "lo", "GLOO_SOCKET_IFNAME": "lo"}
 ATTEMPT_S = 900.0          # LCX_BENCH_ATTEMPT_S: wall-clock budget of one rank set
 TOTAL_S = 1700.0           # LCX_BENCH_TOTAL_S: of the whole ladder (the driver allows a --gpus N job 1 800 s)
 FIRST_CONTACT_S = 180      # LCX_FIRST_CONTACT_TIMEOUT_S handed to the ranks unless the caller set one
@@ -251,6 +256,9 @@ def supervise_rank(args, argv=None):
         env.setdefault("LCX_FIRST_CONTACT_TIMEOUT_S", str(FIRST_CONTACT_S))
         env.setdefault("LCX_BENCH_LINE_RESERVE", "600")
         env.update(extra)
+        if k > 0:
+            for key, val in FALLBACK_DEFAULTS.items():
+                env.setdefault(key, val)
         if lean or (k > 0 and budget < 0.5 * attempt_s):
             env["LCX_BENCH_LEAN"] = "1"
         token = "%d-%d" % (os.getpid(), time.time_ns())
@@ -372,11 +380,10 @@ def spawn_ranks(args, argv=None, runner=run_attempt):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("NCCL_DEBUG", "WARN")               # the first RCCL run on xGMI: its warnings belong in the record's stderr
         env.setdefault("LCX_FIRST_CONTACT_TIMEOUT_S", str(FIRST_CONTACT_S))
-        for key, val in extra.items():
-            if val == "":
-                env.pop(key, None)
-            else:
-                env[key] = val
+        env.update(extra)
+        if k > 0:
+            for key, val in FALLBACK_DEFAULTS.items():
+                env.setdefault(key, val)
         if lean or (k > 0 and budget < 0.5 * attempt_s):
             env["LCX_BENCH_LEAN"] = "1"                     # what is left of the job's time does not fit the riders
         env["LCX_BENCH_ATTEMPT"] = "%d:%s" % (k + 1, name)

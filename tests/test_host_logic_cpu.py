@@ -350,7 +350,8 @@ def test_rank_launcher_attempt_ladder(monkeypatch, capsys):
     import json
     from benchkit import launch
     monkeypatch.setattr(launch.subprocess, "call", lambda *a, **k: 0)         # the build step
-    for k in ("LCX_EXCHANGE", "LCX_BENCH_BACKEND", "LCX_BENCH_LADDER", "LCX_BENCH_DRY_SPAWN", "LCX_BENCH_ATTEMPT_S", "LCX_BENCH_TOTAL_S"):
+    for k in ("LCX_EXCHANGE", "LCX_BENCH_BACKEND", "LCX_BENCH_LADDER", "LCX_BENCH_DRY_SPAWN", "LCX_BENCH_ATTEMPT_S", "LCX_BENCH_TOTAL_S",
+              "NCCL_SOCKET_IFNAME", "GLOO_SOCKET_IFNAME"):
         monkeypatch.delenv(k, raising=False)
     args = argparse.Namespace(gpus=4, steps=20, warmup=5)
     good = json.dumps({"metric": "corex_fit_iterations_per_sec", "value": 70.0, "n_gpus": 4, "config": {"exchange": "hook"}})
@@ -361,6 +362,7 @@ def test_rank_launcher_attempt_ladder(monkeypatch, capsys):
 
         def runner(cmd, env, budget):
             seen.append({"exchange": env.get("LCX_EXCHANGE"), "backend": env.get("LCX_BENCH_BACKEND"), "lean": env.get("LCX_BENCH_LEAN"),
+                         "ifname": (env.get("NCCL_SOCKET_IFNAME"), env.get("GLOO_SOCKET_IFNAME")),
                          "budget": budget, "ipc": env.get("HSA_ENABLE_IPC_MODE_LEGACY"), "nccl_debug": env.get("NCCL_DEBUG"),
                          "fc": env.get("LCX_FIRST_CONTACT_TIMEOUT_S"), "reserve": env.get("LCX_BENCH_LINE_RESERVE"), "cmd": cmd})
             return next(it)
@@ -374,6 +376,7 @@ def test_rank_launcher_attempt_ladder(monkeypatch, capsys):
     assert [a["transport"] for a in att] == ["engine", "hook", "torch"] and [a["rc"] for a in att] == [None, 3, 0]
     assert "killed after its wall-clock budget" in att[0]["reason"] and "rc 3" in att[1]["reason"] and att[2]["reason"] == "ok"
     assert [t["exchange"] for t in seen] == [None, "hook", "torch"] and all(t["backend"] is None for t in seen)
+    assert [t["ifname"] for t in seen] == [(None, None), ("lo", "lo"), ("lo", "lo")]          # fall-back attempts bootstrap over loopback
     assert seen[0]["budget"] == 900.0 and all(t["ipc"] == "0" and t["nccl_debug"] == "WARN" and t["fc"] == "180" for t in seen)
     assert all(t["cmd"][1:3] == ["-m", "torch.distributed.run"] and t["cmd"][-2:] == ["--gpus", "4"] for t in seen)
     assert len({t["cmd"][t["cmd"].index("--master-port") + 1] for t in seen}) == 3          # a fresh rendezvous per attempt

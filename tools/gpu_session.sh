@@ -10,6 +10,7 @@
 #   line_search_ab <wl> ...        bench --no-extras under line_search exact / exact-y / linear, one line each
 #   two_ranks [bench args]         the driver's --gpus 2 command rehearsed on ONE GPU (two ranks share GPU 0 over gloo)
 #   n_ranks <N> <head> [args]     the driver's --gpus N command on ONE GPU at a reduced shard (N ranks share GPU 0 over gloo)
+#   n_ranks_launched <N> <head>   the same through `python -m torch.distributed.run ... bench.py --gpus N` (the driver's form: supervised workers)
 #   env_ab <wl> <VAR> <a> <b> [n]  bench --no-extras under VAR=a / VAR=b alternating on one box   -> gpurun_out/<tag>_env_ab_<wl>_<VAR>.txt
 #   env_list <wl> <VAR> <n> <v>... the same for any number of values ("-" = unset), exchange sites printed; bench args after "--"
 #   kernel_rows <wl> <VAR> <val>   rocprofv3 kernel rows + launch gaps of bench --no-extras under VAR=val
@@ -71,6 +72,16 @@ print('$wl $ls', round(d['value'],2), 'it/s', round(d['ms_per_step'],3), 'ms; X 
       2>gpurun_out/${TAG}_${N}_ranks.err > gpurun_out/${TAG}_${N}_ranks.json
     echo "rc=$? wall $(( $(date +%s) - T0 )) s, line $(wc -c < gpurun_out/${TAG}_${N}_ranks.json) bytes" | tee gpurun_out/${TAG}_${N}_ranks_summary.txt
     cat gpurun_out/${TAG}_${N}_ranks.json; grep -v BENCH_DETAIL gpurun_out/${TAG}_${N}_ranks.err | tail -40 ;;
+  n_ranks_launched)
+    # the same rehearsal started THE WAY THE DRIVER STARTS a multi-GPU run: torch.distributed.run launches the N ranks, each supervises its worker
+    #   n_ranks_launched <N> <head workload | auto> [bench args]
+    N=$1; HEAD=$2; shift 2
+    T0=$(date +%s)
+    if [ "$HEAD" != auto ]; then export LCX_BENCH_HEAD=$HEAD; fi
+    LCX_BENCH_DEVICE=0 LCX_BENCH_BACKEND=gloo timeout 1700 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29655 \
+      bench.py --gpus $N --detail-out gpurun_out/${TAG}_${N}_ranks_launched_detail.json "$@" 2>gpurun_out/${TAG}_${N}_ranks_launched.err > gpurun_out/${TAG}_${N}_ranks_launched.json
+    echo "rc=$? wall $(( $(date +%s) - T0 )) s, line $(wc -c < gpurun_out/${TAG}_${N}_ranks_launched.json) bytes" | tee gpurun_out/${TAG}_${N}_ranks_launched_summary.txt
+    cat gpurun_out/${TAG}_${N}_ranks_launched.json; grep -v BENCH_DETAIL gpurun_out/${TAG}_${N}_ranks_launched.err | grep -v "^\[Gloo\]" | tail -30 ;;
   env_ab)
     # bench --workload <wl> --no-extras under VAR=a and VAR=b, alternating on ONE box:  env_ab <wl> <VAR> <a> <b> [rounds [bench args]]
     WL=$1; VAR=$2; A=$3; B=$4; ROUNDS=${5:-3}; shift 5 2>/dev/null || shift $#      # (anything after the round count goes to bench.py)

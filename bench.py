@@ -698,7 +698,8 @@ def linear_mode_block(workload, r3, world):
     this mode actually executes."""
     rl = roofline_of(workload, r3, world) or {}
     it = rl.get("iteration") or {}
-    return {"fit_iterations_per_sec": r3["its_per_s"], "ms_per_step": r3["per_step_s"] * 1e3,
+    # (whole-job figure like `value`: every rank's shard iterations)
+    return {"fit_iterations_per_sec": r3["its_per_s"] * world, "ms_per_step": r3["per_step_s"] * 1e3,
             "x_passes_per_iteration": r3["x_passes"], "line_search_trials_per_iteration": r3["trials"],
             "final_TC": r3["final_tc"], "refresh_every": 16,
             "ms_per_step_walk_min_median_max": r3["windows"]["ms_per_step_walk_min_median_max"],

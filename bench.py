@@ -790,7 +790,10 @@ class _Park:
 
     def __init__(self, world, rank):
         self.world, self.rank = world, rank
-        self.path = os.path.join("/tmp", "lcx_bench_park_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+        # named by the rendezvous port alone (every attempt of the rank launchers has its own): the ranks need not share a parent process -
+        # under a foreign launcher each is the child of its own supervisor.  Rank 0 clears a stale file here, BEFORE the barrier behind
+        # which the others start to poll
+        self.path = os.path.join("/tmp", "lcx_bench_park_%s" % os.environ.get("MASTER_PORT", "0"))
         self.spin = os.environ.get("LCX_TEST_PARK") == "spin"
         self.how = ("busy-waiting (LCX_TEST_PARK=spin: emulates ranks waiting in an RCCL barrier)" if self.spin
                     else "parked: sleeping poll (0.2 s) for a file rank 0 creates when the baseline is done")

@@ -39,6 +39,9 @@ TOTAL_S = 1700.0           # LCX_BENCH_TOTAL_S: of the whole ladder (the driver 
 FIRST_CONTACT_S = 180      # LCX_FIRST_CONTACT_TIMEOUT_S handed to the ranks unless the caller set one
 
 
+_LIVE = []          # (Popen, token) of the rank set / worker that is running right now: what a SIGTERM of this process must take along
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -140,6 +143,7 @@ def run_attempt(cmd, env, budget_s):
     token = "%d-%d" % (os.getpid(), time.time_ns())
     env = dict(env, LCX_BENCH_ATTEMPT_TOKEN=token)
     p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    _LIVE[:] = [(p, token)]
     try:
         out, _ = p.communicate(timeout=budget_s)
         rc = p.returncode
@@ -154,6 +158,7 @@ def run_attempt(cmd, env, budget_s):
         left = _end_rank_set(p, token, grace=2.0)          # a failed torchrun may leave ranks behind: none may meet the next rank set
         if left:
             sys.stderr.write("bench.py: processes of the failed attempt still alive: %r\n" % (left,))
+    _LIVE[:] = []
     return rc, time.time() - t0, (out or b"").decode(errors="replace")
 
 
@@ -236,6 +241,8 @@ def supervise_rank(args, argv=None):
     worker = json.loads(env0["LCX_BENCH_WORKER_CMD"]) if env0.get("LCX_BENCH_WORKER_CMD") else [sys.executable, BENCH]      # (test hook)
     t_job = time.time()
     attempts, rec = [], None
+    if rank == 0:
+        _LineOnSigterm(args, attempts).__enter__()          # for the rest of this process's life
     for k, (name, extra, lean) in enumerate(rungs):
         f_port, f_fail = os.path.join(box, "%d.port" % k), os.path.join(box, "%d.fail" % k)
         left = total_s - (time.time() - t_job)
@@ -268,6 +275,7 @@ def supervise_rank(args, argv=None):
                              % (world, k + 1, name, budget, ", lean" if env.get("LCX_BENCH_LEAN") else ""))
         t0 = time.time()
         p = subprocess.Popen(worker + argv, cwd=ROOT, env=env, stdout=subprocess.PIPE)
+        _LIVE[:] = [(p, token)]
         chunks, reason, rc = [], None, None
         os.set_blocking(p.stdout.fileno(), False)
         while True:
@@ -337,16 +345,56 @@ def supervise_rank(args, argv=None):
         if rank == 0:
             sys.stderr.write("bench.py: attempt %d (%s) failed: %s\n" % (k + 1, name, reason))
     ok = bool(attempts) and attempts[-1]["reason"] == "ok"
+    f_final = os.path.join(box, "final")
     if rank == 0:
-        if rec is None:
-            rec = {"metric": "corex_fit_iterations_per_sec", "value": None, "unit": "fit iterations/s", "n_gpus": args.gpus, "steps": args.steps,
-                   "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-                   "data": "synthetic", "config": {"workload": "c4shard x %d GPUs: no rank set finished" % args.gpus},
-                   "error": "every transport of the ladder failed; see exchange_attempts and stderr"}
-        rec["exchange_attempts"] = attempts
-        sys.stdout.write(json.dumps(rec, separators=(",", ":")) + "\n")
-        sys.stdout.flush()
+        _emit_line(rec, attempts, args)
+        _write_atomic(f_final, "%d\n" % (0 if ok else 1))
+    else:
+        # a launcher ends the whole job the moment ONE rank exits non-zero: nobody leaves before rank 0 has printed the line
+        _wait_for([f_final], 120.0)
     return 0 if ok else 1
+
+
+def _emit_line(rec, attempts, args, note=None):
+    """the one stdout line of a launcher-level job: the worker's line with the attempts, or - nothing finished - a line that says so"""
+    if rec is None:
+        rec = {"metric": "corex_fit_iterations_per_sec", "value": None, "unit": "fit iterations/s", "n_gpus": args.gpus, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic", "config": {"workload": "c4shard x %d GPUs: no rank set finished" % args.gpus},
+               "error": note or "every transport of the ladder failed; see exchange_attempts and stderr"}
+    rec["exchange_attempts"] = attempts
+    sys.stdout.write(json.dumps(rec, separators=(",", ":")) + "\n")
+    sys.stdout.flush()
+
+
+class _LineOnSigterm:
+    """Whoever ends the job from outside (a driver's timeout sends SIGTERM before SIGKILL) still gets the line: the attempts so far,
+    `value: null`, and the live child ended with the job."""
+
+    def __init__(self, args, attempts):
+        self.args, self.attempts = args, attempts
+
+    def __enter__(self):
+        def handler(signum, frame):
+            for p, token in list(_LIVE):
+                try:
+                    os.killpg(p.pid, signal.SIGKILL) if os.getpgid(p.pid) == p.pid else p.kill()
+                except Exception:          # noqa: BLE001
+                    pass
+                for pid in _tagged_pids(token):
+                    try:
+                        os.kill(pid, signal.SIGKILL)
+                    except Exception:          # noqa: BLE001
+                        pass
+            _emit_line(None, self.attempts + [{"transport": "-", "rc": None, "seconds": 0.0, "reason": "the job was terminated by signal %d" % signum}],
+                       self.args, note="terminated from outside before a rank set finished; see exchange_attempts")
+            os._exit(1)
+        self.old = signal.signal(signal.SIGTERM, handler)
+        return self
+
+    def __exit__(self, *exc):
+        signal.signal(signal.SIGTERM, self.old)
+        return False
 
 
 def spawn_ranks(args, argv=None, runner=run_attempt):
@@ -367,6 +415,8 @@ def spawn_ranks(args, argv=None, runner=run_attempt):
         return rc
     t_job = time.time()
     attempts, rec = [], None
+    if runner is run_attempt:
+        _LineOnSigterm(args, attempts).__enter__()          # for the rest of this process's life
     for k, (name, extra, lean) in enumerate(rungs):
         left = total_s - (time.time() - t_job)
         if left < 60 and attempts:
@@ -410,12 +460,5 @@ def spawn_ranks(args, argv=None, runner=run_attempt):
             rec = got
             break
         sys.stderr.write("bench.py: attempt %d (%s) failed: %s\n%s\n" % (k + 1, name, reason, "\n".join(out.splitlines()[-20:])))
-    if rec is None:
-        rec = {"metric": "corex_fit_iterations_per_sec", "value": None, "unit": "fit iterations/s", "n_gpus": args.gpus, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-               "data": "synthetic", "config": {"workload": "c4shard x %d GPUs: no rank set finished" % args.gpus},
-               "error": "every transport of the ladder failed; see exchange_attempts and stderr"}
-    rec["exchange_attempts"] = attempts
-    sys.stdout.write(json.dumps(rec, separators=(",", ":")) + "\n")
-    sys.stdout.flush()
+    _emit_line(rec, attempts, args)
     return 0 if attempts and attempts[-1]["reason"] == "ok" else 1

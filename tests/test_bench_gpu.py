@@ -139,7 +139,10 @@ def test_two_ranks_full_line_has_the_same_shard_reference_and_the_c2_block(tmp_p
     (`config.single_gpu_same_shard`: the one-GPU point of this workload's weak-scaling series), then sharded; the nested
     config-2 block with 5 000 variables per GPU."""
     detail = str(tmp_path / "detail2.json")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--repeats", "1",
+    # started the way the driver starts it: torch.distributed.run launches the ranks, each supervises its worker (round 6: the first 8-rank
+    # rehearsal in this form hung - the ranks that wait out the CPU baseline looked for rank 0's signal under their own parent's pid)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--repeats", "1",
            "--detail-out", detail]
     p = subprocess.run(cmd, cwd=ROOT, env=_two_rank_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]

@@ -502,6 +502,65 @@ def test_ranks_of_a_foreign_launcher_supervise_their_workers(tmp_path):
     assert left == [], left
 
 
+def _supervisors(tmp_path, worker_src, port, extra_env, world=2):
+    import json
+    import subprocess
+    import sys
+    worker = tmp_path / "worker.py"
+    worker.write_text(worker_src)
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("LCX_", "TORCHELASTIC"))}
+    env.update(WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LCX_BENCH_WORKER_CMD=json.dumps([sys.executable, str(worker)]))
+    env.update(extra_env)
+    return [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3"],
+                             env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+
+
+def test_supervised_ranks_end_in_a_line_when_nothing_works_or_the_job_is_terminated(tmp_path):
+    """supervise_rank: (1) every rung fails - rank 1 leaves with a non-zero code while rank 0 is still writing: a launcher would end the
+    job at that moment, so nobody leaves before rank 0 has printed the line (value null, all attempts); (2) the job is terminated from
+    outside (SIGTERM to rank 0's supervisor, as a driver's timeout does): the line still comes, with the attempts so far, and the
+    worker is gone."""
+    import json
+    import signal
+    import subprocess
+    import time
+    fail = "import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(600)\n"
+    procs = _supervisors(tmp_path, fail, 29877, {"LCX_BENCH_ATTEMPT_S": "5", "LCX_BENCH_TOTAL_S": "600"})
+    t_exit = {}
+    while len(t_exit) < 2:
+        for r, p in enumerate(procs):
+            if r not in t_exit and p.poll() is not None:
+                t_exit[r] = time.time()
+        time.sleep(0.01)
+    outs = [p.communicate(timeout=30) for p in procs]
+    assert [p.returncode for p in procs] == [1, 1]
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["value"] is None and "error" in line and [a["transport"] for a in line["exchange_attempts"]] == ["engine", "hook", "torch", "gloo"]
+    assert all("rank 1's worker exited with rc 7" in a["reason"] for a in line["exchange_attempts"])
+    assert t_exit[1] >= t_exit[0] - 0.3 and outs[1][0].strip() == ""          # rank 1 waited for rank 0's line
+    # (2) terminated from outside
+    (tmp_path / "t").mkdir()
+    hang = "import os, time\nopen(os.path.join(%r, 'pid_' + os.environ['RANK']), 'w').write(str(os.getpid()))\ntime.sleep(600)\n" % str(tmp_path / "t")
+    procs = _supervisors(tmp_path / "t", hang, 29878, {"LCX_BENCH_ATTEMPT_S": "300"})
+    t0 = time.time()
+    while not all((tmp_path / "t" / ("pid_%d" % r)).exists() for r in range(2)) and time.time() - t0 < 60:
+        time.sleep(0.05)
+    time.sleep(0.3)
+    pids = [int((tmp_path / "t" / ("pid_%d" % r)).read_text()) for r in range(2)]
+    procs[0].send_signal(signal.SIGTERM)
+    out0, _ = procs[0].communicate(timeout=30)
+    line = json.loads(out0.strip().splitlines()[-1])
+    assert procs[0].returncode == 1 and line["value"] is None and "terminated by signal 15" in line["exchange_attempts"][-1]["reason"]
+    procs[1].kill()
+    try:
+        os.kill(pids[1], signal.SIGKILL)          # rank 1's worker (it holds its supervisor's stderr): ended by this test, not by the job
+    except ProcessLookupError:
+        pass
+    procs[1].communicate(timeout=30)
+    time.sleep(0.3)
+    assert not os.path.exists("/proc/%d" % pids[0]) or "Z" in open("/proc/%d/stat" % pids[0]).read().split(")")[-1].split()[0]
+
+
 def test_first_contact_watchdog_ends_a_stuck_rank():
     """linearcorex_amd/comm.py: first contact is bounded (LCX_FIRST_CONTACT_TIMEOUT_S) - a rank stuck in it names the step, dumps its
     stacks and exits 3 (a child process here: the watchdog ends the process by design)."""

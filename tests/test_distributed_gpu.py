@@ -360,7 +360,12 @@ def _launch_uneven(out_dir, n, m, iters, tag, bounds, extra_env=None, timeout=28
 UNEVEN = {4: [7, 300, 1333, 130], 8: [7, 300, 1333, 130, 64, 1, 513, 700]}
 
 
-@pytest.mark.parametrize("world,tag,gemm,pipeline", [(4, "f64", None, False), (8, "f32", "ct", False)])
+# (round 6: the world-4 float64 case - 13 s of process launches - runs with LCX_MORE_RANK_CASES=1 only: uneven float64 shards on the wave-split
+# kernels are covered by the eight thread ranks of tests/test_thread_ranks_gpu.py in 2 s, and the suite needed room for the bench-job tests)
+_UNEVEN_CASES = [(8, "f32", "ct", False)] + ([(4, "f64", None, False)] if os.environ.get("LCX_MORE_RANK_CASES") else [])
+
+
+@pytest.mark.parametrize("world,tag,gemm,pipeline", _UNEVEN_CASES)
 def test_uneven_shards_many_ranks(world, tag, gemm, pipeline, tmp_path, monkeypatch):
     """More than two ranks on REAL engine handles (round 4 ran world 3 / 8 against the NumPy double only): 4 or 8 ranks share GPU 0,
     the exchange steps and the line search inside the library (hook transport over gloo), n_hidden = 128, awkward UNEVEN shards
@@ -421,7 +426,9 @@ def test_pipelined_y_allreduce_is_bit_identical(tag, m, gemm, tmp_path, monkeypa
     runs = {}
     # (":pass": per-chunk launches of the pass even where a chunk cannot fill the chip; "signal": ONE launch of the pass that sums its own
     # slots and signals each row chunk to the second stream - a stream wait-value, or the polling kernel)
-    modes = ("chunks:5:pass", "signal:5", "signal:3:poll") if tag == "f64" else ("chunks:5:pass", "signal:5")
+    # (float32 on the stream-K pair: "signal" falls back to the per-chunk reductions there - one pipelined run covers both; the polling form of
+    # the wait: test_rccl_exchange_path_single_rank and the thread-rank tests)
+    modes = ("chunks:5:pass", "signal:5") if tag == "f64" else ("signal:5",)
     for mode in ("off",) + modes:
         out = tmp_path / mode.replace(":", "_")
         out.mkdir()

@@ -935,7 +935,8 @@ def test_fit_transform_reads_the_resident_data(gaussianize, missing):
 
 
 def test_last_committed_gpu_suite_log_is_within_its_time_budget():
-    """The driver gives `pytest -m gpu` 1 200 s; round 4's suite had grown to 702 s (+33 % in one round).  Budget: 600 s for the
+    """The driver gives `pytest -m gpu` 1 200 s; round 4's suite had grown to 702 s (+33 % in one round).  Budget: 480 s (round 5's
+    verdict; 390-462 s box to box in round 6 - the suite is bound by the box's host cores, which it shares) for the
     suite log that was committed last (profiles/rNN_gpu_suite_final.txt, written by `tools/gpu_session.sh suite`), so that a round
     which lets the suite grow past half the driver's limit goes red here, on the CPU tier, and not as a timeout of the GPU tier."""
     import glob
@@ -947,5 +948,5 @@ def test_last_committed_gpu_suite_log_is_within_its_time_budget():
     m = re.search(r"(\d+) passed.* in ([0-9.]+)s", text)
     assert m, logs[-1]
     assert "failed" not in text[m.start():m.end()] and " error" not in text[m.start():m.end()]
-    assert float(m.group(2)) <= 600.0, "%s: the GPU suite took %s s (budget 600 s of the driver's 1 200 s)" % (os.path.basename(logs[-1]), m.group(2))
+    assert float(m.group(2)) <= 480.0, "%s: the GPU suite took %s s (budget 480 s of the driver's 1 200 s)" % (os.path.basename(logs[-1]), m.group(2))
     assert int(m.group(1)) >= 400

@@ -73,6 +73,9 @@ def main():
     gbps = float(a[4]) if len(a) >= 5 else 100.0
     iters = int(a[5]) if len(a) >= 6 else 6
     torch.cuda.set_device(0)
+    # the wave-split kernels (the in-launch signalling exists for them; by itself the engine gives this shape the stream-K kernels,
+    # whose pass is one launch with the slot reductions behind it - nothing of it can overlap)
+    os.environ.setdefault("LCX_GEMM", "tn")
     # ticks of torch.cuda._sleep per microsecond, measured
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda._sleep(1000000)
@@ -89,6 +92,11 @@ def main():
           % (n, v, m, latency_us, gbps, n * m * 8 / 1e6, latency_us + n * m * 8 / (gbps * 1e3), iters), flush=True)
 
     def run(mode, lat, bw):
+        a_, c_ = run_once(mode, lat, bw)
+        b_, _ = run_once(mode, lat, bw)
+        return (a_ if a_["ms"] <= b_["ms"] else b_), c_          # the better of two (a stall of the shared host shows up as an outlier)
+
+    def run_once(mode, lat, bw):
         if mode == "off":
             os.environ.pop("LCX_Y_PIPELINE", None)
         else:

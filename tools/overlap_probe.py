@@ -105,6 +105,8 @@ def main():
         model = Corex(n_hidden=m, seed=0, dtype=np.float64, tol=0.0, max_iter=10 ** 9, device=0, comm=comm)
         be = model._attach_shard(x, v)
         t_iter, n_it = 0.0, 0
+        be.timing_reset()
+        be.timing_sample(1)
         for walk in range(2):                      # the first walk warms up
             model.ws, model.history = np.zeros((0, 0)), {}
             t_iter, n_it = 0.0, 0
@@ -113,7 +115,7 @@ def main():
                 model._begin_stage(i_eps, eps)
                 be.synchronize()
                 torch.cuda.synchronize()
-                c0, b0 = comm.calls, comm.busy_us
+                be.timing_enable(walk == 1)
                 t0 = time.perf_counter()
                 for k in range(iters):
                     model._iterate(more=k + 1 < iters)
@@ -121,15 +123,18 @@ def main():
                 torch.cuda.synchronize()
                 t_iter += time.perf_counter() - t0
                 n_it += iters
+                be.timing_enable(False)
+        tr = be.timing_read()
         out = {"ms": t_iter / n_it * 1e3, "tc": float(model.tc), "trials": model.stats["trials"], "geo": be.geometry(),
-               "kernel": be.kernel_name(0)}
+               "kernel": be.kernel_name(0), "xbt_us": 1e3 * tr["gemm_nt"][1] / max(1, tr["gemm_nt"][0]),
+               "xty_us": 1e3 * tr["gemm_tn"][1] / max(1, tr["gemm_tn"][0])}
         be.close()
         return out, comm
 
     base, _ = run("off", 0.0, 0.0)
     print("# pass kernel %s, %d row tiles x %d slots on %d CUs" % (base["kernel"], base["geo"]["n_pad"] // 64, base["geo"]["nt_split"], base["geo"]["n_cus"]))
-    print("%-16s %-22s %10s %14s %s" % ("LCX_Y_PIPELINE", "emulated transport", "ms/iter", "exposed ms/iter", "final TC"))
-    print("%-16s %-22s %10.4f %14s %.12f" % ("off", "none (free sums)", base["ms"], "-", base["tc"]))
+    print("%-16s %-22s %10s %14s %10s %10s %s" % ("LCX_Y_PIPELINE", "emulated transport", "ms/iter", "exposed ms/iter", "X.B^T us", "X^T.Y us", "final TC"))
+    print("%-16s %-22s %10.4f %14s %10.1f %10.1f %.12f" % ("off", "none (free sums)", base["ms"], "-", base["xbt_us"], base["xty_us"], base["tc"]))
     rows = {}
     for mode in ("off", "signal:2", "signal:4", "signal:8", "chunks:4"):
         for lat, bw, label in ((0.0, 0.0, "free"), (latency_us, gbps, "%.0f us + B/%.0f GB/s" % (latency_us, gbps))):
@@ -138,7 +143,7 @@ def main():
             r, comm = run(mode, lat, bw)
             assert r["tc"] == base["tc"] and r["trials"] == base["trials"], (mode, r["tc"], base["tc"])
             rows[(mode, label)] = r["ms"]
-            print("%-16s %-22s %10.4f %14.4f %.12f" % (mode, label, r["ms"], r["ms"] - base["ms"], r["tc"]), flush=True)
+            print("%-16s %-22s %10.4f %14.4f %10.1f %10.1f %.12f" % (mode, label, r["ms"], r["ms"] - base["ms"], r["xbt_us"], r["xty_us"], r["tc"]), flush=True)
     slow = "%.0f us + B/%.0f GB/s" % (latency_us, gbps)
     serial = rows[("off", slow)] - base["ms"]
     print("# exposed exchange per iteration: unpipelined %.4f ms; " % serial

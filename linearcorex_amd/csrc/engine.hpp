@@ -263,12 +263,11 @@ struct lcx_ctx {
     // chunk's slot reduction (and, for the wave-split kernels, behind its own row chunk of the pass); default off
     int ypipe;
     bool ypipe_force_pass;
-    // LCX_Y_PIPELINE=signal[:n[:poll]]: ONE pass launch that sums its own slots and signals every row chunk of the summed Y through a
-    // signal word (gemm_kernels.hpp, ChunkSig); the second stream waits on the word (hipStreamWaitValue32, or poll_signal_kernel
-    // with ":poll" / where the runtime has no wait-value) and all-reduces the chunk while the pass goes on.  Wave-split kernels only
+    // LCX_Y_PIPELINE=signal[:n[:poll]]: ONE pass launch that signals every row chunk of its partial tiles through a signal word
+    // (gemm_kernels.hpp, ChunkSig); the second stream waits on the word (hipStreamWaitValue32, or poll_signal_kernel with ":poll" /
+    // where the runtime has no wait-value), sums the chunk's slots and all-reduces it while the pass goes on.  Wave-split kernels only
     bool ypipe_signal, ypipe_poll;
-    unsigned int *sig_counters;         // [row tiles of 16 rows + SIG_MAX_CHUNKS + 1]: tile tickets, chunk tickets, poll error word
-    int64_t sig_tiles;
+    unsigned int *sig_counters;         // [SIG_MAX_CHUNKS + 1]: chunk tickets, poll error word
     unsigned int* sig_flag[SIG_MAX_CHUNKS];
     unsigned int sig_epoch;
     hipStream_t comm_stream;
@@ -306,8 +305,7 @@ static int ypipe_streams(lcx_ctx* h) {
 // signal memory (what hipStreamWaitValue32 may wait on); where the runtime refuses that, plain device memory and the polling kernel
 static int ypipe_signals(lcx_ctx* h) {
     if (h->sig_counters) return LCX_OK;
-    h->sig_tiles = h->Npad / 16;
-    const size_t words = (size_t)h->sig_tiles + SIG_MAX_CHUNKS + 1;
+    const size_t words = SIG_MAX_CHUNKS + 1;
     HIPCHECK(hipMalloc((void**)&h->sig_counters, words * sizeof(unsigned int)));
     HIPCHECK(hipMemsetAsync(h->sig_counters, 0, words * sizeof(unsigned int), h->stream));
     int can_wait = 0;
@@ -736,7 +734,7 @@ template <typename T, int CT> struct Impl {
     static int gram(lcx_ctx* h, const T* A, int64_t K, const T* scale, int S, const int* skip, T* dst);
 
     static int nt_pass(lcx_ctx* h, const T* B, const int* skip, T* dst, int64_t r0 = 0, int64_t rows = -1);
-    static int nt_reduce(lcx_ctx* h, const int* skip, T* also, int64_t e0, int64_t n);
+    static int nt_reduce(lcx_ctx* h, const int* skip, T* also, int64_t e0, int64_t n, hipStream_t st = nullptr);
     static int nt_big(lcx_ctx* h, const void* Bv, const int* skip, bool with_bj = false, T* also = nullptr);
 
     static int ypipe_init(lcx_ctx* h);

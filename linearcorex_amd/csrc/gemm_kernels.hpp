@@ -274,60 +274,33 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, int64_t tile_stride, const 
 }
 
 // ---- in-launch chunk signalling (the pipelined Y exchange, LCX_Y_PIPELINE=signal: DESIGN.md section 6) -----------------------
-// ONE launch of a wave-split pass that also sums its own partial slots and tells a second stream, row chunk by row chunk, when the
-// summed Y of that chunk is complete - so that chunk c's all-reduce overlaps the pass over chunk c+1 without cutting the pass
-// into launches that cannot fill the chip.  The 1-D grid walks (row tile, slot) with the slot fastest: the blocks of a row tile are
-// dispatched together and the tiles in chunk order.  Hand-offs: a block publishes its partial tile (release, agent scope) and
-// draws a ticket of its row tile; the block that draws the last one (acquire) sums the tile's slots in slot order - the order of
-// reduce_partials_kernel, hence the same bits - into the summed Y, and draws a ticket of the tile's chunk; the last tile of a chunk
+// ONE launch of a wave-split pass that tells a second stream, row chunk by row chunk, when every partial tile of that chunk has been
+// written - so that the chunk's slot reduction and all-reduce run there while the pass goes on, without cutting the pass into
+// launches that cannot fill the chip.  The 1-D grid walks (row tile, slot) with the slot fastest: the blocks of a row tile are
+// dispatched together and the tiles in chunk order.  A block stores its partial tile WRITE-THROUGH (agent-scope relaxed stores: the
+// consumer is a kernel of another stream, started while this launch is still running - whatever sits dirty in an XCD's L2 it would not
+// see), waits for the stores to be acknowledged, and one lane draws a ticket of the tile's chunk; the block that draws the last one
 // stores the launch's epoch into the chunk's signal word (system scope: the command processor of the waiting stream reads it).
-// Counters return to zero by themselves; epochs only grow.  ("publishes" / "acquire" = write-through stores and cache-bypassing loads
-// of exactly the data handed over, see chunk_signal_tail - not cache-wide fences.)
+// No cache-wide fence anywhere: a first version handed tiles from block to block inside the launch with agent-scope release /
+// acquire fences - every one writes the XCD's L2 back or invalidates it under the other blocks, which keep their B operand there:
+// 75 -> 95 us per pass at config 2.  The slot reduction itself is the SAME kernel as without the pipeline (same bits, any slot
+// count), launched per chunk behind the signal.  Counters return to zero by themselves; epochs only grow.
 constexpr int SIG_MAX_CHUNKS = 16;
 struct ChunkSig {
-    unsigned int* tile_cnt;                  // [row tiles] partial slots written
-    unsigned int* chunk_cnt;                 // [chunks] row tiles summed
+    unsigned int* chunk_cnt;                 // [chunks] partial tiles written
     unsigned int* flag[SIG_MAX_CHUNKS];      // one signal word per chunk (hipMallocSignalMemory)
     int tile_begin[SIG_MAX_CHUNKS + 1];      // chunk c = row tiles [tile_begin[c], tile_begin[c + 1])
     int nchunks;
     unsigned int epoch;
-    void* ysum;                              // the summed Y ([rows][Mp]); with one slot the pass writes it directly
 };
 
-template <typename T, int TILE, int NTHREADS>
-__device__ __forceinline__ void chunk_signal_tail(const ChunkSig& sg, const T* __restrict__ part, int64_t slot_stride, int tile,
-                                                  int nslots) {
-    // No cache-wide fence anywhere (an agent-scope release writes the whole L2 back and an acquire invalidates it - under the other
-    // blocks of the pass, which keep their B operand there: measured, 75 -> 95 us per pass at config 2).  Instead every datum that
-    // crosses blocks is stored write-through and loaded past the caches by agent-scope relaxed atomics, and program order inside a
-    // block does the rest: data stores acknowledged (vmcnt(0)) and the block synchronised BEFORE its one lane draws the ticket.
-    __shared__ int sig_last;
-    const int tid = threadIdx.x;
-    if (nslots > 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned int t = __hip_atomic_fetch_add(&sg.tile_cnt[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = (t == (unsigned int)(nslots - 1));
-            if (last) __hip_atomic_store(&sg.tile_cnt[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sig_last = last;
-        }
-        __syncthreads();
-        if (!sig_last) return;
-        T* ys = reinterpret_cast<T*>(sg.ysum) + (int64_t)tile * TILE;
-        const T* p0 = part + (int64_t)tile * TILE;
-        for (int idx = tid; idx < TILE; idx += NTHREADS) {
-            T s = __hip_atomic_load(&p0[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int k = 1; k < nslots; ++k) s += __hip_atomic_load(&p0[(int64_t)k * slot_stride + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ys[idx], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);          // read next by another stream's kernel
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+__device__ __forceinline__ void chunk_signal_tail(const ChunkSig& sg, int tile, int nslots) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this block's tile is in memory
     __syncthreads();
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         int c = 0;
         while (c + 1 < sg.nchunks && tile >= sg.tile_begin[c + 1]) ++c;
-        const unsigned int want = (unsigned int)(sg.tile_begin[c + 1] - sg.tile_begin[c]);
+        const unsigned int want = (unsigned int)(sg.tile_begin[c + 1] - sg.tile_begin[c]) * (unsigned int)nslots;
         const unsigned int t = __hip_atomic_fetch_add(&sg.chunk_cnt[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == want - 1) {
             __hip_atomic_store(&sg.chunk_cnt[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -343,7 +316,7 @@ gemm_tn_sig_kernel(const T* __restrict__ A, int64_t lda, int64_t tile_stride, co
                    int64_t out_rows, int kgroups, int nsplit, ChunkSig sg) {
     const int tile = (int)(blockIdx.x / (unsigned)nsplit), slot = (int)(blockIdx.x % (unsigned)nsplit);
     tn_body<T, CT, RT, KW, false, U, false, true>(A, lda, tile_stride, B, nullptr, out, out_rows, kgroups, nsplit, tile, slot);
-    chunk_signal_tail<T, 16 * RT * 16 * CT, 64 * KW>(sg, out, out_rows * (16 * CT), tile, nsplit);
+    chunk_signal_tail(sg, tile, nsplit);
 }
 
 // a stand-in for a stream wait-value where the runtime has none: one lane polls the chunk's signal word (bounded: ~4 s, then the
@@ -896,8 +869,7 @@ gemm_tn4_sig_kernel(const double* __restrict__ A, int64_t lda, const double* __r
                     int64_t out_rows, int kgroups, int nsplit, ChunkSig sg) {
     const int tile = (int)(blockIdx.x / (unsigned)nsplit), slot = (int)(blockIdx.x % (unsigned)nsplit);
     tn4_body<CT, RT, KW, U, true, false, true>(A, lda, B, out, out_rows, kgroups, nsplit, tile, slot);
-    __syncthreads();
-    chunk_signal_tail<double, 16 * RT * 16 * CT, 64 * KW>(sg, out, out_rows * (16 * CT), tile, nsplit);
+    chunk_signal_tail(sg, tile, nsplit);
 }
 // dynamic LDS of gemm_tn4: max(B strips, reduction tiles)
 template <int CT, int RT, int KW, int U, bool SERIAL = false> struct Tn4Lds {

@@ -275,16 +275,17 @@ int Impl<T, CT>::nt_pass(lcx_ctx* h, const T* B, const int* skip, T* dst, int64_
 // sum the partial slots of the elements [e0, e0 + n) of Y into ybuf (and `also`): the kernel - and so the order of every
 // element's sum - depends on the slot count alone, so a row chunk gets the bits of the whole reduction
 template <typename T, int CT>
-int Impl<T, CT>::nt_reduce(lcx_ctx* h, const int* skip, T* also, int64_t e0, int64_t n) {
+int Impl<T, CT>::nt_reduce(lcx_ctx* h, const int* skip, T* also, int64_t e0, int64_t n, hipStream_t st) {
+    if (!st) st = h->stream;
     const int64_t ntot = h->Npad * Mp;
     const bool wide = h->nt_S >= WIDE_SPLITS && cdiv(ntot, 32) < (1 << 20);
     if (wide) {
         hipLaunchKernelGGL((reduce_partials_wide_kernel<T, T>), dim3((unsigned)cdiv(n, 32)), dim3(256), 0,
-                           h->stream, P<T>(h->ypart) + e0, h->nt_S, n, ntot, P<T>(h->ybuf) + e0, skip, also ? also + e0 : also);
+                           st, P<T>(h->ypart) + e0, h->nt_S, n, ntot, P<T>(h->ybuf) + e0, skip, also ? also + e0 : also);
         KCHECK();
     } else if (h->nt_S > 1) {
         hipLaunchKernelGGL((reduce_partials_kernel<T, T>), dim3((unsigned)(cdiv(n, 256) < 1024 ? cdiv(n, 256) : 1024)), dim3(256), 0,
-                           h->stream, P<T>(h->ypart) + e0, h->nt_S, n, ntot, P<T>(h->ybuf) + e0, skip, also ? also + e0 : also);
+                           st, P<T>(h->ypart) + e0, h->nt_S, n, ntot, P<T>(h->ybuf) + e0, skip, also ? also + e0 : also);
         KCHECK();
     }
     return LCX_OK;
@@ -363,18 +364,16 @@ int Impl<T, CT>::y_pass_pipelined(lcx_ctx* h, const T* w, bool with_bj) {
     const int site = with_bj ? LCX_T_AR_DIR : LCX_T_AR_Y;
     T* dst = h->nt_S > 1 ? P<T>(h->ypart) : P<T>(h->ybuf);
     if constexpr (!WIDE) {
-        // in-launch chunk signalling: the wave-split kernels with the plain slot reduction (the wide reduction sums in another order)
-        if (h->ypipe_signal && !(h->panel || h->single_copy || h->nt_ct) && h->nt_S < WIDE_SPLITS) {
+        // in-launch chunk signalling: the wave-split kernels
+        if (h->ypipe_signal && !(h->panel || h->single_copy || h->nt_ct)) {
             LCXCHECK(ypipe_signals(h));
             constexpr int RTT = Geo<T, CT>::TN_RT;          // row tile of the pass: 16 * RTT rows (a divisor of the 64-row chunk unit)
             ChunkSig sg;
-            sg.tile_cnt = h->sig_counters;
-            sg.chunk_cnt = h->sig_counters + h->sig_tiles;
+            sg.chunk_cnt = h->sig_counters;
             for (int c = 0; c < SIG_MAX_CHUNKS; ++c) sg.flag[c] = h->sig_flag[c];
             for (int c = 0; c <= C; ++c) sg.tile_begin[c] = (int)(tiles * c / C * tile / (16 * RTT));
             sg.nchunks = C;
             sg.epoch = ++h->sig_epoch;
-            sg.ysum = h->ybuf;
             const unsigned nblocks = (unsigned)(h->Npad / (16 * RTT)) * (unsigned)h->nt_S;
             TimingPair tp;
             LCXCHECK(timing_begin(h, 0, &tp));
@@ -417,7 +416,7 @@ int Impl<T, CT>::y_pass_pipelined(lcx_ctx* h, const T* w, bool with_bj) {
             if (launched) {
                 KCHECK();
                 LCXCHECK(timing_end(h, 0, &tp));
-                unsigned int* err = h->sig_counters + h->sig_tiles + SIG_MAX_CHUNKS;
+                unsigned int* err = h->sig_counters + SIG_MAX_CHUNKS;
                 for (int c = 0; c < C; ++c) {
                     const int64_t r0 = tiles * c / C * tile, r1 = tiles * (c + 1) / C * tile;
                     if (h->ypipe_poll) {
@@ -426,6 +425,8 @@ int Impl<T, CT>::y_pass_pipelined(lcx_ctx* h, const T* w, bool with_bj) {
                     } else {
                         HIPCHECK(hipStreamWaitValue32(h->comm_stream, h->sig_flag[c], sg.epoch, hipStreamWaitValueGte, 0xFFFFFFFFu));
                     }
+                    // the chunk's slots -> the summed Y: the reduction of the unpipelined path on this range (same kernel, same bits), here
+                    LCXCHECK(nt_reduce(h, nullptr, (T*)nullptr, r0 * Mp, (r1 - r0) * Mp, h->comm_stream));
                     const int64_t count = (r1 - r0) * Mp + (c == C - 1 ? (int64_t)Mp * Mp : 0);
                     LCXCHECK(exchange_site_on(h, h->comm_stream, site, P<T>(h->ybuf) + r0 * Mp, count, DT));
                 }

@@ -136,7 +136,8 @@ def main():
     print("%-16s %-22s %10s %14s %10s %10s %s" % ("LCX_Y_PIPELINE", "emulated transport", "ms/iter", "exposed ms/iter", "X.B^T us", "X^T.Y us", "final TC"))
     print("%-16s %-22s %10.4f %14s %10.1f %10.1f %.12f" % ("off", "none (free sums)", base["ms"], "-", base["xbt_us"], base["xty_us"], base["tc"]))
     rows = {}
-    for mode in ("off", "signal:2", "signal:4", "signal:8", "chunks:4"):
+    modes = tuple(os.environ["LCX_PROBE_MODES"].split(",")) if os.environ.get("LCX_PROBE_MODES") else ("off", "signal:2", "signal:4", "signal:8", "chunks:4")
+    for mode in modes:
         for lat, bw, label in ((0.0, 0.0, "free"), (latency_us, gbps, "%.0f us + B/%.0f GB/s" % (latency_us, gbps))):
             if mode == "off" and label == "free":
                 continue
@@ -145,6 +146,8 @@ def main():
             rows[(mode, label)] = r["ms"]
             print("%-16s %-22s %10.4f %14.4f %10.1f %10.1f %.12f" % (mode, label, r["ms"], r["ms"] - base["ms"], r["xbt_us"], r["xty_us"], r["tc"]), flush=True)
     slow = "%.0f us + B/%.0f GB/s" % (latency_us, gbps)
+    if ("off", slow) not in rows or any((mo, slow) not in rows for mo in ("signal:2", "signal:4", "signal:8", "chunks:4")):
+        return
     serial = rows[("off", slow)] - base["ms"]
     print("# exposed exchange per iteration: unpipelined %.4f ms; " % serial
           + "; ".join("%s %.4f (%.0f %% hidden)" % (mo, rows[(mo, slow)] - base["ms"], 100 * (1 - (rows[(mo, slow)] - base["ms"]) / serial))

@@ -159,10 +159,11 @@ int lcx_bind_exchange(lcx_ctx* h, void* ybuf_dev, void* sbuf_dev);
  * of chunk c overlaps the pass of chunk c+1 (:247 -> :259 is where a latency-exposed shard waits) - as long as a chunk's launch
  * still fills the chip ("chunks:n:pass" forces it on any shape).  Every element is summed over
  * slots and ranks as without chunks; every rank issues the same chunks in the same order; the m x m tail rides in the last chunk.
- * LCX_Y_PIPELINE=signal[:n[:poll]]: the same exchange with ONE launch of the wave-split pass - it sums its own partial slots
- * (in the order of the separate reduction: same bits) and stores the launch's epoch into a signal word per row chunk as the chunk
- * completes; the second stream waits on the word (hipStreamWaitValue32; ":poll", or a runtime without wait-value: a one-lane polling
- * kernel, bounded) and hands the chunk to the transport while the pass goes on: 3 us per extra chunk instead of 21. */
+ * LCX_Y_PIPELINE=signal[:n[:poll]]: the same exchange with ONE launch of the wave-split pass - it stores its partial tiles
+ * write-through and the launch's epoch into a signal word per row chunk as the chunk's last tile lands; the second stream waits on the
+ * word (hipStreamWaitValue32; ":poll", or a runtime without wait-value: a one-lane polling kernel, bounded), sums the chunk's slots
+ * with the unpipelined reduction kernel (same bits) and hands the chunk to the transport while the pass goes on: 5 us per extra
+ * chunk instead of 22, the pass itself within 1.5 % of the plain one. */
 #define LCX_COMM_ID_BYTES 128
 typedef int (*lcx_allreduce_fn)(void* user, void* dev_buf, int64_t count, int dtype, void* hip_stream);
 /* local, no collective: LCX_OK iff this process can bind librccl (dlopen).  ncclCommInitRank is collective - the ranks compare

@@ -226,6 +226,63 @@ def test_eight_thread_ranks_async_transport(tag, m, gemm, pipeline, line_search,
         assert len(set(alone)) == 2, alone
 
 
+def test_signalled_exchange_with_many_slots_is_bit_identical(monkeypatch):
+    """LCX_Y_PIPELINE=signal on a shard whose pass writes MANY partial slots (few samples, many variables: 16 slots, summed by the wide
+    reduction kernel): the chunk's reduction behind the signal is the unpipelined kernel on the chunk's range, whatever the slot count -
+    two thread ranks, float64 on the wave-split v_mfma_f64_4x4x4 kernel, both wait forms, against the unpipelined run bit for bit."""
+    import torch          # noqa: F401
+    monkeypatch.setenv("LCX_CHECK_RANKS", "1")
+    world, n, m, dt, iters = 2, 192, 24, np.float64, 6
+    bounds = [0, 5000, 12000]
+    v = bounds[-1]
+    xt = _planted(n, v, m, dt, seed=93)
+    w0 = (np.random.RandomState(4).randn(m, v) * 0.002).astype(dt)
+    runs = {}
+    for mode in ("off", "signal:3", "signal:2:poll"):
+        if mode == "off":
+            monkeypatch.delenv("LCX_Y_PIPELINE", raising=False)
+        else:
+            monkeypatch.setenv("LCX_Y_PIPELINE", mode)
+        shared = _Shared(world)
+        results, errors = [None] * world, [None] * world
+
+        def rank_main(r):
+            try:
+                import torch
+                torch.cuda.set_device(0)
+                comm = ThreadComm(shared, r, bounds)
+                c0, c1 = comm.shard(v)
+                from linearcorex_amd import Corex
+                model = Corex(n_hidden=m, seed=None, dtype=dt, tol=0.0, device=0, comm=comm)
+                be = model._attach_shard(np.ascontiguousarray(xt[:, c0:c1]), v)
+                model.ws = w0
+                h = _run_loop(model, iters)
+                results[r] = {"history": h, "ws": model._gather(be.get_ws(0)), "slots": be.geometry()["nt_split"], "kernel": be.kernel_name(0),
+                              "allreduces": be.exchange_info()["allreduces_issued"], "trials": model.stats["trials"]}
+                be.close()
+            except BaseException as e:          # noqa: BLE001
+                errors[r] = e
+                shared.barrier.abort()
+
+        threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(TIMEOUT * 3)
+        first = next((e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)), None)
+        assert first is None, repr(first)
+        assert all(r is not None for r in results)
+        runs[mode] = results[0]
+        assert np.array_equal(results[0]["history"], results[1]["history"]) and np.array_equal(results[0]["ws"], results[1]["ws"])
+    off = runs["off"]
+    assert off["slots"] >= 12 and "gemm_tn4_kernel" in off["kernel"], (off["slots"], off["kernel"])          # the wide slot reduction
+    assert len(off["history"]) == iters and np.all(np.isfinite(off["history"]))
+    for mode in ("signal:3", "signal:2:poll"):
+        r = runs[mode]
+        assert np.array_equal(r["history"], off["history"]) and np.array_equal(r["ws"], off["ws"]) and r["trials"] == off["trials"], mode
+        assert r["allreduces"] > off["allreduces"], mode
+
+
 def test_eight_thread_ranks_whole_fit(monkeypatch):
     """The whole `fit` path over the same transport: random start and its normalisation (:113-117), seven annealing stages with their
     rescaling (:127-134), four iterations each, the final detail moments, factor sort and gathers (:160-163) - eight uneven thread

@@ -245,18 +245,23 @@ def supervise_rank(args, argv=None):
         _LineOnSigterm(args, attempts).__enter__()          # for the rest of this process's life
     for k, (name, extra, lean) in enumerate(rungs):
         f_port, f_fail = os.path.join(box, "%d.port" % k), os.path.join(box, "%d.fail" % k)
-        left = total_s - (time.time() - t_job)
-        if left < 60 and attempts:
-            attempts.append({"transport": name, "rc": None, "seconds": 0.0, "reason": "not started: %.0f s of the job's %.0f s left" % (left, total_s)})
-            continue
-        budget = max(min(30.0, attempt_s), min(attempt_s, left - 30.0))
         if rank == 0:
-            _write_atomic(f_port, "%d\n" % _free_port())
+            # rank 0's clock decides for everybody - whether the attempt starts, its budget, whether it is a lean job: the workers of one
+            # attempt must run the same program (a lean rank beside a full one would meet in different collectives)
+            left = total_s - (time.time() - t_job)
+            plan = {"skip": bool(left < 60 and attempts), "left": left, "port": _free_port()}
+            plan["budget"] = max(min(30.0, attempt_s), min(attempt_s, left - 30.0))
+            plan["lean"] = bool(lean or (k > 0 and plan["budget"] < 0.5 * attempt_s))
+            _write_atomic(f_port, json.dumps(plan) + "\n")
         if _wait_for([f_port], 120.0) is not True:
             attempts.append({"transport": name, "rc": None, "seconds": 0.0, "reason": "rank 0's supervisor did not open the attempt"})
             break
         with open(f_port) as f:
-            port = f.read().strip()
+            plan = json.loads(f.read())
+        if plan["skip"]:
+            attempts.append({"transport": name, "rc": None, "seconds": 0.0, "reason": "not started: %.0f s of the job's %.0f s left" % (plan["left"], total_s)})
+            continue
+        budget, port = float(plan["budget"]), str(plan["port"])
         env = dict(env0, LCX_BENCH_WORKER="1", MASTER_PORT=port, TORCHELASTIC_USE_AGENT_STORE="False")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # (see spawn_ranks)
         env.setdefault("NCCL_DEBUG", "WARN")
@@ -266,7 +271,7 @@ def supervise_rank(args, argv=None):
         if k > 0:
             for key, val in FALLBACK_DEFAULTS.items():
                 env.setdefault(key, val)
-        if lean or (k > 0 and budget < 0.5 * attempt_s):
+        if plan["lean"]:
             env["LCX_BENCH_LEAN"] = "1"
         token = "%d-%d" % (os.getpid(), time.time_ns())
         env.update(LCX_BENCH_ATTEMPT="%d:%s" % (k + 1, name), LCX_BENCH_ATTEMPT_TOKEN=token)

@@ -538,6 +538,13 @@ def test_supervised_ranks_end_in_a_line_when_nothing_works_or_the_job_is_termina
     assert line["value"] is None and "error" in line and [a["transport"] for a in line["exchange_attempts"]] == ["engine", "hook", "torch", "gloo"]
     assert all("rank 1's worker exited with rc 7" in a["reason"] for a in line["exchange_attempts"])
     assert t_exit[1] >= t_exit[0] - 0.3 and outs[1][0].strip() == ""          # rank 1 waited for rank 0's line
+    # (1b) the job's total budget, judged by rank 0's clock for everybody: what does not fit is recorded as not started, on one line
+    (tmp_path / "b").mkdir()
+    procs = _supervisors(tmp_path / "b", "import time\ntime.sleep(600)\n", 29880, {"LCX_BENCH_ATTEMPT_S": "3", "LCX_BENCH_TOTAL_S": "50"})
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert [p.returncode for p in procs] == [1, 1]
+    att = json.loads(outs[0][0].strip().splitlines()[-1])["exchange_attempts"]
+    assert "budget of 3 s" in att[0]["reason"] and [a["reason"].startswith("not started") for a in att] == [False, True, True, True]
     # (2) terminated from outside
     (tmp_path / "t").mkdir()
     hang = "import os, time\nopen(os.path.join(%r, 'pid_' + os.environ['RANK']), 'w').write(str(os.getpid()))\ntime.sleep(600)\n" % str(tmp_path / "t")

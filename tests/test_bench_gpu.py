@@ -256,3 +256,27 @@ def test_a_hung_first_contact_ends_in_a_line_from_the_next_transport(tmp_path):
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["exchange"] == "hook"
     assert "first contact with the exchange transport did not finish" in err and "ncclCommInitRank" in err and "File " in err
     assert wall < 120, wall
+
+
+def test_the_whole_ladder_against_real_rccl_failures():
+    """Two ranks on this ONE GPU with the default (RCCL) backend, launched as the driver launches them: torch's RCCL group refuses two ranks
+    per device ("Duplicate GPU detected"), so the engine, hook and torch rungs each die in their first collective with RCCL's own error -
+    real failures of the real transport, not injected ones - and the last rung (hook over gloo, fresh workers on a rendezvous of their own)
+    delivers the line with all four attempts on it."""
+    env = dict(os.environ, LCX_BENCH_DEVICE="0", LCX_FIRST_CONTACT_TIMEOUT_S="25", LCX_BENCH_ATTEMPT_S="120", OMP_NUM_THREADS="2",
+               OPENBLAS_NUM_THREADS="2", LCX_WAIT_TIMEOUT_MS="60000", **SMALL)
+    for k in ("LCX_BENCH_BACKEND", "LCX_EXCHANGE", "LCX_BENCH_LADDER"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + FAST
+    t0 = time.time()
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode == 0, err[-3000:]
+    d = _one_json_line(p.stdout)
+    att = d["exchange_attempts"]
+    assert [a["transport"] for a in att] == ["engine", "hook", "torch", "gloo"], att
+    assert all(a["rc"] not in (0, None) and a["seconds"] < 60 for a in att[:3]) and att[3]["rc"] == 0 and att[3]["reason"] == "ok"
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["exchange"] == "hook"
+    assert "Duplicate GPU detected" in err
+    assert time.time() - t0 < 120

@@ -12,6 +12,8 @@ Tolerances (stated per SURVEY.md §8c / BASELINE.md §4):
                                5e-4 (planted), iteration count within 6 %, clusters bit-exact on structured
                                inputs.  The reference itself moves by +-2 iterations between BLAS builds.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -687,8 +689,9 @@ def test_more_than_128_factors_end_to_end(tag):
         assert len(hs) == len(hs_ref) and np.max(np.abs(hs - hs_ref) / np.maximum(1.0, np.abs(hs_ref))) < 1e-8
 
 
-# (520 factors end to end - 8 s on the untuned wide path - left the suite in round 6; 512 / 600 / 1024 factors stay in test_step_level)
-@pytest.mark.parametrize("tag,m", [("f32", 300), ("f64", 300)])
+# (520 factors float32 and 300 factors float64 end to end - 8 + 7 s on the untuned wide path - left the suite in round 6; 300 / 512 / 600 / 1024
+# factors in both precisions stay in test_step_level)
+@pytest.mark.parametrize("tag,m", [("f32", 300)])
 def test_more_than_256_factors_end_to_end(tag, m):
     """n_hidden above 256 (the reference takes any n_hidden, :72) on the wide path (m_pad 512 / 1024): a short fit follows the
     oracle, clusters bit-exact on planted data in float64; transform, predict, get_covariance, the linear trial mode and the
@@ -926,9 +929,14 @@ def test_later_trials_by_linearity_whole_fit(tag, g1):
 # ------------------------------------------------------------------------------------------------------------------------------
 # round 4: ONE panel-major resident copy of the shard for large shards (include/lcx.h, lcx_x_layout; gemm_kernels.hpp, PanelW)
 # ------------------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape,tag", [((1500, 3000, 8), "f32"), ((1500, 3000, 8), "f64"), ((1501, 3001, 40), "f32"), ((1501, 3001, 40), "f64"),
-                                       ((2048, 4096, 64), "f32"), ((1300, 2500, 100), "f32"), ((1300, 2500, 100), "f64"),
-                                       ((900, 2100, 200), "f32")])
+# (round 6: one precision per shape - the other halves, (1500, 3000, 8) f64, (1501, 3001, 40) f32, (1300, 2500, 100) f32, made room for the
+# bench-job tests; LCX_MORE_LAYOUT_CASES=1 brings them back)
+_PANEL_CASES = [((1500, 3000, 8), "f32"), ((1501, 3001, 40), "f64"), ((2048, 4096, 64), "f32"), ((1300, 2500, 100), "f64"), ((900, 2100, 200), "f32")]
+if os.environ.get("LCX_MORE_LAYOUT_CASES"):
+    _PANEL_CASES += [((1500, 3000, 8), "f64"), ((1501, 3001, 40), "f32"), ((1300, 2500, 100), "f32")]
+
+
+@pytest.mark.parametrize("shape,tag", _PANEL_CASES)
 def test_panel_layout_matches_row_major(tag, shape, monkeypatch):
     """The panel-major copy (both X passes on the stream-K kernels from the same bytes) against the row-major + transposed layout on
     the same kernels: X.B^T contracts in another order (rounding), X^T.Y in the same one; same fit to rounding, both at the usual
@@ -1014,7 +1022,8 @@ def test_panel_layout_preprocess_and_generate(gz, missing, monkeypatch):
 # ------------------------------------------------------------------------------------------------------------------------------
 # (round 5: one shape per tile width - 32 / 64 / 128 padded factors, the first two with their merged pass; the opt-in is a rider
 # and the full six-shape matrix of round 4, incl. (2048, 4096, 64), (1300, 2500, 100), (20000, 1500, 40), cost a minute of the suite)
-@pytest.mark.parametrize("shape", [(1500, 3000, 20), (1501, 3001, 40), (2048, 1100, 128)])
+# (round 6: 64 padded factors with the merged pass, and 128; the 32-factor shape (1500, 3000, 20) left the suite with the other rider repeats)
+@pytest.mark.parametrize("shape", [(1501, 3001, 40), (2048, 1100, 128)])
 def test_split_gemm_matches_mfma(shape, monkeypatch):
     """f32_gemm="split" (every operand split exactly into three bf16 numbers, 6 partial products, float32 accumulation) against
     f32_gemm="mfma" (float32 MFMA) on the same panel-major shard: same fit to float32 rounding, both at the float32 bar against the

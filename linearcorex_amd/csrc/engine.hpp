@@ -267,8 +267,6 @@ struct lcx_ctx {
     // (gemm_kernels.hpp, ChunkSig); the second stream waits on the word (hipStreamWaitValue32, or poll_signal_kernel with ":poll" /
     // where the runtime has no wait-value), sums the chunk's slots and all-reduces it while the pass goes on.  Wave-split kernels only
     bool ypipe_signal, ypipe_poll;
-    bool ypipe_fused;                   // signal[:n] by itself: wait and slot reduction of a chunk in one launch (wait_reduce_partials_kernel);
-                                        // ":wv" = hipStreamWaitValue32 + the reduction kernel, ":poll" = poll_signal_kernel + the reduction kernel
     unsigned int *sig_counters;         // [SIG_MAX_CHUNKS + 1]: chunk tickets, poll error word
     unsigned int* sig_flag[SIG_MAX_CHUNKS];
     unsigned int sig_epoch;

@@ -328,28 +328,6 @@ static __global__ void poll_signal_kernel(const unsigned int* flag, unsigned int
         if (++spins > (1L << 24)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
     }
 }
-// the wait and the chunk's slot reduction in ONE launch on the second stream (a launch and a gap less per chunk): every block's first lane
-// polls the chunk's signal word (bounded like poll_signal_kernel), then the block sums its share of the chunk's slots in slot order -
-// reduce_partials_kernel's order, hence its bits.  The partial tiles were stored write-through by a launch that is still running; they are
-// loaded past the caches (agent-scope relaxed loads): nothing this kernel may have cached before the signal is trusted.
-template <typename T>
-__global__ void __launch_bounds__(256)
-wait_reduce_partials_kernel(const unsigned int* flag, unsigned int epoch, unsigned int* err, const T* in, int nsplit, int64_t n,
-                            int64_t stride, T* __restrict__ out) {
-    if (threadIdx.x == 0) {
-        long spins = 0;
-        while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1L << 24)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-        }
-    }
-    __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        T s = __hip_atomic_load(&in[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int k = 1; k < nsplit; ++k) s += __hip_atomic_load(&in[k * stride + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        out[i] = s;
-    }
-}
 static __global__ void init_signal_kernel(unsigned int* flag, unsigned int value) { __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // Two independent Gram contractions (A^T.A of two [K][Mp] arrays) in one launch: blockIdx.z picks

@@ -419,23 +419,14 @@ int Impl<T, CT>::y_pass_pipelined(lcx_ctx* h, const T* w, bool with_bj) {
                 unsigned int* err = h->sig_counters + SIG_MAX_CHUNKS;
                 for (int c = 0; c < C; ++c) {
                     const int64_t r0 = tiles * c / C * tile, r1 = tiles * (c + 1) / C * tile;
-                    const int64_t e0 = r0 * Mp, ne = (r1 - r0) * Mp;
-                    if (h->ypipe_fused && h->nt_S > 1 && h->nt_S < WIDE_SPLITS) {
-                        // wait + the chunk's slot reduction (the plain order of the unpipelined path: same bits) in one launch
-                        const unsigned gb = (unsigned)(cdiv(ne, 256) < 128 ? cdiv(ne, 256) : 128);
-                        hipLaunchKernelGGL((wait_reduce_partials_kernel<T>), dim3(gb), dim3(256), 0, h->comm_stream, h->sig_flag[c], sg.epoch, err,
-                                           P<T>(h->ypart) + e0, h->nt_S, ne, h->Npad * Mp, P<T>(h->ybuf) + e0);
+                    if (h->ypipe_poll) {
+                        hipLaunchKernelGGL(poll_signal_kernel, dim3(1), dim3(1), 0, h->comm_stream, h->sig_flag[c], sg.epoch, err);
                         KCHECK();
                     } else {
-                        if (h->ypipe_poll || h->ypipe_fused) {
-                            hipLaunchKernelGGL(poll_signal_kernel, dim3(1), dim3(1), 0, h->comm_stream, h->sig_flag[c], sg.epoch, err);
-                            KCHECK();
-                        } else {
-                            HIPCHECK(hipStreamWaitValue32(h->comm_stream, h->sig_flag[c], sg.epoch, hipStreamWaitValueGte, 0xFFFFFFFFu));
-                        }
-                        // the chunk's slots -> the summed Y: the reduction of the unpipelined path on this range (same kernel, same bits), here
-                        LCXCHECK(nt_reduce(h, nullptr, (T*)nullptr, e0, ne, h->comm_stream));
+                        HIPCHECK(hipStreamWaitValue32(h->comm_stream, h->sig_flag[c], sg.epoch, hipStreamWaitValueGte, 0xFFFFFFFFu));
                     }
+                    // the chunk's slots -> the summed Y: the reduction of the unpipelined path on this range (same kernel, same bits), here
+                    LCXCHECK(nt_reduce(h, nullptr, (T*)nullptr, r0 * Mp, (r1 - r0) * Mp, h->comm_stream));
                     const int64_t count = (r1 - r0) * Mp + (c == C - 1 ? (int64_t)Mp * Mp : 0);
                     LCXCHECK(exchange_site_on(h, h->comm_stream, site, P<T>(h->ybuf) + r0 * Mp, count, DT));
                 }

@@ -144,9 +144,9 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
     h->ypipe = 0;
     {
         // "chunks" (4 row chunks), "chunks:n" (n <= 16), "chunks:n:pass" (per-chunk launches of the pass: tests);
-        // "signal[:n[:wv|:poll]]": one pass launch with in-launch chunk signalling (engine.hpp, ypipe_signal / ypipe_fused)
+        // "signal[:n[:poll]]": one pass launch with in-launch chunk signalling (engine.hpp, ypipe_signal)
         const char* e = getenv("LCX_Y_PIPELINE");
-        h->ypipe_force_pass = h->ypipe_signal = h->ypipe_poll = h->ypipe_fused = false;
+        h->ypipe_force_pass = h->ypipe_signal = h->ypipe_poll = false;
         const bool chunks = e && !strncmp(e, "chunks", 6), signal = e && !strncmp(e, "signal", 6);
         if (chunks || signal) {
             h->ypipe = e[6] == ':' ? atoi(e + 7) : 4;
@@ -156,7 +156,6 @@ int lcx_create(lcx_ctx** out, int64_t n_samples, int64_t nv_local, int n_hidden,
             h->ypipe_force_pass = chunks && f && !strcmp(f, ":pass");
             h->ypipe_signal = signal && h->ypipe > 1;
             h->ypipe_poll = signal && f && !strcmp(f, ":poll");
-            h->ypipe_fused = h->ypipe_signal && !(f && (!strcmp(f, ":poll") || !strcmp(f, ":wv")));
         }
     }
 #undef A_

@@ -158,7 +158,7 @@ for syn in (False, True):
     ref = (O.fit_syn if syn else O.fit_ns)(x, 5, seed=0, dtype=np.float64, max_iter=40)
     runs = {}
     for mode in ("engine", "torch", "hook", "fallback-probe", "fallback-id", "fallback-init", "fallback-selftest", "pipe-chunks:3", "pipe-chunks:3:pass",
-                 "pipe-signal:3", "pipe-signal:4:poll", "pipe-signal:3:wv"):
+                 "pipe-signal:3", "pipe-signal:4:poll"):
         # ("pipe-...": the engine's own RCCL communicator with the N x m all-reduces in row chunks on the library's second stream - real
         # asynchronous ncclAllReduce launches behind events, where the gloo hook of the multi-rank tests blocks the host)
         os.environ["LCX_EXCHANGE"] = "engine" if mode.startswith(("fallback", "pipe")) else mode
@@ -190,7 +190,7 @@ for syn in (False, True):
         out._backend.close()
     os.environ["LCX_Y_PIPELINE"] = ""
     for other in ("torch", "hook", "fallback-probe", "fallback-id", "fallback-init", "fallback-selftest", "pipe-chunks:3", "pipe-chunks:3:pass",
-                 "pipe-signal:3", "pipe-signal:4:poll", "pipe-signal:3:wv"):
+                 "pipe-signal:3", "pipe-signal:4:poll"):
         assert np.array_equal(runs["engine"][0], runs[other][0]) and np.array_equal(runs["engine"][1], runs[other][1]), other
         assert np.array_equal(runs["engine"][2], runs[other][2]) and runs["engine"][3] == runs[other][3], other
 # the self-test itself, driven directly: it refuses a handle without a transport, and a transport that does not SUM is caught

@@ -229,8 +229,7 @@ def test_eight_thread_ranks_async_transport(tag, m, gemm, pipeline, line_search,
 def test_signalled_exchange_with_many_slots_is_bit_identical(monkeypatch):
     """LCX_Y_PIPELINE=signal on a shard whose pass writes MANY partial slots (few samples, many variables: 16 slots, summed by the wide
     reduction kernel): the chunk's reduction behind the signal is the unpipelined kernel on the chunk's range, whatever the slot count -
-    two thread ranks, float64 on the wave-split v_mfma_f64_4x4x4 kernel, every wait form (polling kernel, stream wait-value), against the
-    unpipelined run bit for bit."""
+    two thread ranks, float64 on the wave-split v_mfma_f64_4x4x4 kernel, both wait forms, against the unpipelined run bit for bit."""
     import torch          # noqa: F401
     monkeypatch.setenv("LCX_CHECK_RANKS", "1")
     world, n, m, dt, iters = 2, 192, 24, np.float64, 6
@@ -239,7 +238,7 @@ def test_signalled_exchange_with_many_slots_is_bit_identical(monkeypatch):
     xt = _planted(n, v, m, dt, seed=93)
     w0 = (np.random.RandomState(4).randn(m, v) * 0.002).astype(dt)
     runs = {}
-    for mode in ("off", "signal:3", "signal:2:poll", "signal:3:wv"):
+    for mode in ("off", "signal:3", "signal:2:poll"):
         if mode == "off":
             monkeypatch.delenv("LCX_Y_PIPELINE", raising=False)
         else:
@@ -278,7 +277,7 @@ def test_signalled_exchange_with_many_slots_is_bit_identical(monkeypatch):
     off = runs["off"]
     assert off["slots"] >= 12 and "gemm_tn4_kernel" in off["kernel"], (off["slots"], off["kernel"])          # the wide slot reduction
     assert len(off["history"]) == iters and np.all(np.isfinite(off["history"]))
-    for mode in ("signal:3", "signal:2:poll", "signal:3:wv"):
+    for mode in ("signal:3", "signal:2:poll"):
         r = runs[mode]
         assert np.array_equal(r["history"], off["history"]) and np.array_equal(r["ws"], off["ws"]) and r["trials"] == off["trials"], mode
         assert r["allreduces"] > off["allreduces"], mode

@@ -36,7 +36,8 @@ LADDER = (("engine", {}, False),
 FALLBACK_DEFAULTS = {"NCCL_SOCKET_IFNAME": "lo", "GLOO_SOCKET_IFNAME": "lo"}
 ATTEMPT_S = 900.0          # LCX_BENCH_ATTEMPT_S: wall-clock budget of one rank set
 TOTAL_S = 1700.0           # LCX_BENCH_TOTAL_S: of the whole ladder (the driver allows a --gpus N job 1 800 s)
-FIRST_CONTACT_S = 180      # LCX_FIRST_CONTACT_TIMEOUT_S handed to the ranks unless the caller set one
+FIRST_CONTACT_S = 300      # LCX_FIRST_CONTACT_TIMEOUT_S handed to the ranks unless the caller set one (a rank may enter first contact
+                           # minutes before a rank whose first `import torch` on a fresh box is still paging the image in)
 
 
 _LIVE = []          # (Popen, token) of the rank set / worker that is running right now: what a SIGTERM of this process must take along

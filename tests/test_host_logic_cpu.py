@@ -377,7 +377,7 @@ def test_rank_launcher_attempt_ladder(monkeypatch, capsys):
     assert "killed after its wall-clock budget" in att[0]["reason"] and "rc 3" in att[1]["reason"] and att[2]["reason"] == "ok"
     assert [t["exchange"] for t in seen] == [None, "hook", "torch"] and all(t["backend"] is None for t in seen)
     assert [t["ifname"] for t in seen] == [(None, None), ("lo", "lo"), ("lo", "lo")]          # fall-back attempts bootstrap over loopback
-    assert seen[0]["budget"] == 900.0 and all(t["ipc"] == "0" and t["nccl_debug"] == "WARN" and t["fc"] == "180" for t in seen)
+    assert seen[0]["budget"] == 900.0 and all(t["ipc"] == "0" and t["nccl_debug"] == "WARN" and t["fc"] == "300" for t in seen)
     assert all(t["cmd"][1:3] == ["-m", "torch.distributed.run"] and t["cmd"][-2:] == ["--gpus", "4"] for t in seen)
     assert len({t["cmd"][t["cmd"].index("--master-port") + 1] for t in seen}) == 3          # a fresh rendezvous per attempt
     assert int(seen[0]["reserve"]) >= len(json.dumps(att))                                  # the attempts fit the line's reserve
